@@ -1,0 +1,185 @@
+/*
+ * stag_hip.h — C ABI of the MI355X-native stochastic-aggregation path.
+ *
+ * This library replaces exactly one thing in yuanqing-wang/stag: the work done
+ * between `StagLayer.forward` and DGL's sparse kernels, i.e.
+ *
+ *     w   = q_a.expand([E, Dn]).sample()            stag/layers.py:115-129
+ *     w   = relu(w) ; w = _in_norm(graph, w)        stag/layers.py:98-105, 8-36
+ *     out = update_all(u_mul_e('h', w), sum|mean)   stag/zoo/gcn.py:94-96,
+ *                                                   stag/zoo/graph_sage.py:71-73
+ *
+ * as ONE fused pass: the noise is never materialised, it is regenerated from a
+ * counter-based Philox4x32-10 stream inside the gather/segmented-reduce kernel.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in
+ *     `_host`; nothing is allocated, freed or kept by the library;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) and the call returns without synchronising;
+ *   - return value: 0 on success, a negative errno-style code otherwise
+ *     (STAG_E*); no C++ exception crosses this boundary;
+ *   - all feature matrices are row-major fp32, a row per node; `ld*` is the row
+ *     stride in floats;
+ *   - edge data handed over by the caller (explicit weights, per-edge
+ *     parameters) is indexed by ORIGINAL edge id, as DGL edge frames are
+ *     (`graph.edata[...]`, stag/zoo/gcn.py:61-63); `csr.eid` maps a CSR
+ *     position to that id.
+ *
+ * Noise stream (normative; the CPU oracle in oracle/ restates it)
+ *   One Philox4x32-10 call yields the noise of 4 consecutive channels of one
+ *   edge:
+ *       gpos = noise_index(position)           (see stag_csr.nidx, pos_base)
+ *       ctr  = { lo32(gpos), chunk | (hi32(gpos) << 20), lo32(offset), hi32(offset) }
+ *       key  = { lo32(seed), hi32(seed) }
+ *       (r0,r1,r2,r3) = philox4x32_10(ctr, key)      channel k = 4*chunk + j uses r_j
+ *   UNIFORM   u_j = (r_j >> 8) * 2^-24                       w = fma(high-low, u_j, low)
+ *   BERNOULLI u_j as above                                   w = u_j < probs ? 1 : 0
+ *   NORMAL    pairs (r0,r1) and (r2,r3): u1 = ((r_a >> 8) + 1) * 2^-24 in (0,1],
+ *             u2 = (r_b >> 8) * 2^-24 in [0,1), rad = sqrt(-2 ln u1),
+ *             z_a = rad * cos(2 pi u2), z_b = rad * sin(2 pi u2)
+ *                                                            w = fma(scale, z, loc)
+ *   then optional relu, then optional in-degree renormalisation.
+ */
+#ifndef STAG_HIP_H
+#define STAG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STAG_ABI_VERSION 1
+
+#define STAG_OK 0
+#define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
+#define STAG_ENOMEM (-12)   /* workspace too small */
+#define STAG_EIO (-5)       /* HIP runtime reported an error at launch */
+#define STAG_ENOSYS (-38)   /* combination not implemented */
+
+/* kind of per-edge multiplicative weight (stag/layers.py:56-64 `q_a`) */
+enum {
+  STAG_NOISE_NONE = 0,      /* w = 1  (base_layer.forward(edge_weight=None)) */
+  STAG_NOISE_EXPLICIT = 1,  /* w given by caller: p0 = w[E, Dn], rows by edge id */
+  STAG_NOISE_NORMAL = 2,    /* p0 = loc,  p1 = scale   */
+  STAG_NOISE_UNIFORM = 3,   /* p0 = low,  p1 = high    */
+  STAG_NOISE_BERNOULLI = 4  /* p0 = probs              */
+};
+
+/* how p0/p1 broadcast to [E, Dn] (`q_a.expand([E, Dn])`, stag/layers.py:117-119) */
+enum {
+  STAG_PARAM_SCALAR = 0,       /* p0_scalar / p1_scalar                          */
+  STAG_PARAM_PER_CHANNEL = 1,  /* p0[Dn], p1[Dn]   (citation_rc: Normal(ones(D))) */
+  STAG_PARAM_PER_EDGE1 = 2,    /* p0[E,1], p1[E,1] (AmortizedDistribution(.,1))   */
+  STAG_PARAM_PER_EDGE = 3      /* p0[E,Dn], p1[E,Dn] (AmortizedDistribution(.,D)) */
+};
+
+enum { STAG_REDUCE_SUM = 0, STAG_REDUCE_MEAN = 1 };
+
+/* Destination-major CSR of one (shard of a) graph. Replaces the DGL graph
+ * handle that `update_all` receives (stag/zoo/gcn.py:94-96). */
+typedef struct stag_csr {
+  int32_t n_dst;          /* M: rows (destination nodes of this shard)              */
+  int32_t n_src;          /* N: rows of the gathered matrix                          */
+  int64_t n_edges;        /* E: edges of this shard                                  */
+  const int32_t* indptr;  /* [M+1]                                                   */
+  const int32_t* indices; /* [E] source row of each CSR position                     */
+  const int32_t* eid;     /* [E] original edge id of each position; NULL = identity  */
+  const int32_t* nidx;    /* [E] noise index of each position (used by the backward
+                             pass, which walks the transposed graph but must redraw
+                             the forward pass's noise); NULL = pos_base + position  */
+} stag_csr;
+
+typedef struct stag_noise_spec {
+  int32_t kind;       /* STAG_NOISE_*  */
+  int32_t param_mode; /* STAG_PARAM_*  */
+  const float* p0;
+  const float* p1;
+  float p0_scalar;
+  float p1_scalar;
+  int32_t relu;    /* w <- max(w, 0)                        stag/layers.py:98-99   */
+  int32_t in_norm; /* w <- w * indeg / sum_in(w) per dst    stag/layers.py:8-36    */
+  uint64_t seed;
+  uint64_t offset;
+  int64_t pos_base; /* global CSR position of this shard's position 0 (multi-GPU) */
+} stag_noise_spec;
+
+/* Launch plan: rows longer than `seg_len` edges are cut into segments that
+ * separate waves reduce; a second kernel adds the segment sums in order, so the
+ * result does not depend on scheduling. Built once per graph on the host. */
+typedef struct stag_plan {
+  int32_t seg_len;
+  int32_t n_long;              /* rows with in-degree > seg_len                */
+  int32_t n_seg;               /* segments over all long rows                  */
+  const int32_t* long_rows;    /* [n_long]   row ids                           */
+  const int32_t* long_seg_ptr; /* [n_long+1] segment range of each long row    */
+  const int32_t* seg_row;      /* [n_seg]    index into long_rows              */
+  const int32_t* seg_start;    /* [n_seg]    first CSR position of the segment */
+  float* workspace;            /* >= stag_plan_workspace_bytes()               */
+  size_t workspace_bytes;
+} stag_plan;
+
+int stag_abi_version(void);
+const char* stag_strerror(int code);
+
+/* ---- host-side planning (plain C++ on host arrays, no GPU call) ---------- */
+int stag_plan_count(const int32_t* indptr_host, int32_t n_dst, int32_t seg_len,
+                    int32_t* n_long_out, int32_t* n_seg_out);
+int stag_plan_fill(const int32_t* indptr_host, int32_t n_dst, int32_t seg_len,
+                   int32_t* long_rows_host, int32_t* long_seg_ptr_host,
+                   int32_t* seg_row_host, int32_t* seg_start_host);
+size_t stag_plan_workspace_bytes(int32_t n_seg, int32_t D, int32_t in_norm);
+
+/* ---- test hook: raw Philox words, out[n_pos][n_chunk][4] ------------------ */
+int stag_philox_raw(uint64_t seed, uint64_t offset, int64_t pos0, int64_t n_pos,
+                    int32_t n_chunk, uint32_t* out, void* stream);
+
+/* ---- the hot path ---------------------------------------------------------
+ * out[v, k] = dscale[v] * s[v, k] * sum_{p in row v} w[p, k] * sscale[u_p] * x[u_p, k]
+ *   u_p     = csr.indices[p]
+ *   w       = noise(spec) at (noise_index(p), k)           Dn == D
+ *   s[v,k]  = in-norm factor (1 when spec.in_norm == 0)
+ *   dscale  = dst_scale[v] (1 if NULL), times 1/max(indeg(v),1) for REDUCE_MEAN
+ *   sscale  = src_scale[u] (1 if NULL)
+ * Replaces: StagLayer.rsample_noise + relu + _in_norm (stag/layers.py:84-129)
+ *           + GCN.forward's degree scaling and update_all (stag/zoo/gcn.py:67-75,
+ *           94-96, 100-108) / GraphSAGE mean (stag/zoo/graph_sage.py:70-73).
+ * `norm_scale_out` (may be NULL): receives s[M, D] for the backward pass.     */
+int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x,
+                 int64_t ldx, int32_t D, const stag_noise_spec* spec,
+                 int32_t reduce, const float* src_scale, const float* dst_scale,
+                 float* out, int64_t ldo, float* norm_scale_out, void* stream);
+
+/* w[eid, k] for every edge of the shard: what the reference keeps in
+ * `self._edge_weight_sample` (stag/layers.py:107). relu and in_norm applied.   */
+int stag_noise_materialize(const stag_csr* csr, const stag_noise_spec* spec,
+                           int32_t Dn, float* w, int64_t ldw, void* stream);
+
+/* dw[eid, k] = sscale[u] * x[u, k] * g[v, k]  (g already carries dst scaling):
+ * gradient of stag_agg_fwd w.r.t. an explicit / reparameterised edge weight.   */
+int stag_agg_bwd_w(const stag_csr* csr, const float* x, int64_t ldx,
+                   const float* g, int64_t ldg, int32_t D,
+                   const float* src_scale, float* dw, int64_t ldw, void* stream);
+
+/* per-graph readout of a batched graph: out[b,:] = sum|mean of x[offsets[b]:offsets[b+1],:]
+ * (dgl.sum_nodes / dgl.mean_nodes, stag/layers.py:165,177)                      */
+int stag_segment_reduce(const float* x, int64_t ldx, int32_t D,
+                        const int32_t* offsets, int32_t n_seg, int32_t reduce,
+                        float* out, int64_t ldo, void* stream);
+
+/* GAT edge attention with noisy logits + softmax + aggregation, one pass per dst:
+ *   e[p,h]  = w[p,h] * leaky_relu(el[u_p,h] + er[v,h])     stag/zoo/gat.py:114-119
+ *   a[p,h]  = softmax over the in-edges of v                stag/zoo/gat.py:122
+ *   out[v,h,:] = sum_p a[p,h] * ft[u_p,h,:]                 stag/zoo/gat.py:125-126
+ * ft is [N, H*F] row-major; attn_out (may be NULL) receives a[eid, h].          */
+int stag_gat_fwd(const stag_csr* csr, const float* el, const float* er,
+                 const float* ft, int32_t H, int32_t F, float neg_slope,
+                 const stag_noise_spec* spec, float* out, float* attn_out,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STAG_HIP_H */

@@ -1,0 +1,126 @@
+"""ctypes binding of libstag_hip.so (include/stag_hip.h) for torch tensors.
+
+The library is the product; there is no CPU or eager-PyTorch fallback behind it:
+a missing library, a tensor that is not on a HIP device, or a non-zero return code
+raises.  torch is imported first on purpose — the library needs the very HIP
+runtime instance torch has loaded (same soname), otherwise torch's streams and
+device pointers would mean nothing to it.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libstag_hip.so")
+
+NOISE_NONE, NOISE_EXPLICIT, NOISE_NORMAL, NOISE_UNIFORM, NOISE_BERNOULLI = range(5)
+PARAM_SCALAR, PARAM_PER_CHANNEL, PARAM_PER_EDGE1, PARAM_PER_EDGE = range(4)
+REDUCE_SUM, REDUCE_MEAN = 0, 1
+
+_vp = C.c_void_p
+
+
+class Csr(C.Structure):
+    _fields_ = [("n_dst", C.c_int32), ("n_src", C.c_int32), ("n_edges", C.c_int64),
+                ("indptr", _vp), ("indices", _vp), ("eid", _vp), ("nidx", _vp)]
+
+
+class NoiseSpec(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("param_mode", C.c_int32), ("p0", _vp), ("p1", _vp),
+                ("p0_scalar", C.c_float), ("p1_scalar", C.c_float),
+                ("relu", C.c_int32), ("in_norm", C.c_int32),
+                ("seed", C.c_uint64), ("offset", C.c_uint64), ("pos_base", C.c_int64)]
+
+
+class Plan(C.Structure):
+    _fields_ = [("seg_len", C.c_int32), ("n_long", C.c_int32), ("n_seg", C.c_int32),
+                ("long_rows", _vp), ("long_seg_ptr", _vp), ("seg_row", _vp), ("seg_start", _vp),
+                ("workspace", _vp), ("workspace_bytes", C.c_size_t)]
+
+
+class StagHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def _hip_runtimes_mapped():
+    names = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    names.add(line.split()[-1])
+    except OSError:
+        pass
+    return names
+
+
+def lib():
+    """Load libstag_hip.so once; raise if it is missing (build with __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise StagHipError(
+            f"{_SO} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or make -C stag_amd/csrc). "
+            "stag_amd has no CPU fallback.")
+    l = C.CDLL(_SO)
+    rts = _hip_runtimes_mapped()
+    if len(rts) > 1:
+        raise StagHipError(f"two HIP runtimes are mapped into this process: {sorted(rts)}")
+    ip = C.POINTER(C.c_int32)
+    l.stag_abi_version.restype = C.c_int
+    l.stag_strerror.restype = C.c_char_p
+    l.stag_strerror.argtypes = [C.c_int]
+    l.stag_plan_count.argtypes = [_vp, C.c_int32, C.c_int32, ip, ip]
+    l.stag_plan_fill.argtypes = [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]
+    l.stag_plan_workspace_bytes.restype = C.c_size_t
+    l.stag_plan_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    l.stag_philox_raw.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]
+    l.stag_agg_fwd.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, C.c_int64, C.c_int32,
+                               C.POINTER(NoiseSpec), C.c_int32, _vp, _vp, _vp, C.c_int64, _vp, _vp]
+    l.stag_noise_materialize.argtypes = [C.POINTER(Csr), C.POINTER(NoiseSpec), C.c_int32, _vp,
+                                         C.c_int64, _vp]
+    l.stag_agg_bwd_w.argtypes = [C.POINTER(Csr), _vp, C.c_int64, _vp, C.c_int64, C.c_int32, _vp,
+                                 _vp, C.c_int64, _vp]
+    l.stag_segment_reduce.argtypes = [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, C.c_int32, _vp,
+                                      C.c_int64, _vp]
+    l.stag_gat_fwd.argtypes = [C.POINTER(Csr), _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_float,
+                               C.POINTER(NoiseSpec), _vp, _vp, _vp]
+    if l.stag_abi_version() != 1:
+        raise StagHipError("libstag_hip.so ABI version mismatch")
+    _lib = l
+    return l
+
+
+def check(rc, what):
+    if rc != 0:
+        raise StagHipError(f"{what}: {lib().stag_strerror(rc).decode()} (rc={rc})")
+
+
+def require_device(*tensors):
+    """Every tensor handed to the library must live on one HIP device."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise StagHipError(
+                "stag_amd runs on a HIP device only (tensor on %s); there is no CPU path" % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise StagHipError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(device):
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,414 @@
+// api.hip — the C ABI of include/stag_hip.h: argument checks, host-side launch
+// planning, and the auxiliary kernels (noise materialisation, weight gradient,
+// readout, raw Philox test hook).  The hot kernel lives in agg_kernel.hpp.
+#include <algorithm>
+#include <cstring>
+
+#include "../../include/stag_hip.h"
+#include "agg_kernel.hpp"
+
+using namespace stag;
+
+namespace stag {
+template <int KIND>
+hipError_t agg_launch(const AggArgs& a, bool vec, hipStream_t stream);
+}
+
+namespace {
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_spec(const stag_noise_spec* s) {
+  if (!s) return STAG_EINVAL;
+  if (s->kind < STAG_NOISE_NONE || s->kind > STAG_NOISE_BERNOULLI) return STAG_EINVAL;
+  if (s->kind == STAG_NOISE_EXPLICIT && !s->p0) return STAG_EINVAL;
+  if (s->kind >= STAG_NOISE_NORMAL) {
+    if (s->param_mode < STAG_PARAM_SCALAR || s->param_mode > STAG_PARAM_PER_EDGE) return STAG_EINVAL;
+    if (s->param_mode != STAG_PARAM_SCALAR) {
+      if (!s->p0) return STAG_EINVAL;
+      if (s->kind != STAG_NOISE_BERNOULLI && !s->p1) return STAG_EINVAL;
+    }
+  }
+  return STAG_OK;
+}
+
+int check_csr(const stag_csr* g) {
+  if (!g || g->n_dst < 0 || g->n_src < 0 || g->n_edges < 0) return STAG_EINVAL;
+  if (g->n_edges > 0x7FFFFFFFll) return STAG_EINVAL;   // int32 CSR positions
+  if (!g->indptr) return STAG_EINVAL;
+  if (g->n_edges > 0 && !g->indices) return STAG_EINVAL;
+  return STAG_OK;
+}
+
+PhiloxKey make_key(const stag_noise_spec* s) {
+  PhiloxKey k;
+  k.k0 = (uint32_t)(s->seed & 0xFFFFFFFFull);
+  k.k1 = (uint32_t)(s->seed >> 32);
+  k.o0 = (uint32_t)(s->offset & 0xFFFFFFFFull);
+  k.o1 = (uint32_t)(s->offset >> 32);
+  return k;
+}
+
+// one thread per (long row, 4 channels): add the segment partials in segment order
+__global__ __launch_bounds__(256) void agg_combine_kernel(const AggArgs a, int vec) {
+  const int nchunk = (a.D + 3) / 4;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)a.n_long * nchunk) return;
+  const int r = (int)(gid / nchunk);
+  const int k0 = (int)(gid % nchunk) * 4;
+  const int v = a.long_rows[r];
+  const int deg = a.indptr[v + 1] - a.indptr[v];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float wsum[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = a.long_seg_ptr[r]; s < a.long_seg_ptr[r + 1]; ++s) {
+    const float* wrow = a.ws + (int64_t)s * a.ws_stride;
+    float t[4];
+    load4(wrow, k0, a.D, vec != 0, t);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += t[j];
+    if (a.in_norm) {
+      load4(wrow + a.D, k0, a.D, vec != 0, t);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wsum[j] += t[j];
+    }
+  }
+  agg_epilogue(a, v, deg, k0, vec != 0, acc, wsum);
+}
+
+// ------------------------------------------------------------------------- //
+__global__ void philox_raw_kernel(PhiloxKey key, int64_t pos0, int64_t n_pos, int n_chunk,
+                                  uint32_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pos * n_chunk) return;
+  uint32_t r[4];
+  philox_at(pos0 + i / n_chunk, (uint32_t)(i % n_chunk), key, r);
+  *reinterpret_cast<uint4*>(out + i * 4) = make_uint4(r[0], r[1], r[2], r[3]);
+}
+
+// w of the 4 channels [k0, k0+4) of the edge at position p, before in-norm
+struct NoiseArgs {
+  const int32_t* indptr;
+  const int32_t* eid;
+  const int32_t* nidx;
+  int32_t n_rows;
+  int32_t Dn;
+  int32_t kind;
+  const float* p0;
+  const float* p1;
+  float p0s, p1s;
+  int32_t pmode, relu, in_norm;
+  PhiloxKey key;
+  int64_t pos_base;
+  float* w;
+  int64_t ldw;
+};
+
+__device__ __forceinline__ void edge_w4(const NoiseArgs& a, int p, int64_t ed, uint32_t chunk,
+                                        float (&w)[4]) {
+  const int k0 = (int)chunk * 4;
+  float pa[4], pb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = k0 + j;
+    const bool in = k < a.Dn;
+    float q0 = a.p0s, q1 = a.p1s;
+    if (a.pmode == 1) { q0 = in ? a.p0[k] : 0.f; q1 = (in && a.p1) ? a.p1[k] : 0.f; }
+    else if (a.pmode == 2) { q0 = a.p0[ed]; q1 = a.p1 ? a.p1[ed] : 0.f; }
+    else if (a.pmode == 3) { q0 = in ? a.p0[ed * a.Dn + k] : 0.f; q1 = (in && a.p1) ? a.p1[ed * a.Dn + k] : 0.f; }
+    pa[j] = q0; pb[j] = q1;
+  }
+  const int64_t gpos = a.nidx ? (int64_t)a.nidx[p] : a.pos_base + p;
+  switch (a.kind) {
+    case kNormal: draw4<kNormal>(gpos, chunk, a.key, pa, pb, a.relu != 0, w); break;
+    case kUniform: draw4<kUniform>(gpos, chunk, a.key, pa, pb, a.relu != 0, w); break;
+    case kBernoulli: draw4<kBernoulli>(gpos, chunk, a.key, pa, pb, a.relu != 0, w); break;
+    case kExplicit:
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = (k0 + j < a.Dn) ? a.p0[ed * a.Dn + k0 + j] : 0.f;
+        w[j] = a.relu ? fmaxf(t, 0.f) : t;
+      }
+      break;
+    default: w[0] = w[1] = w[2] = w[3] = 1.0f;
+  }
+}
+
+// one wave per destination row; lanes = LPE chunk lanes x (64/LPE) edge slots.
+// Writes what StagLayer keeps in `_edge_weight_sample` (stag/layers.py:107).
+template <int LPE>
+__global__ __launch_bounds__(256) void noise_materialize_kernel(const NoiseArgs a) {
+  constexpr int EPT = 64 / LPE;
+  const int lane = threadIdx.x & 63;
+  const int c = lane % LPE, ep = lane / LPE;
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t chunk = blockIdx.y * LPE + c;
+  const int k0 = (int)chunk * 4;
+  const bool rowok = v < a.n_rows;
+  const bool active = rowok && k0 < a.Dn;
+  const int b = rowok ? a.indptr[v] : 0, e = rowok ? a.indptr[v + 1] : 0;
+  float s[4] = {1.f, 1.f, 1.f, 1.f};
+  if (a.in_norm) {
+    float wsum[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active)
+      for (int p = b + ep; p < e; p += EPT) {
+        float w[4];
+        edge_w4(a, p, a.eid ? a.eid[p] : p, chunk, w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wsum[j] += w[j];
+      }
+#pragma unroll
+    for (int m = LPE; m < 64; m <<= 1)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wsum[j] += __shfl_xor(wsum[j], m);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = (wsum[j] != 0.f) ? (float)(e - b) / wsum[j] : 1.f;
+  }
+  if (!active) return;
+  for (int p = b + ep; p < e; p += EPT) {
+    const int64_t ed = a.eid ? a.eid[p] : p;
+    float w[4];
+    edge_w4(a, p, ed, chunk, w);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k0 + j < a.Dn) a.w[ed * a.ldw + k0 + j] = w[j] * s[j];
+  }
+}
+
+// dw[eid, k] = sscale[u] * x[u,k] * g[v,k]; one wave per row, 64 consecutive channels per step
+__global__ __launch_bounds__(256) void agg_bwd_w_kernel(const int32_t* indptr, const int32_t* indices,
+                                                        const int32_t* eid, int n_rows,
+                                                        const float* x, int64_t ldx, const float* g,
+                                                        int64_t ldg, int D, const float* src_scale,
+                                                        float* dw, int64_t ldw) {
+  const int lane = threadIdx.x & 63;
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= n_rows) return;
+  const int b = indptr[v], e = indptr[v + 1];
+  for (int k = lane; k < D; k += 64) {
+    const float gv = g[(int64_t)v * ldg + k];
+    for (int p = b; p < e; ++p) {
+      const int u = indices[p];
+      const int64_t ed = eid ? eid[p] : p;
+      const float ss = src_scale ? src_scale[u] : 1.0f;
+      dw[ed * ldw + k] = ss * x[(int64_t)u * ldx + k] * gv;
+    }
+  }
+}
+
+// out[b, :] = sum | mean of x[offsets[b]:offsets[b+1], :]; one wave per graph of the batch
+__global__ __launch_bounds__(256) void segment_reduce_kernel(const float* x, int64_t ldx, int D,
+                                                             const int32_t* offsets, int n_seg,
+                                                             int mean, float* out, int64_t ldo) {
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= n_seg) return;
+  const int lo = offsets[s], hi = offsets[s + 1];
+  for (int k = lane; k < D; k += 64) {
+    float acc = 0.f;
+    for (int i = lo; i < hi; ++i) acc += x[(int64_t)i * ldx + k];
+    if (mean) acc = (hi > lo) ? acc / (float)(hi - lo) : 0.f;
+    out[(int64_t)s * ldo + k] = acc;
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------- //
+extern "C" {
+
+int stag_abi_version(void) { return STAG_ABI_VERSION; }
+
+const char* stag_strerror(int code) {
+  switch (code) {
+    case STAG_OK: return "ok";
+    case STAG_EINVAL: return "invalid argument";
+    case STAG_ENOMEM: return "workspace too small";
+    case STAG_EIO: return "HIP runtime error at launch";
+    case STAG_ENOSYS: return "not implemented";
+    default: return "unknown error";
+  }
+}
+
+int stag_plan_count(const int32_t* indptr_host, int32_t n_dst, int32_t seg_len,
+                    int32_t* n_long_out, int32_t* n_seg_out) {
+  if (!indptr_host || n_dst < 0 || seg_len <= 0 || !n_long_out || !n_seg_out) return STAG_EINVAL;
+  int64_t nl = 0, ns = 0;
+  for (int32_t v = 0; v < n_dst; ++v) {
+    const int32_t deg = indptr_host[v + 1] - indptr_host[v];
+    if (deg < 0) return STAG_EINVAL;
+    if (deg > seg_len) { ++nl; ns += (deg + seg_len - 1) / seg_len; }
+  }
+  if (ns > 0x7FFFFFFFll) return STAG_EINVAL;
+  *n_long_out = (int32_t)nl;
+  *n_seg_out = (int32_t)ns;
+  return STAG_OK;
+}
+
+int stag_plan_fill(const int32_t* indptr_host, int32_t n_dst, int32_t seg_len,
+                   int32_t* long_rows_host, int32_t* long_seg_ptr_host, int32_t* seg_row_host,
+                   int32_t* seg_start_host) {
+  if (!indptr_host || n_dst < 0 || seg_len <= 0 || !long_seg_ptr_host) return STAG_EINVAL;
+  int32_t r = 0, s = 0;
+  long_seg_ptr_host[0] = 0;
+  for (int32_t v = 0; v < n_dst; ++v) {
+    const int32_t b = indptr_host[v], e = indptr_host[v + 1];
+    if (e - b <= seg_len) continue;
+    if (!long_rows_host || !seg_row_host || !seg_start_host) return STAG_EINVAL;
+    long_rows_host[r] = v;
+    for (int32_t p = b; p < e; p += seg_len) {
+      seg_row_host[s] = r;
+      seg_start_host[s] = p;
+      ++s;
+    }
+    long_seg_ptr_host[++r] = s;
+  }
+  return STAG_OK;
+}
+
+size_t stag_plan_workspace_bytes(int32_t n_seg, int32_t D, int32_t in_norm) {
+  if (n_seg <= 0 || D <= 0) return 0;
+  return (size_t)n_seg * (size_t)D * (in_norm ? 2u : 1u) * sizeof(float);
+}
+
+int stag_philox_raw(uint64_t seed, uint64_t offset, int64_t pos0, int64_t n_pos, int32_t n_chunk,
+                    uint32_t* out, void* stream) {
+  if (!out || n_pos < 0 || n_chunk <= 0 || !aligned16(out)) return STAG_EINVAL;
+  const int64_t n = n_pos * n_chunk;
+  if (n == 0) return STAG_OK;
+  stag_noise_spec s{};
+  s.seed = seed; s.offset = offset;
+  hipLaunchKernelGGL(philox_raw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, make_key(&s), pos0, n_pos, n_chunk, out);
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}
+
+int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int64_t ldx,
+                 int32_t D, const stag_noise_spec* spec, int32_t reduce, const float* src_scale,
+                 const float* dst_scale, float* out, int64_t ldo, float* norm_scale_out,
+                 void* stream) {
+  int rc = check_csr(csr);
+  if (rc) return rc;
+  rc = check_spec(spec);
+  if (rc) return rc;
+  if (!out || D <= 0 || (ldx != 0 && ldx < D) || ldo < D) return STAG_EINVAL;   // ldx == 0: one broadcast row
+  if (csr->n_edges > 0 && !x) return STAG_EINVAL;
+  if (reduce != STAG_REDUCE_SUM && reduce != STAG_REDUCE_MEAN) return STAG_EINVAL;
+  if (csr->n_dst == 0) return STAG_OK;
+
+  AggArgs a{};
+  a.indptr = csr->indptr; a.indices = csr->indices; a.eid = csr->eid; a.nidx = csr->nidx;
+  a.n_rows = csr->n_dst;
+  a.x = x; a.ldx = ldx; a.D = D;
+  a.p0 = spec->p0; a.p1 = spec->p1; a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar;
+  a.pmode = spec->kind >= STAG_NOISE_NORMAL ? spec->param_mode : 0;
+  a.relu = spec->relu; a.in_norm = spec->in_norm;
+  a.key = make_key(spec); a.pos_base = spec->pos_base;
+  a.src_scale = src_scale; a.dst_scale = dst_scale; a.mean = (reduce == STAG_REDUCE_MEAN);
+  a.out = out; a.ldo = ldo; a.norm_scale_out = norm_scale_out;
+
+  const bool use_plan = plan && plan->seg_len > 0 && plan->n_seg > 0;
+  if (use_plan) {
+    if (!plan->long_rows || !plan->long_seg_ptr || !plan->seg_row || !plan->seg_start ||
+        !plan->workspace)
+      return STAG_EINVAL;
+    if (plan->workspace_bytes < stag_plan_workspace_bytes(plan->n_seg, D, spec->in_norm))
+      return STAG_ENOMEM;
+    a.long_rows = plan->long_rows; a.long_seg_ptr = plan->long_seg_ptr;
+    a.seg_row = plan->seg_row; a.seg_start = plan->seg_start;
+    a.ws = plan->workspace; a.ws_stride = D * (spec->in_norm ? 2 : 1);
+    a.n_long = plan->n_long;
+  }
+  a.seg_len = (plan && plan->seg_len > 0) ? plan->seg_len : 0;
+
+  // dwordx4 path needs 16-B aligned rows everywhere a float4 is formed
+  bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) && aligned16(out);
+  if (norm_scale_out) vec = vec && aligned16(norm_scale_out);
+  if (spec->kind == STAG_NOISE_EXPLICIT) vec = vec && aligned16(spec->p0);
+  if (spec->kind >= STAG_NOISE_NORMAL && spec->param_mode != STAG_PARAM_SCALAR &&
+      spec->param_mode != STAG_PARAM_PER_EDGE1)
+    vec = vec && aligned16(spec->p0) && (!spec->p1 || aligned16(spec->p1));
+  if (use_plan) vec = vec && aligned16(plan->workspace);
+
+  hipStream_t s = (hipStream_t)stream;
+  auto launch = [&](const AggArgs& args) -> hipError_t {
+    switch (spec->kind) {
+      case STAG_NOISE_NONE: return agg_launch<kNone>(args, vec, s);
+      case STAG_NOISE_EXPLICIT: return agg_launch<kExplicit>(args, vec, s);
+      case STAG_NOISE_NORMAL: return agg_launch<kNormal>(args, vec, s);
+      case STAG_NOISE_UNIFORM: return agg_launch<kUniform>(args, vec, s);
+      default: return agg_launch<kBernoulli>(args, vec, s);
+    }
+  };
+  if (use_plan) {   // heavy segments first, then the many short rows, then the fix-up
+    AggArgs l = a;
+    l.long_mode = 1; l.n_units = plan->n_seg;
+    if (launch(l) != hipSuccess) return STAG_EIO;
+  }
+  a.long_mode = 0; a.n_units = csr->n_dst;
+  if (launch(a) != hipSuccess) return STAG_EIO;
+  if (use_plan) {
+    const int64_t n = (int64_t)plan->n_long * ((D + 3) / 4);
+    hipLaunchKernelGGL(agg_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a,
+                       vec ? 1 : 0);
+    if (hipGetLastError() != hipSuccess) return STAG_EIO;
+  }
+  return STAG_OK;
+}
+
+int stag_noise_materialize(const stag_csr* csr, const stag_noise_spec* spec, int32_t Dn, float* w,
+                           int64_t ldw, void* stream) {
+  int rc = check_csr(csr);
+  if (rc) return rc;
+  rc = check_spec(spec);
+  if (rc) return rc;
+  if (!w || Dn <= 0 || ldw < Dn) return STAG_EINVAL;
+  if (csr->n_dst == 0 || csr->n_edges == 0) return STAG_OK;
+  NoiseArgs a{};
+  a.indptr = csr->indptr; a.eid = csr->eid; a.nidx = csr->nidx; a.n_rows = csr->n_dst;
+  a.Dn = Dn; a.kind = spec->kind; a.p0 = spec->p0; a.p1 = spec->p1;
+  a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar;
+  a.pmode = spec->kind >= STAG_NOISE_NORMAL ? spec->param_mode : 0;
+  a.relu = spec->relu; a.in_norm = spec->in_norm;
+  a.key = make_key(spec); a.pos_base = spec->pos_base; a.w = w; a.ldw = ldw;
+  const int nchunk = (Dn + 3) / 4;
+  int lpe = 1;
+  while (lpe < nchunk && lpe < 64) lpe <<= 1;
+  dim3 grid((csr->n_dst + 3) / 4, (nchunk + lpe - 1) / lpe);
+  hipStream_t s = (hipStream_t)stream;
+  switch (lpe) {
+    case 64: hipLaunchKernelGGL(noise_materialize_kernel<64>, grid, dim3(256), 0, s, a); break;
+    case 32: hipLaunchKernelGGL(noise_materialize_kernel<32>, grid, dim3(256), 0, s, a); break;
+    case 16: hipLaunchKernelGGL(noise_materialize_kernel<16>, grid, dim3(256), 0, s, a); break;
+    case 8: hipLaunchKernelGGL(noise_materialize_kernel<8>, grid, dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(noise_materialize_kernel<4>, grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(noise_materialize_kernel<2>, grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(noise_materialize_kernel<1>, grid, dim3(256), 0, s, a); break;
+  }
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}
+
+int stag_agg_bwd_w(const stag_csr* csr, const float* x, int64_t ldx, const float* g, int64_t ldg,
+                   int32_t D, const float* src_scale, float* dw, int64_t ldw, void* stream) {
+  int rc = check_csr(csr);
+  if (rc) return rc;
+  if (!x || !g || !dw || D <= 0 || (ldx != 0 && ldx < D) || ldg < D || ldw < D) return STAG_EINVAL;
+  if (csr->n_dst == 0 || csr->n_edges == 0) return STAG_OK;
+  hipLaunchKernelGGL(agg_bwd_w_kernel, dim3((csr->n_dst + 3) / 4), dim3(256), 0,
+                     (hipStream_t)stream, csr->indptr, csr->indices, csr->eid, csr->n_dst, x, ldx,
+                     g, ldg, D, src_scale, dw, ldw);
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}
+
+int stag_segment_reduce(const float* x, int64_t ldx, int32_t D, const int32_t* offsets,
+                        int32_t n_seg, int32_t reduce, float* out, int64_t ldo, void* stream) {
+  if (!offsets || !out || D <= 0 || n_seg < 0 || ldx < D || ldo < D) return STAG_EINVAL;
+  if (reduce != STAG_REDUCE_SUM && reduce != STAG_REDUCE_MEAN) return STAG_EINVAL;
+  if (n_seg == 0) return STAG_OK;
+  if (!x) return STAG_EINVAL;
+  hipLaunchKernelGGL(segment_reduce_kernel, dim3((n_seg + 3) / 4), dim3(256), 0,
+                     (hipStream_t)stream, x, ldx, D, offsets, n_seg,
+                     reduce == STAG_REDUCE_MEAN ? 1 : 0, out, ldo);
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+// noise.hpp — counter-based edge noise for gfx950 (device side).
+//
+// Normative definition of the stream: include/stag_hip.h ("Noise stream").
+// It stands in for `q_a.expand([E, Dn]).sample()` (stag/layers.py:117-127):
+// every (edge, channel) gets an independent draw, but from Philox4x32-10 keyed by
+// (seed, offset, CSR position, channel/4) instead of torch's global generator, so
+// the [E, Dn] tensor never exists and any shard of the graph can redraw it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace stag {
+
+constexpr uint32_t kPhiloxM0 = 0xD2511F53u;
+constexpr uint32_t kPhiloxM1 = 0xCD9E8D57u;
+constexpr uint32_t kPhiloxW0 = 0x9E3779B9u;
+constexpr uint32_t kPhiloxW1 = 0xBB67AE85u;
+
+struct PhiloxKey {   // wave-uniform: lives in SGPRs
+  uint32_t k0, k1;   // lo32(seed), hi32(seed)
+  uint32_t o0, o1;   // lo32(offset), hi32(offset)
+};
+
+// One Philox4x32-10 block. c0 = lo32(gpos), c1 = chunk | hi(gpos) << 20.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, const PhiloxKey& key,
+                                              uint32_t (&r)[4]) {
+  uint32_t c2 = key.o0, c3 = key.o1;
+  uint32_t k0 = key.k0, k1 = key.k1;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint64_t p0 = (uint64_t)kPhiloxM0 * c0;
+    const uint64_t p1 = (uint64_t)kPhiloxM1 * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += kPhiloxW0;   // scalar ALU: the key schedule is wave-uniform
+    k1 += kPhiloxW1;
+  }
+  r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+
+__device__ __forceinline__ void philox_at(int64_t gpos, uint32_t chunk, const PhiloxKey& key,
+                                          uint32_t (&r)[4]) {
+  const uint32_t c0 = (uint32_t)((uint64_t)gpos & 0xFFFFFFFFull);
+  const uint32_t c1 = chunk | ((uint32_t)((uint64_t)gpos >> 32) << 20);
+  philox4x32_10(c0, c1, key, r);
+}
+
+// u in [0,1): 24 random bits, exact in fp32.
+__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * 0x1p-24f; }
+
+// Box-Muller on the hardware transcendentals: v_log_f32 is log2, v_sin/v_cos take
+// revolutions, so neither ln nor 2*pi costs a multiply of its own.
+__device__ __forceinline__ void box_muller(uint32_t ra, uint32_t rb, float& za, float& zb) {
+  const float u1 = (float)((ra >> 8) + 1u) * 0x1p-24f;   // (0, 1]
+  const float u2 = (float)(rb >> 8) * 0x1p-24f;          // [0, 1)
+  // -2 ln(u1) = (-2 ln 2) * log2(u1)
+  const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+  za = rad * __builtin_amdgcn_cosf(u2);
+  zb = rad * __builtin_amdgcn_sinf(u2);
+}
+
+enum : int { kNone = 0, kExplicit = 1, kNormal = 2, kUniform = 3, kBernoulli = 4 };
+
+// The 4 draws of one (edge, chunk): a[j], b[j] are the two distribution parameters
+// of channel 4*chunk + j (loc/scale, low/high, probs/-).
+template <int KIND>
+__device__ __forceinline__ void draw4(int64_t gpos, uint32_t chunk, const PhiloxKey& key,
+                                      const float (&a)[4], const float (&b)[4], bool relu,
+                                      float (&w)[4]) {
+  static_assert(KIND >= kNormal, "draw4 is for sampled noise");
+  uint32_t r[4];
+  philox_at(gpos, chunk, key, r);
+  if constexpr (KIND == kNormal) {
+    float z[4];
+    box_muller(r[0], r[1], z[0], z[1]);
+    box_muller(r[2], r[3], z[2], z[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = __builtin_fmaf(b[j], z[j], a[j]);
+  } else if constexpr (KIND == kUniform) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = __builtin_fmaf(b[j] - a[j], u01(r[j]), a[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = u01(r[j]) < a[j] ? 1.0f : 0.0f;
+  }
+  if (relu) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = fmaxf(w[j], 0.0f);
+  }
+}
+
+}  // namespace stag

@@ -1,0 +1,175 @@
+"""`stag.distributions` API (reference: stag/distributions.py:6-242), kept so the
+layer drops in: `Distribution` protocol, `DeltaDistribution`,
+`ParametrizedDistribution` (buffers `loc/scale`, or parameters `loc/log_scale`
+when vi=True — the state_dict names are part of the contract) and
+`AmortizedDistribution` (per-edge parameters from an MLP on [h_src || h_dst]).
+
+These classes only describe q_a; the draw itself happens in the fused kernel
+(stag_amd/noise.py, stag_amd/csrc/noise.hpp) unless the layer needs gradients
+through the sample (vi=True) or the distribution has no in-kernel sampler.
+"""
+from functools import partial
+from typing import Callable, Union
+
+import torch
+from torch.distributions import constraints
+
+_FORWARDED = ("expand", "rsample", "sample", "log_prob", "cdf", "icdf", "entropy")
+
+
+def _is_positive(constraint):
+    if constraint is constraints.positive:
+        return True
+    inner = getattr(constraint, "base_constraint", None)
+    return inner is constraints.positive
+
+
+class Distribution(torch.nn.Module):
+    """nn.Module wrapper that forwards the torch.distributions protocol to
+    `self.base_distribution` (stag/distributions.py:6-48)."""
+
+    @property
+    def batch_shape(self):
+        return self.base_distribution.batch_shape
+
+    @property
+    def mean(self):
+        return self.base_distribution.mean
+
+    @property
+    def stddev(self):
+        return self.base_distribution.stddev
+
+    @property
+    def variance(self):
+        return self.base_distribution.variance
+
+    def condition(self, *args, **kwargs):
+        return self
+
+
+def _forward(name):
+    def method(self, *args, **kwargs):
+        return getattr(self.base_distribution, name)(*args, **kwargs)
+    method.__name__ = name
+    return method
+
+
+for _name in _FORWARDED:
+    setattr(Distribution, _name, _forward(_name))
+
+
+class DeltaDistribution(Distribution):
+    """Point mass: sample() is the stored value (stag/distributions.py:50-91)."""
+
+    def __init__(self, value=0.0):
+        super().__init__()
+        self.register_buffer("value", torch.as_tensor(value))
+
+    batch_shape = property(lambda self: self.value.shape)
+    mean = property(lambda self: self.value)
+    stddev = property(lambda self: torch.zeros_like(self.value))
+    variance = property(lambda self: torch.zeros_like(self.value))
+
+    def sample(self, *args, **kwargs):
+        return self.value
+
+    rsample = sample
+
+    def _unsupported(self, *args, **kwargs):
+        raise NotImplementedError
+
+    expand = log_prob = cdf = icdf = entropy = _unsupported
+
+
+class ParametrizedDistribution(Distribution):
+    """A torch distribution whose arguments live in the module: buffers when
+    vi=False, nn.Parameters when vi=True with positive-constrained ones stored as
+    `log_<name>` (stag/distributions.py:93-144)."""
+
+    def __init__(self, base_distribution: torch.distributions.Distribution, vi: bool = False):
+        super().__init__()
+        cls = type(base_distribution)
+        names = [n for n in cls.arg_constraints if n != "logits"]
+        stored = []
+        for name in names:
+            value = torch.as_tensor(getattr(base_distribution, name)).detach().clone()
+            if vi and _is_positive(cls.arg_constraints[name]):
+                key, value = "log_" + name, torch.log(value)
+            else:
+                key = name
+            if vi:
+                setattr(self, key, torch.nn.Parameter(value))
+            else:
+                self.register_buffer(key, value)
+            stored.append(key)
+        self.new_parameter_names = stored
+        self.base_distribution_class = partial(cls, validate_args=False)
+        self.distribution_type = cls
+
+    def __repr__(self):
+        return repr(self.base_distribution)
+
+    def arguments(self):
+        """name -> tensor in the distribution's own parametrisation (log_ undone)."""
+        return {k[4:] if k.startswith("log_") else k:
+                (getattr(self, k).exp() if k.startswith("log_") else getattr(self, k))
+                for k in self.new_parameter_names}
+
+    @property
+    def base_distribution(self):
+        return self.base_distribution_class(**self.arguments())
+
+
+class AmortizedDistribution(Distribution):
+    """Per-edge distribution parameters h_e = act(W [h_src || h_dst]), one Linear head
+    per argument (stag/distributions.py:146-242).  `condition(graph, feat)` computes
+    them; the dense MLP is torch, the kernel consumes the resulting [E, out_features]
+    tensors as per-edge loc/scale."""
+
+    def __init__(self, in_features: int, out_features: int,
+                 hidden_features: Union[None, int] = None,
+                 activation: Callable = torch.nn.SiLU(),
+                 base_distribution_class: type = torch.distributions.Normal,
+                 init_like: Union[None, torch.distributions.Distribution, Distribution] = None):
+        super().__init__()
+        hidden_features = out_features if hidden_features is None else hidden_features
+        self.new_parameter_names = [
+            ("log_" + n) if _is_positive(c) else n
+            for n, c in base_distribution_class.arg_constraints.items()]
+        self.embedding_mlp = torch.nn.Sequential(
+            torch.nn.Linear(2 * in_features, hidden_features), activation)
+        self.parameters_mlp = torch.nn.ModuleDict(
+            {k: torch.nn.Linear(hidden_features, out_features) for k in self.new_parameter_names})
+        self.base_distribution_class = base_distribution_class
+        self.distribution_type = base_distribution_class
+        self.out_features = out_features
+        self.new_parameters = None
+        if init_like is not None:
+            self._init_like(init_like)
+
+    def _init_like(self, init_like):
+        if isinstance(init_like, Distribution):
+            init_like = init_like.base_distribution
+        for key in self.new_parameter_names:
+            if key.startswith("log_"):
+                target = torch.log(torch.as_tensor(getattr(init_like, key[4:]))).mean()
+            else:
+                target = torch.as_tensor(getattr(init_like, key)).mean()
+            torch.nn.init.constant_(self.parameters_mlp[key].bias, float(target))
+
+    def condition(self, graph, feat):
+        src, dst = graph.edges()
+        h = self.embedding_mlp(torch.cat([feat[src], feat[dst]], dim=-1))
+        self.new_parameters = {k: self.parameters_mlp[k](h) for k in self.new_parameter_names}
+        return self
+
+    def arguments(self):
+        if self.new_parameters is None:
+            raise RuntimeError("AmortizedDistribution.condition(graph, feat) has not been called")
+        return {k[4:] if k.startswith("log_") else k:
+                (v.exp() if k.startswith("log_") else v) for k, v in self.new_parameters.items()}
+
+    @property
+    def base_distribution(self):
+        return self.base_distribution_class(**self.arguments())

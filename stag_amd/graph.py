@@ -1,0 +1,351 @@
+"""Graph object that stands where DGL's graph stands in stag.
+
+DGL has no ROCm build, so the drop-in boundary owns this type.  It offers exactly
+the surface stag touches: `local_var`, `local_scope`,
+`number_of_edges/nodes`, `in_degrees/out_degrees`, `ndata/edata/srcdata/dstdata`,
+`update_all`, `apply_edges`, `is_block`, `.to()`; edge frames are indexed by the
+ORIGINAL edge id, as in DGL (stag/zoo/gcn.py:61-63).
+
+Device layout (all int32, built once, kept resident in HBM):
+    coo      src[E], dst[E]                        original edge order
+    csr      indptr[N+1], indices[E], eid[E]       destination-major, stable
+    csr_t    indptr[N+1], indices[E], eid[E], nidx[E]
+             source-major twin for the backward pass; nidx = forward CSR position
+             of the edge, so the backward redraws the forward's noise
+    plan     long-row segment lists (stag_plan_*)  per seg_len
+"""
+import contextlib
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import function as fn
+
+DEFAULT_SEG_LEN = 64
+
+
+class CsrView:
+    """Tensors of one CSR plus the ctypes struct the library takes."""
+
+    def __init__(self, n_dst, n_src, indptr, indices, eid=None, nidx=None):
+        self.n_dst, self.n_src = int(n_dst), int(n_src)
+        self.indptr, self.indices, self.eid, self.nidx = indptr, indices, eid, nidx
+        self.n_edges = int(indices.shape[0])
+        self._plans = {}
+        self._degrees = None
+
+    def struct(self):
+        return _lib.Csr(self.n_dst, self.n_src, self.n_edges, _lib.ptr(self.indptr),
+                        _lib.ptr(self.indices), _lib.ptr(self.eid), _lib.ptr(self.nidx))
+
+    @property
+    def degrees(self):
+        if self._degrees is None:
+            self._degrees = (self.indptr[1:] - self.indptr[:-1])
+        return self._degrees
+
+    def plan(self, seg_len=DEFAULT_SEG_LEN):
+        """Host-side split of long rows (stag_plan_count / stag_plan_fill), uploaded once."""
+        if seg_len is None or seg_len <= 0:
+            return None
+        if seg_len not in self._plans:
+            lib = _lib.lib()
+            indptr_h = np.ascontiguousarray(self.indptr.detach().cpu().numpy(), dtype=np.int32)
+            nl, ns = C.c_int32(0), C.c_int32(0)
+            _lib.check(lib.stag_plan_count(indptr_h.ctypes.data, self.n_dst, seg_len,
+                                           C.byref(nl), C.byref(ns)), "stag_plan_count")
+            nl, ns = nl.value, ns.value
+            long_rows = np.zeros(max(nl, 1), np.int32)
+            long_seg_ptr = np.zeros(nl + 1, np.int32)
+            seg_row = np.zeros(max(ns, 1), np.int32)
+            seg_start = np.zeros(max(ns, 1), np.int32)
+            _lib.check(lib.stag_plan_fill(indptr_h.ctypes.data, self.n_dst, seg_len,
+                                          long_rows.ctypes.data, long_seg_ptr.ctypes.data,
+                                          seg_row.ctypes.data, seg_start.ctypes.data),
+                       "stag_plan_fill")
+            dev = self.indptr.device
+            self._plans[seg_len] = dict(
+                seg_len=seg_len, n_long=nl, n_seg=ns,
+                long_rows=torch.from_numpy(long_rows).to(dev),
+                long_seg_ptr=torch.from_numpy(long_seg_ptr).to(dev),
+                seg_row=torch.from_numpy(seg_row).to(dev),
+                seg_start=torch.from_numpy(seg_start).to(dev))
+        return self._plans[seg_len]
+
+
+def build_csr(src, dst, n_src, n_dst):
+    """Stable destination-major CSR from COO (position order inside a row = ascending
+    original edge id).  torch sort/bincount on whatever device the COO lives on."""
+    E = int(src.shape[0])
+    dev = src.device
+    if E == 0:
+        z = torch.zeros(0, dtype=torch.int32, device=dev)
+        return torch.zeros(n_dst + 1, dtype=torch.int32, device=dev), z, z.clone()
+    order = torch.sort(dst.long(), stable=True).indices
+    counts = torch.bincount(dst.long(), minlength=n_dst)
+    indptr = torch.zeros(n_dst + 1, dtype=torch.int64, device=dev)
+    indptr[1:] = torch.cumsum(counts, 0)
+    return indptr.to(torch.int32), src[order].to(torch.int32).contiguous(), order.to(torch.int32)
+
+
+class _EdgeBatch:
+    """What a Python `apply_edges` callable receives (stag/distributions.py:225-227)."""
+
+    def __init__(self, g):
+        s, d = g._src.long(), g._dst.long()
+        self.src = {k: v[s] for k, v in g.srcdata.items()}
+        self.dst = {k: v[d] for k, v in g.dstdata.items()}
+        self.data = g.edata
+
+
+class Graph:
+    is_block = False
+
+    def __init__(self, src, dst, num_nodes=None, batch_num_nodes=None, device=None):
+        src = torch.as_tensor(src)
+        dst = torch.as_tensor(dst)
+        if device is not None:
+            src, dst = src.to(device), dst.to(device)
+        if src.shape != dst.shape or src.dim() != 1:
+            raise ValueError("src and dst must be 1-D tensors of equal length")
+        if num_nodes is None:
+            num_nodes = int(max(src.max().item(), dst.max().item())) + 1 if src.numel() else 0
+        elif src.numel() and int(max(src.max().item(), dst.max().item())) >= num_nodes:
+            raise ValueError("node id out of range")
+        if src.numel() >= 2 ** 31:
+            raise ValueError("more than 2^31-1 edges: shard the graph (stag_amd.partition)")
+        self._src = src.to(torch.int32).contiguous()
+        self._dst = dst.to(torch.int32).contiguous()
+        self._n = int(num_nodes)
+        self._csr = None
+        self._csr_t = None
+        self._in_deg = None
+        self._out_deg = None
+        self._batch_num_nodes = batch_num_nodes
+        self.ndata, self.edata = {}, {}
+
+    # ---- frames -----------------------------------------------------------------
+    srcdata = property(lambda self: self.ndata)
+    dstdata = property(lambda self: self.ndata)
+
+    def _share_structure(self):
+        g = Graph.__new__(Graph)
+        g.__dict__.update(self.__dict__)
+        return g
+
+    def local_var(self):
+        """Same structure (CSR, plans stay shared and cached), private frames."""
+        g = self._share_structure()
+        g.ndata, g.edata = dict(self.ndata), dict(self.edata)
+        g._origin = getattr(self, "_origin", self)
+        return g
+
+    @contextlib.contextmanager
+    def local_scope(self):
+        nd, ed = dict(self.ndata), dict(self.edata)
+        try:
+            yield
+        finally:
+            self.ndata.clear(); self.ndata.update(nd)
+            self.edata.clear(); self.edata.update(ed)
+
+    def _cache_owner(self):
+        return getattr(self, "_origin", self)
+
+    # ---- structure --------------------------------------------------------------
+    @property
+    def device(self):
+        return self._src.device
+
+    def number_of_edges(self): return int(self._src.shape[0])
+    def number_of_nodes(self): return self._n
+    def number_of_src_nodes(self): return self._n
+    def number_of_dst_nodes(self): return self._n
+    num_edges, num_nodes = number_of_edges, number_of_nodes
+    num_src_nodes, num_dst_nodes = number_of_src_nodes, number_of_dst_nodes
+
+    def edges(self):
+        return self._src.long(), self._dst.long()
+
+    def in_degrees(self):
+        o = self._cache_owner()
+        if o._in_deg is None:
+            o._in_deg = torch.bincount(self._dst.long(), minlength=self._n)
+        return o._in_deg
+
+    def out_degrees(self):
+        o = self._cache_owner()
+        if o._out_deg is None:
+            o._out_deg = torch.bincount(self._src.long(), minlength=self._n)
+        return o._out_deg
+
+    @property
+    def batch_size(self):
+        return 1 if self._batch_num_nodes is None else int(self._batch_num_nodes.shape[0])
+
+    def batch_num_nodes(self):
+        if self._batch_num_nodes is None:
+            return torch.tensor([self._n], device=self.device)
+        return self._batch_num_nodes
+
+    @property
+    def csr(self):
+        """Destination-major CSR (forward pass)."""
+        o = self._cache_owner()
+        if o._csr is None:
+            indptr, indices, eid = build_csr(self._src, self._dst, self._n, self._n)
+            o._csr = CsrView(self._n, self._n, indptr, indices, eid)
+        return o._csr
+
+    @property
+    def csr_t(self):
+        """Source-major CSR of the same edges; nidx[q] = forward CSR position of the edge
+        at transposed position q (backward pass regenerates the forward noise)."""
+        o = self._cache_owner()
+        if o._csr_t is None:
+            fwd = self.csr
+            indptr, indices, eid = build_csr(self._dst, self._src, self._n, self._n)
+            E = self.number_of_edges()
+            pos_of_eid = torch.empty(E, dtype=torch.int32, device=self.device)
+            if E:
+                pos_of_eid[fwd.eid.long()] = torch.arange(E, dtype=torch.int32, device=self.device)
+                nidx = pos_of_eid[eid.long()].contiguous()
+            else:
+                nidx = pos_of_eid
+            o._csr_t = CsrView(self._n, self._n, indptr, indices, eid, nidx)
+        return o._csr_t
+
+    def to(self, device):
+        device = torch.device(device)
+        if device == self.device:
+            return self
+        g = Graph(self._src.to(device), self._dst.to(device), self._n,
+                  None if self._batch_num_nodes is None else self._batch_num_nodes.to(device))
+        g.ndata = {k: v.to(device) for k, v in self.ndata.items()}
+        g.edata = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in self.edata.items()}
+        return g
+
+    def __repr__(self):
+        return f"Graph(num_nodes={self._n}, num_edges={self.number_of_edges()}, device={self.device})"
+
+    # ---- message passing --------------------------------------------------------
+    def update_all(self, message_func, reduce_func):
+        """`update_all(u_mul_e | copy_u | copy_e, sum | mean)` on the HIP path.
+
+        This is the call the reference's zoo layers make (stag/zoo/gcn.py:94-96,
+        stag/zoo/graph_sage.py:71-73, stag/layers.py:12-15)."""
+        from . import ops
+        from .noise import EdgeNoise
+        if not isinstance(message_func, fn.Message) or not isinstance(reduce_func, fn.Reduce):
+            raise TypeError("update_all takes stag_amd.function builtins")
+        if reduce_func.kind == "max":
+            raise NotImplementedError("max reducer (SAGE 'pool') is outside the accelerated path")
+        kind = message_func.kind
+        if kind == "copy_u":
+            x, w = self.srcdata[message_func.fields[0]], None
+        elif kind == "u_mul_e":
+            x, w = self.srcdata[message_func.fields[0]], self.edata[message_func.fields[1]]
+        elif kind == "copy_e":
+            w = self.edata[message_func.fields[0]]
+            x = None
+        else:
+            raise NotImplementedError(f"update_all with message {kind}")
+        if x is None:   # sum of edge data: gather a broadcast row of ones
+            shape = w.shape
+            w2 = w.reshape(shape[0], -1)
+            ones = torch.ones(1, w2.shape[1], dtype=w2.dtype, device=w2.device)
+            out = ops.aggregate(self, ones, w2, reduce=reduce_func.kind, _broadcast_x=True)
+            self.dstdata[reduce_func.out] = out.reshape((self._n,) + tuple(shape[1:]))
+            return
+        shape = x.shape
+        x2 = x.reshape(shape[0], -1)
+        if torch.is_tensor(w):
+            if tuple(w.shape[1:]) != tuple(shape[1:]):   # DGL broadcasting, e.g. [E,H,1] x [N,H,F]
+                while w.dim() < x.dim():
+                    w = w.unsqueeze(-1)
+                w = w.expand((w.shape[0],) + tuple(shape[1:]))
+            w = w.reshape(w.shape[0], -1)
+        elif w is not None and not isinstance(w, EdgeNoise):
+            raise TypeError("edge weight must be a tensor or an EdgeNoise")
+        out = ops.aggregate(self, x2, w, reduce=reduce_func.kind)
+        self.dstdata[reduce_func.out] = out.reshape((self._n,) + tuple(shape[1:]))
+
+    def apply_edges(self, func):
+        if isinstance(func, fn.Message):
+            s, d = self._src.long(), self._dst.long()
+            if func.kind == "u_add_v":
+                self.edata[func.fields[2]] = (self.srcdata[func.fields[0]][s]
+                                              + self.dstdata[func.fields[1]][d])
+            elif func.kind == "copy_u":
+                self.edata[func.fields[1]] = self.srcdata[func.fields[0]][s]
+            else:
+                raise NotImplementedError(f"apply_edges with message {func.kind}")
+        else:
+            self.edata.update(func(_EdgeBatch(self)))
+
+
+# ---- constructors / transforms (dgl.* free functions the scripts use) --------------
+def graph(data, num_nodes=None, device=None):
+    src, dst = data
+    return Graph(src, dst, num_nodes=num_nodes, device=device)
+
+
+def rand_graph(num_nodes, num_edges, device=None, generator=None):
+    """`dgl.rand_graph` of the reference's tests (stag/tests/test_layers.py:17)."""
+    src = torch.randint(0, num_nodes, (num_edges,), generator=generator)
+    dst = torch.randint(0, num_nodes, (num_edges,), generator=generator)
+    return Graph(src, dst, num_nodes, device=device)
+
+
+def remove_self_loop(g):
+    keep = g._src != g._dst
+    return Graph(g._src[keep], g._dst[keep], g._n)
+
+
+def add_self_loop(g):
+    loop = torch.arange(g._n, dtype=torch.int32, device=g.device)
+    return Graph(torch.cat([g._src, loop]), torch.cat([g._dst, loop]), g._n)
+
+
+def add_reverse_edges(g):
+    return Graph(torch.cat([g._src, g._dst]), torch.cat([g._dst, g._src]), g._n)
+
+
+def batch(graphs):
+    """Block-diagonal union (`dgl.batch`, scripts/ppi_mle/run.py:12-14)."""
+    offs, srcs, dsts, sizes = 0, [], [], []
+    for g in graphs:
+        srcs.append(g._src + offs)
+        dsts.append(g._dst + offs)
+        sizes.append(g._n)
+        offs += g._n
+    dev = graphs[0].device
+    out = Graph(torch.cat(srcs), torch.cat(dsts), offs,
+                batch_num_nodes=torch.tensor(sizes, dtype=torch.int64, device=dev))
+    keys = set(graphs[0].ndata)
+    for k in keys:
+        out.ndata[k] = torch.cat([g.ndata[k] for g in graphs], 0)
+    for k in set(graphs[0].edata):
+        out.edata[k] = torch.cat([g.edata[k] for g in graphs], 0)
+    return out
+
+
+def _readout(g, name, reduce):
+    from . import ops
+    x = g.ndata[name]
+    sizes = g.batch_num_nodes().to(torch.int64)
+    offsets = torch.zeros(sizes.shape[0] + 1, dtype=torch.int32, device=x.device)
+    offsets[1:] = torch.cumsum(sizes, 0).to(torch.int32)
+    shape = x.shape
+    out = ops.segment_reduce(x.reshape(shape[0], -1), offsets, reduce)
+    return out.reshape((sizes.shape[0],) + tuple(shape[1:]))
+
+
+def sum_nodes(g, name):
+    return _readout(g, name, "sum")
+
+
+def mean_nodes(g, name):
+    return _readout(g, name, "mean")

@@ -1,0 +1,188 @@
+"""`stag.layers` API on the MI355X path (reference: stag/layers.py:8-178).
+
+`StagLayer(base_layer, q_a, p_a, norm, relu, vi).forward(graph, feat)` keeps the
+reference's contract, but where the reference samples an [E, Dn] tensor and
+hands it down (stag/layers.py:96-113), this layer hands down an `EdgeNoise`
+descriptor and the base layer's aggregation kernel draws the weights itself.
+The tensor only appears when (a) gradients must flow into q_a (vi=True: the
+reparameterised sample w = loc + scale * z is formed with z drawn by the HIP
+kernel), (b) q_a has no in-kernel sampler, or (c) the base layer cannot take a
+descriptor; in all three the aggregation still runs on the explicit-weight
+kernel, never on a CPU or eager-PyTorch fallback.
+"""
+from typing import Union
+
+import torch
+
+from . import _lib
+from . import function as fn
+from . import graph as _graph
+from . import random as _random
+from .distributions import Distribution, ParametrizedDistribution
+from .noise import EdgeNoise, fusable
+
+
+def _in_norm(graph, edge_weight_sample):
+    """Rescale weights so each destination's incoming weights sum to its in-degree,
+    per channel (stag/layers.py:8-36): s = indeg / sum_in(w) where the sum is
+    non-zero, else 1.  Tensor form, used when the weights are materialised."""
+    graph = graph.local_var()
+    graph.edata["h_a"] = edge_weight_sample
+    graph.update_all(fn.copy_e("h_a", "m_a"), fn.sum("m_a", "h_a"))
+    current = graph.ndata["h_a"]
+    desired = graph.in_degrees().unsqueeze(-1).to(current.dtype)
+    scaling = torch.where(current != 0.0, desired / current, torch.ones_like(current))
+    _, dst = graph.edges()
+    return edge_weight_sample * scaling[dst]
+
+
+class StagLayer(torch.nn.Module):
+    """Make a graph conv layer stochastic: multiply every message by a freshly drawn
+    per-edge, per-channel weight ~ q_a each forward pass."""
+
+    def __init__(
+        self,
+        base_layer: torch.nn.Module,
+        q_a: Union[Distribution, torch.distributions.Distribution] = torch.distributions.Normal(1.0, 1.0),
+        p_a: Union[None, Distribution, torch.distributions.Distribution] = torch.distributions.Normal(1.0, 1.0),
+        norm: bool = False,
+        relu: bool = False,
+        vi: bool = False,
+        generator: Union[None, _random.NoiseGenerator] = None,
+    ) -> None:
+        super().__init__()
+        self.base_layer = base_layer
+        if isinstance(q_a, torch.distributions.Distribution):
+            q_a = ParametrizedDistribution(q_a, vi=vi)
+        if isinstance(p_a, torch.distributions.MixtureSameFamily):
+            p_a.base_distribution = p_a
+        elif isinstance(p_a, torch.distributions.Distribution):
+            p_a = ParametrizedDistribution(p_a, vi=vi)
+        elif p_a is None:
+            p_a = ParametrizedDistribution(q_a.base_distribution, vi=vi)
+        self.add_module("q_a", q_a)
+        self.p_a = p_a
+        self.norm, self.relu, self.vi = norm, relu, vi
+        self.generator = generator
+        self._edge_weight_handle = None
+
+    # ---- the [E, Dn] weight of the last forward (stag/layers.py:107) ----------------
+    @property
+    def _edge_weight_sample(self):
+        h = self._edge_weight_handle
+        if isinstance(h, EdgeNoise):
+            h = h.materialize()
+            self._edge_weight_handle = h
+        return h
+
+    @_edge_weight_sample.setter
+    def _edge_weight_sample(self, value):
+        self._edge_weight_handle = value
+
+    def _generator(self):
+        return self.generator if self.generator is not None else _random.default_generator
+
+    def _sample_dimension(self, feat):
+        # GAT draws one weight per head (stag/zoo/gat.py:11), everything else per channel
+        return getattr(self.base_layer, "sample_dimension", feat.shape[-1])
+
+    def forward(self, graph, feat):
+        graph = graph.local_var()
+        self.q_a.condition(graph, feat)
+        dn = self._sample_dimension(feat)
+        w = self.rsample_noise(graph, dn)
+        if not isinstance(w, EdgeNoise):
+            if self.relu:
+                w = w.relu()
+            if self.norm:
+                w = _in_norm(graph, w)
+        self._edge_weight_handle = w
+        return self.base_layer.forward(graph=graph, feat=feat, edge_weight=w)
+
+    def rsample_noise(self, graph, sample_dimension):
+        """Edge weights of shape [E, sample_dimension] (stag/layers.py:115-129): an
+        EdgeNoise descriptor when the draw can be fused into the aggregation (relu and
+        in-norm ride along in the descriptor), else a tensor."""
+        E = graph.number_of_edges()
+        dist = self.q_a.base_distribution
+        gen = self._generator()
+        fused_ok = fusable(dist) and getattr(self.base_layer, "supports_edge_noise", False)
+        if fused_ok and not self.vi:
+            return EdgeNoise.from_distribution(
+                graph, sample_dimension, dist, relu=self.relu, in_norm=self.norm,
+                seed=gen.seed, offset=gen.next_offset())
+        if fusable(dist) and self.vi and type(dist) in (torch.distributions.Normal,
+                                                       torch.distributions.Uniform):
+            # reparameterised draw: standard noise from the HIP stream, affine map in
+            # torch so autograd reaches loc / log_scale (rsample, stag/layers.py:123-124)
+            std = (EdgeNoise(graph, sample_dimension, _lib.NOISE_NORMAL, 0.0, 1.0,
+                             seed=gen.seed, offset=gen.next_offset())
+                   if isinstance(dist, torch.distributions.Normal) else
+                   EdgeNoise(graph, sample_dimension, _lib.NOISE_UNIFORM, 0.0, 1.0,
+                             seed=gen.seed, offset=gen.next_offset()))
+            z = std.materialize()
+            if isinstance(dist, torch.distributions.Normal):
+                return dist.loc + dist.scale * z
+            return dist.low + (dist.high - dist.low) * z
+        if fusable(dist):   # base layer that cannot take a descriptor: draw, then hand a tensor
+            with torch.no_grad():
+                return EdgeNoise.from_distribution(graph, sample_dimension, dist,
+                                                   seed=gen.seed, offset=gen.next_offset()).materialize()
+        expanded = self.q_a.expand([E, sample_dimension])
+        if self.vi:
+            return expanded.rsample()
+        with torch.no_grad():
+            return expanded.sample()
+
+    def kl_divergence(self):
+        """KL(q_a || p_a) averaged over parameter entries; sample-based estimate when
+        torch has no closed form for the pair (stag/layers.py:132-145)."""
+        if not self.vi:
+            return 0.0
+        try:
+            return torch.distributions.kl_divergence(
+                self.q_a.base_distribution, self.p_a.base_distribution).mean()
+        except Exception:   # the reference falls back on ANY failure (stag/layers.py:141)
+            w = self._edge_weight_sample
+            return (self.q_a.log_prob(w).sum(dim=-1).mean()
+                    - self.p_a.log_prob(w).sum(dim=-1).mean())
+
+
+class FeatOnlyLayer(torch.nn.Module):
+    """Apply a dense module, ignore the graph (stag/layers.py:147-154)."""
+    vi = False
+
+    def __init__(self, layer):
+        super().__init__()
+        self.layer = layer
+
+    def forward(self, graph, feat):
+        return self.layer(feat)
+
+
+class SumNodes(torch.nn.Module):
+    """Per-graph sum readout of a batched graph (stag/layers.py:156-166)."""
+    vi = False
+
+    def __init__(self, name="to_sum"):
+        super().__init__()
+        self.name = name
+
+    def forward(self, graph, feat):
+        graph = graph.local_var()
+        graph.ndata[self.name] = feat
+        return _graph.sum_nodes(graph, self.name)
+
+
+class MeanNodes(torch.nn.Module):
+    """Per-graph mean readout of a batched graph (stag/layers.py:168-178)."""
+    vi = False
+
+    def __init__(self, name="to_mean"):
+        super().__init__()
+        self.name = name
+
+    def forward(self, graph, feat):
+        graph = graph.local_var()
+        graph.ndata[self.name] = feat
+        return _graph.mean_nodes(graph, self.name)

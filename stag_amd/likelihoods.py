@@ -1,0 +1,34 @@
+"""Observation models on top of the last layer's probabilities
+(reference: stag/likelihoods.py:1-38; dense epilogue, no graph work)."""
+import abc
+
+import torch
+
+
+class Likelihood(torch.nn.Module, abc.ABC):
+    def __init__(self, distribution):
+        super().__init__()
+        self.distribution = distribution
+
+    @abc.abstractmethod
+    def condition(self, feat):
+        raise NotImplementedError
+
+    def log_prob(self, feat, y):
+        return self.condition(feat).log_prob(y)
+
+
+class CategoricalLikelihood(Likelihood):
+    def __init__(self):
+        super().__init__(torch.distributions.Categorical)
+
+    def condition(self, feat):
+        return self.distribution(probs=feat)
+
+
+class BernoulliLikelihood(Likelihood):
+    def __init__(self):
+        super().__init__(torch.distributions.Bernoulli)
+
+    def condition(self, feat):
+        return self.distribution(probs=feat)

@@ -1,0 +1,103 @@
+"""Model wrappers with the reference's interface (stag/models.py:7-146): pure-torch
+callers of the stochastic layers — the Monte-Carlo loop, NLL + KL objective — kept so
+scripts written against `stag.models` run unchanged on top of the HIP layers."""
+from typing import List
+
+import torch
+
+from .likelihoods import CategoricalLikelihood, Likelihood
+
+
+def nll_contrastive(q_a, graph, feat):
+    """Contrastive term for an AmortizedDistribution (stag/models.py:7-25): real edges
+    should carry weight 1, uniformly drawn fake edges weight 0."""
+    n, E = graph.number_of_nodes(), graph.number_of_edges()
+    fake_src = torch.randint(high=n, size=[E], device=feat.device)
+    fake_dst = torch.randint(high=n, size=[E], device=feat.device)
+    h_fake = q_a.embedding_mlp(torch.cat([feat[fake_src], feat[fake_dst]], dim=-1))
+    fake = {k: q_a.parameters_mlp[k](h_fake) for k in q_a.new_parameter_names}
+    q_neg = q_a.base_distribution_class(
+        **{k[4:] if k.startswith("log_") else k: (v.exp() if k.startswith("log_") else v)
+           for k, v in fake.items()})
+    nll = (-q_a.log_prob(torch.tensor(1.0, device=feat.device))
+           - q_neg.log_prob(torch.tensor(0.0, device=feat.device)))
+    return nll.sum(dim=-1).mean()
+
+
+class StagModel(torch.nn.Module):
+    def __init__(self, layers: List[torch.nn.Module], likelihood: Likelihood = None,
+                 kl_scaling=1.0):
+        super().__init__()
+        self.layers = layers
+        self.likelihood = CategoricalLikelihood() if likelihood is None else likelihood
+        self.kl_scaling = kl_scaling
+
+    def _forward(self, graph, feat):
+        graph = graph.local_var()
+        for layer in self.layers:
+            feat = layer(graph, feat)
+        return feat
+
+    def _mc_mean(self, graph, feat, n_samples):
+        return torch.stack([self._forward(graph, feat) for _ in range(n_samples)], 0).mean(0)
+
+    def forward(self, graph, feat, n_samples=1, return_parameters=False):
+        """Monte-Carlo average over `n_samples` noisy passes; noise stays on at eval time
+        (stag/models.py:45-61)."""
+        feat = self._mc_mean(graph, feat, n_samples)
+        if return_parameters is True:
+            return feat
+        return self.likelihood.condition(feat).sample()
+
+    def _regulariser(self):
+        reg = 0.0
+        for layer in self.layers:
+            if layer.vi:
+                reg = reg + layer.kl_divergence()
+        return reg
+
+    def loss_terms(self, graph, feat, y, mask=None, n_samples=1, kl_scaling=None):
+        kl_scaling = self.kl_scaling if kl_scaling is None else kl_scaling
+        total_nll = total_reg = 0.0
+        for _ in range(n_samples):
+            out = self._forward(graph, feat)
+            nll = -self.likelihood.log_prob(out, y)
+            if mask is not None:
+                nll = nll[mask]
+            total_nll = total_nll + nll.mean()
+            total_reg = total_reg + self._regulariser()
+        return total_nll / n_samples, total_reg / n_samples * kl_scaling
+
+    def loss(self, graph, feat, y, mask=None, n_samples=1, kl_scaling=None):
+        nll, reg = self.loss_terms(graph, feat, y, mask=mask, n_samples=n_samples,
+                                   kl_scaling=kl_scaling)
+        return nll + reg
+
+
+class StagModelContrastive(StagModel):
+    """Adds the last q_a-bearing layer's contrastive NLL to the regulariser
+    (stag/models.py:92-146)."""
+
+    def _forward(self, graph, feat):
+        graph = graph.local_var()
+        contrastive = 0.0
+        for layer in self.layers:
+            out = layer(graph, feat)
+            contrastive = nll_contrastive(layer.q_a, graph, feat) if hasattr(layer, "q_a") else 0.0
+            feat = out
+        return feat, contrastive
+
+    def _mc_mean(self, graph, feat, n_samples):
+        return torch.stack([self._forward(graph, feat)[0] for _ in range(n_samples)], 0).mean(0)
+
+    def loss_terms(self, graph, feat, y, mask=None, n_samples=1, kl_scaling=None):
+        kl_scaling = self.kl_scaling if kl_scaling is None else kl_scaling
+        total_nll = total_reg = 0.0
+        for _ in range(n_samples):
+            out, contrastive = self._forward(graph, feat)
+            nll = -self.likelihood.log_prob(out, y)
+            if mask is not None:
+                nll = nll[mask]
+            total_nll = total_nll + nll.mean()
+            total_reg = total_reg + contrastive + self._regulariser()
+        return total_nll / n_samples, total_reg / n_samples * kl_scaling

@@ -1,0 +1,100 @@
+"""EdgeNoise: the [E, Dn] multiplicative edge weight of a StagLayer, kept lazy.
+
+The reference materialises `q_a.expand([E, Dn]).sample()` and hands the tensor to
+`base_layer.forward(edge_weight=...)` (stag/layers.py:96-113).  Here the handle
+that travels is this descriptor: the fused kernel redraws the weights from
+(seed, offset, CSR position, channel) on the fly, and `materialize()` produces the
+reference's tensor only when somebody asks for it (`_edge_weight_sample`,
+the sample-based KL fallback of stag/layers.py:142).
+"""
+import torch
+
+from . import _lib
+
+_KIND_OF = {
+    torch.distributions.Normal: _lib.NOISE_NORMAL,
+    torch.distributions.Uniform: _lib.NOISE_UNIFORM,
+    torch.distributions.Bernoulli: _lib.NOISE_BERNOULLI,
+}
+
+
+def fusable(dist):
+    """True if `dist` (a torch distribution) has an in-kernel sampler."""
+    return type(dist) in _KIND_OF
+
+
+def _param_mode(p, n_edges, dn):
+    """Classify how a parameter tensor broadcasts against [E, Dn] (`.expand([E, Dn])`)."""
+    if p.dim() == 0 or p.numel() == 1:
+        return _lib.PARAM_SCALAR
+    if p.dim() == 1 and p.shape[0] == dn:
+        return _lib.PARAM_PER_CHANNEL
+    if p.dim() == 2 and p.shape[0] == n_edges and p.shape[1] == 1:
+        return _lib.PARAM_PER_EDGE1
+    if p.dim() == 2 and p.shape == (n_edges, dn):
+        return _lib.PARAM_PER_EDGE
+    if p.dim() == 2 and p.shape[0] == 1 and p.shape[1] == dn:
+        return _lib.PARAM_PER_CHANNEL
+    raise ValueError(f"parameter of shape {tuple(p.shape)} does not broadcast to [{n_edges}, {dn}]")
+
+
+class EdgeNoise:
+    def __init__(self, graph, dn, kind, p0, p1=None, relu=False, in_norm=False, seed=0, offset=0,
+                 pos_base=0):
+        self.graph, self.dn, self.kind = graph, int(dn), int(kind)
+        self.relu, self.in_norm = bool(relu), bool(in_norm)
+        self.seed, self.offset, self.pos_base = int(seed), int(offset), int(pos_base)
+        E = graph.number_of_edges()
+        dev = graph.device
+        self.param_mode = _lib.PARAM_SCALAR
+        self.p0 = self.p1 = None
+        self.p0_scalar = self.p1_scalar = 0.0
+        if kind >= _lib.NOISE_NORMAL:
+            ps = [torch.as_tensor(p, dtype=torch.float32) for p in ((p0,) if p1 is None else (p0, p1))]
+            mode = max(_param_mode(p, E, dn) for p in ps)
+            self.param_mode = mode
+            if mode == _lib.PARAM_SCALAR:
+                self.p0_scalar = float(ps[0].reshape(()))
+                if p1 is not None:
+                    self.p1_scalar = float(ps[1].reshape(()))
+            else:
+                shape = {_lib.PARAM_PER_CHANNEL: (dn,), _lib.PARAM_PER_EDGE1: (E, 1),
+                         _lib.PARAM_PER_EDGE: (E, dn)}[mode]
+                ex = [p.detach().to(dev).expand(shape).contiguous() for p in ps]
+                self.p0 = ex[0]
+                self.p1 = ex[1] if p1 is not None else None
+
+    @classmethod
+    def from_distribution(cls, graph, dn, dist, **kw):
+        """dist: torch Normal / Uniform / Bernoulli with scalar, [Dn], [E,1] or [E,Dn] params."""
+        kind = _KIND_OF[type(dist)]
+        if kind == _lib.NOISE_NORMAL:
+            return cls(graph, dn, kind, dist.loc, dist.scale, **kw)
+        if kind == _lib.NOISE_UNIFORM:
+            return cls(graph, dn, kind, dist.low, dist.high, **kw)
+        return cls(graph, dn, kind, dist.probs, None, **kw)
+
+    @property
+    def shape(self):
+        return torch.Size([self.graph.number_of_edges(), self.dn])
+
+    def unsqueeze(self, dim):   # stag/zoo/gat.py:118 does edge_weight.unsqueeze(-1)
+        return self
+
+    def spec(self):
+        s = _lib.NoiseSpec()
+        s.kind, s.param_mode = self.kind, self.param_mode
+        s.p0, s.p1 = _lib.ptr(self.p0), _lib.ptr(self.p1)
+        s.p0_scalar, s.p1_scalar = self.p0_scalar, self.p1_scalar
+        s.relu, s.in_norm = int(self.relu), int(self.in_norm)
+        s.seed, s.offset, s.pos_base = self.seed, self.offset, self.pos_base
+        return s
+
+    def materialize(self):
+        from . import ops
+        return ops.materialize_noise(self.graph, self)
+
+    def __repr__(self):
+        names = {2: "Normal", 3: "Uniform", 4: "Bernoulli"}
+        return (f"EdgeNoise({names.get(self.kind, self.kind)}, shape={list(self.shape)}, "
+                f"seed={self.seed:#x}, offset={self.offset}, relu={self.relu}, in_norm={self.in_norm})")

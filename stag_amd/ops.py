@@ -1,0 +1,248 @@
+"""Autograd-aware operators over libstag_hip.so.
+
+`aggregate` is the hot path: one call = noise draw + relu + in-norm + degree
+scaling + `update_all(u_mul_e, sum|mean)` of the reference (stag/layers.py:84-113,
+stag/zoo/gcn.py:67-108), as one fused HIP pass.  Its backward walks the
+source-major CSR and REDRAWS the forward's noise from the Philox counters
+(`csr_t.nidx`), so no [E, D] tensor is saved for autograd.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .graph import DEFAULT_SEG_LEN
+from .noise import EdgeNoise
+
+_REDUCE = {"sum": _lib.REDUCE_SUM, "mean": _lib.REDUCE_MEAN}
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _none_spec():
+    s = _lib.NoiseSpec()
+    s.kind = _lib.NOISE_NONE
+    return s
+
+
+def _explicit_spec(w, relu=False, in_norm=False):
+    s = _lib.NoiseSpec()
+    s.kind = _lib.NOISE_EXPLICIT
+    s.p0 = w.data_ptr()
+    s.relu, s.in_norm = int(relu), int(in_norm)
+    return s
+
+
+def _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len, want_norm_scale=False,
+             broadcast_x=False):
+    """One stag_agg_fwd launch on csrv (a CsrView). x: [n_src, D] fp32 contiguous."""
+    dev = _lib.require_device(x, csrv.indptr, src_scale, dst_scale)
+    out = torch.empty((csrv.n_dst, D), dtype=torch.float32, device=dev)
+    ns = torch.empty((csrv.n_dst, D), dtype=torch.float32, device=dev) if want_norm_scale else None
+    plan_t = csrv.plan(seg_len)
+    plan_c = None
+    ws = None
+    if plan_t is not None and plan_t["n_seg"] > 0:
+        nbytes = _lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], D, int(spec.in_norm))
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        plan_c = _lib.Plan(plan_t["seg_len"], plan_t["n_long"], plan_t["n_seg"],
+                           _lib.ptr(plan_t["long_rows"]), _lib.ptr(plan_t["long_seg_ptr"]),
+                           _lib.ptr(plan_t["seg_row"]), _lib.ptr(plan_t["seg_start"]),
+                           _lib.ptr(ws), nbytes)
+    cs = csrv.struct()
+    with torch.cuda.device(dev):
+        rc = _lib.lib().stag_agg_fwd(
+            C.byref(cs), C.byref(plan_c) if plan_c is not None else None, _lib.ptr(x),
+            0 if broadcast_x else x.stride(0), D, C.byref(spec), reduce, _lib.ptr(src_scale),
+            _lib.ptr(dst_scale), _lib.ptr(out), D, _lib.ptr(ns), _lib.stream_of(dev))
+    _lib.check(rc, "stag_agg_fwd")
+    return out, ns
+
+
+def _bwd_w_raw(csrv, x, g, D, src_scale, broadcast_x=False):
+    dev = _lib.require_device(x, g)
+    dw = torch.empty((csrv.n_edges, D), dtype=torch.float32, device=dev)
+    cs = csrv.struct()
+    with torch.cuda.device(dev):
+        rc = _lib.lib().stag_agg_bwd_w(C.byref(cs), _lib.ptr(x), 0 if broadcast_x else x.stride(0),
+                                       _lib.ptr(g), g.stride(0), D, _lib.ptr(src_scale),
+                                       _lib.ptr(dw), D, _lib.stream_of(dev))
+    _lib.check(rc, "stag_agg_bwd_w")
+    return dw
+
+
+class _Aggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, graph, noise, reduce, src_scale, dst_scale, seg_len, broadcast_x):
+        x = _f32c(x)
+        D = x.shape[1]
+        csrv = graph.csr
+        keep = []
+        if noise is not None:
+            spec = noise.spec()
+            keep += [noise.p0, noise.p1]
+        elif w is not None:
+            w = _f32c(w)
+            spec = _explicit_spec(w)
+            keep.append(w)
+        else:
+            spec = _none_spec()
+        out, ns = _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len,
+                           want_norm_scale=bool(spec.in_norm), broadcast_x=broadcast_x)
+        ctx.graph, ctx.noise, ctx.reduce, ctx.seg_len = graph, noise, reduce, seg_len
+        ctx.broadcast_x = broadcast_x
+        ctx.D = D
+        need_x = w is not None and ctx.needs_input_grad[1]   # x is only read by dw
+        ctx.save_for_backward(x if need_x else None, w, src_scale, dst_scale, ns)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, w, src_scale, dst_scale, ns = ctx.saved_tensors
+        graph, noise = ctx.graph, ctx.noise
+        D = ctx.D
+        g = _f32c(grad_out)
+        if ns is not None:                      # in-norm factor is a constant of the backward
+            g = g * ns
+        dvec = dst_scale
+        if ctx.reduce == _lib.REDUCE_MEAN:
+            inv = 1.0 / graph.csr.degrees.clamp(min=1).to(torch.float32)
+            dvec = inv if dvec is None else dvec * inv
+        dx = dw = None
+        if ctx.needs_input_grad[0] and not ctx.broadcast_x:
+            if noise is not None:
+                spec = noise.spec()
+                spec.in_norm = 0
+            elif w is not None:
+                spec = _explicit_spec(w)
+            else:
+                spec = _none_spec()
+            # dx[u,:] = ss[u] * sum_{p: src_p = u} w[p,:] * dvec[v_p] * g[v_p,:]
+            dx, _ = _agg_raw(graph.csr_t, g, D, spec, _lib.REDUCE_SUM, dvec, src_scale, ctx.seg_len)
+        if w is not None and ctx.needs_input_grad[1]:
+            gg = g if dvec is None else g * dvec.unsqueeze(1)
+            dw = _bwd_w_raw(graph.csr, x, gg.contiguous(), D, src_scale, broadcast_x=ctx.broadcast_x)
+        return dx, dw, None, None, None, None, None, None, None
+
+
+def aggregate(graph, x, weight=None, reduce="sum", src_scale=None, dst_scale=None,
+              seg_len=DEFAULT_SEG_LEN, _broadcast_x=False):
+    """out[v,:] = dscale[v] * sum|mean_{e=(u->v)} w[e,:] * sscale[u] * x[u,:]
+
+    weight: None (plain copy_u), a tensor [E, D] indexed by edge id (explicit
+    `edge_weight`, stag/zoo/gcn.py:60-63), or an EdgeNoise (fused sampling)."""
+    if x.dim() != 2:
+        raise ValueError("aggregate expects x of shape [N, D]")
+    noise = weight if isinstance(weight, EdgeNoise) else None
+    w = weight if torch.is_tensor(weight) else None
+    D = x.shape[1]
+    if w is not None:
+        if w.shape[0] != graph.number_of_edges():
+            raise AssertionError("edge_weight.shape[0] != number_of_edges")   # zoo/gcn.py:61
+        if w.dim() == 1:
+            w = w.unsqueeze(1)
+        if w.shape[1] != D:
+            w = w.expand(w.shape[0], D)
+    if noise is not None and noise.dn != D:
+        raise ValueError(f"noise width {noise.dn} != feature width {D}")
+    return _Aggregate.apply(x, w, graph, noise, _REDUCE[reduce], _f32c(src_scale),
+                            _f32c(dst_scale), seg_len, _broadcast_x)
+
+
+def materialize_noise(graph, noise):
+    """The [E, Dn] tensor the reference would have sampled (rows by edge id)."""
+    csrv = graph.csr
+    dev = _lib.require_device(csrv.indptr)
+    w = torch.empty((csrv.n_edges, noise.dn), dtype=torch.float32, device=dev)
+    spec, cs = noise.spec(), csrv.struct()
+    with torch.cuda.device(dev):
+        rc = _lib.lib().stag_noise_materialize(C.byref(cs), C.byref(spec), noise.dn, _lib.ptr(w),
+                                               noise.dn, _lib.stream_of(dev))
+    _lib.check(rc, "stag_noise_materialize")
+    return w
+
+
+def philox_raw(seed, offset, pos0, n_pos, n_chunk, device):
+    out = torch.empty((n_pos, n_chunk, 4), dtype=torch.int32, device=device)
+    dev = _lib.require_device(out)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().stag_philox_raw(seed, offset, pos0, n_pos, n_chunk, _lib.ptr(out),
+                                        _lib.stream_of(dev))
+    _lib.check(rc, "stag_philox_raw")
+    return out
+
+
+class _SegmentReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, offsets, reduce):
+        x = _f32c(x)
+        dev = _lib.require_device(x, offsets)
+        B, D = offsets.shape[0] - 1, x.shape[1]
+        out = torch.empty((B, D), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().stag_segment_reduce(_lib.ptr(x), x.stride(0), D, _lib.ptr(offsets), B,
+                                                reduce, _lib.ptr(out), D, _lib.stream_of(dev))
+        _lib.check(rc, "stag_segment_reduce")
+        ctx.reduce = reduce
+        ctx.save_for_backward(offsets)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (offsets,) = ctx.saved_tensors
+        sizes = (offsets[1:] - offsets[:-1]).long()
+        if ctx.reduce == _lib.REDUCE_MEAN:
+            g = g / sizes.clamp(min=1).to(g.dtype).unsqueeze(1)
+        return torch.repeat_interleave(g, sizes, dim=0), None, None
+
+
+def segment_reduce(x, offsets, reduce="sum"):
+    """Per-graph readout over a batched graph (dgl.sum_nodes / mean_nodes)."""
+    return _SegmentReduce.apply(x, offsets.to(torch.int32).contiguous(), _REDUCE[reduce])
+
+
+class _GatAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, el, er, ft, w, graph, noise, neg_slope, want_attn):
+        el, er, ft = _f32c(el), _f32c(er), _f32c(ft)
+        H, F = ft.shape[1], ft.shape[2]
+        csrv = graph.csr
+        dev = _lib.require_device(el, er, ft, csrv.indptr)
+        if noise is not None:
+            spec = noise.spec()
+        elif w is not None:
+            w = _f32c(w)
+            spec = _explicit_spec(w)
+        else:
+            spec = _none_spec()
+        out = torch.empty((csrv.n_dst, H, F), dtype=torch.float32, device=dev)
+        attn = torch.empty((csrv.n_edges, H), dtype=torch.float32, device=dev) if want_attn else None
+        cs = csrv.struct()
+        with torch.cuda.device(dev):
+            rc = _lib.lib().stag_gat_fwd(C.byref(cs), _lib.ptr(el), _lib.ptr(er), _lib.ptr(ft), H, F,
+                                         float(neg_slope), C.byref(spec), _lib.ptr(out),
+                                         _lib.ptr(attn), _lib.stream_of(dev))
+        _lib.check(rc, "stag_gat_fwd")
+        ctx.mark_non_differentiable(*([attn] if attn is not None else []))
+        return (out, attn) if want_attn else out
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError(
+            "stag_gat_fwd has no backward kernel yet (DESIGN.md, 'next'): GAT is inference-only")
+
+
+def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False):
+    """Fused noisy-logit edge softmax + aggregation (stag/zoo/gat.py:114-126).
+    el: [N,H], er: [N,H], ft: [N,H,F]; weight: None | [E,H] tensor | EdgeNoise(dn=H)."""
+    noise = weight if isinstance(weight, EdgeNoise) else None
+    w = weight if torch.is_tensor(weight) else None
+    if w is not None and w.shape[0] != graph.number_of_edges():
+        raise AssertionError("edge_weight.shape[0] != number_of_edges")
+    return _GatAggregate.apply(el, er, ft, w, graph, noise, neg_slope, want_attn)

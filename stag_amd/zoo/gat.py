@@ -1,0 +1,64 @@
+"""GAT layer (reference: stag/zoo/gat.py:7-149; DGL GATConv layout).  The edge
+weight has one column per head (`sample_dimension = num_heads`, :11) and scales the
+leaky-relu'd logit BEFORE the edge softmax (:117-119).  Logits, noise, softmax and
+the weighted sum are one fused kernel (`ops.gat_aggregate`)."""
+import torch
+
+from .. import ops
+
+
+class GAT(torch.nn.Module):
+    supports_edge_noise = True
+
+    def __init__(self, in_feats, out_feats, num_heads=4, feat_drop=0.0, attn_drop=0.0,
+                 negative_slope=0.2, residual=False, activation=None, allow_zero_in_degree=False,
+                 bias=True, last=False):
+        super().__init__()
+        self._num_heads, self._in_feats, self._out_feats = num_heads, in_feats, out_feats
+        self._negative_slope = negative_slope
+        self.fc = torch.nn.Linear(in_feats, out_feats * num_heads, bias=False)
+        self.attn_l = torch.nn.Parameter(torch.empty(1, num_heads, out_feats))
+        self.attn_r = torch.nn.Parameter(torch.empty(1, num_heads, out_feats))
+        self.feat_drop = torch.nn.Dropout(feat_drop)
+        if attn_drop != 0.0:
+            raise NotImplementedError("attention dropout is not fused; use attn_drop=0")
+        self.bias = torch.nn.Parameter(torch.empty(num_heads * out_feats)) if bias else None
+        if residual:
+            self.res_fc = (torch.nn.Linear(in_feats, num_heads * out_feats, bias=False)
+                           if in_feats != num_heads * out_feats else torch.nn.Identity())
+        else:
+            self.res_fc = None
+        self.activation = activation
+        self.last = last
+        self.sample_dimension = num_heads
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        gain = torch.nn.init.calculate_gain("relu")
+        torch.nn.init.xavier_uniform_(self.fc.weight, gain=gain)
+        torch.nn.init.xavier_uniform_(self.attn_l, gain=gain)
+        torch.nn.init.xavier_uniform_(self.attn_r, gain=gain)
+        if self.bias is not None:
+            torch.nn.init.constant_(self.bias, 0)
+        if isinstance(self.res_fc, torch.nn.Linear):
+            torch.nn.init.xavier_uniform_(self.res_fc.weight, gain=gain)
+
+    def forward(self, graph, feat, get_attention=False, edge_weight=None):
+        H, F = self._num_heads, self._out_feats
+        h = self.feat_drop(feat)
+        ft = self.fc(h).view(-1, H, F)
+        el = (ft * self.attn_l).sum(dim=-1)          # [N, H]  (zoo/gat.py:109)
+        er = (ft * self.attn_r).sum(dim=-1)          # [N, H]  (zoo/gat.py:110)
+        if edge_weight is not None:
+            assert edge_weight.shape[0] == graph.number_of_edges()
+        res = ops.gat_aggregate(graph, el, er, ft, self._negative_slope, edge_weight,
+                                want_attn=get_attention)
+        rst, attn = res if get_attention else (res, None)
+        if self.res_fc is not None:
+            rst = rst + self.res_fc(h).view(h.shape[0], -1, F)
+        if self.bias is not None:
+            rst = rst + self.bias.view(1, H, F)
+        rst = rst.mean(-2) if self.last else rst.flatten(-2, -1)
+        if self.activation:
+            rst = self.activation(rst)
+        return (rst, attn.unsqueeze(-1)) if get_attention else rst

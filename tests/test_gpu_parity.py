@@ -1,0 +1,273 @@
+"""HIP path vs CPU oracle on the same seeded inputs (run on the GPU box: -m gpu).
+
+Bit-exact: CSR arrays, raw Philox words, Uniform and Bernoulli draws.
+Within |a-b| <= 1e-5 (1+|b|): Normal draws (hardware log/sin/cos vs libm) and every
+aggregated feature.
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import TOL, assert_close, oracle_graph, random_graph, scaled_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _noise(g, dn, kind, p0, p1=None, **kw):
+    import stag_amd
+    from stag_amd import _lib
+    k = {"normal": _lib.NOISE_NORMAL, "uniform": _lib.NOISE_UNIFORM, "bernoulli": _lib.NOISE_BERNOULLI}[kind]
+    return stag_amd.EdgeNoise(g, dn, k, p0, p1, **kw)
+
+
+def _np(p):
+    return p.detach().cpu().numpy() if torch.is_tensor(p) else p
+
+
+def _ospec(O, g, dn, kind, p0, p1=None, **kw):
+    return O.make_spec(kind, _np(p0), _np(p1), Dn=dn, n_edges=g.number_of_edges(), **kw)
+
+
+def test_library_loaded_is_in_tree():
+    from stag_amd import _lib
+    _lib.lib()
+    maps = open("/proc/self/maps").read()
+    assert "stag_amd/libstag_hip.so" in maps
+
+
+def test_philox_words_bit_exact(dev, oracle):
+    from stag_amd import ops
+    for seed, offset, pos0 in [(0, 0, 0), (0x5747A6, 3, 12345), (2**63 + 5, 2**40 + 9, 2**33 + 17)]:
+        got = ops.philox_raw(seed, offset, pos0, 257, 5, dev).cpu().numpy().view(np.uint32)
+        ref = oracle.philox_raw(seed, offset, pos0, 257, 5)
+        assert np.array_equal(got, ref)
+
+
+def test_csr_bit_exact(dev, oracle):
+    g = random_graph(300, 4000, seed=3, hub=500, device=dev)
+    src, dst = (t.cpu().numpy() for t in g.edges())
+    indptr, indices, eid, ind, outd = oracle.csr_build(src, dst, 300, 300)
+    assert np.array_equal(g.csr.indptr.cpu().numpy(), indptr)
+    assert np.array_equal(g.csr.indices.cpu().numpy(), indices)
+    assert np.array_equal(g.csr.eid.cpu().numpy(), eid)
+    assert np.array_equal(g.in_degrees().cpu().numpy(), ind)
+    assert np.array_equal(g.out_degrees().cpu().numpy(), outd)
+    # transposed twin: nidx maps back to the forward position of the same edge
+    t = g.csr_t
+    assert np.array_equal(g.csr.eid.cpu().numpy()[t.nidx.cpu().numpy()], t.eid.cpu().numpy())
+
+
+@pytest.mark.parametrize("dn", [1, 5, 16, 128, 130])
+def test_uniform_and_bernoulli_draws_bit_exact(dev, oracle, dn):
+    g = random_graph(64, 700, seed=dn, hub=90, device=dev)
+    og = oracle_graph(oracle, g)
+    for kind, p0, p1 in [("uniform", 0.25, 1.75), ("bernoulli", 0.7, None)]:
+        for relu, norm in [(False, False), (True, kind == "bernoulli")]:
+            kw = dict(relu=relu, in_norm=norm, seed=99, offset=4)
+            got = _noise(g, dn, kind, p0, p1, **kw).materialize().cpu().numpy()
+            ref = oracle.noise_materialize(og, _ospec(oracle, g, dn, kind, p0, p1, **kw), dn)
+            if norm:   # division by a sum: same values up to the order of the sum
+                assert_close(got, ref, what=f"{kind} in_norm dn={dn}")
+            else:
+                assert np.array_equal(got, ref), f"{kind} dn={dn}"
+
+
+@pytest.mark.parametrize("dn", [4, 7, 128])
+def test_normal_draws(dev, oracle, dn):
+    g = random_graph(100, 3000, seed=dn + 1, device=dev)
+    og = oracle_graph(oracle, g)
+    got = _noise(g, dn, "normal", 1.0, 0.5, seed=5, offset=1).materialize().cpu().numpy()
+    ref = oracle.noise_materialize(og, _ospec(oracle, g, dn, "normal", 1.0, 0.5, seed=5, offset=1), dn)
+    assert np.abs(got - ref).max() <= 2e-6, np.abs(got - ref).max()
+
+
+PARAM_CASES = ["scalar", "per_channel", "per_edge1", "per_edge"]
+
+
+def _params(mode, E, D, rng):
+    if mode == "scalar":
+        return 1.0, 0.5
+    if mode == "per_channel":
+        return (torch.from_numpy(rng.uniform(0.5, 1.5, D).astype(np.float32)),
+                torch.from_numpy(rng.uniform(0.1, 1.0, D).astype(np.float32)))
+    if mode == "per_edge1":
+        return (torch.from_numpy(rng.uniform(0.5, 1.5, (E, 1)).astype(np.float32)),
+                torch.from_numpy(rng.uniform(0.1, 1.0, (E, 1)).astype(np.float32)))
+    return (torch.from_numpy(rng.uniform(0.5, 1.5, (E, D)).astype(np.float32)),
+            torch.from_numpy(rng.uniform(0.1, 1.0, (E, D)).astype(np.float32)))
+
+
+@pytest.mark.parametrize("D", [1, 3, 4, 9, 16, 50, 64, 128, 256, 300, 1433])
+@pytest.mark.parametrize("kind", ["none", "explicit", "normal", "uniform", "bernoulli"])
+def test_agg_fwd_vs_oracle(dev, oracle, D, kind):
+    from stag_amd import ops
+    rng = np.random.default_rng(D * 7 + len(kind))
+    n, e = (40, 300) if D > 512 else (200, 1500)
+    g = random_graph(n, e, seed=D, hub=150, device=dev)
+    E = g.number_of_edges()
+    og = oracle_graph(oracle, g)
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    ss = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    ds = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    xd = torch.from_numpy(x).to(dev)
+    for reduce in ("sum", "mean"):
+        if kind == "none":
+            w, spec = None, oracle.make_spec("none")
+        elif kind == "explicit":
+            wt = rng.uniform(-1, 2, (E, D)).astype(np.float32)
+            w, spec = torch.from_numpy(wt).to(dev), oracle.make_spec("explicit", wt)
+        else:
+            p0, p1 = (0.7, None) if kind == "bernoulli" else ((0.2, 1.8) if kind == "uniform" else (1.0, 0.5))
+            w = _noise(g, D, kind, p0, p1, seed=11, offset=2)
+            spec = _ospec(oracle, g, D, kind, p0, p1, seed=11, offset=2)
+        got = ops.aggregate(g, xd, w, reduce=reduce, src_scale=torch.from_numpy(ss).to(dev),
+                            dst_scale=torch.from_numpy(ds).to(dev), seg_len=32)
+        ref = oracle.agg_fwd(og, x, spec, reduce=oracle.REDUCE_MEAN if reduce == "mean" else oracle.REDUCE_SUM,
+                             src_scale=ss, dst_scale=ds)
+        assert_close(got, ref, what=f"agg {kind} D={D} {reduce}")
+
+
+@pytest.mark.parametrize("mode", PARAM_CASES)
+@pytest.mark.parametrize("kind", ["normal", "uniform", "bernoulli"])
+@pytest.mark.parametrize("D", [6, 128])
+def test_agg_param_modes_relu_innorm(dev, oracle, mode, kind, D):
+    from stag_amd import ops
+    rng = np.random.default_rng(len(mode) * 13 + D)
+    g = random_graph(150, 1200, seed=D + 2, hub=200, device=dev)
+    E = g.number_of_edges()
+    og = oracle_graph(oracle, g)
+    x = rng.standard_normal((150, D)).astype(np.float32)
+    p0, p1 = _params(mode, E, D, rng)
+    if kind == "bernoulli":
+        p0, p1 = (p0 * 0.5 if torch.is_tensor(p0) else 0.6), None
+    elif kind == "uniform" and torch.is_tensor(p0):
+        p1 = p0 + p1
+    elif kind == "uniform":
+        p0, p1 = 0.5, 1.5
+    for relu, norm in [(False, False), (True, False), (False, True)]:
+        if norm and kind == "normal":
+            continue   # sum of normals may pass arbitrarily close to 0: ill-conditioned by design
+        kw = dict(relu=relu, in_norm=norm, seed=21, offset=7)
+        w = _noise(g, D, kind, p0, p1, **kw)
+        got = ops.aggregate(g, torch.from_numpy(x).to(dev), w, seg_len=48)
+        ref = oracle.agg_fwd(og, x, _ospec(oracle, g, D, kind, p0, p1, **kw))
+        assert_close(got, ref, what=f"{kind}/{mode} D={D} relu={relu} norm={norm}")
+        # the materialised weights are the weights the fused kernel used
+        wm = w.materialize()
+        got2 = ops.aggregate(g, torch.from_numpy(x).to(dev), wm)
+        assert_close(got2, ref, what=f"materialised {kind}/{mode}")
+
+
+def test_empty_and_degenerate_graphs(dev, oracle):
+    import stag_amd
+    from stag_amd import ops
+    # no edges at all
+    g = stag_amd.Graph(torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64), 5, device=dev)
+    out = ops.aggregate(g, torch.randn(5, 8, device=dev), _noise(g, 8, "normal", 1.0, 1.0))
+    assert out.shape == (5, 8) and float(out.abs().max()) == 0.0
+    # single node, self loops only
+    g = stag_amd.Graph(torch.zeros(3, dtype=torch.int64), torch.zeros(3, dtype=torch.int64), 1, device=dev)
+    x = torch.ones(1, 4, device=dev)
+    out = ops.aggregate(g, x, None)
+    assert torch.allclose(out, torch.full((1, 4), 3.0, device=dev))
+    # mean over a zero-in-degree node is 0 (DGL mean reducer)
+    g = stag_amd.Graph(torch.tensor([0, 0]), torch.tensor([1, 1]), 3, device=dev)
+    out = ops.aggregate(g, torch.ones(3, 4, device=dev), None, reduce="mean")
+    assert torch.allclose(out, torch.tensor([[0.0] * 4, [1.0] * 4, [0.0] * 4], device=dev))
+
+
+def test_seg_len_and_determinism(dev, oracle):
+    from stag_amd import ops
+    g = random_graph(500, 20000, seed=8, hub=5000, device=dev)
+    x = torch.randn(500, 128, device=dev)
+    w = _noise(g, 128, "normal", 1.0, 0.5, seed=3, offset=0)
+    a = ops.aggregate(g, x, w, seg_len=64)
+    b = ops.aggregate(g, x, w, seg_len=64)
+    assert torch.equal(a, b), "same seed, same plan => same bits"
+    for sl in (16, 1000, 0):
+        c = ops.aggregate(g, x, w, seg_len=sl)
+        assert scaled_err(c.cpu().numpy(), a.cpu().numpy()) <= TOL
+    og = oracle_graph(oracle, g)
+    ref = oracle.agg_fwd(og, x.cpu().numpy(), _ospec(oracle, g, 128, "normal", 1.0, 0.5, seed=3, offset=0))
+    assert_close(a, ref, what="hub rows")
+
+
+def test_backward_vs_oracle(dev, oracle):
+    from stag_amd import ops
+    rng = np.random.default_rng(5)
+    n, D = 120, 20
+    g = random_graph(n, 900, seed=4, hub=130, device=dev)
+    E = g.number_of_edges()
+    og, ogt = oracle_graph(oracle, g), oracle_graph(oracle, g, transposed=True)
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    gout = rng.standard_normal((n, D)).astype(np.float32)
+    ss = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    ds = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    # fused noise: dx on the transposed graph redraws the forward noise
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    w = _noise(g, D, "normal", 1.0, 0.5, seed=2, offset=9)
+    out = ops.aggregate(g, xd, w, src_scale=torch.from_numpy(ss).to(dev), dst_scale=torch.from_numpy(ds).to(dev),
+                        seg_len=32)
+    out.backward(torch.from_numpy(gout).to(dev))
+    wm = oracle.noise_materialize(og, _ospec(oracle, g, D, "normal", 1.0, 0.5, seed=2, offset=9), D)
+    src, dst = (t.cpu().numpy() for t in g.edges())
+    ref_dx = np.zeros((n, D))
+    np.add.at(ref_dx, src, wm.astype(np.float64) * (gout * ds[:, None])[dst] * ss[src][:, None])
+    assert_close(xd.grad, ref_dx, what="dx fused")
+    # oracle statement of the same thing: aggregation over the transposed CSR with nidx
+    ref2 = oracle.agg_fwd(ogt, gout, _ospec(oracle, g, D, "normal", 1.0, 0.5, seed=2, offset=9),
+                          src_scale=ds, dst_scale=ss)
+    assert_close(xd.grad, ref2, what="dx fused vs transposed oracle")
+    # explicit weights: dx and dw
+    wt = torch.from_numpy(rng.uniform(0.5, 1.5, (E, D)).astype(np.float32)).to(dev).requires_grad_(True)
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    out = ops.aggregate(g, xd, wt, reduce="mean", src_scale=torch.from_numpy(ss).to(dev))
+    out.backward(torch.from_numpy(gout).to(dev))
+    deg = np.maximum(np.bincount(dst, minlength=n), 1)
+    gs = gout / deg[:, None]
+    ref_dw = oracle.agg_bwd_w(og, x, gs, src_scale=ss)
+    assert_close(wt.grad, ref_dw, what="dw explicit")
+    ref_dx = np.zeros((n, D))
+    np.add.at(ref_dx, src, wt.detach().cpu().numpy().astype(np.float64) * gs[dst] * ss[src][:, None])
+    assert_close(xd.grad, ref_dx, what="dx explicit")
+
+
+def test_segment_reduce(dev, oracle):
+    from stag_amd import ops
+    rng = np.random.default_rng(0)
+    sizes = np.array([3, 0, 17, 1, 40, 5])
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    x = rng.standard_normal((int(sizes.sum()), 37)).astype(np.float32)
+    for red in ("sum", "mean"):
+        got = ops.segment_reduce(torch.from_numpy(x).to(dev), torch.from_numpy(offs).to(dev), red)
+        ref = oracle.segment_reduce(x, offs, oracle.REDUCE_MEAN if red == "mean" else oracle.REDUCE_SUM)
+        assert_close(got, ref, what=f"segment {red}")
+
+
+@pytest.mark.parametrize("H,F", [(3, 4), (8, 32), (4, 5), (1, 64), (8, 64)])
+@pytest.mark.parametrize("kind", ["none", "explicit", "normal", "bernoulli"])
+def test_gat_fwd_vs_oracle(dev, oracle, H, F, kind):
+    from stag_amd import ops
+    rng = np.random.default_rng(H * 31 + F)
+    n = 150
+    g = random_graph(n, 1200, seed=H + F, hub=300, device=dev)
+    E = g.number_of_edges()
+    og = oracle_graph(oracle, g)
+    el = rng.standard_normal((n, H)).astype(np.float32)
+    er = rng.standard_normal((n, H)).astype(np.float32)
+    ft = rng.standard_normal((n, H, F)).astype(np.float32)
+    if kind == "none":
+        w, spec = None, oracle.make_spec("none")
+    elif kind == "explicit":
+        wt = rng.uniform(0.5, 1.5, (E, H)).astype(np.float32)
+        w, spec = torch.from_numpy(wt).to(dev), oracle.make_spec("explicit", wt)
+    else:
+        p0, p1 = (0.7, None) if kind == "bernoulli" else (1.0, 0.5)
+        norm = kind == "bernoulli"
+        w = _noise(g, H, kind, p0, p1, seed=17, offset=3, in_norm=norm)
+        spec = _ospec(oracle, g, H, kind, p0, p1, seed=17, offset=3, in_norm=norm)
+    out, attn = ops.gat_aggregate(g, torch.from_numpy(el).to(dev), torch.from_numpy(er).to(dev),
+                                  torch.from_numpy(ft).to(dev), 0.2, w, want_attn=True)
+    ref, ref_attn = oracle.gat_fwd(og, el, er, ft, 0.2, spec, want_attn=True)
+    assert_close(out, ref, what=f"gat out {kind} H={H} F={F}")
+    assert_close(attn, ref_attn, what=f"gat attn {kind}")
