@@ -49,30 +49,64 @@ PhiloxKey make_key(const stag_noise_spec* s) {
   return k;
 }
 
-// one thread per (long row, 4 channels): add the segment partials in segment order
+// One 256-thread block per long row: LPE chunk lanes x (256/LPE) segment slots.  Slot s
+// adds segments s, s+S, s+2S, ... (4 loads in flight), then the slots are added in slot
+// order through LDS, so the sum has ONE fixed association whatever the schedule.
+template <int LPE>
 __global__ __launch_bounds__(256) void agg_combine_kernel(const AggArgs a, int vec) {
-  const int nchunk = (a.D + 3) / 4;
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (int64_t)a.n_long * nchunk) return;
-  const int r = (int)(gid / nchunk);
-  const int k0 = (int)(gid % nchunk) * 4;
+  constexpr int SLOTS = 256 / LPE;
+  __shared__ float red[2][SLOTS][LPE][4];
+  const int r = blockIdx.x;
+  const int c = threadIdx.x % LPE, slot = threadIdx.x / LPE;
   const int v = a.long_rows[r];
   const int deg = a.indptr[v + 1] - a.indptr[v];
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  float wsum[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int s = a.long_seg_ptr[r]; s < a.long_seg_ptr[r + 1]; ++s) {
-    const float* wrow = a.ws + (int64_t)s * a.ws_stride;
-    float t[4];
-    load4(wrow, k0, a.D, vec != 0, t);
+  const int s0 = a.long_seg_ptr[r], s1 = a.long_seg_ptr[r + 1];
+  const int nchunk = (a.D + 3) / 4;
+  for (int tile = 0; tile * LPE < nchunk; ++tile) {
+    const int k0 = (tile * LPE + c) * 4;
+    const bool kin = k0 < a.D;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float wsum[4] = {0.f, 0.f, 0.f, 0.f};
+    if (kin) {
+      for (int s = s0 + slot; s < s1; s += 4 * SLOTS) {
+        float t[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] += t[j];
-    if (a.in_norm) {
-      load4(wrow + a.D, k0, a.D, vec != 0, t);
+        for (int i = 0; i < 4; ++i) {
+          const int si = s + i * SLOTS;
+          if (si < s1) load4(a.ws + (int64_t)si * a.ws_stride, k0, a.D, vec != 0, t[i]);
+          else t[i][0] = t[i][1] = t[i][2] = t[i][3] = 0.f;
+        }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wsum[j] += t[j];
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] += t[i][j];
+        if (a.in_norm) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int si = s + i * SLOTS;
+            if (si < s1) load4(a.ws + (int64_t)si * a.ws_stride + a.D, k0, a.D, vec != 0, t[i]);
+            else t[i][0] = t[i][1] = t[i][2] = t[i][3] = 0.f;
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wsum[j] += t[i][j];
+        }
+      }
+    }
+    __syncthreads();   // previous tile's readers are done with `red`
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[0][slot][c][j] = acc[j]; red[1][slot][c][j] = wsum[j]; }
+    __syncthreads();
+    if (slot == 0 && kin) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[j] = red[0][0][c][j]; wsum[j] = red[1][0][c][j]; }
+      for (int q = 1; q < SLOTS; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] += red[0][q][c][j]; wsum[j] += red[1][q][c][j]; }
+      agg_epilogue(a, v, deg, k0, vec != 0, acc, wsum);
     }
   }
-  agg_epilogue(a, v, deg, k0, vec != 0, acc, wsum);
 }
 
 // ------------------------------------------------------------------------- //
@@ -347,9 +381,12 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int
   a.long_mode = 0; a.n_units = csr->n_dst;
   if (launch(a) != hipSuccess) return STAG_EIO;
   if (use_plan) {
-    const int64_t n = (int64_t)plan->n_long * ((D + 3) / 4);
-    hipLaunchKernelGGL(agg_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a,
-                       vec ? 1 : 0);
+    const int nchunk = (D + 3) / 4;
+    const dim3 grid(plan->n_long), block(256);
+    if (nchunk > 32)      hipLaunchKernelGGL(agg_combine_kernel<64>, grid, block, 0, s, a, vec ? 1 : 0);
+    else if (nchunk > 16) hipLaunchKernelGGL(agg_combine_kernel<32>, grid, block, 0, s, a, vec ? 1 : 0);
+    else if (nchunk > 4)  hipLaunchKernelGGL(agg_combine_kernel<16>, grid, block, 0, s, a, vec ? 1 : 0);
+    else                  hipLaunchKernelGGL(agg_combine_kernel<4>, grid, block, 0, s, a, vec ? 1 : 0);
     if (hipGetLastError() != hipSuccess) return STAG_EIO;
   }
   return STAG_OK;

@@ -30,8 +30,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, const Ph
   for (int i = 0; i < 10; ++i) {
     const uint64_t p0 = (uint64_t)kPhiloxM0 * c0;
     const uint64_t p1 = (uint64_t)kPhiloxM1 * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    // one v_bitop3_b32 (truth table 0x96 = a ^ b ^ c) per output word; the key is an SGPR
+    const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+    const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
     c1 = (uint32_t)p1;
     c3 = (uint32_t)p0;
     c0 = n0;
