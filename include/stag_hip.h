@@ -106,18 +106,28 @@ typedef struct stag_noise_spec {
   int64_t pos_base; /* global CSR position of this shard's position 0 (multi-GPU) */
 } stag_noise_spec;
 
-/* Launch plan: rows longer than `seg_len` edges are cut into segments that
- * separate waves reduce; a second kernel adds the segment sums in order, so the
- * result does not depend on scheduling. Built once per graph on the host. */
+/* Launch plan, built once per graph on the host (stag_plan_count / stag_plan_fill).
+ * The aggregation kernel walks UNITS: a unit is a whole destination row, or one
+ * segment (<= seg_len edges) of a row longer than seg_len.  Units are sorted by
+ * length, longest first: lanes that share a wave then run equal trip counts and the
+ * heavy units are dispatched first.  Segment sums go to `workspace` and a second
+ * kernel adds them in segment order, so the result does not depend on scheduling. */
+typedef struct stag_unit {
+  int32_t row;   /* destination row                                              */
+  int32_t start; /* first CSR position                                           */
+  int32_t len;   /* number of edges                                              */
+  int32_t slot;  /* -1: the unit is the whole row; >= 0: segment id (workspace)  */
+} stag_unit;
+
 typedef struct stag_plan {
   int32_t seg_len;
-  int32_t n_long;              /* rows with in-degree > seg_len                */
-  int32_t n_seg;               /* segments over all long rows                  */
-  const int32_t* long_rows;    /* [n_long]   row ids                           */
-  const int32_t* long_seg_ptr; /* [n_long+1] segment range of each long row    */
-  const int32_t* seg_row;      /* [n_seg]    index into long_rows              */
-  const int32_t* seg_start;    /* [n_seg]    first CSR position of the segment */
-  float* workspace;            /* >= stag_plan_workspace_bytes()               */
+  int32_t n_units;             /* rows not split + segments                        */
+  int32_t n_long;              /* rows with in-degree > seg_len                    */
+  int32_t n_seg;               /* segments over all long rows                      */
+  const stag_unit* units;      /* [n_units], 16-byte aligned                       */
+  const int32_t* long_rows;    /* [n_long]   row ids                               */
+  const int32_t* long_seg_ptr; /* [n_long+1] segment-id range of each long row     */
+  float* workspace;            /* >= stag_plan_workspace_bytes()                   */
   size_t workspace_bytes;
 } stag_plan;
 
@@ -126,10 +136,10 @@ const char* stag_strerror(int code);
 
 /* ---- host-side planning (plain C++ on host arrays, no GPU call) ---------- */
 int stag_plan_count(const int32_t* indptr_host, int32_t n_dst, int32_t seg_len,
-                    int32_t* n_long_out, int32_t* n_seg_out);
+                    int32_t* n_units_out, int32_t* n_long_out, int32_t* n_seg_out);
 int stag_plan_fill(const int32_t* indptr_host, int32_t n_dst, int32_t seg_len,
-                   int32_t* long_rows_host, int32_t* long_seg_ptr_host,
-                   int32_t* seg_row_host, int32_t* seg_start_host);
+                   stag_unit* units_host, int32_t* long_rows_host,
+                   int32_t* long_seg_ptr_host);
 size_t stag_plan_workspace_bytes(int32_t n_seg, int32_t D, int32_t in_norm);
 
 /* ---- test hook: raw Philox words, out[n_pos][n_chunk][4] ------------------ */
@@ -146,7 +156,9 @@ int stag_philox_raw(uint64_t seed, uint64_t offset, int64_t pos0, int64_t n_pos,
  * Replaces: StagLayer.rsample_noise + relu + _in_norm (stag/layers.py:84-129)
  *           + GCN.forward's degree scaling and update_all (stag/zoo/gcn.py:67-75,
  *           94-96, 100-108) / GraphSAGE mean (stag/zoo/graph_sage.py:70-73).
- * `norm_scale_out` (may be NULL): receives s[M, D] for the backward pass.     */
+ * `norm_scale_out` (may be NULL; written only when spec.in_norm): s[M, D], kept for
+ * the backward pass.  `plan` may be NULL: one unit per row, in row order, no split.
+ * ldx == 0 gathers one broadcast row (sum of edge data, stag/layers.py:12-15).   */
 int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x,
                  int64_t ldx, int32_t D, const stag_noise_spec* spec,
                  int32_t reduce, const float* src_scale, const float* dst_scale,

@@ -34,8 +34,8 @@ class NoiseSpec(C.Structure):
 
 
 class Plan(C.Structure):
-    _fields_ = [("seg_len", C.c_int32), ("n_long", C.c_int32), ("n_seg", C.c_int32),
-                ("long_rows", _vp), ("long_seg_ptr", _vp), ("seg_row", _vp), ("seg_start", _vp),
+    _fields_ = [("seg_len", C.c_int32), ("n_units", C.c_int32), ("n_long", C.c_int32),
+                ("n_seg", C.c_int32), ("units", _vp), ("long_rows", _vp), ("long_seg_ptr", _vp),
                 ("workspace", _vp), ("workspace_bytes", C.c_size_t)]
 
 
@@ -76,8 +76,8 @@ def lib():
     l.stag_abi_version.restype = C.c_int
     l.stag_strerror.restype = C.c_char_p
     l.stag_strerror.argtypes = [C.c_int]
-    l.stag_plan_count.argtypes = [_vp, C.c_int32, C.c_int32, ip, ip]
-    l.stag_plan_fill.argtypes = [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]
+    l.stag_plan_count.argtypes = [_vp, C.c_int32, C.c_int32, ip, ip, ip]
+    l.stag_plan_fill.argtypes = [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]
     l.stag_plan_workspace_bytes.restype = C.c_size_t
     l.stag_plan_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     l.stag_philox_raw.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]

@@ -5,15 +5,23 @@
 //   update_all(u_mul_e('h','_edge_weight'), sum)      stag/zoo/gcn.py:94-96
 //   the degree scalings around it                     stag/zoo/gcn.py:67-75, 100-108
 //
-// Work decomposition (wave = 64 lanes):
-//   A "team" of LPE*EPT lanes owns one destination row (or one segment of a long
-//   row).  LPE lanes span the channel tile, 4 channels (one dwordx4, one Philox
-//   block) per lane; EPT edge slots run side by side.  For D = 128 a team is a
-//   whole wave: 32 lanes x float4 = one 512-B row per half-wave, 2 edges at once.
-//   Rows longer than plan.seg_len are cut into segments (long mode) whose partial
-//   sums go to a workspace and are added in segment order by agg_combine_kernel,
-//   so hub rows neither serialise a wave nor make the result order-dependent.
+// Work decomposition (wave = 64 lanes)
+//   The launch walks a list of UNITS (stag_plan): a unit is a whole destination row,
+//   or one segment (<= seg_len edges) of a long row.  Units are sorted by length,
+//   longest first, so (a) the teams that share a wave have equal trip counts and
+//   (b) the heavy units are dispatched first (no hub-row tail).
+//   A TEAM of LPE lanes owns one unit: lane c holds channels [4c, 4c+4) of the
+//   channel tile — one dwordx4 of the gathered row, one Philox block of noise, four
+//   accumulators.  D = 128 -> LPE = 32, two rows per wave; D = 256 -> one row per
+//   wave; D = 16 -> sixteen rows per wave.  Nothing is reduced across lanes.
+//   The kernel is VALU(RNG)-bound at D = 128, so the loop is built to add as few
+//   vector instructions as possible around draw4(): indices come in with one
+//   coalesced load per LPE edges and are handed round with ds_bpermute, rows are
+//   fetched four edges at a time, optional work hides behind wave-uniform branches.
+//   Segment partials go to a workspace; agg_combine_kernel adds them in segment
+//   order, so results do not depend on scheduling.
 #pragma once
+#include "../../include/stag_hip.h"
 #include "noise.hpp"
 
 namespace stag {
@@ -46,16 +54,13 @@ struct AggArgs {
   int64_t ldo;
   float* norm_scale_out;   // [n_rows, D] or null
   // plan
-  int32_t long_mode;   // 0: one team per row (rows > seg_len skipped); 1: one team per segment
-  int32_t seg_len;     // <= 0: no splitting
-  int32_t n_units;     // rows (short) or segments (long)
+  const stag_unit* units;  // null: unit i = row i, unsplit
+  int32_t n_units;
   const int32_t* long_rows;
   const int32_t* long_seg_ptr;
-  const int32_t* seg_row;
-  const int32_t* seg_start;
-  float* ws;           // [n_seg][ws_stride]: D partial sums, then D weight sums if in_norm
-  int32_t ws_stride;
   int32_t n_long;
+  float* ws;               // [n_seg][ws_stride]: D partial sums, then D weight sums if in_norm
+  int32_t ws_stride;
 };
 
 __device__ __forceinline__ void load4(const float* p, int k0, int D, bool vec, float (&v)[4]) {
@@ -78,60 +83,57 @@ __device__ __forceinline__ void store4(float* p, int k0, int D, bool vec, const 
   }
 }
 
-// epilogue shared by the short path and the combine kernel
+// epilogue shared by whole-row units and the combine kernel
 __device__ __forceinline__ void agg_epilogue(const AggArgs& a, int v, int deg, int k0, bool vec,
                                              float (&acc)[4], const float (&wsum)[4]) {
   float dv = a.dst_scale ? a.dst_scale[v] : 1.0f;
-  if (a.mean) dv /= (float)(deg > 1 ? deg : 1);
-  float s[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+  if (a.mean) dv *= __builtin_amdgcn_rcpf((float)(deg > 1 ? deg : 1));
   if (a.in_norm) {
     // stag/layers.py:24-28: indeg / cur where cur != 0, else 1
+    float s[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] = (wsum[j] != 0.0f) ? (float)deg / wsum[j] : 1.0f;
+    for (int j = 0; j < 4; ++j) {
+      s[j] = (wsum[j] != 0.0f) ? (float)deg / wsum[j] : 1.0f;
+      acc[j] *= s[j];
+    }
+    if (a.norm_scale_out) store4(a.norm_scale_out + (int64_t)v * a.D, k0, a.D, vec, s);
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = acc[j] * s[j] * dv;
+  for (int j = 0; j < 4; ++j) acc[j] *= dv;
   store4(a.out + (int64_t)v * a.ldo, k0, a.D, vec, acc);
-  if (a.norm_scale_out) store4(a.norm_scale_out + (int64_t)v * a.D, k0, a.D, vec, s);
 }
 
-template <int KIND, int LPE, int EPT, bool VEC, bool PEDGE>
+template <int KIND, int LPE, bool VEC, bool PEDGE>
 __global__ __launch_bounds__(256) void agg_kernel(const AggArgs a) {
-  constexpr int TEAM = LPE * EPT;
-  constexpr int TEAMS_PER_BLOCK = 256 / TEAM;
-  static_assert(TEAM <= 64 && (64 % TEAM) == 0, "a team must not straddle waves");
-  constexpr int UNROLL = 4;
+  constexpr int TEAMS_PER_BLOCK = 256 / LPE;
+  constexpr int BLK = 4;   // edges whose rows are in flight together
 
-  const int t = threadIdx.x % TEAM;
-  const int c = t % LPE;    // chunk lane inside the channel tile
-  const int ep = t / LPE;   // edge slot
-  const int unit = blockIdx.x * TEAMS_PER_BLOCK + threadIdx.x / TEAM;
+  const int lane = threadIdx.x & 63;
+  const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
+  const int team_lane0 = lane - c;                // first lane of this team inside the wave
+  const int unit = blockIdx.x * TEAMS_PER_BLOCK + threadIdx.x / LPE;
   const uint32_t chunk = blockIdx.y * LPE + c;
   const int k0 = (int)chunk * 4;
-  const bool active = (unit < a.n_units) && (k0 < a.D);
+  const bool has_unit = unit < a.n_units;
+  const bool active = has_unit && (k0 < a.D);
 
-  int v = 0, b = 0, e = 0, row_deg = 0;
-  if (unit < a.n_units) {
-    if (a.long_mode) {
-      v = a.long_rows[a.seg_row[unit]];
-      b = a.seg_start[unit];
-      const int row_end = a.indptr[v + 1];
-      e = min(b + a.seg_len, row_end);
+  int v = 0, b = 0, len = 0, slot = -1;
+  if (has_unit) {
+    if (a.units) {
+      const int4 q = *reinterpret_cast<const int4*>(a.units + unit);
+      v = q.x; b = q.y; len = q.z; slot = q.w;
     } else {
       v = unit;
       b = a.indptr[v];
-      e = a.indptr[v + 1];
-      row_deg = e - b;
-      if (a.seg_len > 0 && row_deg > a.seg_len) e = b;   // long row: long mode owns it
+      len = a.indptr[v + 1] - b;
     }
   }
-  const bool skip_store = (!a.long_mode) && (a.seg_len > 0) && (row_deg > a.seg_len);
 
   // distribution parameters of this lane's 4 channels
   float pa[4] = {a.p0s, a.p0s, a.p0s, a.p0s};
   float pb[4] = {a.p1s, a.p1s, a.p1s, a.p1s};
   if constexpr (KIND >= kNormal) {
-    if (a.pmode == 1 && active) {   // per-channel
+    if (a.pmode == STAG_PARAM_PER_CHANNEL && active) {
       load4(a.p0, k0, a.D, VEC, pa);
       if (a.p1) load4(a.p1, k0, a.D, VEC, pb);
     }
@@ -139,81 +141,89 @@ __global__ __launch_bounds__(256) void agg_kernel(const AggArgs a) {
 
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   float wsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool want_ss = a.src_scale != nullptr;
+  const bool want_wsum = a.in_norm != 0;
 
-  if (active) {
-    for (int p0 = b + ep; p0 < e; p0 += UNROLL * EPT) {
-      int u[UNROLL];
-      float xs[UNROLL];
-      float xv[UNROLL][4];
+  // Edges are consumed LPE at a time: lane c fetches the column id (and, if asked for,
+  // the edge id) of edge i0 + c with one coalesced load; ds_bpermute then hands edge
+  // i0 + j to every lane of the team.
+  for (int i0 = 0; i0 < len; i0 += LPE) {
+    const int nb = min(LPE, len - i0);
+    int my_u = 0, my_e = 0;
+    if (c < nb) {
+      const int p = b + i0 + c;
+      my_u = a.indices[p];
+      if constexpr (KIND == kExplicit || PEDGE) my_e = a.eid ? a.eid[p] : p;
+      else if constexpr (KIND >= kNormal) my_e = a.nidx ? a.nidx[p] : 0;
+    }
+    for (int j0 = 0; j0 < nb; j0 += BLK) {
+      int u[BLK], ee[BLK];
+      float xv[BLK][4], xs[BLK];
 #pragma unroll
-      for (int i = 0; i < UNROLL; ++i) {
-        const int p = p0 + i * EPT;
-        u[i] = (p < e) ? a.indices[p] : -1;
+      for (int j = 0; j < BLK; ++j) {
+        const int src_lane = (team_lane0 + j0 + j) << 2;
+        u[j] = __builtin_amdgcn_ds_bpermute(src_lane, my_u);
+        if constexpr (KIND != kNone) ee[j] = __builtin_amdgcn_ds_bpermute(src_lane, my_e);
       }
 #pragma unroll
-      for (int i = 0; i < UNROLL; ++i) {
-        if (u[i] >= 0) {
-          load4(a.x + (int64_t)u[i] * a.ldx, k0, a.D, VEC, xv[i]);
-          xs[i] = a.src_scale ? a.src_scale[u[i]] : 1.0f;
+      for (int j = 0; j < BLK; ++j) {
+        if (j0 + j < nb && active) {
+          load4(a.x + (int64_t)u[j] * a.ldx, k0, a.D, VEC, xv[j]);
+          if (want_ss) xs[j] = a.src_scale[u[j]];
         }
       }
 #pragma unroll
-      for (int i = 0; i < UNROLL; ++i) {
-        if (u[i] >= 0) {
-          const int p = p0 + i * EPT;
+      for (int j = 0; j < BLK; ++j) {
+        if (j0 + j < nb && active) {
+          const int p = b + i0 + j0 + j;
           float w[4];
           if constexpr (KIND == kNone) {
             w[0] = w[1] = w[2] = w[3] = 1.0f;
           } else if constexpr (KIND == kExplicit) {
-            const int64_t ed = a.eid ? a.eid[p] : p;
-            load4(a.p0 + ed * (int64_t)a.D, k0, a.D, VEC, w);
+            load4(a.p0 + (int64_t)ee[j] * a.D, k0, a.D, VEC, w);
             if (a.relu) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) w[j] = fmaxf(w[j], 0.0f);
+              for (int q = 0; q < 4; ++q) w[q] = fmaxf(w[q], 0.0f);
             }
           } else {
             if constexpr (PEDGE) {
-              const int64_t ed = a.eid ? a.eid[p] : p;
-              if (a.pmode == 2) {
-                const float q0 = a.p0[ed];
-                const float q1 = a.p1 ? a.p1[ed] : 0.0f;
+              if (a.pmode == STAG_PARAM_PER_EDGE1) {
+                const float q0 = a.p0[ee[j]];
+                const float q1 = a.p1 ? a.p1[ee[j]] : 0.0f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { pa[j] = q0; pb[j] = q1; }
+                for (int q = 0; q < 4; ++q) { pa[q] = q0; pb[q] = q1; }
               } else {
-                load4(a.p0 + ed * (int64_t)a.D, k0, a.D, VEC, pa);
-                if (a.p1) load4(a.p1 + ed * (int64_t)a.D, k0, a.D, VEC, pb);
+                load4(a.p0 + (int64_t)ee[j] * a.D, k0, a.D, VEC, pa);
+                if (a.p1) load4(a.p1 + (int64_t)ee[j] * a.D, k0, a.D, VEC, pb);
               }
             }
-            const int64_t gpos = a.nidx ? (int64_t)a.nidx[p] : a.pos_base + p;
+            int64_t gpos;
+            if constexpr (PEDGE) gpos = a.nidx ? (int64_t)a.nidx[p] : a.pos_base + p;
+            else gpos = a.nidx ? (int64_t)ee[j] : a.pos_base + p;
             draw4<KIND>(gpos, chunk, a.key, pa, pb, a.relu != 0, w);
           }
+          if (want_ss) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc[j] = __builtin_fmaf(w[j], xv[i][j] * xs[i], acc[j]);
-            wsum[j] += w[j];
+            for (int q = 0; q < 4; ++q) xv[j][q] *= xs[j];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = __builtin_fmaf(w[q], xv[j][q], acc[q]);
+          if (want_wsum) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wsum[q] += w[q];
           }
         }
       }
     }
   }
 
-  // add the EPT edge slots of the team (fixed order => deterministic)
-#pragma unroll
-  for (int m = LPE; m < TEAM; m <<= 1) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      acc[j] += __shfl_xor(acc[j], m);
-      wsum[j] += __shfl_xor(wsum[j], m);
-    }
-  }
-
-  if (!active || ep != 0) return;
-  if (a.long_mode) {
-    float* wrow = a.ws + (int64_t)unit * a.ws_stride;
+  if (!active) return;
+  if (slot >= 0) {
+    float* wrow = a.ws + (int64_t)slot * a.ws_stride;
     store4(wrow, k0, a.D, VEC, acc);
-    if (a.in_norm) store4(wrow + a.D, k0, a.D, VEC, wsum);
-  } else if (!skip_store) {
-    agg_epilogue(a, v, row_deg, k0, VEC, acc, wsum);
+    if (want_wsum) store4(wrow + a.D, k0, a.D, VEC, wsum);
+  } else {
+    agg_epilogue(a, v, len, k0, VEC, acc, wsum);
   }
 }
 
@@ -222,38 +232,38 @@ __global__ __launch_bounds__(256) void agg_kernel(const AggArgs a) {
 template <int KIND>
 hipError_t agg_launch(const AggArgs& a, bool vec, hipStream_t stream);
 
-template <int KIND, int LPE, int EPT>
-inline void agg_launch_shape(const AggArgs& a, bool vec, bool pedge, dim3 tiles, hipStream_t s) {
-  constexpr int TPB = 256 / (LPE * EPT);
-  dim3 grid((a.n_units + TPB - 1) / TPB, tiles.y);
+template <int KIND, int LPE>
+inline void agg_launch_shape(const AggArgs& a, bool vec, bool pedge, int tiles, hipStream_t s) {
+  constexpr int TPB = 256 / LPE;
+  dim3 grid((a.n_units + TPB - 1) / TPB, tiles);
   if (grid.x == 0) return;
   if constexpr (KIND >= kNormal) {
     if (pedge) {
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, EPT, true, true>), grid, dim3(256), 0, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, EPT, false, true>), grid, dim3(256), 0, s, a);
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, true>), grid, dim3(256), 0, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, true>), grid, dim3(256), 0, s, a);
       return;
     }
   }
-  if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, EPT, true, false>), grid, dim3(256), 0, s, a);
-  else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, EPT, false, false>), grid, dim3(256), 0, s, a);
+  if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, false>), grid, dim3(256), 0, s, a);
+  else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, false>), grid, dim3(256), 0, s, a);
 }
 
 template <int KIND>
 inline hipError_t agg_launch_impl(const AggArgs& a, bool vec, hipStream_t s) {
   const int nchunk = (a.D + 3) / 4;
-  const bool pedge = (KIND >= kNormal) && (a.pmode >= 2);
-  // lanes per edge: smallest power of two covering the row, capped at a wave
+  const bool pedge = (KIND >= kNormal) && (a.pmode >= STAG_PARAM_PER_EDGE1);
+  // lanes per unit: smallest power of two covering the row, capped at a wave
   int lpe = 1;
   while (lpe < nchunk && lpe < 64) lpe <<= 1;
-  dim3 tiles(1, (nchunk + lpe - 1) / lpe);
+  const int tiles = (nchunk + lpe - 1) / lpe;
   switch (lpe) {
-    case 64: agg_launch_shape<KIND, 64, 1>(a, vec, pedge, tiles, s); break;
-    case 32: agg_launch_shape<KIND, 32, 2>(a, vec, pedge, tiles, s); break;
-    case 16: agg_launch_shape<KIND, 16, 4>(a, vec, pedge, tiles, s); break;
-    case 8:  agg_launch_shape<KIND, 8, 4>(a, vec, pedge, tiles, s); break;
-    case 4:  agg_launch_shape<KIND, 4, 4>(a, vec, pedge, tiles, s); break;
-    case 2:  agg_launch_shape<KIND, 2, 8>(a, vec, pedge, tiles, s); break;
-    default: agg_launch_shape<KIND, 1, 16>(a, vec, pedge, tiles, s); break;
+    case 64: agg_launch_shape<KIND, 64>(a, vec, pedge, tiles, s); break;
+    case 32: agg_launch_shape<KIND, 32>(a, vec, pedge, tiles, s); break;
+    case 16: agg_launch_shape<KIND, 16>(a, vec, pedge, tiles, s); break;
+    case 8:  agg_launch_shape<KIND, 8>(a, vec, pedge, tiles, s); break;
+    case 4:  agg_launch_shape<KIND, 4>(a, vec, pedge, tiles, s); break;
+    case 2:  agg_launch_shape<KIND, 2>(a, vec, pedge, tiles, s); break;
+    default: agg_launch_shape<KIND, 1>(a, vec, pedge, tiles, s); break;
   }
   return hipGetLastError();
 }

@@ -3,6 +3,7 @@
 // readout, raw Philox test hook).  The hot kernel lives in agg_kernel.hpp.
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "../../include/stag_hip.h"
 #include "agg_kernel.hpp"
@@ -264,34 +265,57 @@ const char* stag_strerror(int code) {
 }
 
 int stag_plan_count(const int32_t* indptr_host, int32_t n_dst, int32_t seg_len,
-                    int32_t* n_long_out, int32_t* n_seg_out) {
-  if (!indptr_host || n_dst < 0 || seg_len <= 0 || !n_long_out || !n_seg_out) return STAG_EINVAL;
+                    int32_t* n_units_out, int32_t* n_long_out, int32_t* n_seg_out) {
+  if (!indptr_host || n_dst < 0 || seg_len <= 0 || seg_len > (1 << 20) || !n_units_out || !n_long_out || !n_seg_out)
+    return STAG_EINVAL;
   int64_t nl = 0, ns = 0;
   for (int32_t v = 0; v < n_dst; ++v) {
     const int32_t deg = indptr_host[v + 1] - indptr_host[v];
     if (deg < 0) return STAG_EINVAL;
     if (deg > seg_len) { ++nl; ns += (deg + seg_len - 1) / seg_len; }
   }
-  if (ns > 0x7FFFFFFFll) return STAG_EINVAL;
+  const int64_t nu = (int64_t)n_dst - nl + ns;
+  if (nu > 0x7FFFFFFFll) return STAG_EINVAL;
+  *n_units_out = (int32_t)nu;
   *n_long_out = (int32_t)nl;
   *n_seg_out = (int32_t)ns;
   return STAG_OK;
 }
 
 int stag_plan_fill(const int32_t* indptr_host, int32_t n_dst, int32_t seg_len,
-                   int32_t* long_rows_host, int32_t* long_seg_ptr_host, int32_t* seg_row_host,
-                   int32_t* seg_start_host) {
-  if (!indptr_host || n_dst < 0 || seg_len <= 0 || !long_seg_ptr_host) return STAG_EINVAL;
+                   stag_unit* units_host, int32_t* long_rows_host, int32_t* long_seg_ptr_host) {
+  if (!indptr_host || n_dst < 0 || seg_len <= 0 || seg_len > (1 << 20) || !long_seg_ptr_host)
+    return STAG_EINVAL;
+  if (n_dst > 0 && !units_host) return STAG_EINVAL;
+  // counting sort by length, longest first (every length is in [0, seg_len])
+  std::vector<int64_t> bucket((size_t)seg_len + 2, 0);
+  int32_t n_long = 0;
+  for (int32_t v = 0; v < n_dst; ++v) {
+    const int32_t deg = indptr_host[v + 1] - indptr_host[v];
+    if (deg > seg_len) {
+      ++n_long;
+      bucket[seg_len] += deg / seg_len;
+      if (deg % seg_len) bucket[deg % seg_len] += 1;
+    } else {
+      bucket[deg] += 1;
+    }
+  }
+  if (n_long > 0 && !long_rows_host) return STAG_EINVAL;
+  std::vector<int64_t> cursor((size_t)seg_len + 1, 0);
+  int64_t run = 0;
+  for (int32_t l = seg_len; l >= 0; --l) { cursor[l] = run; run += bucket[l]; }
   int32_t r = 0, s = 0;
   long_seg_ptr_host[0] = 0;
   for (int32_t v = 0; v < n_dst; ++v) {
     const int32_t b = indptr_host[v], e = indptr_host[v + 1];
-    if (e - b <= seg_len) continue;
-    if (!long_rows_host || !seg_row_host || !seg_start_host) return STAG_EINVAL;
+    if (e - b <= seg_len) {
+      units_host[cursor[e - b]++] = stag_unit{v, b, e - b, -1};
+      continue;
+    }
     long_rows_host[r] = v;
     for (int32_t p = b; p < e; p += seg_len) {
-      seg_row_host[s] = r;
-      seg_start_host[s] = p;
+      const int32_t l = (e - p < seg_len) ? (e - p) : seg_len;
+      units_host[cursor[l]++] = stag_unit{v, p, l, s};
       ++s;
     }
     long_seg_ptr_host[++r] = s;
@@ -340,19 +364,22 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int
   a.src_scale = src_scale; a.dst_scale = dst_scale; a.mean = (reduce == STAG_REDUCE_MEAN);
   a.out = out; a.ldo = ldo; a.norm_scale_out = norm_scale_out;
 
-  const bool use_plan = plan && plan->seg_len > 0 && plan->n_seg > 0;
+  const bool use_plan = plan && plan->n_units > 0;
+  const bool has_segs = use_plan && plan->n_seg > 0;
+  a.n_units = csr->n_dst;
   if (use_plan) {
-    if (!plan->long_rows || !plan->long_seg_ptr || !plan->seg_row || !plan->seg_start ||
-        !plan->workspace)
-      return STAG_EINVAL;
+    if (!plan->units || !aligned16(plan->units)) return STAG_EINVAL;
+    a.units = static_cast<const stag_unit*>(plan->units);
+    a.n_units = plan->n_units;
+  }
+  if (has_segs) {
+    if (!plan->long_rows || !plan->long_seg_ptr || !plan->workspace) return STAG_EINVAL;
     if (plan->workspace_bytes < stag_plan_workspace_bytes(plan->n_seg, D, spec->in_norm))
       return STAG_ENOMEM;
     a.long_rows = plan->long_rows; a.long_seg_ptr = plan->long_seg_ptr;
-    a.seg_row = plan->seg_row; a.seg_start = plan->seg_start;
     a.ws = plan->workspace; a.ws_stride = D * (spec->in_norm ? 2 : 1);
     a.n_long = plan->n_long;
   }
-  a.seg_len = (plan && plan->seg_len > 0) ? plan->seg_len : 0;
 
   // dwordx4 path needs 16-B aligned rows everywhere a float4 is formed
   bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) && aligned16(out);
@@ -361,7 +388,7 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int
   if (spec->kind >= STAG_NOISE_NORMAL && spec->param_mode != STAG_PARAM_SCALAR &&
       spec->param_mode != STAG_PARAM_PER_EDGE1)
     vec = vec && aligned16(spec->p0) && (!spec->p1 || aligned16(spec->p1));
-  if (use_plan) vec = vec && aligned16(plan->workspace);
+  if (has_segs) vec = vec && aligned16(plan->workspace);
 
   hipStream_t s = (hipStream_t)stream;
   auto launch = [&](const AggArgs& args) -> hipError_t {
@@ -373,14 +400,8 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int
       default: return agg_launch<kBernoulli>(args, vec, s);
     }
   };
-  if (use_plan) {   // heavy segments first, then the many short rows, then the fix-up
-    AggArgs l = a;
-    l.long_mode = 1; l.n_units = plan->n_seg;
-    if (launch(l) != hipSuccess) return STAG_EIO;
-  }
-  a.long_mode = 0; a.n_units = csr->n_dst;
   if (launch(a) != hipSuccess) return STAG_EIO;
-  if (use_plan) {
+  if (has_segs) {
     const int nchunk = (D + 3) / 4;
     const dim3 grid(plan->n_long), block(256);
     if (nchunk > 32)      hipLaunchKernelGGL(agg_combine_kernel<64>, grid, block, 0, s, a, vec ? 1 : 0);

@@ -47,31 +47,29 @@ class CsrView:
         return self._degrees
 
     def plan(self, seg_len=DEFAULT_SEG_LEN):
-        """Host-side split of long rows (stag_plan_count / stag_plan_fill), uploaded once."""
+        """Launch plan (stag_plan_count / stag_plan_fill on the host, uploaded once): units
+        sorted by length, long rows cut into segments of seg_len edges."""
         if seg_len is None or seg_len <= 0:
             return None
         if seg_len not in self._plans:
             lib = _lib.lib()
             indptr_h = np.ascontiguousarray(self.indptr.detach().cpu().numpy(), dtype=np.int32)
-            nl, ns = C.c_int32(0), C.c_int32(0)
-            _lib.check(lib.stag_plan_count(indptr_h.ctypes.data, self.n_dst, seg_len,
+            nu, nl, ns = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+            _lib.check(lib.stag_plan_count(indptr_h.ctypes.data, self.n_dst, seg_len, C.byref(nu),
                                            C.byref(nl), C.byref(ns)), "stag_plan_count")
-            nl, ns = nl.value, ns.value
+            nu, nl, ns = nu.value, nl.value, ns.value
+            units = np.zeros((max(nu, 1), 4), np.int32)
             long_rows = np.zeros(max(nl, 1), np.int32)
             long_seg_ptr = np.zeros(nl + 1, np.int32)
-            seg_row = np.zeros(max(ns, 1), np.int32)
-            seg_start = np.zeros(max(ns, 1), np.int32)
             _lib.check(lib.stag_plan_fill(indptr_h.ctypes.data, self.n_dst, seg_len,
-                                          long_rows.ctypes.data, long_seg_ptr.ctypes.data,
-                                          seg_row.ctypes.data, seg_start.ctypes.data),
-                       "stag_plan_fill")
+                                          units.ctypes.data, long_rows.ctypes.data,
+                                          long_seg_ptr.ctypes.data), "stag_plan_fill")
             dev = self.indptr.device
             self._plans[seg_len] = dict(
-                seg_len=seg_len, n_long=nl, n_seg=ns,
+                seg_len=seg_len, n_units=nu, n_long=nl, n_seg=ns,
+                units=torch.from_numpy(units).to(dev),
                 long_rows=torch.from_numpy(long_rows).to(dev),
-                long_seg_ptr=torch.from_numpy(long_seg_ptr).to(dev),
-                seg_row=torch.from_numpy(seg_row).to(dev),
-                seg_start=torch.from_numpy(seg_start).to(dev))
+                long_seg_ptr=torch.from_numpy(long_seg_ptr).to(dev))
         return self._plans[seg_len]
 
 

@@ -48,13 +48,13 @@ def _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len, want_norm_
     plan_t = csrv.plan(seg_len)
     plan_c = None
     ws = None
-    if plan_t is not None and plan_t["n_seg"] > 0:
+    if plan_t is not None:
         nbytes = _lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], D, int(spec.in_norm))
-        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-        plan_c = _lib.Plan(plan_t["seg_len"], plan_t["n_long"], plan_t["n_seg"],
-                           _lib.ptr(plan_t["long_rows"]), _lib.ptr(plan_t["long_seg_ptr"]),
-                           _lib.ptr(plan_t["seg_row"]), _lib.ptr(plan_t["seg_start"]),
-                           _lib.ptr(ws), nbytes)
+        if nbytes:
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        plan_c = _lib.Plan(plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"],
+                           _lib.ptr(plan_t["units"]), _lib.ptr(plan_t["long_rows"]),
+                           _lib.ptr(plan_t["long_seg_ptr"]), _lib.ptr(ws), nbytes)
     cs = csrv.struct()
     with torch.cuda.device(dev):
         rc = _lib.lib().stag_agg_fwd(

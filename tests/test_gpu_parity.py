@@ -184,9 +184,11 @@ def test_seg_len_and_determinism(dev, oracle):
     a = ops.aggregate(g, x, w, seg_len=64)
     b = ops.aggregate(g, x, w, seg_len=64)
     assert torch.equal(a, b), "same seed, same plan => same bits"
-    for sl in (16, 1000, 0):
+    # other segmentations are the same sum in another fp32 association: the 5000-edge hub
+    # row drifts ~1e-5 when summed in runs of 1000+ (why the default plan cuts at 64)
+    for sl in (16, 256, 1000, 0):
         c = ops.aggregate(g, x, w, seg_len=sl)
-        assert scaled_err(c.cpu().numpy(), a.cpu().numpy()) <= TOL
+        assert scaled_err(c.cpu().numpy(), a.cpu().numpy()) <= 3 * TOL
     og = oracle_graph(oracle, g)
     ref = oracle.agg_fwd(og, x.cpu().numpy(), _ospec(oracle, g, 128, "normal", 1.0, 0.5, seed=3, offset=0))
     assert_close(a, ref, what="hub rows")
