@@ -33,10 +33,11 @@
  *       ctr  = { lo32(gpos), chunk | (hi32(gpos) << 20), lo32(offset), hi32(offset) }
  *       key  = { lo32(seed), hi32(seed) }
  *       (r0,r1,r2,r3) = philox4x32_10(ctr, key)      channel k = 4*chunk + j uses r_j
- *   UNIFORM   u_j = (r_j >> 8) * 2^-24                       w = fma(high-low, u_j, low)
+ *   f12(r) = the fp32 in [1,2) with mantissa (r & 0x7FFFFF)   (23 random bits, exact)
+ *   UNIFORM   u_j = f12(r_j) - 1 in [0,1)                    w = fma(high-low, u_j, low)
  *   BERNOULLI u_j as above                                   w = u_j < probs ? 1 : 0
- *   NORMAL    pairs (r0,r1) and (r2,r3): u1 = ((r_a >> 8) + 1) * 2^-24 in (0,1],
- *             u2 = (r_b >> 8) * 2^-24 in [0,1), rad = sqrt(-2 ln u1),
+ *   NORMAL    pairs (r0,r1) and (r2,r3): u1 = 2 - f12(r_a) in (0,1],
+ *             u2 = f12(r_b) - 1 in [0,1), rad = sqrt(-2 ln u1),
  *             z_a = rad * cos(2 pi u2), z_b = rad * sin(2 pi u2)
  *                                                            w = fma(scale, z, loc)
  *   then optional relu, then optional in-degree renormalisation.

@@ -88,15 +88,22 @@ int stag_philox_raw_cpu(uint64_t seed, uint64_t offset, int64_t pos0,
   return STAG_OK;
 }
 
-/* standard (parameter-free) draws for 4 channels: uniform u in [0,1) or normal z */
+/* standard (parameter-free) draws for 4 channels: uniform u in [0,1) or normal z.
+ * f12(r) = the float in [1,2) whose mantissa is the low 23 bits of r (include/stag_hip.h). */
+static inline float f12(uint32_t r) {
+  union { uint32_t u; float f; } v;
+  v.u = (r & 0x007FFFFFu) | 0x3F800000u;
+  return v.f;
+}
+
 static inline void std_uniform4(const uint32_t r[4], float u[4]) {
-  for (int j = 0; j < 4; ++j) u[j] = (float)(r[j] >> 8) * 0x1p-24f;
+  for (int j = 0; j < 4; ++j) u[j] = f12(r[j]) - 1.0f;
 }
 
 static inline void std_normal4(const uint32_t r[4], float z[4]) {
   for (int h = 0; h < 2; ++h) {
-    double u1 = ((double)(r[2 * h] >> 8) + 1.0) * 0x1p-24;
-    double u2 = (double)(r[2 * h + 1] >> 8) * 0x1p-24;
+    double u1 = 2.0 - (double)f12(r[2 * h]);           /* (0, 1] */
+    double u2 = (double)f12(r[2 * h + 1]) - 1.0;       /* [0, 1) */
     double rad = sqrt(-2.0 * log(u1));
     double ang = 6.283185307179586476925286766559 * u2;
     z[2 * h] = (float)(rad * cos(ang));

@@ -15,9 +15,11 @@
 //   accumulators.  D = 128 -> LPE = 32, two rows per wave; D = 256 -> one row per
 //   wave; D = 16 -> sixteen rows per wave.  Nothing is reduced across lanes.
 //   The kernel is VALU(RNG)-bound at D = 128, so the loop is built to add as few
-//   vector instructions as possible around draw4(): indices come in with one
-//   coalesced load per LPE edges and are handed round with ds_bpermute, rows are
-//   fetched four edges at a time, optional work hides behind wave-uniform branches.
+//   vector instructions as possible around draw4(): column ids are broadcast loads
+//   with immediate offsets (ds_bpermute costs ~22 cycles per wave-op here), row
+//   addresses are 32-bit offsets from a scalar base (64-bit vector adds are quarter
+//   rate), rows are fetched four edges at a time, optional work hides behind
+//   wave-uniform branches.
 //   Segment partials go to a workspace; agg_combine_kernel adds them in segment
 //   order, so results do not depend on scheduling.
 #pragma once
@@ -37,6 +39,10 @@ struct AggArgs {
   const float* x;
   int64_t ldx;
   int32_t D;
+  uint32_t ldxb;   // row stride of x in bytes (0: one broadcast row)
+  uint32_t ldwb;   // row stride in bytes of explicit weights / per-edge parameters
+  uint32_t x_bytes;   // extent of x when it fits a buffer descriptor
+  int32_t wide;    // bit 0: x, bit 1: edge data — byte offsets / ids too big for the 32-bit form
   // noise
   const float* p0;
   const float* p1;
@@ -44,7 +50,7 @@ struct AggArgs {
   int32_t pmode;   // STAG_PARAM_*
   int32_t relu, in_norm;
   PhiloxKey key;
-  int64_t pos_base;
+  uint32_t pos_lo, pos_hi;   // lo32 / hi32 of the shard's global position base
   // scaling / reduce
   const float* src_scale;
   const float* dst_scale;
@@ -103,125 +109,168 @@ __device__ __forceinline__ void agg_epilogue(const AggArgs& a, int v, int deg, i
   store4(a.out + (int64_t)v * a.ldo, k0, a.D, vec, acc);
 }
 
+// row `idx` of a row-major fp32 matrix, `koff` bytes into the row.  Narrow form: one
+// v_mul_u32_u24 and a 32-bit offset from a scalar base (global_load ... saddr), instead of
+// 64-bit vector address arithmetic, which is quarter rate on gfx950.
+__device__ __forceinline__ const float* row_at(const float* base, int idx, uint32_t stride_bytes,
+                                               uint32_t koff, bool wide) {
+  const char* b = reinterpret_cast<const char*>(base);
+  if (wide) return reinterpret_cast<const float*>(b + (uint64_t)(uint32_t)idx * stride_bytes + koff);
+  return reinterpret_cast<const float*>(b + (__umul24((uint32_t)idx, stride_bytes) + koff));
+}
+
+// Gathered row through a buffer descriptor: ONE v_mad_u32_u24 of address arithmetic and a
+// `buffer_load_dwordx4 ... offen` with a 32-bit offset (out-of-range offsets read 0).
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bufrow4(__amdgpu_buffer_rsrc_t rsrc, int idx, uint32_t stride_bytes,
+                                        uint32_t koff, float (&v)[4]) {
+  const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(
+      rsrc, (int)(__umul24((uint32_t)idx, stride_bytes) + koff), 0, 0);
+  v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y);
+  v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+}
+
+__device__ __forceinline__ void loadrow4(const float* p, int k0, int D, bool vec, float (&v)[4]) {
+  if (vec) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (k0 + j < D) ? p[j] : 0.0f;
+  }
+}
+
+constexpr int kKahanMinLen = 16;
+
 template <int KIND, int LPE, bool VEC, bool PEDGE>
 __global__ __launch_bounds__(256) void agg_kernel(const AggArgs a) {
   constexpr int TEAMS_PER_BLOCK = 256 / LPE;
   constexpr int BLK = 4;   // edges whose rows are in flight together
+  constexpr bool NEED_EID = (KIND == kExplicit) || PEDGE;
 
-  const int lane = threadIdx.x & 63;
   const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
-  const int team_lane0 = lane - c;                // first lane of this team inside the wave
   const int unit = blockIdx.x * TEAMS_PER_BLOCK + threadIdx.x / LPE;
   const uint32_t chunk = blockIdx.y * LPE + c;
   const int k0 = (int)chunk * 4;
-  const bool has_unit = unit < a.n_units;
-  const bool active = has_unit && (k0 < a.D);
+  const uint32_t koff = (uint32_t)k0 * 4u;
+  if (unit >= a.n_units || k0 >= a.D) return;   // teams never talk to each other: no barrier below
 
-  int v = 0, b = 0, len = 0, slot = -1;
-  if (has_unit) {
-    if (a.units) {
-      const int4 q = *reinterpret_cast<const int4*>(a.units + unit);
-      v = q.x; b = q.y; len = q.z; slot = q.w;
-    } else {
-      v = unit;
-      b = a.indptr[v];
-      len = a.indptr[v + 1] - b;
-    }
+  int v, b, len, slot = -1;
+  if (a.units) {
+    const int4 q = *reinterpret_cast<const int4*>(a.units + unit);
+    v = q.x; b = q.y; len = q.z; slot = q.w;
+  } else {
+    v = unit;
+    b = a.indptr[v];
+    len = a.indptr[v + 1] - b;
   }
 
   // distribution parameters of this lane's 4 channels
   float pa[4] = {a.p0s, a.p0s, a.p0s, a.p0s};
   float pb[4] = {a.p1s, a.p1s, a.p1s, a.p1s};
   if constexpr (KIND >= kNormal) {
-    if (a.pmode == STAG_PARAM_PER_CHANNEL && active) {
+    if (a.pmode == STAG_PARAM_PER_CHANNEL) {
       load4(a.p0, k0, a.D, VEC, pa);
       if (a.p1) load4(a.p1, k0, a.D, VEC, pb);
     }
   }
+  // Philox counter word 1 is a per-lane constant: chunk | hi32(position) << 20
+  const uint32_t c1 = chunk | (a.pos_hi << 20);
 
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float acc[4] = {0.f, 0.f, 0.f, 0.f}, comp[4] = {0.f, 0.f, 0.f, 0.f};
   float wsum[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool want_ss = a.src_scale != nullptr;
-  const bool want_wsum = a.in_norm != 0;
 
-  // Edges are consumed LPE at a time: lane c fetches the column id (and, if asked for,
-  // the edge id) of edge i0 + c with one coalesced load; ds_bpermute then hands edge
-  // i0 + j to every lane of the team.
-  for (int i0 = 0; i0 < len; i0 += LPE) {
-    const int nb = min(LPE, len - i0);
-    int my_u = 0, my_e = 0;
-    if (c < nb) {
-      const int p = b + i0 + c;
-      my_u = a.indices[p];
-      if constexpr (KIND == kExplicit || PEDGE) my_e = a.eid ? a.eid[p] : p;
-      else if constexpr (KIND >= kNormal) my_e = a.nidx ? a.nidx[p] : 0;
+  // descriptor of x for the narrow (< 4 GB, ids < 2^24) case; built from kernel arguments only
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  const bool x_buf = VEC && (a.wide & 1) == 0;
+
+  const int pend = b + len;
+  for (int p0 = b; p0 < pend; p0 += BLK) {
+    // every lane of the team reads the same 4 column ids: one broadcast dword each, no
+    // vector arithmetic (immediate offsets), and the row fetches below depend only on them
+    int u[BLK], ee[BLK];
+    uint32_t nn[BLK];
+#pragma unroll
+    for (int j = 0; j < BLK; ++j) {
+      const int p = p0 + j;
+      if (p < pend) {
+        u[j] = a.indices[p];
+        if constexpr (NEED_EID) ee[j] = a.eid ? a.eid[p] : p;
+        if constexpr (KIND >= kNormal) nn[j] = a.nidx ? (uint32_t)a.nidx[p] : a.pos_lo + (uint32_t)p;
+      }
     }
-    for (int j0 = 0; j0 < nb; j0 += BLK) {
-      int u[BLK], ee[BLK];
-      float xv[BLK][4], xs[BLK];
+    float xv[BLK][4], xs[BLK];
 #pragma unroll
-      for (int j = 0; j < BLK; ++j) {
-        const int src_lane = (team_lane0 + j0 + j) << 2;
-        u[j] = __builtin_amdgcn_ds_bpermute(src_lane, my_u);
-        if constexpr (KIND != kNone) ee[j] = __builtin_amdgcn_ds_bpermute(src_lane, my_e);
+    for (int j = 0; j < BLK; ++j) {
+      if (p0 + j < pend) {
+        if (x_buf) bufrow4(rx, u[j], a.ldxb, koff, xv[j]);
+        else loadrow4(row_at(a.x, u[j], a.ldxb, koff, (a.wide & 1) != 0), k0, a.D, VEC, xv[j]);
+        if (a.src_scale) xs[j] = a.src_scale[u[j]];
       }
+    }
+    // block sums: 4 edges into fresh accumulators (small magnitudes => small rounding)
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < BLK; ++j) {
-        if (j0 + j < nb && active) {
-          load4(a.x + (int64_t)u[j] * a.ldx, k0, a.D, VEC, xv[j]);
-          if (want_ss) xs[j] = a.src_scale[u[j]];
+    for (int j = 0; j < BLK; ++j) {
+      if (p0 + j < pend) {
+        float w[4];
+        if constexpr (KIND == kNone) {
+          w[0] = w[1] = w[2] = w[3] = 1.0f;
+        } else if constexpr (KIND == kExplicit) {
+          loadrow4(row_at(a.p0, ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, w);
+          if (a.relu) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = fmaxf(w[q], 0.0f);
+          }
+        } else {
+          if constexpr (PEDGE) {
+            if (a.pmode == STAG_PARAM_PER_EDGE1) {
+              const float q0 = a.p0[ee[j]];
+              const float q1 = a.p1 ? a.p1[ee[j]] : 0.0f;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { pa[q] = q0; pb[q] = q1; }
+            } else {
+              loadrow4(row_at(a.p0, ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, pa);
+              if (a.p1) loadrow4(row_at(a.p1, ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, pb);
+            }
+          }
+          draw4<KIND>(nn[j], c1, a.key, pa, pb, a.relu != 0, w);
+        }
+        if (a.src_scale) {
+          asm volatile("" ::: "memory");   // keep this a branch: as selects it costs 6 VALU ops per edge
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xv[j][q] *= xs[j];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = __builtin_fmaf(w[q], xv[j][q], t[q]);
+        if (a.in_norm) {
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int q = 0; q < 4; ++q) wsum[q] += w[q];   // 0/1 draws (Bernoulli + norm): exact
         }
       }
+    }
+    // fold the block into the unit's sum; compensated (Kahan) once a unit is long enough for
+    // the running sum to dwarf a block, so a 13k-edge hub row keeps ~1e-6 relative accuracy
+    if (len > kKahanMinLen) {
 #pragma unroll
-      for (int j = 0; j < BLK; ++j) {
-        if (j0 + j < nb && active) {
-          const int p = b + i0 + j0 + j;
-          float w[4];
-          if constexpr (KIND == kNone) {
-            w[0] = w[1] = w[2] = w[3] = 1.0f;
-          } else if constexpr (KIND == kExplicit) {
-            load4(a.p0 + (int64_t)ee[j] * a.D, k0, a.D, VEC, w);
-            if (a.relu) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) w[q] = fmaxf(w[q], 0.0f);
-            }
-          } else {
-            if constexpr (PEDGE) {
-              if (a.pmode == STAG_PARAM_PER_EDGE1) {
-                const float q0 = a.p0[ee[j]];
-                const float q1 = a.p1 ? a.p1[ee[j]] : 0.0f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { pa[q] = q0; pb[q] = q1; }
-              } else {
-                load4(a.p0 + (int64_t)ee[j] * a.D, k0, a.D, VEC, pa);
-                if (a.p1) load4(a.p1 + (int64_t)ee[j] * a.D, k0, a.D, VEC, pb);
-              }
-            }
-            int64_t gpos;
-            if constexpr (PEDGE) gpos = a.nidx ? (int64_t)a.nidx[p] : a.pos_base + p;
-            else gpos = a.nidx ? (int64_t)ee[j] : a.pos_base + p;
-            draw4<KIND>(gpos, chunk, a.key, pa, pb, a.relu != 0, w);
-          }
-          if (want_ss) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xv[j][q] *= xs[j];
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q] = __builtin_fmaf(w[q], xv[j][q], acc[q]);
-          if (want_wsum) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wsum[q] += w[q];
-          }
-        }
+      for (int q = 0; q < 4; ++q) {
+        const float y = t[q] - comp[q];
+        const float sum = acc[q] + y;
+        comp[q] = (sum - acc[q]) - y;
+        acc[q] = sum;
       }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] += t[q];
     }
   }
 
-  if (!active) return;
   if (slot >= 0) {
     float* wrow = a.ws + (int64_t)slot * a.ws_stride;
     store4(wrow, k0, a.D, VEC, acc);
-    if (want_wsum) store4(wrow + a.D, k0, a.D, VEC, wsum);
+    if (a.in_norm) store4(wrow + a.D, k0, a.D, VEC, wsum);
   } else {
     agg_epilogue(a, v, len, k0, VEC, acc, wsum);
   }

@@ -56,7 +56,7 @@ PhiloxKey make_key(const stag_noise_spec* s) {
 template <int LPE>
 __global__ __launch_bounds__(256) void agg_combine_kernel(const AggArgs a, int vec) {
   constexpr int SLOTS = 256 / LPE;
-  __shared__ float red[2][SLOTS][LPE][4];
+  __shared__ double red[2][SLOTS][LPE][4];
   const int r = blockIdx.x;
   const int c = threadIdx.x % LPE, slot = threadIdx.x / LPE;
   const int v = a.long_rows[r];
@@ -66,8 +66,9 @@ __global__ __launch_bounds__(256) void agg_combine_kernel(const AggArgs a, int v
   for (int tile = 0; tile * LPE < nchunk; ++tile) {
     const int k0 = (tile * LPE + c) * 4;
     const bool kin = k0 < a.D;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    float wsum[4] = {0.f, 0.f, 0.f, 0.f};
+    // fp64: a hub row has hundreds of partials; their sum must not cost accuracy
+    double acc[4] = {0., 0., 0., 0.};
+    double wsum[4] = {0., 0., 0., 0.};
     if (kin) {
       for (int s = s0 + slot; s < s1; s += 4 * SLOTS) {
         float t[4][4];
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void agg_combine_kernel(const AggArgs a, int v
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] += t[i][j];
+          for (int j = 0; j < 4; ++j) acc[j] += (double)t[i][j];
         if (a.in_norm) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void agg_combine_kernel(const AggArgs a, int v
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wsum[j] += t[i][j];
+            for (int j = 0; j < 4; ++j) wsum[j] += (double)t[i][j];
         }
       }
     }
@@ -100,12 +101,13 @@ __global__ __launch_bounds__(256) void agg_combine_kernel(const AggArgs a, int v
     for (int j = 0; j < 4; ++j) { red[0][slot][c][j] = acc[j]; red[1][slot][c][j] = wsum[j]; }
     __syncthreads();
     if (slot == 0 && kin) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { acc[j] = red[0][0][c][j]; wsum[j] = red[1][0][c][j]; }
       for (int q = 1; q < SLOTS; ++q)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { acc[j] += red[0][q][c][j]; wsum[j] += red[1][q][c][j]; }
-      agg_epilogue(a, v, deg, k0, vec != 0, acc, wsum);
+      float accf[4], wsumf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { accf[j] = (float)acc[j]; wsumf[j] = (float)wsum[j]; }
+      agg_epilogue(a, v, deg, k0, vec != 0, accf, wsumf);
     }
   }
 }
@@ -154,9 +156,9 @@ __device__ __forceinline__ void edge_w4(const NoiseArgs& a, int p, int64_t ed, u
   }
   const int64_t gpos = a.nidx ? (int64_t)a.nidx[p] : a.pos_base + p;
   switch (a.kind) {
-    case kNormal: draw4<kNormal>(gpos, chunk, a.key, pa, pb, a.relu != 0, w); break;
-    case kUniform: draw4<kUniform>(gpos, chunk, a.key, pa, pb, a.relu != 0, w); break;
-    case kBernoulli: draw4<kBernoulli>(gpos, chunk, a.key, pa, pb, a.relu != 0, w); break;
+    case kNormal: draw4<kNormal>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.relu != 0, w); break;
+    case kUniform: draw4<kUniform>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.relu != 0, w); break;
+    case kBernoulli: draw4<kBernoulli>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.relu != 0, w); break;
     case kExplicit:
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -357,10 +359,27 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int
   a.indptr = csr->indptr; a.indices = csr->indices; a.eid = csr->eid; a.nidx = csr->nidx;
   a.n_rows = csr->n_dst;
   a.x = x; a.ldx = ldx; a.D = D;
+  a.ldxb = (uint32_t)(ldx * 4); a.ldwb = (uint32_t)D * 4u;
+  {
+    // 32-bit byte offsets + 24-bit multiplies when everything fits, else 64-bit addressing
+    const uint64_t xbytes = (uint64_t)csr->n_src * (uint64_t)ldx * 4u;
+    const uint64_t wbytes = (uint64_t)csr->n_edges * (uint64_t)D * 4u;
+    const bool x_narrow = xbytes < (1ull << 32) && csr->n_src < (1 << 24) && (uint64_t)ldx * 4u < (1u << 24);
+    const bool w_narrow = wbytes < (1ull << 32) && csr->n_edges < (1 << 24) && (uint64_t)D * 4u < (1u << 24);
+    a.wide = (x_narrow ? 0 : 1) | (w_narrow ? 0 : 2);
+    a.x_bytes = x_narrow ? (uint32_t)(ldx == 0 ? (uint64_t)D * 4u : xbytes) : 0u;
+  }
   a.p0 = spec->p0; a.p1 = spec->p1; a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar;
   a.pmode = spec->kind >= STAG_NOISE_NORMAL ? spec->param_mode : 0;
   a.relu = spec->relu; a.in_norm = spec->in_norm;
-  a.key = make_key(spec); a.pos_base = spec->pos_base;
+  a.key = make_key(spec);
+  a.pos_lo = (uint32_t)((uint64_t)spec->pos_base & 0xFFFFFFFFull);
+  a.pos_hi = (uint32_t)((uint64_t)spec->pos_base >> 32);
+  // one launch must not straddle a 2^32 boundary of the global position space (the kernel
+  // keeps hi32 in a scalar): shards are < 2^31 edges, so split the call at the boundary
+  if (spec->kind >= STAG_NOISE_NORMAL && !csr->nidx &&
+      (uint64_t)a.pos_lo + (uint64_t)csr->n_edges > (1ull << 32))
+    return STAG_ENOSYS;
   a.src_scale = src_scale; a.dst_scale = dst_scale; a.mean = (reduce == STAG_REDUCE_MEAN);
   a.out = out; a.ldo = ldo; a.norm_scale_out = norm_scale_out;
 

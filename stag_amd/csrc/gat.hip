@@ -58,9 +58,9 @@ __device__ __forceinline__ void head_w4(const GatArgs& a, int p, int64_t ed, uin
   }
   const int64_t gpos = a.nidx ? (int64_t)a.nidx[p] : a.pos_base + p;
   switch (a.kind) {
-    case kNormal: draw4<kNormal>(gpos, chunk, a.key, pa, pb, a.relu != 0, w); break;
-    case kUniform: draw4<kUniform>(gpos, chunk, a.key, pa, pb, a.relu != 0, w); break;
-    case kBernoulli: draw4<kBernoulli>(gpos, chunk, a.key, pa, pb, a.relu != 0, w); break;
+    case kNormal: draw4<kNormal>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.relu != 0, w); break;
+    case kUniform: draw4<kUniform>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.relu != 0, w); break;
+    case kBernoulli: draw4<kBernoulli>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.relu != 0, w); break;
     case kExplicit:
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

@@ -50,31 +50,43 @@ __device__ __forceinline__ void philox_at(int64_t gpos, uint32_t chunk, const Ph
   philox4x32_10(c0, c1, key, r);
 }
 
-// u in [0,1): 24 random bits, exact in fp32.
-__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * 0x1p-24f; }
+__device__ __forceinline__ uint32_t ctr1_of(int64_t gpos, uint32_t chunk) {
+  return chunk | ((uint32_t)((uint64_t)gpos >> 32) << 20);
+}
 
-// Box-Muller on the hardware transcendentals: v_log_f32 is log2, v_sin/v_cos take
-// revolutions, so neither ln nor 2*pi costs a multiply of its own.
+// f in [1,2): the low 23 bits of r become the mantissa.  One v_and_or_b32 (1.0f is an
+// inline constant) instead of shift + int->float convert (v_cvt_f32_u32 is half rate).
+__device__ __forceinline__ float f12(uint32_t r) {
+  return __uint_as_float((r & 0x007FFFFFu) | 0x3F800000u);
+}
+
+// u in [0,1): 23 random bits, exact in fp32.
+__device__ __forceinline__ float u01(uint32_t r) { return f12(r) - 1.0f; }
+
+// Box-Muller on the hardware transcendentals: v_log_f32 is log2 and v_sin/v_cos take
+// revolutions (and are periodic in them), so neither ln, nor 2*pi, nor the "- 1" of the
+// angle costs an instruction: u1 = 2 - f12(ra) in (0,1], angle = f12(rb) revolutions.
 __device__ __forceinline__ void box_muller(uint32_t ra, uint32_t rb, float& za, float& zb) {
-  const float u1 = (float)((ra >> 8) + 1u) * 0x1p-24f;   // (0, 1]
-  const float u2 = (float)(rb >> 8) * 0x1p-24f;          // [0, 1)
+  const float u1 = 2.0f - f12(ra);
+  const float th = f12(rb);
   // -2 ln(u1) = (-2 ln 2) * log2(u1)
   const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
-  za = rad * __builtin_amdgcn_cosf(u2);
-  zb = rad * __builtin_amdgcn_sinf(u2);
+  za = rad * __builtin_amdgcn_cosf(th);
+  zb = rad * __builtin_amdgcn_sinf(th);
 }
 
 enum : int { kNone = 0, kExplicit = 1, kNormal = 2, kUniform = 3, kBernoulli = 4 };
 
 // The 4 draws of one (edge, chunk): a[j], b[j] are the two distribution parameters
 // of channel 4*chunk + j (loc/scale, low/high, probs/-).
+// (c0, c1) = Philox counter words 0 and 1: lo32(position), chunk | hi32(position) << 20.
 template <int KIND>
-__device__ __forceinline__ void draw4(int64_t gpos, uint32_t chunk, const PhiloxKey& key,
+__device__ __forceinline__ void draw4(uint32_t c0, uint32_t c1, const PhiloxKey& key,
                                       const float (&a)[4], const float (&b)[4], bool relu,
                                       float (&w)[4]) {
   static_assert(KIND >= kNormal, "draw4 is for sampled noise");
   uint32_t r[4];
-  philox_at(gpos, chunk, key, r);
+  philox4x32_10(c0, c1, key, r);
   if constexpr (KIND == kNormal) {
     float z[4];
     box_muller(r[0], r[1], z[0], z[1]);

@@ -58,6 +58,27 @@ __global__ __launch_bounds__(256) void probe(uint32_t* out, uint32_t seed) {
       a0 += 1;
     } else if constexpr (OP == 10) {  // v_sqrt_f32
       f0 = __builtin_amdgcn_sqrtf(f0) + 1.f; f1 = __builtin_amdgcn_sqrtf(f1) + 1.f; f2 = __builtin_amdgcn_sqrtf(f2) + 1.f; f3 = __builtin_amdgcn_sqrtf(f3) + 1.f;
+    } else if constexpr (OP == 12) {  // v_cvt_f32_u32
+      f0 = (float)a0; a0 = __float_as_uint(f0) + 3u; f1 = (float)a1; a1 = __float_as_uint(f1) + 3u;
+      f2 = (float)a2; a2 = __float_as_uint(f2) + 3u; f3 = (float)a3; a3 = __float_as_uint(f3) + 3u;
+    } else if constexpr (OP == 13) {  // v_pk_fma_f32
+      typedef float f2_t __attribute__((ext_vector_type(2)));
+      f2_t x = {f0, f1}, y = {f2, f3}, k = {1.0001f, 0.9999f};
+      x = __builtin_elementwise_fma(x, k, y); y = __builtin_elementwise_fma(y, k, x);
+      x = __builtin_elementwise_fma(x, k, y); y = __builtin_elementwise_fma(y, k, x);
+      f0 = x.x; f1 = x.y; f2 = y.x; f3 = y.y;
+    } else if constexpr (OP == 14) {  // v_bitop3_b32
+      a0 = __builtin_amdgcn_bitop3_b32(a0, a1, a2, 0x96); a1 = __builtin_amdgcn_bitop3_b32(a1, a2, a3, 0x96);
+      a2 = __builtin_amdgcn_bitop3_b32(a2, a3, a0, 0x96); a3 = __builtin_amdgcn_bitop3_b32(a3, a0, a1, 0x96);
+    } else if constexpr (OP == 15) {  // v_lshl_add_u64
+      q0 = (q0 << 2) + q1; q1 = (q1 << 2) + q2; q2 = (q2 << 2) + q3; q3 = (q3 << 2) + q0;
+    } else if constexpr (OP == 16) {  // ds_bpermute_b32
+      a0 = __builtin_amdgcn_ds_bpermute(a1 & 252, a0); a1 = __builtin_amdgcn_ds_bpermute(a2 & 252, a1);
+      a2 = __builtin_amdgcn_ds_bpermute(a3 & 252, a2); a3 = __builtin_amdgcn_ds_bpermute(a0 & 252, a3);
+    } else if constexpr (OP == 17) {  // v_cndmask_b32 (vcc from v_cmp)
+      a0 = (a1 > a2) ? a0 + 1 : a3; a1 = (a2 > a3) ? a1 + 1 : a0; a2 = (a3 > a0) ? a2 + 1 : a1; a3 = (a0 > a1) ? a3 + 1 : a2;
+    } else if constexpr (OP == 18) {  // v_mul_lo_u32 (variable operands)
+      a0 = a0 * a1 + 1u; a1 = a1 * a2 + 1u; a2 = a2 * a3 + 1u; a3 = a3 * a0 + 1u;
     } else if constexpr (OP == 11) {  // v_mul_u32_u24 pair
       a0 = __umul24(a0, a1) + 1; a1 = __umul24(a1, a2) + 1;
       a2 = __umul24(a2, a3) + 1; a3 = __umul24(a3, a0) + 1;
@@ -108,6 +129,13 @@ int main() {
   run<3>("v_log_f32(+fma)", 4, d);
   run<4>("v_sin_f32", 4, d);
   run<10>("v_sqrt_f32(+add)", 4, d);
+  run<12>("v_cvt_f32_u32(+add)", 4, d);
+  run<13>("v_pk_fma_f32", 4, d);
+  run<14>("v_bitop3_b32", 4, d);
+  run<15>("v_lshl_add_u64", 4, d);
+  run<16>("ds_bpermute_b32(+and)", 4, d);
+  run<17>("cmp+add+cndmask", 4, d);
+  run<18>("v_mul_lo_u32(+add)", 4, d);
   run<7>("philox4x32_10 block", 1, d);
   run<8>("philox + 4 normals", 1, d);
   run<9>("philox + 4 uniforms", 1, d);
