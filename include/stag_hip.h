@@ -111,10 +111,11 @@ typedef struct stag_noise_spec {
  * The aggregation kernel walks UNITS: a unit is a whole destination row, or one
  * segment (<= seg_len edges) of a row longer than seg_len.  Units are sorted by
  * length, longest first: lanes that share a wave then run equal trip counts and the
- * heavy units are dispatched first.  Segment sums go to `workspace` and a second
- * kernel adds them in segment order, so the result does not depend on scheduling. */
+ * heavy units are dispatched first.  Segment sums go to `workspace`; the segment that
+ * finishes last (an arrival counter per long row) adds them in segment order, in the
+ * same launch, so the result does not depend on scheduling. */
 typedef struct stag_unit {
-  int32_t row;   /* destination row                                              */
+  int32_t row;   /* slot < 0: destination row; slot >= 0: index into long_rows    */
   int32_t start; /* first CSR position                                           */
   int32_t len;   /* number of edges                                              */
   int32_t slot;  /* -1: the unit is the whole row; >= 0: segment id (workspace)  */
@@ -126,9 +127,12 @@ typedef struct stag_plan {
   int32_t n_long;              /* rows with in-degree > seg_len                    */
   int32_t n_seg;               /* segments over all long rows                      */
   const stag_unit* units;      /* [n_units], 16-byte aligned                       */
-  const int32_t* long_rows;    /* [n_long]   row ids                               */
+  const int32_t* long_rows;    /* [n_long]   row ids, largest in-degree first      */
   const int32_t* long_seg_ptr; /* [n_long+1] segment-id range of each long row     */
-  float* workspace;            /* >= stag_plan_workspace_bytes()                   */
+  int32_t* seg_counters;       /* [n_long * ceil(D / 256)] arrival counters: ZERO on
+                                  entry, left zero by every completed call         */
+  float* workspace;            /* >= stag_plan_workspace_bytes(); one call at a
+                                  time may use a plan's workspace and counters     */
   size_t workspace_bytes;
 } stag_plan;
 

@@ -75,6 +75,12 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    """Number of OpenMP threads the oracle uses (libgomp's omp_set_num_threads)."""
+    gomp = C.CDLL("libgomp.so.1")
+    gomp.omp_set_num_threads(int(n))
+
+
 def _f32(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
 

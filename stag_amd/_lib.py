@@ -36,7 +36,7 @@ class NoiseSpec(C.Structure):
 class Plan(C.Structure):
     _fields_ = [("seg_len", C.c_int32), ("n_units", C.c_int32), ("n_long", C.c_int32),
                 ("n_seg", C.c_int32), ("units", _vp), ("long_rows", _vp), ("long_seg_ptr", _vp),
-                ("workspace", _vp), ("workspace_bytes", C.c_size_t)]
+                ("seg_counters", _vp), ("workspace", _vp), ("workspace_bytes", C.c_size_t)]
 
 
 class StagHipError(RuntimeError):

@@ -20,8 +20,10 @@
 //   addresses are 32-bit offsets from a scalar base (64-bit vector adds are quarter
 //   rate), rows are fetched four edges at a time, optional work hides behind
 //   wave-uniform branches.
-//   Segment partials go to a workspace; agg_combine_kernel adds them in segment
-//   order, so results do not depend on scheduling.
+//   Segment partials go to a workspace; the segment of a row that finishes LAST
+//   (agent-scope release / counter / acquire, cdna_hip_programming.md Guideline 16) adds
+//   them in segment order in fp64, so results do not depend on scheduling and there is
+//   no second launch.
 #pragma once
 #include "../../include/stag_hip.h"
 #include "noise.hpp"
@@ -65,8 +67,10 @@ struct AggArgs {
   const int32_t* long_rows;
   const int32_t* long_seg_ptr;
   int32_t n_long;
+  int32_t* seg_counters;   // [n_long] arrival counters, zero between launches
   float* ws;               // [n_seg][ws_stride]: D partial sums, then D weight sums if in_norm
   int32_t ws_stride;
+  uint32_t ws_bytes;
 };
 
 __device__ __forceinline__ void load4(const float* p, int k0, int D, bool vec, float (&v)[4]) {
@@ -89,7 +93,49 @@ __device__ __forceinline__ void store4(float* p, int k0, int D, bool vec, const 
   }
 }
 
-// epilogue shared by whole-row units and the combine kernel
+// write-through (sc1) store of 4 channels through a buffer descriptor: aux = 16
+__device__ __forceinline__ void store4_sc1(__amdgpu_buffer_rsrc_t rsrc, uint32_t off, int k0, int D,
+                                           bool vec, const float (&v)[4]) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  if (vec) {
+    const u32x4 t = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                     __float_as_uint(v[3])};
+    __builtin_amdgcn_raw_buffer_store_b128(t, rsrc, (int)off, 0, 16);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k0 + j < D)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j]), rsrc, (int)(off + 4u * j), 0, 16);
+  }
+}
+
+// sum[q] = sum over segments s0..s1-1 of ws[s][k0+q], in segment order, Kahan-compensated
+template <int NF, bool VEC>
+__device__ __forceinline__ void kahan_sum_partials(const float* ws, int ws_stride, int s0, int s1,
+                                                   int k0, int D, float (&sum)[4]) {
+  float comp[4] = {0.f, 0.f, 0.f, 0.f};
+  sum[0] = sum[1] = sum[2] = sum[3] = 0.f;
+#pragma unroll 1
+  for (int s = s0; s < s1; s += NF) {
+    float t[NF][4];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      if (s + i < s1) load4(ws + (int64_t)(s + i) * ws_stride, k0, D, VEC, t[i]);
+      else t[i][0] = t[i][1] = t[i][2] = t[i][3] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float y = t[i][q] - comp[q];
+        const float n = sum[q] + y;
+        comp[q] = (n - sum[q]) - y;
+        sum[q] = n;
+      }
+  }
+}
+
+// epilogue shared by whole-row units and the last-arriver combine
 __device__ __forceinline__ void agg_epilogue(const AggArgs& a, int v, int deg, int k0, bool vec,
                                              float (&acc)[4], const float (&wsum)[4]) {
   float dv = a.dst_scale ? a.dst_scale[v] : 1.0f;
@@ -140,76 +186,77 @@ __device__ __forceinline__ void loadrow4(const float* p, int k0, int D, bool vec
   }
 }
 
-constexpr int kKahanMinLen = 16;
+#ifndef STAG_KAHAN_MIN_LEN
+#define STAG_KAHAN_MIN_LEN 16
+#endif
+constexpr int kKahanMinLen = STAG_KAHAN_MIN_LEN;
 
-template <int KIND, int LPE, bool VEC, bool PEDGE>
-__global__ __launch_bounds__(256) void agg_kernel(const AggArgs a) {
-  constexpr int TEAMS_PER_BLOCK = 256 / LPE;
-  constexpr int BLK = 4;   // edges whose rows are in flight together
-  constexpr bool NEED_EID = (KIND == kExplicit) || PEDGE;
+// Tuning knobs (tools/ab_bench.py builds variants with -D...): edges per block for the
+// RNG-bound and the gather-bound kinds, waves per SIMD asked of the register allocator.
+#ifndef STAG_BLK_RNG
+#define STAG_BLK_RNG 2
+#endif
+#ifndef STAG_BLK_MEM
+#define STAG_BLK_MEM 2
+#endif
+#ifndef STAG_WAVES_PER_SIMD
+#define STAG_WAVES_PER_SIMD 1
+#endif
 
-  const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
-  const int unit = blockIdx.x * TEAMS_PER_BLOCK + threadIdx.x / LPE;
-  const uint32_t chunk = blockIdx.y * LPE + c;
-  const int k0 = (int)chunk * 4;
-  const uint32_t koff = (uint32_t)k0 * 4u;
-  if (unit >= a.n_units || k0 >= a.D) return;   // teams never talk to each other: no barrier below
+// Register image of one block of BLK edges of a unit.
+template <int BLK>
+struct EdgeIdx {        // what the index fetch brings in
+  int u[BLK];           // column id (row of x)
+  int ee[BLK];          // original edge id (explicit weights / per-edge parameters)
+  uint32_t nn[BLK];     // Philox counter word 0 (noise index)
+};
+template <int BLK>
+struct EdgeRows {       // what the row fetch brings in
+  float xv[BLK][4];
+  float xs[BLK];
+};
 
-  int v, b, len, slot = -1;
-  if (a.units) {
-    const int4 q = *reinterpret_cast<const int4*>(a.units + unit);
-    v = q.x; b = q.y; len = q.z; slot = q.w;
-  } else {
-    v = unit;
-    b = a.indptr[v];
-    len = a.indptr[v + 1] - b;
-  }
-
-  // distribution parameters of this lane's 4 channels
-  float pa[4] = {a.p0s, a.p0s, a.p0s, a.p0s};
-  float pb[4] = {a.p1s, a.p1s, a.p1s, a.p1s};
-  if constexpr (KIND >= kNormal) {
-    if (a.pmode == STAG_PARAM_PER_CHANNEL) {
-      load4(a.p0, k0, a.D, VEC, pa);
-      if (a.p1) load4(a.p1, k0, a.D, VEC, pb);
-    }
-  }
-  // Philox counter word 1 is a per-lane constant: chunk | hi32(position) << 20
-  const uint32_t c1 = chunk | (a.pos_hi << 20);
-
+template <int KIND, int LPE, bool VEC, bool PEDGE, int BLK>
+struct AggTeam {
+  static constexpr bool NEED_EID = (KIND == kExplicit) || PEDGE;
+  const AggArgs& a;
+  const int k0;
+  const uint32_t koff, c1;
+  const int pend;
+  const __amdgpu_buffer_rsrc_t rx;
+  const bool x_buf;
+  float pa[4], pb[4];
   float acc[4] = {0.f, 0.f, 0.f, 0.f}, comp[4] = {0.f, 0.f, 0.f, 0.f};
   float wsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool kahan;
 
-  // descriptor of x for the narrow (< 4 GB, ids < 2^24) case; built from kernel arguments only
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-  const bool x_buf = VEC && (a.wide & 1) == 0;
-
-  const int pend = b + len;
-  for (int p0 = b; p0 < pend; p0 += BLK) {
-    // every lane of the team reads the same 4 column ids: one broadcast dword each, no
-    // vector arithmetic (immediate offsets), and the row fetches below depend only on them
-    int u[BLK], ee[BLK];
-    uint32_t nn[BLK];
+  // every lane of the team reads the same BLK column ids: broadcast dword loads with
+  // immediate offsets, no per-edge vector arithmetic
+  __device__ __forceinline__ void fetch_idx(EdgeIdx<BLK>& I, int p0) const {
 #pragma unroll
     for (int j = 0; j < BLK; ++j) {
       const int p = p0 + j;
       if (p < pend) {
-        u[j] = a.indices[p];
-        if constexpr (NEED_EID) ee[j] = a.eid ? a.eid[p] : p;
-        if constexpr (KIND >= kNormal) nn[j] = a.nidx ? (uint32_t)a.nidx[p] : a.pos_lo + (uint32_t)p;
+        I.u[j] = a.indices[p];
+        if constexpr (NEED_EID) I.ee[j] = a.eid ? a.eid[p] : p;
+        if constexpr (KIND >= kNormal) I.nn[j] = a.nidx ? (uint32_t)a.nidx[p] : a.pos_lo + (uint32_t)p;
       }
     }
-    float xv[BLK][4], xs[BLK];
+  }
+
+  __device__ __forceinline__ void fetch_rows(EdgeRows<BLK>& R, const EdgeIdx<BLK>& I, int p0) const {
 #pragma unroll
     for (int j = 0; j < BLK; ++j) {
       if (p0 + j < pend) {
-        if (x_buf) bufrow4(rx, u[j], a.ldxb, koff, xv[j]);
-        else loadrow4(row_at(a.x, u[j], a.ldxb, koff, (a.wide & 1) != 0), k0, a.D, VEC, xv[j]);
-        if (a.src_scale) xs[j] = a.src_scale[u[j]];
+        if (x_buf) bufrow4(rx, I.u[j], a.ldxb, koff, R.xv[j]);
+        else loadrow4(row_at(a.x, I.u[j], a.ldxb, koff, (a.wide & 1) != 0), k0, a.D, VEC, R.xv[j]);
+        if (a.src_scale) R.xs[j] = a.src_scale[I.u[j]];
       }
     }
-    // block sums: 4 edges into fresh accumulators (small magnitudes => small rounding)
+  }
+
+  __device__ __forceinline__ void compute(EdgeRows<BLK>& R, const EdgeIdx<BLK>& I, int p0) {
+    // block sums go into fresh accumulators (small magnitudes => small rounding)
     float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < BLK; ++j) {
@@ -218,7 +265,7 @@ __global__ __launch_bounds__(256) void agg_kernel(const AggArgs a) {
         if constexpr (KIND == kNone) {
           w[0] = w[1] = w[2] = w[3] = 1.0f;
         } else if constexpr (KIND == kExplicit) {
-          loadrow4(row_at(a.p0, ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, w);
+          loadrow4(row_at(a.p0, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, w);
           if (a.relu) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) w[q] = fmaxf(w[q], 0.0f);
@@ -226,24 +273,24 @@ __global__ __launch_bounds__(256) void agg_kernel(const AggArgs a) {
         } else {
           if constexpr (PEDGE) {
             if (a.pmode == STAG_PARAM_PER_EDGE1) {
-              const float q0 = a.p0[ee[j]];
-              const float q1 = a.p1 ? a.p1[ee[j]] : 0.0f;
+              const float q0 = a.p0[I.ee[j]];
+              const float q1 = a.p1 ? a.p1[I.ee[j]] : 0.0f;
 #pragma unroll
               for (int q = 0; q < 4; ++q) { pa[q] = q0; pb[q] = q1; }
             } else {
-              loadrow4(row_at(a.p0, ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, pa);
-              if (a.p1) loadrow4(row_at(a.p1, ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, pb);
+              loadrow4(row_at(a.p0, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, pa);
+              if (a.p1) loadrow4(row_at(a.p1, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, pb);
             }
           }
-          draw4<KIND>(nn[j], c1, a.key, pa, pb, a.relu != 0, w);
+          draw4<KIND>(I.nn[j], c1, a.key, pa, pb, a.relu != 0, w);
         }
         if (a.src_scale) {
           asm volatile("" ::: "memory");   // keep this a branch: as selects it costs 6 VALU ops per edge
 #pragma unroll
-          for (int q = 0; q < 4; ++q) xv[j][q] *= xs[j];
+          for (int q = 0; q < 4; ++q) R.xv[j][q] *= R.xs[j];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t[q] = __builtin_fmaf(w[q], xv[j][q], t[q]);
+        for (int q = 0; q < 4; ++q) t[q] = __builtin_fmaf(w[q], R.xv[j][q], t[q]);
         if (a.in_norm) {
           asm volatile("" ::: "memory");
 #pragma unroll
@@ -253,7 +300,7 @@ __global__ __launch_bounds__(256) void agg_kernel(const AggArgs a) {
     }
     // fold the block into the unit's sum; compensated (Kahan) once a unit is long enough for
     // the running sum to dwarf a block, so a 13k-edge hub row keeps ~1e-6 relative accuracy
-    if (len > kKahanMinLen) {
+    if (kahan) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float y = t[q] - comp[q];
@@ -266,14 +313,104 @@ __global__ __launch_bounds__(256) void agg_kernel(const AggArgs a) {
       for (int q = 0; q < 4; ++q) acc[q] += t[q];
     }
   }
+};
 
-  if (slot >= 0) {
-    float* wrow = a.ws + (int64_t)slot * a.ws_stride;
-    store4(wrow, k0, a.D, VEC, acc);
-    if (a.in_norm) store4(wrow + a.D, k0, a.D, VEC, wsum);
+template <int KIND, int LPE, bool VEC, bool PEDGE>
+__global__ __launch_bounds__(256, STAG_WAVES_PER_SIMD) void agg_kernel(const AggArgs a) {
+  constexpr int TEAMS_PER_BLOCK = 256 / LPE;
+  // edges per block: the RNG kinds are VALU-bound and register-hungry, the others want
+  // more rows in flight
+  constexpr int BLK = (KIND >= kNormal) ? STAG_BLK_RNG : STAG_BLK_MEM;
+
+  const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
+  const int unit = blockIdx.x * TEAMS_PER_BLOCK + threadIdx.x / LPE;
+  const uint32_t chunk = blockIdx.y * LPE + c;
+  const int k0 = (int)chunk * 4;
+  if (unit >= a.n_units || k0 >= a.D) return;   // teams never talk to each other: no barrier below
+
+  int v, b, len, slot = -1;
+  if (a.units) {
+    const int4 q = *reinterpret_cast<const int4*>(a.units + unit);
+    v = q.x; b = q.y; len = q.z; slot = q.w;
   } else {
-    agg_epilogue(a, v, len, k0, VEC, acc, wsum);
+    v = unit;
+    b = a.indptr[v];
+    len = a.indptr[v + 1] - b;
   }
+
+  // Long units are the critical path of the launch: a SIMD round-robins its waves, so a
+  // 64-edge unit would take 8x its own issue time at 8 waves per SIMD.  They are dispatched
+  // first (plan order) and run at raised priority; the short rows fill in behind them.
+#ifndef STAG_PRIO_MIN_LEN
+#define STAG_PRIO_MIN_LEN 24
+#endif
+  if (len > STAG_PRIO_MIN_LEN) __builtin_amdgcn_s_setprio(2);
+
+  AggTeam<KIND, LPE, VEC, PEDGE, BLK> T{
+      a, k0, (uint32_t)k0 * 4u,
+      chunk | (a.pos_hi << 20),           // Philox counter word 1: a per-lane constant
+      b + len,
+      // descriptor of x for the narrow (< 4 GB, ids < 2^24) case; kernel arguments only
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000),
+      VEC && (a.wide & 1) == 0,
+      {a.p0s, a.p0s, a.p0s, a.p0s}, {a.p1s, a.p1s, a.p1s, a.p1s},
+      {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f},
+      len > kKahanMinLen};
+  if constexpr (KIND >= kNormal) {
+    if (a.pmode == STAG_PARAM_PER_CHANNEL) {   // distribution parameters of this lane's 4 channels
+      load4(a.p0, k0, a.D, VEC, T.pa);
+      if (a.p1) load4(a.p1, k0, a.D, VEC, T.pb);
+    }
+  }
+
+  // One block at a time: ids -> rows -> draws.  Measured on MI355X (tools/ab_bench.py, cfg2,
+  // Normal noise): this loop at 2 edges per block 113 us/step; 4 edges per block 126 us;
+  // an A/B software pipeline that keeps the next block's rows in flight 133 us (the extra
+  // registers cost a wave per SIMD, and occupancy hides the gather latency better).
+  const int pend = b + len;
+  EdgeIdx<BLK> I;
+  EdgeRows<BLK> R;
+  for (int p0 = b; p0 < pend; p0 += BLK) {
+    T.fetch_idx(I, p0);
+    T.fetch_rows(R, I, p0);
+    T.compute(R, I, p0);
+  }
+
+  if (slot < 0) {
+    agg_epilogue(a, v, len, k0, VEC, T.acc, T.wsum);
+    return;
+  }
+  // ---- segment of a long row: publish the partial, the last arriver sums the row ----------
+  const int r = v;                      // for segments the unit names the long row by index
+  // Producer side (Guideline 16, R1): the partial is stored WRITE-THROUGH (sc1), so there is
+  // no release fence (a buffer_wbl2 per segment made the whole launch 2x slower); every
+  // storing wave drains its stores, then one lane per team takes a ticket.
+  const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)a.ws_bytes, 0x00020000);
+  const uint32_t woff = (uint32_t)slot * ((uint32_t)a.ws_stride * 4u) + (uint32_t)k0 * 4u;
+  store4_sc1(rws, woff, k0, a.D, VEC, T.acc);
+  if (a.in_norm) store4_sc1(rws, woff + (uint32_t)a.D * 4u, k0, a.D, VEC, T.wsum);
+  const int s0 = a.long_seg_ptr[r], s1 = a.long_seg_ptr[r + 1];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int ticket = 0;
+  int32_t* counter = a.seg_counters + (int64_t)blockIdx.y * a.n_long + r;   // per channel tile
+  if (c == 0)
+    ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ticket = __builtin_amdgcn_ds_bpermute(((int)(threadIdx.x & 63) - c) << 2, ticket);
+  if (ticket != (s1 - s0) - 1) return;
+  // consumer side: this team drew the last ticket; acquire, then plain loads
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (c == 0) *counter = 0;             // leave the counter ready for the next call
+  const int row = a.long_rows[r];
+  const int deg = a.indptr[row + 1] - a.indptr[row];
+  // Sum the row's partials in segment order with compensated (Kahan) fp32 adds: a hub row has
+  // hundreds of them.  NF partials are in flight at a time; the tail is written to stay under
+  // the hot loop's register count (fp64 accumulators or a wider NF cost a wave per SIMD).
+  constexpr int NF = 8;
+  float facc[4], fws[4] = {0.f, 0.f, 0.f, 0.f};
+  kahan_sum_partials<NF, VEC>(a.ws, a.ws_stride, s0, s1, k0, a.D, facc);
+  if (a.in_norm) kahan_sum_partials<NF, VEC>(a.ws + a.D, a.ws_stride, s0, s1, k0, a.D, fws);
+  agg_epilogue(a, row, deg, k0, VEC, facc, fws);
 }
 
 // Launch one (KIND, PEDGE) family; defined per kind in agg_<kind>.hip so the

@@ -50,68 +50,6 @@ PhiloxKey make_key(const stag_noise_spec* s) {
   return k;
 }
 
-// One 256-thread block per long row: LPE chunk lanes x (256/LPE) segment slots.  Slot s
-// adds segments s, s+S, s+2S, ... (4 loads in flight), then the slots are added in slot
-// order through LDS, so the sum has ONE fixed association whatever the schedule.
-template <int LPE>
-__global__ __launch_bounds__(256) void agg_combine_kernel(const AggArgs a, int vec) {
-  constexpr int SLOTS = 256 / LPE;
-  __shared__ double red[2][SLOTS][LPE][4];
-  const int r = blockIdx.x;
-  const int c = threadIdx.x % LPE, slot = threadIdx.x / LPE;
-  const int v = a.long_rows[r];
-  const int deg = a.indptr[v + 1] - a.indptr[v];
-  const int s0 = a.long_seg_ptr[r], s1 = a.long_seg_ptr[r + 1];
-  const int nchunk = (a.D + 3) / 4;
-  for (int tile = 0; tile * LPE < nchunk; ++tile) {
-    const int k0 = (tile * LPE + c) * 4;
-    const bool kin = k0 < a.D;
-    // fp64: a hub row has hundreds of partials; their sum must not cost accuracy
-    double acc[4] = {0., 0., 0., 0.};
-    double wsum[4] = {0., 0., 0., 0.};
-    if (kin) {
-      for (int s = s0 + slot; s < s1; s += 4 * SLOTS) {
-        float t[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int si = s + i * SLOTS;
-          if (si < s1) load4(a.ws + (int64_t)si * a.ws_stride, k0, a.D, vec != 0, t[i]);
-          else t[i][0] = t[i][1] = t[i][2] = t[i][3] = 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] += (double)t[i][j];
-        if (a.in_norm) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int si = s + i * SLOTS;
-            if (si < s1) load4(a.ws + (int64_t)si * a.ws_stride + a.D, k0, a.D, vec != 0, t[i]);
-            else t[i][0] = t[i][1] = t[i][2] = t[i][3] = 0.f;
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wsum[j] += (double)t[i][j];
-        }
-      }
-    }
-    __syncthreads();   // previous tile's readers are done with `red`
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { red[0][slot][c][j] = acc[j]; red[1][slot][c][j] = wsum[j]; }
-    __syncthreads();
-    if (slot == 0 && kin) {
-      for (int q = 1; q < SLOTS; ++q)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { acc[j] += red[0][q][c][j]; wsum[j] += red[1][q][c][j]; }
-      float accf[4], wsumf[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { accf[j] = (float)acc[j]; wsumf[j] = (float)wsum[j]; }
-      agg_epilogue(a, v, deg, k0, vec != 0, accf, wsumf);
-    }
-  }
-}
-
 // ------------------------------------------------------------------------- //
 __global__ void philox_raw_kernel(PhiloxKey key, int64_t pos0, int64_t n_pos, int n_chunk,
                                   uint32_t* out) {
@@ -291,36 +229,42 @@ int stag_plan_fill(const int32_t* indptr_host, int32_t n_dst, int32_t seg_len,
   if (n_dst > 0 && !units_host) return STAG_EINVAL;
   // counting sort by length, longest first (every length is in [0, seg_len])
   std::vector<int64_t> bucket((size_t)seg_len + 2, 0);
-  int32_t n_long = 0;
+  std::vector<int32_t> longs;
   for (int32_t v = 0; v < n_dst; ++v) {
     const int32_t deg = indptr_host[v + 1] - indptr_host[v];
     if (deg > seg_len) {
-      ++n_long;
+      longs.push_back(v);
       bucket[seg_len] += deg / seg_len;
       if (deg % seg_len) bucket[deg % seg_len] += 1;
     } else {
       bucket[deg] += 1;
     }
   }
-  if (n_long > 0 && !long_rows_host) return STAG_EINVAL;
+  if (!longs.empty() && !long_rows_host) return STAG_EINVAL;
+  // hubs first: the row with the most segments gets the earliest blocks, so the segment
+  // that arrives last (and adds the partials) is done long before the launch ends
+  std::stable_sort(longs.begin(), longs.end(), [&](int32_t x, int32_t y) {
+    return indptr_host[x + 1] - indptr_host[x] > indptr_host[y + 1] - indptr_host[y];
+  });
   std::vector<int64_t> cursor((size_t)seg_len + 1, 0);
   int64_t run = 0;
   for (int32_t l = seg_len; l >= 0; --l) { cursor[l] = run; run += bucket[l]; }
-  int32_t r = 0, s = 0;
+  int32_t s = 0;
   long_seg_ptr_host[0] = 0;
-  for (int32_t v = 0; v < n_dst; ++v) {
+  for (size_t r = 0; r < longs.size(); ++r) {
+    const int32_t v = longs[r];
     const int32_t b = indptr_host[v], e = indptr_host[v + 1];
-    if (e - b <= seg_len) {
-      units_host[cursor[e - b]++] = stag_unit{v, b, e - b, -1};
-      continue;
-    }
     long_rows_host[r] = v;
     for (int32_t p = b; p < e; p += seg_len) {
       const int32_t l = (e - p < seg_len) ? (e - p) : seg_len;
-      units_host[cursor[l]++] = stag_unit{v, p, l, s};
+      units_host[cursor[l]++] = stag_unit{(int32_t)r, p, l, s};
       ++s;
     }
-    long_seg_ptr_host[++r] = s;
+    long_seg_ptr_host[r + 1] = s;
+  }
+  for (int32_t v = 0; v < n_dst; ++v) {
+    const int32_t b = indptr_host[v], e = indptr_host[v + 1];
+    if (e - b <= seg_len) units_host[cursor[e - b]++] = stag_unit{v, b, e - b, -1};
   }
   return STAG_OK;
 }
@@ -392,12 +336,15 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int
     a.n_units = plan->n_units;
   }
   if (has_segs) {
-    if (!plan->long_rows || !plan->long_seg_ptr || !plan->workspace) return STAG_EINVAL;
+    if (!plan->long_rows || !plan->long_seg_ptr || !plan->workspace || !plan->seg_counters)
+      return STAG_EINVAL;
     if (plan->workspace_bytes < stag_plan_workspace_bytes(plan->n_seg, D, spec->in_norm))
       return STAG_ENOMEM;
     a.long_rows = plan->long_rows; a.long_seg_ptr = plan->long_seg_ptr;
-    a.ws = plan->workspace; a.ws_stride = D * (spec->in_norm ? 2 : 1);
-    a.n_long = plan->n_long;
+    const size_t need = stag_plan_workspace_bytes(plan->n_seg, D, spec->in_norm);
+    if (need >= (1ull << 32)) return STAG_ENOSYS;   // partials go through a 32-bit buffer descriptor
+    a.ws = plan->workspace; a.ws_stride = D * (spec->in_norm ? 2 : 1); a.ws_bytes = (uint32_t)need;
+    a.n_long = plan->n_long; a.seg_counters = plan->seg_counters;
   }
 
   // dwordx4 path needs 16-B aligned rows everywhere a float4 is formed
@@ -420,15 +367,6 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int
     }
   };
   if (launch(a) != hipSuccess) return STAG_EIO;
-  if (has_segs) {
-    const int nchunk = (D + 3) / 4;
-    const dim3 grid(plan->n_long), block(256);
-    if (nchunk > 32)      hipLaunchKernelGGL(agg_combine_kernel<64>, grid, block, 0, s, a, vec ? 1 : 0);
-    else if (nchunk > 16) hipLaunchKernelGGL(agg_combine_kernel<32>, grid, block, 0, s, a, vec ? 1 : 0);
-    else if (nchunk > 4)  hipLaunchKernelGGL(agg_combine_kernel<16>, grid, block, 0, s, a, vec ? 1 : 0);
-    else                  hipLaunchKernelGGL(agg_combine_kernel<4>, grid, block, 0, s, a, vec ? 1 : 0);
-    if (hipGetLastError() != hipSuccess) return STAG_EIO;
-  }
   return STAG_OK;
 }
 

@@ -69,7 +69,8 @@ class CsrView:
                 seg_len=seg_len, n_units=nu, n_long=nl, n_seg=ns,
                 units=torch.from_numpy(units).to(dev),
                 long_rows=torch.from_numpy(long_rows).to(dev),
-                long_seg_ptr=torch.from_numpy(long_seg_ptr).to(dev))
+                long_seg_ptr=torch.from_numpy(long_seg_ptr).to(dev),
+                counters={})
         return self._plans[seg_len]
 
 

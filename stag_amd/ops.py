@@ -52,9 +52,15 @@ def _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len, want_norm_
         nbytes = _lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], D, int(spec.in_norm))
         if nbytes:
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        tiles = (D + 255) // 256
+        counters = plan_t["counters"].get(tiles)
+        if counters is None:   # zero once; every completed launch leaves them zero again
+            counters = torch.zeros(max(plan_t["n_long"], 1) * tiles, dtype=torch.int32, device=dev)
+            plan_t["counters"][tiles] = counters
         plan_c = _lib.Plan(plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"],
                            _lib.ptr(plan_t["units"]), _lib.ptr(plan_t["long_rows"]),
-                           _lib.ptr(plan_t["long_seg_ptr"]), _lib.ptr(ws), nbytes)
+                           _lib.ptr(plan_t["long_seg_ptr"]), _lib.ptr(counters), _lib.ptr(ws),
+                           nbytes)
     cs = csrv.struct()
     with torch.cuda.device(dev):
         rc = _lib.lib().stag_agg_fwd(
@@ -93,8 +99,10 @@ class _Aggregate(torch.autograd.Function):
             keep.append(w)
         else:
             spec = _none_spec()
+        # the in-norm factor is only kept (one more [N, D] store) when a backward can follow
+        want_ns = bool(spec.in_norm) and any(ctx.needs_input_grad[:2])
         out, ns = _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len,
-                           want_norm_scale=bool(spec.in_norm), broadcast_x=broadcast_x)
+                           want_norm_scale=want_ns, broadcast_x=broadcast_x)
         ctx.graph, ctx.noise, ctx.reduce, ctx.seg_len = graph, noise, reduce, seg_len
         ctx.broadcast_x = broadcast_x
         ctx.D = D
