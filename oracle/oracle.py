@@ -118,15 +118,18 @@ class CsrGraph:
         return np.repeat(np.arange(self.n_dst, dtype=np.int32), np.diff(self.indptr))
 
     def transpose(self):
-        """src-major CSR of the same edges with nidx = forward position (for backward)."""
-        dst = self.dst_of_pos
-        order = np.argsort(self.indices, kind="stable")
-        indptr_t = np.zeros(self.n_src + 1, dtype=np.int64)
-        np.add.at(indptr_t, self.indices.astype(np.int64) + 1, 1)
-        indptr_t = np.cumsum(indptr_t).astype(np.int32)
-        eid = self.eid if self.eid is not None else np.arange(self.n_edges, dtype=np.int32)
-        return CsrGraph(indptr_t, dst[order], eid=eid[order],
-                        nidx=order.astype(np.int32), n_src=self.n_dst)
+        """src-major CSR of the same edges (stable in original edge id, like csr_build on the
+        swapped COO) with nidx = forward CSR position of each edge (for the backward pass)."""
+        E = self.n_edges
+        eid = self.eid if self.eid is not None else np.arange(E, dtype=np.int32)
+        pos_of_eid = np.empty(E, dtype=np.int32)
+        pos_of_eid[eid] = np.arange(E, dtype=np.int32)
+        src_coo = np.empty(E, dtype=np.int32)
+        dst_coo = np.empty(E, dtype=np.int32)
+        src_coo[eid] = self.indices
+        dst_coo[eid] = self.dst_of_pos
+        indptr_t, indices_t, eid_t, _, _ = csr_build(dst_coo, src_coo, self.n_dst, self.n_src)
+        return CsrGraph(indptr_t, indices_t, eid=eid_t, nidx=pos_of_eid[eid_t], n_src=self.n_dst)
 
 
 def csr_build(src, dst, n_src, n_dst):

@@ -90,11 +90,12 @@ class ParametrizedDistribution(Distribution):
     def __init__(self, base_distribution: torch.distributions.Distribution, vi: bool = False):
         super().__init__()
         cls = type(base_distribution)
-        names = [n for n in cls.arg_constraints if n != "logits"]
+        arg_constraints = base_distribution.arg_constraints   # instance level: a property for Uniform
+        names = [n for n in arg_constraints if n != "logits"]
         stored = []
         for name in names:
             value = torch.as_tensor(getattr(base_distribution, name)).detach().clone()
-            if vi and _is_positive(cls.arg_constraints[name]):
+            if vi and _is_positive(arg_constraints[name]):
                 key, value = "log_" + name, torch.log(value)
             else:
                 key = name

@@ -1,0 +1,248 @@
+"""The drop-in layer API on the GPU against fixtures computed by the reference's own
+source (tests/golden/make_golden.py), plus the reference's shape contracts
+(stag/tests/test_layers.py) and full-size, size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+from util import TOL, assert_close, oracle_graph, scaled_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(golden, name, dev):
+    import stag_amd
+    return stag_amd.Graph(torch.from_numpy(golden[f"{name}_src"]), torch.from_numpy(golden[f"{name}_dst"]),
+                          int(golden[f"{name}_n"]), device=dev)
+
+
+def _sd(golden, prefix, dev):
+    return {k[len(prefix):]: torch.from_numpy(golden[k]).to(dev) for k in golden.files if k.startswith(prefix)}
+
+
+# ---- reference shape contracts (stag/tests/test_layers.py:13-54) ------------------------------
+@pytest.mark.parametrize("mode", ["r1", "rc", "re", "rec"])
+def test_forward_shapes_like_reference_tests(dev, mode):
+    import stag_amd
+    q = {"r1": None,
+         "rc": torch.distributions.Normal(torch.ones(16), torch.ones(16)),
+         "re": stag_amd.distributions.AmortizedDistribution(16, 1),
+         "rec": stag_amd.distributions.AmortizedDistribution(16, 16)}[mode]
+    layer = stag_amd.zoo.GCN(16, 32)
+    layer = stag_amd.layers.StagLayer(layer) if q is None else stag_amd.layers.StagLayer(layer, q_a=q)
+    layer = layer.to(dev)
+    g = stag_amd.rand_graph(3, 9, device=dev)
+    h = layer(g, torch.randn(3, 16, device=dev))
+    assert h.shape == torch.Size([3, 32])
+    assert layer._edge_weight_sample.shape == (9, 16)
+
+
+def test_layer_golden_with_injected_weights(dev, golden):
+    """StagLayer over a sum aggregator: hand the reference's sampled w to the explicit-weight
+    kernel and compare with the reference's layer output."""
+    from stag_amd import ops
+    for name in golden["layer_cases"]:
+        name = str(name)
+        g = _graph(golden, name.split("_")[1], dev)
+        x = torch.from_numpy(golden[name + "_x"]).to(dev)
+        w = torch.from_numpy(golden[name + "_w"]).to(dev)
+        assert_close(ops.aggregate(g, x, w), golden[name + "_out"], what=name)
+        # the DGL-style call the reference makes: update_all(u_mul_e, sum)
+        import stag_amd.function as fn
+        h = g.local_var()
+        h.ndata["h"], h.edata["w"] = x, w
+        h.update_all(fn.u_mul_e("h", "w", "m"), fn.sum("m", "out"))
+        assert_close(h.ndata["out"], golden[name + "_out"], what=name + " update_all")
+
+
+def test_in_norm_tensor_path_golden(dev, golden):
+    from stag_amd.layers import _in_norm
+    for name in golden["layer_cases"]:
+        name = str(name)
+        if name.endswith("_bern"):
+            g = _graph(golden, name.split("_")[1], dev)
+            w_final = golden[name + "_w"]
+            w_raw = torch.from_numpy((w_final != 0).astype(np.float32)).to(dev)
+            assert_close(_in_norm(g, w_raw), w_final, what=name)
+
+
+def test_gcn_sage_gat_modules_golden(dev, golden):
+    import stag_amd
+    g = _graph(golden, "hub40", dev)
+    x = torch.from_numpy(golden["zoo_x"]).to(dev)
+    w = torch.from_numpy(golden["zoo_w"]).to(dev)
+    gcn = stag_amd.zoo.GCN(16, 8).to(dev)
+    gcn.load_state_dict({"weight": torch.from_numpy(golden["gcn_weight"]), "bias": torch.from_numpy(golden["gcn_bias"])})
+    assert_close(gcn(g, x, edge_weight=w), golden["gcn_out"], what="GCN")
+    assert_close(gcn(g, x), golden["gcn_out_noweight"], what="GCN no weight")
+    sage = stag_amd.zoo.GraphSAGE(16, 8, activation=torch.relu).to(dev)
+    sage.load_state_dict(_sd(golden, "sage_sd_", dev))
+    assert_close(sage(g, x, edge_weight=w), golden["sage_out"], what="GraphSAGE")
+    for tag, last in (("gat", False), ("gat_last", True)):
+        gat = stag_amd.zoo.GAT(16, 4, num_heads=3, last=last).to(dev)
+        gat.load_state_dict(_sd(golden, tag + "_sd_", dev))
+        out, attn = gat(g, x, get_attention=True, edge_weight=torch.from_numpy(golden[tag + "_w"]).to(dev))
+        assert_close(out, golden[tag + "_out"], what=tag)
+        assert_close(attn, golden[tag + "_attn"], what=tag + " attention")
+
+
+def test_stag_model_loss_and_grads_golden(dev, golden, monkeypatch):
+    """2-layer vi=True GCN stack: NLL, KL and gradients equal the reference's when the layers
+    are fed the reference's sampled weights (stag/models.py:63-85)."""
+    import stag_amd
+    g = _graph(golden, "hub40", dev)
+    x = torch.from_numpy(golden["zoo_x"]).to(dev)
+    y = torch.from_numpy(golden["model_y"]).to(dev)
+    N = torch.distributions.Normal
+    l1 = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(16, 8, activation=torch.relu), q_a=N(1.0, 0.4), vi=True)
+    l2 = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(8, 4, activation=lambda t: torch.softmax(t, dim=-1)),
+                                   q_a=N(1.0, 0.4), vi=True)
+    model = stag_amd.models.StagModel(layers=torch.nn.ModuleList([l1, l2]), kl_scaling=0.5).to(dev)
+    for i, l in enumerate((l1, l2)):
+        l.base_layer.load_state_dict({"weight": torch.from_numpy(golden[f"model_l{i}_weight"]),
+                                      "bias": torch.from_numpy(golden[f"model_l{i}_bias"])})
+    # replay the reference's draws: z = (w - loc) / scale, then w = loc + scale * z in-graph
+    for l, key in ((l1, "model_w1"), (l2, "model_w2")):
+        z = (torch.from_numpy(golden[key]).to(dev) - 1.0) / 0.4
+        monkeypatch.setattr(l, "rsample_noise",
+                            lambda graph, dn, l=l, z=z: l.q_a.loc + l.q_a.log_scale.exp() * z)
+    nll, reg = model.loss_terms(g, x, y, n_samples=1)
+    assert_close(torch.stack([nll, reg]), golden["model_nll_reg"], tol=2e-5, what="nll, reg")
+    (nll + reg).backward()
+    assert_close(l1.base_layer.weight.grad, golden["model_l0_weight_grad"], tol=2e-5, what="dL/dW0")
+    assert_close(l1.q_a.loc.grad, golden["model_l0_qa_loc_grad"], tol=2e-5, what="dL/dloc")
+    assert_close(l1.q_a.log_scale.grad, golden["model_l0_qa_log_scale_grad"], tol=2e-5, what="dL/dlog_scale")
+
+
+def test_fused_layer_equals_materialised_layer(dev, oracle):
+    """The fused path and `_edge_weight_sample` describe the same draw."""
+    import stag_amd
+    from stag_amd import ops
+    from util import random_graph
+    g = random_graph(300, 4000, seed=5, hub=700, device=dev)
+    x = torch.randn(300, 32, device=dev)
+    for kw in (dict(q_a=torch.distributions.Normal(1.0, 0.5)),
+               dict(q_a=torch.distributions.Normal(0.2, 1.0), relu=True),
+               dict(q_a=torch.distributions.Bernoulli(probs=0.7), norm=True),
+               dict(q_a=torch.distributions.Uniform(0.5, 1.5))):
+        for base in (stag_amd.zoo.GCN(32, 16), stag_amd.zoo.GraphSAGE(32, 16), stag_amd.zoo.GIN(32, 16)):
+            layer = stag_amd.layers.StagLayer(base, **kw).to(dev)
+            stag_amd.manual_seed(42)
+            out = layer(g, x)
+            w = layer._edge_weight_sample                    # materialised on demand
+            assert w.shape == (g.number_of_edges(), 32)
+            assert_close(base(g, x, edge_weight=w), out.detach().cpu().numpy(), what=f"{type(base).__name__} {kw}")
+            stag_amd.manual_seed(42)
+            assert torch.equal(layer(g, x), out), "same seed => same bits"
+            assert not torch.equal(layer(g, x), out), "next forward draws fresh noise"
+
+
+def test_training_step_reduces_loss(dev):
+    """End to end: 3-layer GCN stack of scripts/arxiv_mle/gcn/run.py shape, Adam steps."""
+    import stag_amd
+    from util import random_graph
+    torch.manual_seed(0)
+    g = random_graph(400, 4000, seed=9, device=dev)
+    x = torch.randn(400, 32, device=dev)
+    y = torch.randint(0, 5, (400,), device=dev)
+    q = torch.distributions.Normal(1.0, 0.3)
+    L, Z = stag_amd.layers, stag_amd.zoo
+    layers = torch.nn.ModuleList([
+        L.StagLayer(Z.GCN(32, 32), q_a=q),
+        L.FeatOnlyLayer(torch.nn.Sequential(torch.nn.BatchNorm1d(32), torch.nn.ReLU())),
+        L.StagLayer(Z.GCN(32, 32), q_a=q),
+        L.FeatOnlyLayer(torch.nn.Sequential(torch.nn.BatchNorm1d(32), torch.nn.ReLU())),
+        L.StagLayer(Z.GCN(32, 5, activation=lambda t: torch.softmax(t, dim=-1)), q_a=q)])
+    model = stag_amd.models.StagModel(layers=layers).to(dev)
+    opt = torch.optim.Adam(model.parameters(), 1e-2)
+    losses = []
+    for _ in range(30):
+        opt.zero_grad()
+        loss = model.loss(g, x, y, n_samples=2)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0] - 0.05
+    with torch.no_grad():
+        p = model(g, x, n_samples=4, return_parameters=True)
+    assert p.shape == (400, 5) and torch.allclose(p.sum(-1), torch.ones(400, device=dev), atol=1e-4)
+
+
+def test_readout_layers(dev, oracle):
+    import stag_amd
+    gs = [stag_amd.rand_graph(n, 3 * n, device=dev) for n in (5, 1, 9)]
+    b = stag_amd.batch(gs)
+    x = torch.randn(15, 7, device=dev, requires_grad=True)
+    for layer, red in ((stag_amd.layers.SumNodes(), oracle.REDUCE_SUM), (stag_amd.layers.MeanNodes(), oracle.REDUCE_MEAN)):
+        out = layer(b, x)
+        assert_close(out, oracle.segment_reduce(x.detach().cpu().numpy(), np.array([0, 5, 6, 15], np.int32), red))
+        out.sum().backward()
+    assert x.grad is not None and x.grad.shape == x.shape
+
+
+def test_shard_equals_whole_graph(dev):
+    """world=1 GraphShard == Graph, and a 2-way split computed on one GPU reproduces the
+    whole-graph result bit for bit (global Philox positions)."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    from stag_amd.partition import GraphShard
+    rng = np.random.default_rng(3)
+    n, D = 500, 128
+    dst = np.concatenate([rng.integers(0, n, 6000), np.full(900, 17)])
+    src = rng.integers(0, n, len(dst))
+    x = torch.randn(n, D, device=dev)
+    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
+    mk = lambda graph: stag_amd.EdgeNoise(graph, D, _lib.NOISE_NORMAL, 1.0, 0.5, seed=8, offset=3)
+    whole = ops.aggregate(g, x, mk(g))
+    sh = GraphShard(src, dst, n, 0, 1, device=dev)
+    assert torch.equal(sh.aggregate(x, mk(sh)), whole)
+    parts = []
+    for r in range(2):
+        sh = GraphShard(src, dst, n, r, 2, device=dev)
+        buf = torch.zeros(2 * sh.max_rows, D, device=dev)      # what the all-gather would deliver
+        for q in range(2):
+            lo, hi = int(sh.bounds[q]), int(sh.bounds[q + 1])
+            buf[q * sh.max_rows:q * sh.max_rows + hi - lo] = x[lo:hi]
+        noise = mk(sh)
+        noise.pos_base = sh.pos_base
+        parts.append(ops.aggregate(sh, buf, noise))
+    assert torch.equal(torch.cat(parts, 0), whole)
+
+
+def test_full_size_properties(dev):
+    """BASELINE cfg2 size (N=169,343, E=1,166,243, D=128): properties that need no oracle run."""
+    import stag_amd
+    from stag_amd import _lib, ops, synthetic
+    src, dst = synthetic.arxiv_like(seed=1)
+    n = synthetic.ARXIV_NODES
+    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
+    D = 128
+    x = torch.randn(n, D, device=dev)
+    y = torch.randn(n, D, device=dev)
+    mk = lambda **kw: stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, 1.0, 0.5, seed=0x5747A6, offset=0, **kw)
+    a = ops.aggregate(g, x, mk())
+    assert torch.equal(a, ops.aggregate(g, x, mk())), "deterministic"
+    # linearity in x for a fixed noise field
+    lin = ops.aggregate(g, 2.0 * x + y, mk())
+    ref = 2.0 * a + ops.aggregate(g, y, mk())
+    assert scaled_err(lin.cpu().numpy(), ref.cpu().numpy()) <= 2 * TOL
+    # zero in-degree rows are exactly zero; noise-free aggregation of ones counts in-degrees
+    deg = g.in_degrees()
+    assert float(a[deg == 0].abs().max()) == 0.0
+    ones = ops.aggregate(g, torch.ones(n, D, device=dev), None)
+    assert torch.equal(ones[:, 0], deg.float()) and torch.equal(ones[:, 127], deg.float())
+    # E[w] = 1: the noisy aggregate of ones is the in-degree up to sampling error
+    noisy = ops.aggregate(g, torch.ones(n, D, device=dev), mk())
+    hub = int(deg.argmax())
+    assert abs(float(noisy[hub].mean()) / float(deg[hub]) - 1.0) < 5e-3
+    # Bernoulli + in-norm: every destination's weights sum to its in-degree
+    b = stag_amd.EdgeNoise(g, D, _lib.NOISE_BERNOULLI, 0.5, None, seed=1, offset=0, in_norm=True)
+    s = ops.aggregate(g, torch.ones(n, D, device=dev), b)
+    alive = s != 0
+    assert scaled_err(s[alive].cpu().numpy(), deg.float().unsqueeze(1).expand(n, D)[alive].cpu().numpy()) <= TOL
+    # backward = transpose: <A x, y> == <x, A^T y> with the same noise
+    xr = x.clone().requires_grad_(True)
+    out = ops.aggregate(g, xr, mk())
+    out.backward(y)
+    lhs, rhs = float((out.detach().double() * y.double()).sum()), float((x.double() * xr.grad.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * (abs(lhs) + abs(rhs))

@@ -1,0 +1,254 @@
+"""Host-side logic on CPU (no kernel launch): graph build, launch plan, ABI surface,
+noise descriptors, the distributions API, loud failure without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    """libstag_hip.so loads without a GPU and exports each function include/stag_hip.h declares."""
+    from stag_amd import _lib
+    lib = _lib.lib()
+    header = open(os.path.join(ROOT, "include", "stag_hip.h")).read()
+    names = set(re.findall(r"\b(stag_[a-z0-9_]+)\s*\(", header))
+    assert {"stag_agg_fwd", "stag_noise_materialize", "stag_gat_fwd", "stag_plan_fill"} <= names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/stag_hip.h but not exported"
+    assert lib.stag_abi_version() == 1
+    assert lib.stag_strerror(-22) == b"invalid argument"
+
+
+def test_abi_struct_layouts_match_header():
+    from stag_amd import _lib
+    assert ctypes.sizeof(_lib.Csr) == 48
+    assert ctypes.sizeof(_lib.NoiseSpec) == 64
+    assert ctypes.sizeof(_lib.Plan) == 64
+    assert _lib.NoiseSpec.seed.offset == 40 and _lib.NoiseSpec.pos_base.offset == 56
+
+
+def test_graph_csr_matches_oracle(oracle):
+    import stag_amd
+    rng = np.random.default_rng(0)
+    src, dst = rng.integers(0, 70, 900), rng.integers(0, 70, 900)
+    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), 70)
+    indptr, indices, eid, ind, outd = oracle.csr_build(src, dst, 70, 70)
+    assert np.array_equal(g.csr.indptr.numpy(), indptr)
+    assert np.array_equal(g.csr.indices.numpy(), indices)
+    assert np.array_equal(g.csr.eid.numpy(), eid)
+    assert np.array_equal(g.in_degrees().numpy(), ind) and np.array_equal(g.out_degrees().numpy(), outd)
+    t = g.csr_t
+    indptr_t, indices_t, eid_t, *_ = oracle.csr_build(dst, src, 70, 70)
+    assert np.array_equal(t.indptr.numpy(), indptr_t) and np.array_equal(t.indices.numpy(), indices_t)
+    assert np.array_equal(t.eid.numpy(), eid_t)
+    assert np.array_equal(eid[t.nidx.numpy()], eid_t)     # nidx = forward position of the same edge
+    og = oracle.CsrGraph(indptr, indices, eid, n_src=70).transpose()
+    assert np.array_equal(og.nidx, t.nidx.numpy())
+
+
+def test_graph_surface():
+    import stag_amd
+    g = stag_amd.rand_graph(3, 9)                      # stag/tests/test_layers.py:17
+    assert g.number_of_nodes() == 3 and g.number_of_edges() == 9 and not g.is_block
+    g.ndata["h"] = torch.ones(3, 2)
+    h = g.local_var()
+    h.ndata["h"] = torch.zeros(3, 2)
+    h.edata["w"] = torch.ones(9)
+    assert g.ndata["h"].sum() == 6 and "w" not in g.edata       # caller's frames untouched
+    with g.local_scope():
+        g.ndata["tmp"] = torch.zeros(3)
+    assert "tmp" not in g.ndata
+    assert h.csr is g.csr                                       # structure is shared and cached
+    with pytest.raises(ValueError):
+        stag_amd.Graph(torch.tensor([0, 5]), torch.tensor([1, 1]), 3)
+    g2 = stag_amd.add_reverse_edges(stag_amd.add_self_loop(stag_amd.remove_self_loop(g)))
+    assert g2.number_of_edges() == 2 * (int((g._src != g._dst).sum()) + 3)
+    b = stag_amd.batch([stag_amd.rand_graph(4, 5), stag_amd.rand_graph(2, 3)])
+    assert b.number_of_nodes() == 6 and b.batch_size == 2 and b.batch_num_nodes().tolist() == [4, 2]
+    assert int(b._dst[5:].min()) >= 4
+
+
+@pytest.mark.parametrize("seg_len", [1, 3, 64])
+def test_plan_covers_every_edge_once(seg_len):
+    import stag_amd
+    rng = np.random.default_rng(seg_len)
+    n = 300
+    dst = np.concatenate([rng.integers(0, n - 5, 2000), np.full(700, 7), np.full(150, 9)])
+    src = rng.integers(0, n, len(dst))
+    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n)
+    p = g.csr.plan(seg_len)
+    units = p["units"].numpy()
+    indptr = g.csr.indptr.numpy()
+    deg = np.diff(indptr)
+    assert p["n_units"] == len(units) == (deg <= seg_len).sum() + p["n_seg"]
+    assert (np.diff(units[:, 2]) <= 0).all(), "units sorted by length, longest first"
+    assert units[:, 2].max() <= seg_len
+    covered = np.zeros(len(dst), np.int32)
+    long_rows, lsp = p["long_rows"].numpy(), p["long_seg_ptr"].numpy()
+    for row, start, ln, slot in units:
+        covered[start:start + ln] += 1
+        if slot < 0:
+            assert start == indptr[row] and ln == deg[row]
+        else:
+            v = long_rows[row]
+            assert indptr[v] <= start and start + ln <= indptr[v + 1]
+            assert lsp[row] <= slot < lsp[row + 1]
+    assert (covered == 1).all()
+    assert p["n_long"] == (deg > seg_len).sum()
+    ld = deg[long_rows[:p["n_long"]]]
+    assert (np.diff(ld) <= 0).all(), "hub rows first"
+    assert set(units[units[:, 3] >= 0][:, 3]) == set(range(p["n_seg"]))
+
+
+def test_edge_noise_param_modes():
+    import stag_amd
+    from stag_amd import _lib
+    g = stag_amd.rand_graph(5, 12)
+    N = torch.distributions.Normal
+    mk = lambda d, dn: stag_amd.EdgeNoise.from_distribution(g, dn, d)
+    assert mk(N(1.0, 0.5), 8).param_mode == _lib.PARAM_SCALAR
+    e = mk(N(torch.ones(8), torch.ones(8)), 8)
+    assert e.param_mode == _lib.PARAM_PER_CHANNEL and e.p0.shape == (8,)
+    e = mk(N(torch.ones(12, 1), torch.ones(12, 1)), 8)
+    assert e.param_mode == _lib.PARAM_PER_EDGE1 and e.p1.shape == (12, 1)
+    e = mk(N(torch.ones(12, 8), torch.ones(12, 1)), 8)          # mixed: widest mode wins
+    assert e.param_mode == _lib.PARAM_PER_EDGE and e.p1.shape == (12, 8)
+    assert e.shape == torch.Size([12, 8]) and e.unsqueeze(-1) is e
+    assert mk(torch.distributions.Bernoulli(probs=0.9), 4).kind == _lib.NOISE_BERNOULLI
+    assert mk(torch.distributions.Uniform(0.0, 2.0), 4).kind == _lib.NOISE_UNIFORM
+    with pytest.raises(ValueError):
+        mk(N(torch.ones(7), torch.ones(7)), 8)
+    s = mk(N(1.0, 0.5), 8).spec()
+    assert s.kind == _lib.NOISE_NORMAL and abs(s.p1_scalar - 0.5) < 1e-7
+
+
+def test_noise_generator_offsets():
+    from stag_amd import random as R
+    gen = R.NoiseGenerator(seed=5)
+    assert [gen.next_offset() for _ in range(3)] == [0, 1, 2]
+    st = gen.get_state()
+    gen.manual_seed(5)
+    assert gen.next_offset() == 0
+    gen.set_state(st)
+    assert gen.next_offset() == 3
+
+
+def test_no_cpu_fallback():
+    """The product path fails loudly without a HIP device (no oracle, no eager fallback)."""
+    import stag_amd
+    from stag_amd._lib import StagHipError
+    g = stag_amd.rand_graph(3, 9)
+    layer = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(16, 32))
+    with pytest.raises(StagHipError):
+        layer(g, torch.randn(3, 16))
+    with pytest.raises(StagHipError):
+        stag_amd.ops.aggregate(g, torch.randn(3, 4), None)
+    src = open(os.path.join(ROOT, "stag_amd", "ops.py")).read() + open(os.path.join(ROOT, "stag_amd", "layers.py")).read()
+    assert "oracle" not in src
+
+
+# ---- stag.distributions contracts (reference: stag/tests/test_distributions.py) ---------------
+def test_parametrized_distribution_names_and_values(golden):
+    from stag_amd.distributions import ParametrizedDistribution
+    d = ParametrizedDistribution(torch.distributions.Normal(1.0, 0.5), vi=True)
+    assert sorted(n for n, _ in d.named_parameters()) == list(golden["pd_vi_names"])
+    assert np.allclose(d.loc.item(), golden["pd_vi_loc"]) and np.allclose(d.log_scale.item(), golden["pd_vi_log_scale"])
+    d = ParametrizedDistribution(torch.distributions.Normal(1.0, 0.5))
+    assert sorted(n for n, _ in d.named_buffers()) == list(golden["pd_buf_names"])
+    assert len(list(d.parameters())) == 0
+    half = 0.3 * np.sqrt(3.0)
+    d = ParametrizedDistribution(torch.distributions.Uniform(1.0 - half, 1.0 + half, validate_args=False))
+    assert sorted(n for n, _ in d.named_buffers()) == list(golden["pd_uniform_names"])
+    assert np.allclose([d.low.item(), d.high.item()], golden["pd_uniform_low_high"])
+    d = ParametrizedDistribution(torch.distributions.Bernoulli(probs=float(golden["pd_bernoulli_probs"][0])))
+    assert sorted(n for n, _ in d.named_buffers()) == list(golden["pd_bernoulli_names"])   # no 'logits'
+    assert isinstance(d.base_distribution, torch.distributions.Bernoulli)
+
+
+def test_parametrized_distribution_expand_shapes(golden):
+    from stag_amd.distributions import ParametrizedDistribution
+    d = ParametrizedDistribution(torch.distributions.Normal(0, 1))
+    assert d.expand(torch.Size([10, 8])).rsample().shape == (10, 8)
+    d = ParametrizedDistribution(torch.distributions.Normal(torch.zeros(10, 8), torch.ones(10, 8)))
+    assert list(d.expand(torch.Size([12, 11, 10, 8])).rsample().shape) == list(golden["pd_expand_shape"])
+    assert d.batch_shape == (10, 8) and float(d.mean.sum()) == 0.0
+
+
+def test_delta_distribution():
+    from stag_amd.distributions import DeltaDistribution
+    d = DeltaDistribution(0.0)
+    assert d.sample() == 0.0 and d.rsample() == 0.0 and d.stddev == 0.0
+    with pytest.raises(NotImplementedError):
+        d.log_prob(torch.tensor(0.0))
+
+
+@pytest.mark.parametrize("tag,of", [("re", 1), ("rec", 16)])
+def test_amortized_distribution_condition_golden(golden, tag, of):
+    """Same state_dict => same per-edge loc / log_scale as the reference computed."""
+    import stag_amd
+    from stag_amd.distributions import AmortizedDistribution
+    q = AmortizedDistribution(16, of)
+    sd = {k[len(f"amort_{tag}_sd_"):]: torch.from_numpy(golden[k]) for k in golden.files
+          if k.startswith(f"amort_{tag}_sd_")}
+    q.load_state_dict(sd)                                     # names are part of the contract
+    g = stag_amd.Graph(torch.from_numpy(golden["hub40_src"]), torch.from_numpy(golden["hub40_dst"]), 40)
+    q.condition(g, torch.from_numpy(golden[f"amort_{tag}_x"]))
+    assert torch.allclose(q.new_parameters["loc"], torch.from_numpy(golden[f"amort_{tag}_loc"]), atol=1e-5)
+    assert torch.allclose(q.new_parameters["log_scale"], torch.from_numpy(golden[f"amort_{tag}_log_scale"]), atol=1e-5)
+    assert q.base_distribution.scale.shape == (g.number_of_edges(), of)
+    init = AmortizedDistribution(4, 2, init_like=torch.distributions.Normal(1.0, 0.3))
+    assert torch.allclose(init.parameters_mlp["loc"].bias, torch.ones(2))
+    assert torch.allclose(init.parameters_mlp["log_scale"].bias, torch.full((2,), float(np.log(0.3))))
+
+
+def test_stag_layer_construction_and_state_dict():
+    import stag_amd
+    L = stag_amd.layers.StagLayer
+    layer = L(stag_amd.zoo.GCN(16, 32))
+    assert sorted(layer.state_dict()) == ["base_layer.bias", "base_layer.weight", "p_a.loc", "p_a.scale",
+                                          "q_a.loc", "q_a.scale"]
+    assert layer.kl_divergence() == 0.0 and layer.vi is False
+    vi = L(stag_amd.zoo.GCN(16, 32), q_a=torch.distributions.Normal(1.0, 0.4), vi=True)
+    assert {"q_a.loc", "q_a.log_scale", "p_a.loc", "p_a.log_scale"} <= set(dict(vi.named_parameters()))
+    kl = vi.kl_divergence()        # closed form Normal||Normal (stag/layers.py:136-139)
+    want = torch.distributions.kl_divergence(torch.distributions.Normal(1.0, 0.4), torch.distributions.Normal(1.0, 1.0))
+    assert torch.allclose(kl, want)
+    assert stag_amd.zoo.GAT(16, 4, num_heads=3).sample_dimension == 3
+    for cls in (stag_amd.layers.FeatOnlyLayer, stag_amd.layers.SumNodes, stag_amd.layers.MeanNodes):
+        assert cls.vi is False
+
+
+def test_zoo_error_behaviour():
+    import stag_amd
+    from stag_amd.zoo._common import DGLError
+    g = stag_amd.rand_graph(4, 6)
+    with pytest.raises(AssertionError):     # stag/zoo/gcn.py:61
+        stag_amd.zoo.GCN(4, 4)(g, torch.randn(4, 4), edge_weight=torch.ones(5, 4))
+    with pytest.raises(DGLError):           # stag/zoo/gcn.py:77-81
+        stag_amd.zoo.GCN(4, 4)(g, torch.randn(4, 4), weight=torch.ones(4, 4))
+    with pytest.raises(KeyError):           # stag/zoo/graph_sage.py:101
+        stag_amd.zoo.GraphSAGE(4, 4, aggregator_type="bogus")
+
+
+def test_early_stopping():
+    from stag_amd.utils import EarlyStopping
+    es, m = EarlyStopping(patience=2), torch.nn.Linear(1, 1)
+    assert es([1.0, 1.0], m) is False
+    assert es([0.5, 0.9], m) is False and es.best_state is not None
+    assert es([0.6, 0.8], m) is False and es.best_losses == [0.5, 0.8]
+    assert es([0.7, 0.9], m) is False
+    assert es([0.7, 0.9], m) is True
+
+
+def test_synthetic_graph_shape():
+    from stag_amd import synthetic
+    src, dst = synthetic.arxiv_like(n_nodes=20000, n_edges=140000, max_in_degree=1500, seed=1)
+    deg = np.bincount(dst, minlength=20000)
+    assert len(src) == 140000 and deg.max() > 1000 and 0.02 < (deg == 0).mean() < 0.25
+    s2, d2 = synthetic.arxiv_like(n_nodes=20000, n_edges=140000, max_in_degree=1500, seed=1)
+    assert np.array_equal(src, s2) and np.array_equal(dst, d2)
