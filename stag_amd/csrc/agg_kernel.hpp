@@ -202,6 +202,9 @@ constexpr int kKahanMinLen = STAG_KAHAN_MIN_LEN;
 #ifndef STAG_WAVES_PER_SIMD
 #define STAG_WAVES_PER_SIMD 1
 #endif
+#ifndef STAG_BLOCK_THREADS
+#define STAG_BLOCK_THREADS 256
+#endif
 
 // Register image of one block of BLK edges of a unit.
 template <int BLK>
@@ -316,8 +319,8 @@ struct AggTeam {
 };
 
 template <int KIND, int LPE, bool VEC, bool PEDGE>
-__global__ __launch_bounds__(256, STAG_WAVES_PER_SIMD) void agg_kernel(const AggArgs a) {
-  constexpr int TEAMS_PER_BLOCK = 256 / LPE;
+__global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_kernel(const AggArgs a) {
+  constexpr int TEAMS_PER_BLOCK = STAG_BLOCK_THREADS / LPE;
   // edges per block: the RNG kinds are VALU-bound and register-hungry, the others want
   // more rows in flight
   constexpr int BLK = (KIND >= kNormal) ? STAG_BLK_RNG : STAG_BLK_MEM;
@@ -420,18 +423,18 @@ hipError_t agg_launch(const AggArgs& a, bool vec, hipStream_t stream);
 
 template <int KIND, int LPE>
 inline void agg_launch_shape(const AggArgs& a, bool vec, bool pedge, int tiles, hipStream_t s) {
-  constexpr int TPB = 256 / LPE;
+  constexpr int TPB = STAG_BLOCK_THREADS / LPE;
   dim3 grid((a.n_units + TPB - 1) / TPB, tiles);
   if (grid.x == 0) return;
   if constexpr (KIND >= kNormal) {
     if (pedge) {
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, true>), grid, dim3(256), 0, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, true>), grid, dim3(256), 0, s, a);
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, true>), grid, dim3(STAG_BLOCK_THREADS), 0, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, true>), grid, dim3(STAG_BLOCK_THREADS), 0, s, a);
       return;
     }
   }
-  if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, false>), grid, dim3(256), 0, s, a);
-  else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, false>), grid, dim3(256), 0, s, a);
+  if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, false>), grid, dim3(STAG_BLOCK_THREADS), 0, s, a);
+  else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, false>), grid, dim3(STAG_BLOCK_THREADS), 0, s, a);
 }
 
 template <int KIND>
