@@ -186,15 +186,20 @@ int stag_segment_reduce(const float* x, int64_t ldx, int32_t D,
                         const int32_t* offsets, int32_t n_seg, int32_t reduce,
                         float* out, int64_t ldo, void* stream);
 
-/* GAT edge attention with noisy logits + softmax + aggregation, one pass per dst:
+/* GAT edge attention with noisy logits + softmax + aggregation, one launch:
  *   e[p,h]  = w[p,h] * leaky_relu(el[u_p,h] + er[v,h])     stag/zoo/gat.py:114-119
  *   a[p,h]  = softmax over the in-edges of v                stag/zoo/gat.py:122
  *   out[v,h,:] = sum_p a[p,h] * ft[u_p,h,:]                 stag/zoo/gat.py:125-126
- * ft is [N, H*F] row-major; attn_out (may be NULL) receives a[eid, h].          */
-int stag_gat_fwd(const stag_csr* csr, const float* el, const float* er,
+ * ft is [N, H*F] row-major (H*F <= 256, H <= 64); attn_out (may be NULL) receives a[eid, h].
+ * `plan` as for stag_agg_fwd, with a workspace of stag_gat_workspace_bytes() (long rows
+ * are merged from per-segment softmax states).  When spec.in_norm is set, `norm_scale`
+ * [M, H] must hold indeg / sum_in(w) per destination and head (stag/layers.py:8-36):
+ * obtain the sums with stag_agg_fwd over a broadcast row of ones (D = H, ldx = 0).      */
+size_t stag_gat_workspace_bytes(int32_t n_seg, int32_t H, int32_t F);
+int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const float* el, const float* er,
                  const float* ft, int32_t H, int32_t F, float neg_slope,
-                 const stag_noise_spec* spec, float* out, float* attn_out,
-                 void* stream);
+                 const stag_noise_spec* spec, const float* norm_scale, float* out,
+                 float* attn_out, void* stream);
 
 #ifdef __cplusplus
 }

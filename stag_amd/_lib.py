@@ -89,8 +89,10 @@ def lib():
                                  _vp, C.c_int64, _vp]
     l.stag_segment_reduce.argtypes = [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, C.c_int32, _vp,
                                       C.c_int64, _vp]
-    l.stag_gat_fwd.argtypes = [C.POINTER(Csr), _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_float,
-                               C.POINTER(NoiseSpec), _vp, _vp, _vp]
+    l.stag_gat_workspace_bytes.restype = C.c_size_t
+    l.stag_gat_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    l.stag_gat_fwd.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp, C.c_int32, C.c_int32,
+                               C.c_float, C.POINTER(NoiseSpec), _vp, _vp, _vp, _vp]
     if l.stag_abi_version() != 1:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     _lib = l

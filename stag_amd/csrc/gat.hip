@@ -1,19 +1,23 @@
 // gat.hip — GAT edge attention with noisy logits, softmax and aggregation fused
-// into one pass per destination row (stag/zoo/gat.py:114-126):
+// (stag/zoo/gat.py:114-126):
 //     e[p,h]     = w[p,h] * leaky_relu(el[u_p,h] + er[v,h])
 //     a[p,h]     = softmax_p(e[.,h])           (DGL edge_softmax: per dst, per head)
 //     out[v,h,:] = sum_p a[p,h] * ft[u_p,h,:]
 // Noise width is H (`sample_dimension`, stag/zoo/gat.py:11): one Philox block per
-// (edge, 4 heads), so this path is gather-bound, not RNG-bound.
+// (edge, 4 heads), so this path is gather-bound (an H*F*4-byte row per edge), not RNG-bound.
 //
-// One wave per destination row.  Per batch of 64 in-edges:
-//   phase 1 (edge-parallel): lane i draws the H weights of edge i, forms the H
-//           logits and parks them in LDS (no redundant RNG work across lanes);
-//   phase 2 (channel-parallel): lane l owns channels [CPL*l, CPL*l+CPL) of head
-//           h_l, walks the batch, and folds each edge into an online softmax
-//           (running max m, running sum l, rescaled accumulator).
+// Same decomposition as the aggregation kernel (agg_kernel.hpp): the launch walks the
+// plan's UNITS (whole rows, or <= seg_len-edge segments of long rows, longest first); a
+// TEAM of LPE = H*F/4 lanes owns one unit.  Per batch of LPE edges of the unit:
+//   phase 1 (edge-parallel)    lane i draws the H weights of edge i, forms the H logits and
+//                              parks them in LDS — no RNG work is repeated across lanes;
+//   phase 2 (channel-parallel) lane c owns channels [4c, 4c+4) of head h_c: batch max, then
+//                              p = exp(logit - max), running sum and weighted row sum.
+// A unit ends with a softmax state (m, l, acc) per lane.  Whole rows normalise and store;
+// segments publish their state (sc1 stores + ticket, as in agg_kernel) and the last arriver
+// merges the states in segment order: m = max m_i, l = sum l_i e^(m_i-m), acc likewise.
 #include "../../include/stag_hip.h"
-#include "noise.hpp"
+#include "agg_kernel.hpp"
 
 using namespace stag;
 
@@ -28,21 +32,34 @@ struct GatArgs {
   const float* el;
   const float* er;
   const float* ft;
-  int32_t H, F;
+  const float* nscale;   // [n_rows, H] in-norm factor (null: 1)
+  int32_t H, F, HF;
   float neg_slope;
   int32_t kind;
   const float* p0;
   const float* p1;
   float p0s, p1s;
-  int32_t pmode, relu, in_norm;
+  int32_t pmode, relu;
   PhiloxKey key;
-  int64_t pos_base;
+  uint32_t pos_lo, pos_hi;
   float* out;
-  float* attn;
+  float* attn;           // [E, H] by edge id, or null
+  uint32_t attn_bytes;
+  uint32_t ft_bytes;     // extent of ft when it fits a buffer descriptor, else 0
+  // plan
+  const stag_unit* units;
+  int32_t n_units;
+  const int32_t* long_rows;
+  const int32_t* long_seg_ptr;
+  int32_t n_long;
+  int32_t* seg_counters;
+  float* ws;             // [n_seg][HF + 2*H]: acc, then m[H], l[H]
+  int32_t ws_stride;
+  uint32_t ws_bytes;
 };
 
-// the 4 weights of heads [4c, 4c+4) of the edge at position p
-__device__ __forceinline__ void head_w4(const GatArgs& a, int p, int64_t ed, uint32_t chunk,
+// the 4 weights of heads [4c, 4c+4) of the edge with noise index n and edge id ed
+__device__ __forceinline__ void head_w4(const GatArgs& a, uint32_t n, int64_t ed, uint32_t chunk,
                                         float (&w)[4]) {
   const int h0 = (int)chunk * 4;
   float pa[4], pb[4];
@@ -51,16 +68,19 @@ __device__ __forceinline__ void head_w4(const GatArgs& a, int p, int64_t ed, uin
     const int h = h0 + j;
     const bool in = h < a.H;
     float q0 = a.p0s, q1 = a.p1s;
-    if (a.pmode == 1) { q0 = in ? a.p0[h] : 0.f; q1 = (in && a.p1) ? a.p1[h] : 0.f; }
-    else if (a.pmode == 2) { q0 = a.p0[ed]; q1 = a.p1 ? a.p1[ed] : 0.f; }
-    else if (a.pmode == 3) { q0 = in ? a.p0[ed * a.H + h] : 0.f; q1 = (in && a.p1) ? a.p1[ed * a.H + h] : 0.f; }
+    if (a.pmode == STAG_PARAM_PER_CHANNEL) { q0 = in ? a.p0[h] : 0.f; q1 = (in && a.p1) ? a.p1[h] : 0.f; }
+    else if (a.pmode == STAG_PARAM_PER_EDGE1) { q0 = a.p0[ed]; q1 = a.p1 ? a.p1[ed] : 0.f; }
+    else if (a.pmode == STAG_PARAM_PER_EDGE) {
+      q0 = in ? a.p0[ed * a.H + h] : 0.f;
+      q1 = (in && a.p1) ? a.p1[ed * a.H + h] : 0.f;
+    }
     pa[j] = q0; pb[j] = q1;
   }
-  const int64_t gpos = a.nidx ? (int64_t)a.nidx[p] : a.pos_base + p;
+  const uint32_t c1 = chunk | (a.pos_hi << 20);
   switch (a.kind) {
-    case kNormal: draw4<kNormal>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.relu != 0, w); break;
-    case kUniform: draw4<kUniform>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.relu != 0, w); break;
-    case kBernoulli: draw4<kBernoulli>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.relu != 0, w); break;
+    case kNormal: draw4<kNormal>(n, c1, a.key, pa, pb, a.relu != 0, w); break;
+    case kUniform: draw4<kUniform>(n, c1, a.key, pa, pb, a.relu != 0, w); break;
+    case kBernoulli: draw4<kBernoulli>(n, c1, a.key, pa, pb, a.relu != 0, w); break;
     case kExplicit:
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -79,128 +99,224 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
-  return x;
-}
-
-// CPL channels per lane: 4 (dwordx4, needs F % 4 == 0) or 1
-template <int CPL>
+// LPE lanes per unit (H*F/4 rounded up to a power of two, 4..64); VEC: dwordx4 rows
+template <int LPE, bool VEC>
 __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatArgs a) {
   extern __shared__ __align__(16) float lds[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int H = a.H, F = a.F, HF = H * F;
-  float* logit = lds + (size_t)wave * (64 * H + 3 * H);   // [64][H]
-  float* nscale = logit + 64 * H;                          // [H] in-norm factor
-  float* stat_m = nscale + H;                              // [H]
-  float* stat_l = stat_m + H;                              // [H]
+  constexpr int TEAMS_PER_BLOCK = 256 / LPE;
+  const int H = a.H, F = a.F, HF = a.HF;
+  const int team = threadIdx.x / LPE;
+  const int c = threadIdx.x % LPE;
+  const int team_lane0 = (int)(threadIdx.x & 63) - c;
+  float* logit = lds + (size_t)team * (LPE * H);      // [LPE edges][H]
+  const int unit = blockIdx.x * TEAMS_PER_BLOCK + team;
+  if (unit >= a.n_units) return;   // teams are independent: no block-level barrier below
 
-  const int v = blockIdx.x * 4 + wave;
-  if (v >= a.n_rows) return;   // whole wave leaves together: no block-level barrier is used
-  const int b = a.indptr[v], e = a.indptr[v + 1];
-  const int nchunk = (H + 3) / 4;
+  int v, b, len, slot = -1;
+  if (a.units) {
+    const int4 q = *reinterpret_cast<const int4*>(a.units + unit);
+    v = q.x; b = q.y; len = q.z; slot = q.w;
+  } else {
+    v = unit;
+    b = a.indptr[v];
+    len = a.indptr[v + 1] - b;
+  }
+  const int row = (slot >= 0) ? a.long_rows[v] : v;
+  if (len > 24) __builtin_amdgcn_s_setprio(2);
 
-  // in-norm over the H-wide weights (stag/layers.py:8-36) needs the row sums first
-  for (int h = lane; h < H; h += 64) nscale[h] = 1.0f;
-  if (a.in_norm) {
-    for (int c = 0; c < nchunk; ++c) {
-      float s[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int p = b + lane; p < e; p += 64) {
-        float w[4];
-        head_w4(a, p, a.eid ? a.eid[p] : p, (uint32_t)c, w);
+  const int k0 = c * 4;                    // channels [k0, k0+4) of the H*F row
+  const bool kin = k0 < HF;
+  // head of each of the lane's 4 channels: all equal when F % 4 == 0 (the VEC path); with
+  // an odd F a lane's channels can straddle two heads, so the softmax state is per channel
+  int hq[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s[j] += w[j];
+  for (int q = 0; q < 4; ++q) hq[q] = (k0 + q < HF) ? (k0 + q) / F : 0;
+  const int hl = hq[0];
+  const int nchunk = (H + 3) / 4;
+  const __amdgpu_buffer_rsrc_t rft =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ft), 0, (int)a.ft_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rattn =
+      __builtin_amdgcn_make_buffer_rsrc(a.attn, 0, (int)a.attn_bytes, 0x00020000);
+  const bool ft_buf = VEC && a.ft_bytes != 0;
+
+  constexpr int NS = VEC ? 1 : 4;          // softmax states per lane
+  float m[NS], l[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) { m[q] = -INFINITY; l[q] = 0.f; }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+
+  for (int i0 = 0; i0 < len; i0 += LPE) {
+    const int nb = min(LPE, len - i0);
+    // ---- phase 1: lane c computes the H logits of edge i0 + c ------------------------------
+    wave_sync();
+    int u = 0;
+    if (c < nb) {
+      const int p = b + i0 + c;
+      u = a.indices[p];
+      const int64_t ed = a.eid ? a.eid[p] : p;
+      const uint32_t n = a.nidx ? (uint32_t)a.nidx[p] : a.pos_lo + (uint32_t)p;
+      for (int cc = 0; cc < nchunk; ++cc) {
+        float w[4];
+        head_w4(a, n, ed, (uint32_t)cc, w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int h = 4 * cc + j;
+          if (h < H) {
+            const float s = a.el[(int64_t)u * H + h] + a.er[(int64_t)row * H + h];
+            const float lr = s > 0.f ? s : a.neg_slope * s;
+            const float ns = a.nscale ? a.nscale[(int64_t)row * H + h] : 1.0f;
+            const float lg = (w[j] * ns) * lr;
+            logit[c * H + h] = lg;
+            // raw logit, write-through: whoever finalises the row normalises it (below)
+            if (a.attn)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lg), rattn,
+                                                    (int)(((uint32_t)ed * (uint32_t)H + (uint32_t)h) * 4u), 0, 16);
+          }
+        }
+      }
+    }
+    wave_sync();
+    // ---- phase 2: fold the batch into this lane's head --------------------------------------
+    if (kin) {
+#pragma unroll
+      for (int sI = 0; sI < NS; ++sI) {
+        float bm = -INFINITY;
+        for (int i = 0; i < nb; ++i) bm = fmaxf(bm, logit[i * H + hq[sI]]);
+        const float mn = fmaxf(m[sI], bm);
+        const float corr = __expf(m[sI] - mn);     // 0 on the first batch (m = -inf)
+        l[sI] *= corr;
+        if constexpr (VEC) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] *= corr;
+        } else {
+          acc[sI] *= corr;
+        }
+        m[sI] = mn;
+      }
+    }
+    for (int i = 0; i < nb; i += 4) {
+      int ui[4];
+      float fv[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ui[j] = __builtin_amdgcn_ds_bpermute((team_lane0 + i + j) << 2, u);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (i + j < nb && kin) {
+          if (ft_buf) bufrow4(rft, ui[j], (uint32_t)HF * 4u, (uint32_t)k0 * 4u, fv[j]);
+          else loadrow4(a.ft + (int64_t)ui[j] * HF + k0, k0, HF, VEC, fv[j]);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float t = wave_sum(s[j]);
-        if (lane == 0 && 4 * c + j < H) nscale[4 * c + j] = (t != 0.f) ? (float)(e - b) / t : 1.f;
-      }
-    }
-  }
-  wave_sync();
-
-  const int ntile = (HF + 64 * CPL - 1) / (64 * CPL);
-  for (int tile = 0; tile < ntile; ++tile) {
-    const int k0 = (tile * 64 + lane) * CPL;
-    const bool kin = k0 < HF;
-    const int hl = kin ? k0 / F : 0;
-    float m = -INFINITY, l = 0.f;
-    float acc[CPL];
+        if (i + j < nb && kin) {
+          if constexpr (VEC) {
+            const float pe = __expf(logit[(i + j) * H + hl] - m[0]);
+            l[0] += pe;
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
-
-    for (int p0 = b; p0 < e; p0 += 64) {
-      const int nb = min(64, e - p0);
-      // ---- phase 1: logits of edge p0+lane into LDS -------------------------
-      wave_sync();
-      int u = 0;
-      if (lane < nb) {
-        const int p = p0 + lane;
-        u = a.indices[p];
-        const int64_t ed = a.eid ? a.eid[p] : p;
-        for (int c = 0; c < nchunk; ++c) {
-          float w[4];
-          head_w4(a, p, ed, (uint32_t)c, w);
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_fmaf(pe, fv[j][q], acc[q]);
+          } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int h = 4 * c + j;
-            if (h < H) {
-              const float s = a.el[(int64_t)u * H + h] + a.er[(int64_t)v * H + h];
-              const float lr = s > 0.f ? s : a.neg_slope * s;
-              const float lg = (w[j] * nscale[h]) * lr;
-              logit[lane * H + h] = lg;
-              if (a.attn && tile == 0) a.attn[ed * H + h] = lg;   // normalised below
+            for (int q = 0; q < 4; ++q) {
+              const float pe = __expf(logit[(i + j) * H + hq[q]] - m[q]);
+              l[q] += pe;
+              acc[q] = __builtin_fmaf(pe, fv[j][q], acc[q]);
             }
           }
         }
       }
-      wave_sync();
-      // ---- phase 2: fold the batch into this lane's head ----------------------
-      for (int i = 0; i < nb; ++i) {
-        const int ui = __shfl(u, i);
-        if (kin) {
-          const float s = logit[i * H + hl];
-          const float mn = fmaxf(m, s);
-          const float corr = __expf(m - mn);
-          const float pe = __expf(s - mn);
-          l = l * corr + pe;
-          m = mn;
-          const float* fr = a.ft + (int64_t)ui * HF + k0;
-          if constexpr (CPL == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(fr);
-            acc[0] = acc[0] * corr + pe * t.x;
-            acc[1] = acc[1] * corr + pe * t.y;
-            acc[2] = acc[2] * corr + pe * t.z;
-            acc[3] = acc[3] * corr + pe * t.w;
+    }
+  }
+
+  float* stat = logit;   // [2][H] softmax statistics for the attention pass (LDS reuse)
+  if (slot < 0) {
+    // ---- whole row: normalise and store ------------------------------------------------------
+    if (kin) {
+      float o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float lq = l[VEC ? 0 : q];
+        o[q] = acc[q] * ((lq > 0.f) ? 1.0f / lq : 0.f);
+      }
+      store4(a.out + (int64_t)row * HF, k0, HF, VEC, o);
+    }
+    if (!a.attn) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this team's own logit stores have landed
+    wave_sync();
+    // the lane holding a head's first channel publishes that head's statistics
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+      if (k0 + q < HF && (k0 + q) % F == 0) { stat[hq[q]] = m[q]; stat[H + hq[q]] = l[q]; }
+  } else {
+    // ---- segment: publish (acc, m, l) write-through, take a ticket ---------------------------
+    const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)a.ws_bytes, 0x00020000);
+    const uint32_t base = (uint32_t)slot * ((uint32_t)a.ws_stride * 4u);
+    if (kin) {
+      store4_sc1(rws, base + (uint32_t)k0 * 4u, k0, HF, VEC, acc);
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+        if (k0 + q < HF && (k0 + q) % F == 0) {
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[q]), rws, (int)(base + (uint32_t)(HF + hq[q]) * 4u), 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l[q]), rws, (int)(base + (uint32_t)(HF + H + hq[q]) * 4u), 0, 16);
+        }
+    }
+    const int s0 = a.long_seg_ptr[v], s1 = a.long_seg_ptr[v + 1];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int ticket = 0;
+    if (c == 0)
+      ticket = __hip_atomic_fetch_add(a.seg_counters + v, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_ds_bpermute(team_lane0 << 2, ticket);
+    if (ticket != (s1 - s0) - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (c == 0) a.seg_counters[v] = 0;
+    // merge the segment states in segment order
+    float M[NS], L[NS];
+    float A[4] = {0.f, 0.f, 0.f, 0.f};
+    if (kin) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        M[q] = -INFINITY; L[q] = 0.f;
+        for (int s = s0; s < s1; ++s) M[q] = fmaxf(M[q], a.ws[(int64_t)s * a.ws_stride + HF + hq[q]]);
+      }
+      for (int s = s0; s < s1; ++s) {
+        const float* wr = a.ws + (int64_t)s * a.ws_stride;
+        float t[4];
+        load4(wr, k0, HF, VEC, t);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const float sc = __expf(wr[HF + hq[q]] - M[q]);
+          L[q] += wr[HF + H + hq[q]] * sc;
+          if constexpr (VEC) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[r] = __builtin_fmaf(t[r], sc, A[r]);
           } else {
-            acc[0] = acc[0] * corr + pe * fr[0];
+            A[q] = __builtin_fmaf(t[q], sc, A[q]);
           }
         }
       }
-    }
-    if (kin) {
-      const float inv = (l > 0.f) ? 1.0f / l : 0.f;
-      float* o = a.out + (int64_t)v * HF + k0;
-      if constexpr (CPL == 4) {
-        *reinterpret_cast<float4*>(o) = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
-      } else {
-        o[0] = acc[0] * inv;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float lq = L[VEC ? 0 : q];
+        A[q] *= (lq > 0.f) ? 1.0f / lq : 0.f;
       }
-      // the lane holding a head's first channel publishes its softmax statistics
-      if (k0 % F == 0) { stat_m[hl] = m; stat_l[hl] = l; }
+      store4(a.out + (int64_t)row * HF, k0, HF, VEC, A);
     }
-  }
-  // ---- attention values a[eid, h] (get_attention=True, stag/zoo/gat.py:146-147) --
-  if (a.attn) {
+    if (!a.attn) return;
     wave_sync();
-    for (int p = b + lane; p < e; p += 64) {
-      const int64_t ed = a.eid ? a.eid[p] : p;
-      for (int h = 0; h < H; ++h) {
-        const float lg = a.attn[ed * H + h];
-        a.attn[ed * H + h] = __expf(lg - stat_m[h]) / stat_l[h];
-      }
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+      if (kin && k0 + q < HF && (k0 + q) % F == 0) { stat[hq[q]] = M[q]; stat[H + hq[q]] = L[q]; }
+  }
+  // ---- attention values a[eid, h] = exp(logit - m) / l over the WHOLE row
+  //      (get_attention=True, stag/zoo/gat.py:146-147).  The raw logits were stored
+  //      write-through and drained before any ticket, and this team is behind its acquire.
+  wave_sync();
+  const int rb = a.indptr[row], re = a.indptr[row + 1];
+  for (int p = rb + c; p < re; p += LPE) {
+    const int64_t ed = a.eid ? a.eid[p] : p;
+    for (int h = 0; h < H; ++h) {
+      const float lg = a.attn[ed * H + h];
+      a.attn[ed * H + h] = __expf(lg - stat[h]) / stat[H + h];
     }
   }
 }
@@ -209,35 +325,92 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-extern "C" int stag_gat_fwd(const stag_csr* csr, const float* el, const float* er, const float* ft,
-                            int32_t H, int32_t F, float neg_slope, const stag_noise_spec* spec,
-                            float* out, float* attn_out, void* stream) {
+extern "C" size_t stag_gat_workspace_bytes(int32_t n_seg, int32_t H, int32_t F) {
+  if (n_seg <= 0 || H <= 0 || F <= 0) return 0;
+  return (size_t)n_seg * (size_t)(H * F + 2 * H) * sizeof(float);
+}
+
+extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const float* el,
+                            const float* er, const float* ft, int32_t H, int32_t F, float neg_slope,
+                            const stag_noise_spec* spec, const float* norm_scale, float* out,
+                            float* attn_out, void* stream) {
   if (!csr || !csr->indptr || csr->n_dst < 0 || csr->n_edges < 0) return STAG_EINVAL;
   if (!spec || spec->kind < STAG_NOISE_NONE || spec->kind > STAG_NOISE_BERNOULLI) return STAG_EINVAL;
   if (!out || H <= 0 || F <= 0) return STAG_EINVAL;
-  if (H > 64) return STAG_ENOSYS;   // LDS logit tile is [64][H] per wave
+  const int64_t HF64 = (int64_t)H * F;
+  if (H > 64 || HF64 > 256) return STAG_ENOSYS;   // one wave spans the H*F row; LDS tile is [64][H]
+  if (spec->in_norm && !norm_scale) return STAG_EINVAL;   // the caller runs the row-sum pass first
   if (csr->n_dst == 0) return STAG_OK;
   if (csr->n_edges > 0 && (!csr->indices || !el || !er || !ft)) return STAG_EINVAL;
   if (spec->kind == STAG_NOISE_EXPLICIT && !spec->p0) return STAG_EINVAL;
   if (spec->kind >= STAG_NOISE_NORMAL && spec->param_mode != STAG_PARAM_SCALAR &&
       (!spec->p0 || (spec->kind != STAG_NOISE_BERNOULLI && !spec->p1)))
     return STAG_EINVAL;
+  const int HF = (int)HF64;
 
   GatArgs a{};
   a.indptr = csr->indptr; a.indices = csr->indices; a.eid = csr->eid; a.nidx = csr->nidx;
-  a.n_rows = csr->n_dst; a.el = el; a.er = er; a.ft = ft; a.H = H; a.F = F;
+  a.n_rows = csr->n_dst; a.el = el; a.er = er; a.ft = ft;
+  a.nscale = spec->in_norm ? norm_scale : nullptr;
+  a.H = H; a.F = F; a.HF = HF;
   a.neg_slope = neg_slope; a.kind = spec->kind; a.p0 = spec->p0; a.p1 = spec->p1;
   a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar;
   a.pmode = spec->kind >= STAG_NOISE_NORMAL ? spec->param_mode : 0;
-  a.relu = spec->relu; a.in_norm = spec->in_norm;
+  a.relu = spec->relu;
   a.key.k0 = (uint32_t)(spec->seed & 0xFFFFFFFFull); a.key.k1 = (uint32_t)(spec->seed >> 32);
   a.key.o0 = (uint32_t)(spec->offset & 0xFFFFFFFFull); a.key.o1 = (uint32_t)(spec->offset >> 32);
-  a.pos_base = spec->pos_base; a.out = out; a.attn = attn_out;
+  a.pos_lo = (uint32_t)((uint64_t)spec->pos_base & 0xFFFFFFFFull);
+  a.pos_hi = (uint32_t)((uint64_t)spec->pos_base >> 32);
+  if (spec->kind >= STAG_NOISE_NORMAL && !csr->nidx &&
+      (uint64_t)a.pos_lo + (uint64_t)csr->n_edges > (1ull << 32))
+    return STAG_ENOSYS;
+  a.out = out; a.attn = attn_out;
+  if (attn_out) {
+    const uint64_t ab = (uint64_t)csr->n_edges * (uint64_t)H * 4u;
+    if (ab >= (1ull << 32)) return STAG_ENOSYS;
+    a.attn_bytes = (uint32_t)ab;
+  }
+  const uint64_t ftb = (uint64_t)csr->n_src * (uint64_t)HF * 4u;
+  a.ft_bytes = (ftb < (1ull << 32) && csr->n_src < (1 << 24)) ? (uint32_t)ftb : 0u;
 
-  const size_t lds_bytes = 4u * (size_t)(64 * H + 3 * H) * sizeof(float);
-  dim3 grid((csr->n_dst + 3) / 4);
-  const bool vec = (F % 4 == 0) && aligned16(ft) && aligned16(out);
-  if (vec) hipLaunchKernelGGL(gat_fwd_kernel<4>, grid, dim3(256), lds_bytes, (hipStream_t)stream, a);
-  else     hipLaunchKernelGGL(gat_fwd_kernel<1>, grid, dim3(256), lds_bytes, (hipStream_t)stream, a);
+  a.n_units = csr->n_dst;
+  const bool use_plan = plan && plan->n_units > 0;
+  if (use_plan) {
+    if (!plan->units || !aligned16(plan->units)) return STAG_EINVAL;
+    a.units = plan->units; a.n_units = plan->n_units;
+    if (plan->n_seg > 0) {
+      if (!plan->long_rows || !plan->long_seg_ptr || !plan->workspace || !plan->seg_counters)
+        return STAG_EINVAL;
+      const size_t need = stag_gat_workspace_bytes(plan->n_seg, H, F);
+      if (plan->workspace_bytes < need) return STAG_ENOMEM;
+      if (need >= (1ull << 32)) return STAG_ENOSYS;
+      a.long_rows = plan->long_rows; a.long_seg_ptr = plan->long_seg_ptr; a.n_long = plan->n_long;
+      a.seg_counters = plan->seg_counters; a.ws = plan->workspace;
+      a.ws_stride = HF + 2 * H; a.ws_bytes = (uint32_t)need;
+    }
+  }
+  bool vec = (F % 4 == 0) && aligned16(ft) && aligned16(out);
+  if (a.ws) vec = vec && aligned16(a.ws) && (a.ws_stride % 4 == 0);
+
+  const int nchunk = (HF + 3) / 4;
+  int lpe = 4;
+  while (lpe < nchunk) lpe <<= 1;
+  const int tpb = 256 / lpe;
+  const dim3 grid((a.n_units + tpb - 1) / tpb);
+  const size_t lds_bytes = (size_t)256 * H * sizeof(float);   // [teams][LPE][H]
+  hipStream_t s = (hipStream_t)stream;
+#define STAG_GAT_LAUNCH(L)                                                                         \
+  do {                                                                                             \
+    if (vec) hipLaunchKernelGGL((gat_fwd_kernel<L, true>), grid, dim3(256), lds_bytes, s, a);     \
+    else     hipLaunchKernelGGL((gat_fwd_kernel<L, false>), grid, dim3(256), lds_bytes, s, a);    \
+  } while (0)
+  switch (lpe) {
+    case 64: STAG_GAT_LAUNCH(64); break;
+    case 32: STAG_GAT_LAUNCH(32); break;
+    case 16: STAG_GAT_LAUNCH(16); break;
+    case 8: STAG_GAT_LAUNCH(8); break;
+    default: STAG_GAT_LAUNCH(4); break;
+  }
+#undef STAG_GAT_LAUNCH
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }

@@ -39,6 +39,22 @@ def _explicit_spec(w, relu=False, in_norm=False):
     return s
 
 
+def _plan_struct(csrv, seg_len, tiles, nbytes, dev):
+    """ctypes stag_plan for csrv (None when planning is off), plus the tensors it points into."""
+    plan_t = csrv.plan(seg_len)
+    if plan_t is None:
+        return None, None
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev) if nbytes else None
+    counters = plan_t["counters"].get(tiles)
+    if counters is None:   # zero once; every completed launch leaves them zero again
+        counters = torch.zeros(max(plan_t["n_long"], 1) * tiles, dtype=torch.int32, device=dev)
+        plan_t["counters"][tiles] = counters
+    plan_c = _lib.Plan(plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"],
+                       _lib.ptr(plan_t["units"]), _lib.ptr(plan_t["long_rows"]),
+                       _lib.ptr(plan_t["long_seg_ptr"]), _lib.ptr(counters), _lib.ptr(ws), nbytes)
+    return plan_c, (ws, counters)
+
+
 def _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len, want_norm_scale=False,
              broadcast_x=False):
     """One stag_agg_fwd launch on csrv (a CsrView). x: [n_src, D] fp32 contiguous."""
@@ -46,21 +62,9 @@ def _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len, want_norm_
     out = torch.empty((csrv.n_dst, D), dtype=torch.float32, device=dev)
     ns = torch.empty((csrv.n_dst, D), dtype=torch.float32, device=dev) if want_norm_scale else None
     plan_t = csrv.plan(seg_len)
-    plan_c = None
-    ws = None
-    if plan_t is not None:
-        nbytes = _lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], D, int(spec.in_norm))
-        if nbytes:
-            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-        tiles = (D + 255) // 256
-        counters = plan_t["counters"].get(tiles)
-        if counters is None:   # zero once; every completed launch leaves them zero again
-            counters = torch.zeros(max(plan_t["n_long"], 1) * tiles, dtype=torch.int32, device=dev)
-            plan_t["counters"][tiles] = counters
-        plan_c = _lib.Plan(plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"],
-                           _lib.ptr(plan_t["units"]), _lib.ptr(plan_t["long_rows"]),
-                           _lib.ptr(plan_t["long_seg_ptr"]), _lib.ptr(counters), _lib.ptr(ws),
-                           nbytes)
+    nbytes = (_lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], D, int(spec.in_norm))
+              if plan_t is not None else 0)
+    plan_c, _keep = _plan_struct(csrv, seg_len, (D + 255) // 256, nbytes, dev)
     cs = csrv.struct()
     with torch.cuda.device(dev):
         rc = _lib.lib().stag_agg_fwd(
@@ -217,7 +221,7 @@ def segment_reduce(x, offsets, reduce="sum"):
 
 class _GatAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, el, er, ft, w, graph, noise, neg_slope, want_attn):
+    def forward(ctx, el, er, ft, w, graph, noise, neg_slope, want_attn, seg_len):
         el, er, ft = _f32c(el), _f32c(er), _f32c(ft)
         H, F = ft.shape[1], ft.shape[2]
         csrv = graph.csr
@@ -229,13 +233,27 @@ class _GatAggregate(torch.autograd.Function):
             spec = _explicit_spec(w)
         else:
             spec = _none_spec()
+        nscale = None
+        if spec.in_norm:
+            # row sums of the H-wide weights first (stag/layers.py:8-36), on the same kernel:
+            # aggregate a broadcast row of ones with the same noise, in-norm off
+            s2 = noise.spec()
+            s2.in_norm = 0
+            ones = torch.ones(1, H, dtype=torch.float32, device=dev)
+            sums, _ = _agg_raw(csrv, ones, H, s2, _lib.REDUCE_SUM, None, None, seg_len, broadcast_x=True)
+            deg = csrv.degrees.to(torch.float32).unsqueeze(1)
+            nscale = torch.where(sums != 0, deg / sums, torch.ones_like(sums)).contiguous()
         out = torch.empty((csrv.n_dst, H, F), dtype=torch.float32, device=dev)
         attn = torch.empty((csrv.n_edges, H), dtype=torch.float32, device=dev) if want_attn else None
+        plan_t = csrv.plan(seg_len)
+        nbytes = _lib.lib().stag_gat_workspace_bytes(plan_t["n_seg"], H, F) if plan_t is not None else 0
+        plan_c, _keep = _plan_struct(csrv, seg_len, 1, nbytes, dev)
         cs = csrv.struct()
         with torch.cuda.device(dev):
-            rc = _lib.lib().stag_gat_fwd(C.byref(cs), _lib.ptr(el), _lib.ptr(er), _lib.ptr(ft), H, F,
-                                         float(neg_slope), C.byref(spec), _lib.ptr(out),
-                                         _lib.ptr(attn), _lib.stream_of(dev))
+            rc = _lib.lib().stag_gat_fwd(C.byref(cs), C.byref(plan_c) if plan_c is not None else None,
+                                         _lib.ptr(el), _lib.ptr(er), _lib.ptr(ft), H, F,
+                                         float(neg_slope), C.byref(spec), _lib.ptr(nscale),
+                                         _lib.ptr(out), _lib.ptr(attn), _lib.stream_of(dev))
         _lib.check(rc, "stag_gat_fwd")
         ctx.mark_non_differentiable(*([attn] if attn is not None else []))
         return (out, attn) if want_attn else out
@@ -246,11 +264,12 @@ class _GatAggregate(torch.autograd.Function):
             "stag_gat_fwd has no backward kernel yet (DESIGN.md, 'next'): GAT is inference-only")
 
 
-def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False):
+def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False,
+                  seg_len=DEFAULT_SEG_LEN):
     """Fused noisy-logit edge softmax + aggregation (stag/zoo/gat.py:114-126).
     el: [N,H], er: [N,H], ft: [N,H,F]; weight: None | [E,H] tensor | EdgeNoise(dn=H)."""
     noise = weight if isinstance(weight, EdgeNoise) else None
     w = weight if torch.is_tensor(weight) else None
     if w is not None and w.shape[0] != graph.number_of_edges():
         raise AssertionError("edge_weight.shape[0] != number_of_edges")
-    return _GatAggregate.apply(el, er, ft, w, graph, noise, neg_slope, want_attn)
+    return _GatAggregate.apply(el, er, ft, w, graph, noise, neg_slope, want_attn, seg_len)

@@ -246,7 +246,7 @@ def test_segment_reduce(dev, oracle):
         assert_close(got, ref, what=f"segment {red}")
 
 
-@pytest.mark.parametrize("H,F", [(3, 4), (8, 32), (4, 5), (1, 64), (8, 64)])
+@pytest.mark.parametrize("H,F", [(3, 4), (8, 32), (4, 5), (1, 64), (4, 64), (2, 6)])
 @pytest.mark.parametrize("kind", ["none", "explicit", "normal", "bernoulli"])
 def test_gat_fwd_vs_oracle(dev, oracle, H, F, kind):
     from stag_amd import ops
@@ -273,3 +273,30 @@ def test_gat_fwd_vs_oracle(dev, oracle, H, F, kind):
     ref, ref_attn = oracle.gat_fwd(og, el, er, ft, 0.2, spec, want_attn=True)
     assert_close(out, ref, what=f"gat out {kind} H={H} F={F}")
     assert_close(attn, ref_attn, what=f"gat attn {kind}")
+
+
+def test_gat_hub_rows_and_seg_len(dev, oracle):
+    """13k-ish hub row: per-segment softmax states merged by the last arriver == one pass."""
+    from stag_amd import ops
+    rng = np.random.default_rng(2)
+    n, H, F = 400, 8, 32
+    g = random_graph(n, 6000, seed=21, hub=9000, device=dev)
+    og = oracle_graph(oracle, g)
+    el = (3 * rng.standard_normal((n, H))).astype(np.float32)     # spread logits: exercises the max shift
+    er = (3 * rng.standard_normal((n, H))).astype(np.float32)
+    ft = rng.standard_normal((n, H, F)).astype(np.float32)
+    w = _noise(g, H, "normal", 1.0, 0.5, seed=4, offset=1)
+    ref, ref_attn = oracle.gat_fwd(og, el, er, ft, 0.2, _ospec(oracle, g, H, "normal", 1.0, 0.5, seed=4, offset=1),
+                                   want_attn=True)
+    args = [torch.from_numpy(t).to(dev) for t in (el, er, ft)]
+    for sl in (64, 16, 1000, 0):
+        out, attn = ops.gat_aggregate(g, *args, 0.2, w, want_attn=True, seg_len=sl)
+        # one 9000-term fp32 sum (no plan) drifts past 1e-5; the default plan (64) must not
+        tol = TOL if 0 < sl <= 64 else 3 * TOL
+        assert_close(out, ref, tol=tol, what=f"gat hub seg_len={sl}")
+        assert_close(attn, ref_attn, what=f"gat hub attn seg_len={sl}")
+        out2 = ops.gat_aggregate(g, *args, 0.2, w, seg_len=sl)
+        assert torch.equal(out2, out), "attention output must not change the result"
+    with pytest.raises(Exception):
+        ops.gat_aggregate(g, torch.zeros(n, 8, device=dev), torch.zeros(n, 8, device=dev),
+                          torch.zeros(n, 8, 64, device=dev))        # H*F > 256: STAG_ENOSYS
