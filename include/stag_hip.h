@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 1
+#define STAG_ABI_VERSION 2
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -102,6 +102,11 @@ typedef struct stag_noise_spec {
   float p1_scalar;
   int32_t relu;    /* w <- max(w, 0)                        stag/layers.py:98-99   */
   int32_t in_norm; /* w <- w * indeg / sum_in(w) per dst    stag/layers.py:8-36    */
+  int32_t deriv;   /* 0: the weight w.  Backward of a reparameterised (`rsample`,
+                      stag/layers.py:123-124) NORMAL / UNIFORM draw: 1: dw/dp0, 2: dw/dp1
+                      (times 1[w > 0] under relu) — same counters, so the [E, Dn] noise is
+                      regenerated, never stored.  Requires in_norm == 0.                  */
+  int32_t reserved;
   uint64_t seed;
   uint64_t offset;
   int64_t pos_base; /* global CSR position of this shard's position 0 (multi-GPU) */
@@ -174,11 +179,15 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x,
 int stag_noise_materialize(const stag_csr* csr, const stag_noise_spec* spec,
                            int32_t Dn, float* w, int64_t ldw, void* stream);
 
-/* dw[eid, k] = sscale[u] * x[u, k] * g[v, k]  (g already carries dst scaling):
- * gradient of stag_agg_fwd w.r.t. an explicit / reparameterised edge weight.   */
+/* Gradient w.r.t. per-edge weights or per-edge distribution parameters:
+ *   dw[eid, k] = D[p, k] * sscale[u] * x[u, k] * g[v, k]      (g already carries dst scaling)
+ * D = 1 for an explicit weight (spec NULL or kind NONE/EXPLICIT); D = dw/dp0 | dw/dp1 of the
+ * regenerated draw when spec.deriv = 1 | 2 (AmortizedDistribution with vi=True).
+ * reduce_k != 0: dw is [E, 1] = sum over k (per-edge parameters of shape [E, 1]).       */
 int stag_agg_bwd_w(const stag_csr* csr, const float* x, int64_t ldx,
                    const float* g, int64_t ldg, int32_t D,
-                   const float* src_scale, float* dw, int64_t ldw, void* stream);
+                   const float* src_scale, const stag_noise_spec* spec, int32_t reduce_k,
+                   float* dw, int64_t ldw, void* stream);
 
 /* per-graph readout of a batched graph: out[b,:] = sum|mean of x[offsets[b]:offsets[b+1],:]
  * (dgl.sum_nodes / dgl.mean_nodes, stag/layers.py:165,177)                      */

@@ -31,8 +31,8 @@ class NoiseSpec(C.Structure):
     _fields_ = [("kind", C.c_int32), ("param_mode", C.c_int32),
                 ("p0", _f32p), ("p1", _f32p),
                 ("p0_scalar", C.c_float), ("p1_scalar", C.c_float),
-                ("relu", C.c_int32), ("in_norm", C.c_int32),
-                ("seed", C.c_uint64), ("offset", C.c_uint64), ("pos_base", C.c_int64)]
+                ("relu", C.c_int32), ("in_norm", C.c_int32), ("deriv", C.c_int32),
+                ("reserved", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64), ("pos_base", C.c_int64)]
 
 
 def build(force=False):
@@ -64,7 +64,8 @@ def lib():
                                                    C.c_int64, C.c_int32, C.POINTER(NoiseSpec),
                                                    _f32p, _f32p, _f32p, C.c_int64]
         _lib.stag_agg_bwd_w_cpu.argtypes = [C.POINTER(Csr), _f32p, C.c_int64, _f32p, C.c_int64,
-                                            C.c_int32, _f32p, _f32p, C.c_int64]
+                                            C.c_int32, _f32p, C.POINTER(NoiseSpec), C.c_int32,
+                                            _f32p, C.c_int64]
         _lib.stag_csr_build_cpu.argtypes = [_i32p, _i32p, C.c_int32, C.c_int32, C.c_int64,
                                             _i32p, _i32p, _i32p, _i32p, _i32p]
         _lib.stag_segment_reduce_cpu.argtypes = [_f32p, C.c_int64, C.c_int32, _i32p, C.c_int32,
@@ -147,12 +148,12 @@ def csr_build(src, dst, n_src, n_dst):
 
 
 def make_spec(kind="none", p0=None, p1=None, relu=False, in_norm=False, seed=0, offset=0,
-              pos_base=0, Dn=None, n_edges=None):
+              pos_base=0, Dn=None, n_edges=None, deriv=0):
     """Build a NoiseSpec; p0/p1 may be python floats or arrays ([Dn], [E,1], [E,Dn])."""
     k = KIND[kind] if isinstance(kind, str) else int(kind)
     keep = []
     s = NoiseSpec()
-    s.kind, s.relu, s.in_norm = k, int(relu), int(in_norm)
+    s.kind, s.relu, s.in_norm, s.deriv = k, int(relu), int(in_norm), int(deriv)
     s.seed, s.offset, s.pos_base = int(seed), int(offset), int(pos_base)
     s.param_mode = PARAM_SCALAR
 
@@ -244,13 +245,14 @@ def agg_ref_dataflow(g, coo_src, coo_dst, x, spec, bufs=None):
     return out
 
 
-def agg_bwd_w(g, x, grad, src_scale=None):
+def agg_bwd_w(g, x, grad, src_scale=None, spec=None, reduce_k=False):
     x, grad = _f32(x), _f32(grad)
     D = x.shape[1]
     ss = _f32(src_scale)
-    dw = np.zeros((g.n_edges, D), np.float32)
+    dw = np.zeros((g.n_edges, 1 if reduce_k else D), np.float32)
     _check(lib().stag_agg_bwd_w_cpu(C.byref(g.c), _p(x, _f32p), D, _p(grad, _f32p), D, D,
-                                    _p(ss, _f32p), _p(dw, _f32p), D), "agg_bwd_w")
+                                    _p(ss, _f32p), C.byref(spec) if spec is not None else None,
+                                    int(reduce_k), _p(dw, _f32p), dw.shape[1]), "agg_bwd_w")
     return dw
 
 

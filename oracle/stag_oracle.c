@@ -143,16 +143,23 @@ static void edge_weights4(const stag_csr* csr, const stag_noise_spec* s,
       int32_t k = k0 + j;
       if (k >= Dn) { w[j] = 0.0f; continue; }
       float a = param_at(s->p0, s->p0_scalar, s->param_mode, eid, k, Dn);
+      float d1 = 1.0f, d2 = t[j];                     /* dw/dp0, dw/dp1 */
       if (s->kind == STAG_NOISE_NORMAL) {
         float b = param_at(s->p1, s->p1_scalar, s->param_mode, eid, k, Dn);
         w[j] = fmaf(b, t[j], a);                      /* loc + scale * z */
       } else if (s->kind == STAG_NOISE_UNIFORM) {
         float b = param_at(s->p1, s->p1_scalar, s->param_mode, eid, k, Dn);
         w[j] = fmaf(b - a, t[j], a);                  /* low + (high-low) * u */
+        d1 = 1.0f - t[j];
       } else {
         w[j] = t[j] < a ? 1.0f : 0.0f;                /* Bernoulli(probs) */
       }
+      if (s->deriv) {                                 /* backward of rsample, stag/layers.py:123-124 */
+        float mask = (s->relu && !(w[j] > 0.0f)) ? 0.0f : 1.0f;
+        w[j] = (s->deriv == 1 ? d1 : d2) * mask;
+      }
     }
+    if (s->deriv) return;
   }
   if (s->relu)
     for (int j = 0; j < 4; ++j) w[j] = w[j] > 0.0f ? w[j] : 0.0f;
@@ -162,6 +169,9 @@ static int check_spec(const stag_noise_spec* s) {
   if (!s) return STAG_EINVAL;
   if (s->kind < STAG_NOISE_NONE || s->kind > STAG_NOISE_BERNOULLI) return STAG_EINVAL;
   if (s->kind == STAG_NOISE_EXPLICIT && !s->p0) return STAG_EINVAL;
+  if (s->deriv < 0 || s->deriv > 2) return STAG_EINVAL;
+  if (s->deriv != 0 && (s->in_norm || (s->kind != STAG_NOISE_NORMAL && s->kind != STAG_NOISE_UNIFORM)))
+    return STAG_EINVAL;
   if (s->kind >= STAG_NOISE_NORMAL) {
     if (s->param_mode < STAG_PARAM_SCALAR || s->param_mode > STAG_PARAM_PER_EDGE)
       return STAG_EINVAL;
@@ -313,17 +323,29 @@ int stag_agg_ref_dataflow_cpu(const stag_csr* csr, const int32_t* coo_src,
 /* ------------------------------------------------------------------------- */
 int stag_agg_bwd_w_cpu(const stag_csr* csr, const float* x, int64_t ldx,
                        const float* g, int64_t ldg, int32_t D,
-                       const float* src_scale, float* dw, int64_t ldw) {
+                       const float* src_scale, const stag_noise_spec* spec, int32_t reduce_k,
+                       float* dw, int64_t ldw) {
   if (!csr || !x || !g || !dw || D <= 0) return STAG_EINVAL;
+  const int use_d = spec && spec->kind >= STAG_NOISE_NORMAL && spec->deriv != 0;
+  int32_t nchunk = (D + 3) / 4;
 #pragma omp parallel for schedule(dynamic, 64)
   for (int32_t v = 0; v < csr->n_dst; ++v) {
     for (int32_t p = csr->indptr[v]; p < csr->indptr[v + 1]; ++p) {
       int64_t eid = csr->eid ? csr->eid[p] : p;
       int32_t u = csr->indices[p];
       double su = src_scale ? (double)src_scale[u] : 1.0;
-      for (int32_t k = 0; k < D; ++k)
-        dw[eid * ldw + k] =
-            (float)((double)x[(int64_t)u * ldx + k] * su * (double)g[(int64_t)v * ldg + k]);
+      double tot = 0.0;
+      for (int32_t c = 0; c < nchunk; ++c) {
+        float d[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (use_d) edge_weights4(csr, spec, p, c, D, d);
+        for (int j = 0; j < 4; ++j) {
+          int32_t k = 4 * c + j;
+          if (k >= D) break;
+          double val = (double)d[j] * (double)x[(int64_t)u * ldx + k] * su * (double)g[(int64_t)v * ldg + k];
+          if (reduce_k) tot += val; else dw[eid * ldw + k] = (float)val;
+        }
+      }
+      if (reduce_k) dw[eid * ldw] = (float)tot;
     }
   }
   return STAG_OK;

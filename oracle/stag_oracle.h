@@ -26,7 +26,8 @@ int stag_agg_ref_dataflow_cpu(const stag_csr* csr, const int32_t* coo_src,
                               float* m_buf, float* out, int64_t ldo);
 int stag_agg_bwd_w_cpu(const stag_csr* csr, const float* x, int64_t ldx,
                        const float* g, int64_t ldg, int32_t D,
-                       const float* src_scale, float* dw, int64_t ldw);
+                       const float* src_scale, const stag_noise_spec* spec, int32_t reduce_k,
+                       float* dw, int64_t ldw);
 int stag_csr_build_cpu(const int32_t* src, const int32_t* dst, int32_t n_src,
                        int32_t n_dst, int64_t E, int32_t* indptr, int32_t* indices,
                        int32_t* eid, int32_t* in_deg, int32_t* out_deg);

@@ -29,8 +29,8 @@ class Csr(C.Structure):
 class NoiseSpec(C.Structure):
     _fields_ = [("kind", C.c_int32), ("param_mode", C.c_int32), ("p0", _vp), ("p1", _vp),
                 ("p0_scalar", C.c_float), ("p1_scalar", C.c_float),
-                ("relu", C.c_int32), ("in_norm", C.c_int32),
-                ("seed", C.c_uint64), ("offset", C.c_uint64), ("pos_base", C.c_int64)]
+                ("relu", C.c_int32), ("in_norm", C.c_int32), ("deriv", C.c_int32),
+                ("reserved", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64), ("pos_base", C.c_int64)]
 
 
 class Plan(C.Structure):
@@ -86,14 +86,14 @@ def lib():
     l.stag_noise_materialize.argtypes = [C.POINTER(Csr), C.POINTER(NoiseSpec), C.c_int32, _vp,
                                          C.c_int64, _vp]
     l.stag_agg_bwd_w.argtypes = [C.POINTER(Csr), _vp, C.c_int64, _vp, C.c_int64, C.c_int32, _vp,
-                                 _vp, C.c_int64, _vp]
+                                 C.POINTER(NoiseSpec), C.c_int32, _vp, C.c_int64, _vp]
     l.stag_segment_reduce.argtypes = [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, C.c_int32, _vp,
                                       C.c_int64, _vp]
     l.stag_gat_workspace_bytes.restype = C.c_size_t
     l.stag_gat_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     l.stag_gat_fwd.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp, C.c_int32, C.c_int32,
                                C.c_float, C.POINTER(NoiseSpec), _vp, _vp, _vp, _vp]
-    if l.stag_abi_version() != 1:
+    if l.stag_abi_version() != 2:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     _lib = l
     return l

@@ -50,7 +50,7 @@ struct AggArgs {
   const float* p1;
   float p0s, p1s;
   int32_t pmode;   // STAG_PARAM_*
-  int32_t relu, in_norm;
+  int32_t relu, in_norm;   // relu: noise flags = relu | deriv << 1 (noise.hpp)
   PhiloxKey key;
   uint32_t pos_lo, pos_hi;   // lo32 / hi32 of the shard's global position base
   // scaling / reduce
@@ -269,7 +269,7 @@ struct AggTeam {
           w[0] = w[1] = w[2] = w[3] = 1.0f;
         } else if constexpr (KIND == kExplicit) {
           loadrow4(row_at(a.p0, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, w);
-          if (a.relu) {
+          if (a.relu & kFlagRelu) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) w[q] = fmaxf(w[q], 0.0f);
           }
@@ -285,7 +285,7 @@ struct AggTeam {
               if (a.p1) loadrow4(row_at(a.p1, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, pb);
             }
           }
-          draw4<KIND>(I.nn[j], c1, a.key, pa, pb, a.relu != 0, w);
+          draw4<KIND>(I.nn[j], c1, a.key, pa, pb, a.relu, w);
         }
         if (a.src_scale) {
           asm volatile("" ::: "memory");   // keep this a branch: as selects it costs 6 VALU ops per edge

@@ -23,6 +23,9 @@ int check_spec(const stag_noise_spec* s) {
   if (!s) return STAG_EINVAL;
   if (s->kind < STAG_NOISE_NONE || s->kind > STAG_NOISE_BERNOULLI) return STAG_EINVAL;
   if (s->kind == STAG_NOISE_EXPLICIT && !s->p0) return STAG_EINVAL;
+  if (s->deriv < 0 || s->deriv > 2) return STAG_EINVAL;
+  if (s->deriv != 0 && (s->in_norm || (s->kind != STAG_NOISE_NORMAL && s->kind != STAG_NOISE_UNIFORM)))
+    return STAG_EINVAL;   // only reparameterised draws have a derivative; in-norm is not differentiated here
   if (s->kind >= STAG_NOISE_NORMAL) {
     if (s->param_mode < STAG_PARAM_SCALAR || s->param_mode > STAG_PARAM_PER_EDGE) return STAG_EINVAL;
     if (s->param_mode != STAG_PARAM_SCALAR) {
@@ -71,7 +74,7 @@ struct NoiseArgs {
   const float* p0;
   const float* p1;
   float p0s, p1s;
-  int32_t pmode, relu, in_norm;
+  int32_t pmode, nflags, in_norm;   // nflags: relu | deriv << 1 (noise.hpp)
   PhiloxKey key;
   int64_t pos_base;
   float* w;
@@ -94,14 +97,14 @@ __device__ __forceinline__ void edge_w4(const NoiseArgs& a, int p, int64_t ed, u
   }
   const int64_t gpos = a.nidx ? (int64_t)a.nidx[p] : a.pos_base + p;
   switch (a.kind) {
-    case kNormal: draw4<kNormal>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.relu != 0, w); break;
-    case kUniform: draw4<kUniform>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.relu != 0, w); break;
-    case kBernoulli: draw4<kBernoulli>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.relu != 0, w); break;
+    case kNormal: draw4<kNormal>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.nflags, w); break;
+    case kUniform: draw4<kUniform>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.nflags, w); break;
+    case kBernoulli: draw4<kBernoulli>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.nflags, w); break;
     case kExplicit:
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float t = (k0 + j < a.Dn) ? a.p0[ed * a.Dn + k0 + j] : 0.f;
-        w[j] = a.relu ? fmaxf(t, 0.f) : t;
+        w[j] = (a.nflags & kFlagRelu) ? fmaxf(t, 0.f) : t;
       }
       break;
     default: w[0] = w[1] = w[2] = w[3] = 1.0f;
@@ -149,23 +152,62 @@ __global__ __launch_bounds__(256) void noise_materialize_kernel(const NoiseArgs 
   }
 }
 
-// dw[eid, k] = sscale[u] * x[u,k] * g[v,k]; one wave per row, 64 consecutive channels per step
-__global__ __launch_bounds__(256) void agg_bwd_w_kernel(const int32_t* indptr, const int32_t* indices,
-                                                        const int32_t* eid, int n_rows,
-                                                        const float* x, int64_t ldx, const float* g,
-                                                        int64_t ldg, int D, const float* src_scale,
-                                                        float* dw, int64_t ldw) {
+// dw[eid, k] = D[p,k] * sscale[u] * x[u,k] * g[v,k]   (stag_agg_bwd_w)
+// One wave per destination row; lanes = LPE chunk lanes x (64/LPE) edge slots, the channel
+// tiles are walked inside the team so that the optional reduction over k is one fixed-order sum.
+struct BwdWArgs {
+  NoiseArgs n;          // n.kind < kNormal or n.nflags >> 1 == 0  =>  D = 1
+  const int32_t* indices;
+  const float* x;
+  int64_t ldx;
+  const float* g;
+  int64_t ldg;
+  const float* src_scale;
+  int32_t reduce_k;
+};
+
+template <int LPE>
+__global__ __launch_bounds__(256) void agg_bwd_w_kernel(const BwdWArgs b) {
+  constexpr int EPT = 64 / LPE;
+  const NoiseArgs& a = b.n;
   const int lane = threadIdx.x & 63;
+  const int c = lane % LPE, ep = lane / LPE;
   const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (v >= n_rows) return;
-  const int b = indptr[v], e = indptr[v + 1];
-  for (int k = lane; k < D; k += 64) {
-    const float gv = g[(int64_t)v * ldg + k];
-    for (int p = b; p < e; ++p) {
-      const int u = indices[p];
-      const int64_t ed = eid ? eid[p] : p;
-      const float ss = src_scale ? src_scale[u] : 1.0f;
-      dw[ed * ldw + k] = ss * x[(int64_t)u * ldx + k] * gv;
+  if (v >= a.n_rows) return;
+  const int D = a.Dn;
+  const int nchunk = (D + 3) / 4;
+  const bool use_d = a.kind >= kNormal && (a.nflags >> kDerivShift) != 0;
+  const int rb = a.indptr[v], re = a.indptr[v + 1];
+  for (int p0 = rb; p0 < re; p0 += EPT) {
+    const int p = p0 + ep;
+    const bool live = p < re;
+    const int u = live ? b.indices[p] : 0;
+    const int64_t ed = live ? (a.eid ? a.eid[p] : p) : 0;
+    const float ss = (live && b.src_scale) ? b.src_scale[u] : 1.0f;
+    float tot = 0.f;
+    for (int tile = 0; tile * LPE < nchunk; ++tile) {
+      const uint32_t chunk = tile * LPE + c;
+      const int k0 = (int)chunk * 4;
+      float val[4] = {0.f, 0.f, 0.f, 0.f};
+      if (live && k0 < D) {
+        float dwt[4] = {1.f, 1.f, 1.f, 1.f};
+        if (use_d) edge_w4(a, p, ed, chunk, dwt);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (k0 + j < D)
+            val[j] = dwt[j] * (ss * b.x[(int64_t)u * b.ldx + k0 + j]) * b.g[(int64_t)v * b.ldg + k0 + j];
+        if (!b.reduce_k) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (k0 + j < D) a.w[ed * a.ldw + k0 + j] = val[j];
+        }
+      }
+      tot += (val[0] + val[1]) + (val[2] + val[3]);
+    }
+    if (b.reduce_k) {
+#pragma unroll
+      for (int m = 1; m < LPE; m <<= 1) tot += __shfl_xor(tot, m);
+      if (live && c == 0) a.w[ed * a.ldw] = tot;
     }
   }
 }
@@ -315,7 +357,7 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int
   }
   a.p0 = spec->p0; a.p1 = spec->p1; a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar;
   a.pmode = spec->kind >= STAG_NOISE_NORMAL ? spec->param_mode : 0;
-  a.relu = spec->relu; a.in_norm = spec->in_norm;
+  a.relu = (spec->relu ? kFlagRelu : 0) | (spec->deriv << kDerivShift); a.in_norm = spec->in_norm;
   a.key = make_key(spec);
   a.pos_lo = (uint32_t)((uint64_t)spec->pos_base & 0xFFFFFFFFull);
   a.pos_hi = (uint32_t)((uint64_t)spec->pos_base >> 32);
@@ -383,7 +425,7 @@ int stag_noise_materialize(const stag_csr* csr, const stag_noise_spec* spec, int
   a.Dn = Dn; a.kind = spec->kind; a.p0 = spec->p0; a.p1 = spec->p1;
   a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar;
   a.pmode = spec->kind >= STAG_NOISE_NORMAL ? spec->param_mode : 0;
-  a.relu = spec->relu; a.in_norm = spec->in_norm;
+  a.nflags = (spec->relu ? kFlagRelu : 0) | (spec->deriv << kDerivShift); a.in_norm = spec->in_norm;
   a.key = make_key(spec); a.pos_base = spec->pos_base; a.w = w; a.ldw = ldw;
   const int nchunk = (Dn + 3) / 4;
   int lpe = 1;
@@ -403,14 +445,40 @@ int stag_noise_materialize(const stag_csr* csr, const stag_noise_spec* spec, int
 }
 
 int stag_agg_bwd_w(const stag_csr* csr, const float* x, int64_t ldx, const float* g, int64_t ldg,
-                   int32_t D, const float* src_scale, float* dw, int64_t ldw, void* stream) {
+                   int32_t D, const float* src_scale, const stag_noise_spec* spec, int32_t reduce_k,
+                   float* dw, int64_t ldw, void* stream) {
   int rc = check_csr(csr);
   if (rc) return rc;
-  if (!x || !g || !dw || D <= 0 || (ldx != 0 && ldx < D) || ldg < D || ldw < D) return STAG_EINVAL;
+  if (spec) { rc = check_spec(spec); if (rc) return rc; }
+  if (!x || !g || !dw || D <= 0 || (ldx != 0 && ldx < D) || ldg < D) return STAG_EINVAL;
+  if (ldw < (reduce_k ? 1 : D)) return STAG_EINVAL;
   if (csr->n_dst == 0 || csr->n_edges == 0) return STAG_OK;
-  hipLaunchKernelGGL(agg_bwd_w_kernel, dim3((csr->n_dst + 3) / 4), dim3(256), 0,
-                     (hipStream_t)stream, csr->indptr, csr->indices, csr->eid, csr->n_dst, x, ldx,
-                     g, ldg, D, src_scale, dw, ldw);
+  BwdWArgs b{};
+  NoiseArgs& a = b.n;
+  a.indptr = csr->indptr; a.eid = csr->eid; a.nidx = csr->nidx; a.n_rows = csr->n_dst; a.Dn = D;
+  if (spec && spec->kind >= STAG_NOISE_NORMAL && spec->deriv != 0) {
+    a.kind = spec->kind; a.p0 = spec->p0; a.p1 = spec->p1;
+    a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar; a.pmode = spec->param_mode;
+    a.nflags = (spec->relu ? kFlagRelu : 0) | (spec->deriv << kDerivShift);
+    a.key = make_key(spec); a.pos_base = spec->pos_base;
+  }
+  a.w = dw; a.ldw = ldw;
+  b.indices = csr->indices; b.x = x; b.ldx = ldx; b.g = g; b.ldg = ldg; b.src_scale = src_scale;
+  b.reduce_k = reduce_k ? 1 : 0;
+  const int nchunk = (D + 3) / 4;
+  int lpe = 1;
+  while (lpe < nchunk && lpe < 64) lpe <<= 1;
+  const dim3 grid((csr->n_dst + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  switch (lpe) {
+    case 64: hipLaunchKernelGGL(agg_bwd_w_kernel<64>, grid, dim3(256), 0, s, b); break;
+    case 32: hipLaunchKernelGGL(agg_bwd_w_kernel<32>, grid, dim3(256), 0, s, b); break;
+    case 16: hipLaunchKernelGGL(agg_bwd_w_kernel<16>, grid, dim3(256), 0, s, b); break;
+    case 8: hipLaunchKernelGGL(agg_bwd_w_kernel<8>, grid, dim3(256), 0, s, b); break;
+    case 4: hipLaunchKernelGGL(agg_bwd_w_kernel<4>, grid, dim3(256), 0, s, b); break;
+    case 2: hipLaunchKernelGGL(agg_bwd_w_kernel<2>, grid, dim3(256), 0, s, b); break;
+    default: hipLaunchKernelGGL(agg_bwd_w_kernel<1>, grid, dim3(256), 0, s, b); break;
+  }
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }
 

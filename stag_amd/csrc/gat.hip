@@ -78,14 +78,14 @@ __device__ __forceinline__ void head_w4(const GatArgs& a, uint32_t n, int64_t ed
   }
   const uint32_t c1 = chunk | (a.pos_hi << 20);
   switch (a.kind) {
-    case kNormal: draw4<kNormal>(n, c1, a.key, pa, pb, a.relu != 0, w); break;
-    case kUniform: draw4<kUniform>(n, c1, a.key, pa, pb, a.relu != 0, w); break;
-    case kBernoulli: draw4<kBernoulli>(n, c1, a.key, pa, pb, a.relu != 0, w); break;
+    case kNormal: draw4<kNormal>(n, c1, a.key, pa, pb, a.relu, w); break;
+    case kUniform: draw4<kUniform>(n, c1, a.key, pa, pb, a.relu, w); break;
+    case kBernoulli: draw4<kBernoulli>(n, c1, a.key, pa, pb, a.relu, w); break;
     case kExplicit:
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float t = (h0 + j < a.H) ? a.p0[ed * a.H + h0 + j] : 0.f;
-        w[j] = a.relu ? fmaxf(t, 0.f) : t;
+        w[j] = (a.relu & kFlagRelu) ? fmaxf(t, 0.f) : t;
       }
       break;
     default: w[0] = w[1] = w[2] = w[3] = 1.0f;
@@ -356,7 +356,8 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
   a.neg_slope = neg_slope; a.kind = spec->kind; a.p0 = spec->p0; a.p1 = spec->p1;
   a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar;
   a.pmode = spec->kind >= STAG_NOISE_NORMAL ? spec->param_mode : 0;
-  a.relu = spec->relu;
+  a.relu = spec->relu ? kFlagRelu : 0;
+  if (spec->deriv != 0) return STAG_EINVAL;
   a.key.k0 = (uint32_t)(spec->seed & 0xFFFFFFFFull); a.key.k1 = (uint32_t)(spec->seed >> 32);
   a.key.o0 = (uint32_t)(spec->offset & 0xFFFFFFFFull); a.key.o1 = (uint32_t)(spec->offset >> 32);
   a.pos_lo = (uint32_t)((uint64_t)spec->pos_base & 0xFFFFFFFFull);

@@ -80,29 +80,47 @@ enum : int { kNone = 0, kExplicit = 1, kNormal = 2, kUniform = 3, kBernoulli = 4
 // The 4 draws of one (edge, chunk): a[j], b[j] are the two distribution parameters
 // of channel 4*chunk + j (loc/scale, low/high, probs/-).
 // (c0, c1) = Philox counter words 0 and 1: lo32(position), chunk | hi32(position) << 20.
+// flags (wave-uniform): bit 0 = relu; bits 1-2 = derivative selector for the backward pass of
+// a reparameterised draw (stag/layers.py:123-124, `rsample`): 0 -> w itself,
+// 1 -> dw/dp0 (loc | low), 2 -> dw/dp1 (scale | high), each times 1[w > 0] under relu.
+enum : int { kFlagRelu = 1, kDerivShift = 1 };
+
 template <int KIND>
 __device__ __forceinline__ void draw4(uint32_t c0, uint32_t c1, const PhiloxKey& key,
-                                      const float (&a)[4], const float (&b)[4], bool relu,
+                                      const float (&a)[4], const float (&b)[4], int flags,
                                       float (&w)[4]) {
   static_assert(KIND >= kNormal, "draw4 is for sampled noise");
   uint32_t r[4];
   philox4x32_10(c0, c1, key, r);
+  float t[4];   // the parameter-free draw: z ~ N(0,1) or u ~ U[0,1)
   if constexpr (KIND == kNormal) {
-    float z[4];
-    box_muller(r[0], r[1], z[0], z[1]);
-    box_muller(r[2], r[3], z[2], z[3]);
+    box_muller(r[0], r[1], t[0], t[1]);
+    box_muller(r[2], r[3], t[2], t[3]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = __builtin_fmaf(b[j], z[j], a[j]);
+    for (int j = 0; j < 4; ++j) w[j] = __builtin_fmaf(b[j], t[j], a[j]);
   } else if constexpr (KIND == kUniform) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = __builtin_fmaf(b[j] - a[j], u01(r[j]), a[j]);
+    for (int j = 0; j < 4; ++j) { t[j] = u01(r[j]); w[j] = __builtin_fmaf(b[j] - a[j], t[j], a[j]); }
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) w[j] = u01(r[j]) < a[j] ? 1.0f : 0.0f;
   }
-  if (relu) {
+  if (flags == 0) return;
+  const int deriv = flags >> kDerivShift;
+  if (deriv == 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) w[j] = fmaxf(w[j], 0.0f);
+    return;
+  }
+  if constexpr (KIND != kBernoulli) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float mask = ((flags & kFlagRelu) && !(w[j] > 0.0f)) ? 0.0f : 1.0f;
+      float d;
+      if constexpr (KIND == kNormal) d = (deriv == 1) ? 1.0f : t[j];           // w = loc + scale z
+      else d = (deriv == 1) ? 1.0f - t[j] : t[j];                             // w = low + (high-low) u
+      w[j] = d * mask;
+    }
   }
 }
 

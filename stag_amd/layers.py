@@ -111,6 +111,14 @@ class StagLayer(torch.nn.Module):
             return EdgeNoise.from_distribution(
                 graph, sample_dimension, dist, relu=self.relu, in_norm=self.norm,
                 seed=gen.seed, offset=gen.next_offset())
+        reparam = type(dist) in (torch.distributions.Normal, torch.distributions.Uniform)
+        if (fused_ok and self.vi and reparam and not self.norm
+                and getattr(self.base_layer, "supports_edge_noise_grad", False)):
+            # vi=True on the fused path: the descriptor keeps the live loc / scale tensors and
+            # ops.aggregate returns their gradients by regenerating the noise in the backward
+            return EdgeNoise.from_distribution(
+                graph, sample_dimension, dist, relu=self.relu, differentiable=True,
+                seed=gen.seed, offset=gen.next_offset())
         if fusable(dist) and self.vi and type(dist) in (torch.distributions.Normal,
                                                        torch.distributions.Uniform):
             # reparameterised draw: standard noise from the HIP stream, affine map in

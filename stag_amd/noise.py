@@ -40,8 +40,14 @@ def _param_mode(p, n_edges, dn):
 
 class EdgeNoise:
     def __init__(self, graph, dn, kind, p0, p1=None, relu=False, in_norm=False, seed=0, offset=0,
-                 pos_base=0):
+                 pos_base=0, differentiable=False):
         self.graph, self.dn, self.kind = graph, int(dn), int(kind)
+        # vi=True: keep the live parameter tensors so ops.aggregate can return their gradients
+        # (reparameterised draw; the backward regenerates the noise with spec.deriv = 1 | 2)
+        self.grad_params = None
+        if differentiable and kind in (_lib.NOISE_NORMAL, _lib.NOISE_UNIFORM):
+            self.grad_params = (p0, p1)
+        self.deriv = 0
         self.relu, self.in_norm = bool(relu), bool(in_norm)
         self.seed, self.offset, self.pos_base = int(seed), int(offset), int(pos_base)
         E = graph.number_of_edges()
@@ -86,7 +92,7 @@ class EdgeNoise:
         s.kind, s.param_mode = self.kind, self.param_mode
         s.p0, s.p1 = _lib.ptr(self.p0), _lib.ptr(self.p1)
         s.p0_scalar, s.p1_scalar = self.p0_scalar, self.p1_scalar
-        s.relu, s.in_norm = int(self.relu), int(self.in_norm)
+        s.relu, s.in_norm, s.deriv = int(self.relu), int(self.in_norm), int(self.deriv)
         s.seed, s.offset, s.pos_base = self.seed, self.offset, self.pos_base
         return s
 

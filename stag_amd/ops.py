@@ -75,14 +75,16 @@ def _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len, want_norm_
     return out, ns
 
 
-def _bwd_w_raw(csrv, x, g, D, src_scale, broadcast_x=False):
+def _bwd_w_raw(csrv, x, g, D, src_scale, broadcast_x=False, spec=None, reduce_k=False):
     dev = _lib.require_device(x, g)
-    dw = torch.empty((csrv.n_edges, D), dtype=torch.float32, device=dev)
+    cols = 1 if reduce_k else D
+    dw = torch.empty((csrv.n_edges, cols), dtype=torch.float32, device=dev)
     cs = csrv.struct()
     with torch.cuda.device(dev):
         rc = _lib.lib().stag_agg_bwd_w(C.byref(cs), _lib.ptr(x), 0 if broadcast_x else x.stride(0),
                                        _lib.ptr(g), g.stride(0), D, _lib.ptr(src_scale),
-                                       _lib.ptr(dw), D, _lib.stream_of(dev))
+                                       C.byref(spec) if spec is not None else None, int(reduce_k),
+                                       _lib.ptr(dw), cols, _lib.stream_of(dev))
     _lib.check(rc, "stag_agg_bwd_w")
     return dw
 
@@ -143,6 +145,68 @@ class _Aggregate(torch.autograd.Function):
         return dx, dw, None, None, None, None, None, None, None
 
 
+class _AggregateVI(torch.autograd.Function):
+    """Fused aggregation whose noise parameters carry gradients (`vi=True`, reparameterised
+    draw w = p0 + p1 * z | low + (high-low) u; stag/layers.py:123-124).  Nothing [E, D]-sized
+    is saved: the backward redraws z from the counters with spec.deriv = 1 | 2."""
+
+    @staticmethod
+    def forward(ctx, x, p0, p1, graph, noise, reduce, src_scale, dst_scale, seg_len):
+        x = _f32c(x)
+        D = x.shape[1]
+        spec = noise.spec()
+        out, _ = _agg_raw(graph.csr, x, D, spec, reduce, src_scale, dst_scale, seg_len)
+        ctx.graph, ctx.noise, ctx.reduce, ctx.seg_len, ctx.D = graph, noise, reduce, seg_len, D
+        ctx.shapes = (p0.shape, p1.shape)
+        ctx.save_for_backward(x, src_scale, dst_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, src_scale, dst_scale = ctx.saved_tensors
+        graph, noise, D = ctx.graph, ctx.noise, ctx.D
+        g = _f32c(grad_out)
+        dvec = dst_scale
+        if ctx.reduce == _lib.REDUCE_MEAN:
+            inv = 1.0 / graph.csr.degrees.clamp(min=1).to(torch.float32)
+            dvec = inv if dvec is None else dvec * inv
+        dx = dp0 = dp1 = None
+
+        def transposed(deriv):
+            if deriv == 1 and not noise.relu and noise.kind == _lib.NOISE_NORMAL:
+                spec = _none_spec()              # dw/dloc == 1 everywhere: a noise-free pass
+            else:
+                noise.deriv = deriv
+                spec = noise.spec()
+                noise.deriv = 0
+            return _agg_raw(graph.csr_t, g, D, spec, _lib.REDUCE_SUM, dvec, src_scale, ctx.seg_len)[0]
+
+        if ctx.needs_input_grad[0]:
+            dx = transposed(0)
+        per_edge = noise.param_mode >= _lib.PARAM_PER_EDGE1
+        gg = None
+        for which, need in ((1, ctx.needs_input_grad[1]), (2, ctx.needs_input_grad[2])):
+            if not need:
+                continue
+            if per_edge:
+                if gg is None:
+                    gg = (g if dvec is None else g * dvec.unsqueeze(1)).contiguous()
+                noise.deriv = which
+                d = _bwd_w_raw(graph.csr, x, gg, D, src_scale, spec=noise.spec(),
+                               reduce_k=noise.param_mode == _lib.PARAM_PER_EDGE1)
+                noise.deriv = 0
+            else:
+                # sum_e D[e,k] * s_u x[u,k] * g'[v,k]  =  sum_u x[u,k] * (A_D^T g')[u,k]
+                d = (x * transposed(which)).sum(0)
+            shape = ctx.shapes[which - 1]
+            d = d.sum_to_size(shape) if d.dim() >= len(shape) and shape != d.shape else d.reshape(shape)
+            if which == 1:
+                dp0 = d
+            else:
+                dp1 = d
+        return dx, dp0, dp1, None, None, None, None, None, None
+
+
 def aggregate(graph, x, weight=None, reduce="sum", src_scale=None, dst_scale=None,
               seg_len=DEFAULT_SEG_LEN, _broadcast_x=False):
     """out[v,:] = dscale[v] * sum|mean_{e=(u->v)} w[e,:] * sscale[u] * x[u,:]
@@ -163,6 +227,14 @@ def aggregate(graph, x, weight=None, reduce="sum", src_scale=None, dst_scale=Non
             w = w.expand(w.shape[0], D)
     if noise is not None and noise.dn != D:
         raise ValueError(f"noise width {noise.dn} != feature width {D}")
+    if noise is not None and noise.grad_params is not None and torch.is_grad_enabled():
+        p0, p1 = (torch.as_tensor(p, dtype=torch.float32, device=x.device) for p in noise.grad_params)
+        if p0.requires_grad or p1.requires_grad:
+            if noise.in_norm:
+                raise ValueError("in-norm is not differentiated on the fused path; "
+                                 "StagLayer materialises the weights for vi=True with norm=True")
+            return _AggregateVI.apply(x, p0, p1, graph, noise, _REDUCE[reduce], _f32c(src_scale),
+                                      _f32c(dst_scale), seg_len)
     return _Aggregate.apply(x, w, graph, noise, _REDUCE[reduce], _f32c(src_scale),
                             _f32c(dst_scale), seg_len, _broadcast_x)
 

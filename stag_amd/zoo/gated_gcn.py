@@ -9,6 +9,7 @@ from ._common import check_edge_weight
 
 class GatedGCN(torch.nn.Module):
     supports_edge_noise = True
+    supports_edge_noise_grad = True   # vi=True stays fused (ops._AggregateVI)
 
     def __init__(self, input_dim, output_dim, dropout=0.0, batch_norm=True, residual=False):
         super().__init__()

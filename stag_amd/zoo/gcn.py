@@ -17,6 +17,7 @@ from ._common import DGLError, check_edge_weight, degree_scale, expand_as_pair
 
 class GCN(torch.nn.Module):
     supports_edge_noise = True
+    supports_edge_noise_grad = True   # vi=True stays fused (ops._AggregateVI)
 
     def __init__(self, in_feats, out_feats, norm="both", weight=True, bias=True, activation=None,
                  allow_zero_in_degree=False):

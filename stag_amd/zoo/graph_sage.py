@@ -10,6 +10,7 @@ from ._common import check_edge_weight
 
 class GraphSAGE(torch.nn.Module):
     supports_edge_noise = True
+    supports_edge_noise_grad = True   # vi=True stays fused (ops._AggregateVI)
 
     def __init__(self, in_features, out_features, activation=None, aggregator_type="mean",
                  feat_drop=0.0, bias=True, norm=None):

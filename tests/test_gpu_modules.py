@@ -246,3 +246,75 @@ def test_full_size_properties(dev):
     out.backward(y)
     lhs, rhs = float((out.detach().double() * y.double()).sum()), float((x.double() * xr.grad.double()).sum())
     assert abs(lhs - rhs) <= 1e-5 * (abs(lhs) + abs(rhs))
+
+
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("pmode", ["scalar", "per_channel", "per_edge1", "per_edge"])
+@pytest.mark.parametrize("kind", ["normal", "uniform"])
+def test_fused_vi_gradients(dev, oracle, kind, pmode, relu):
+    """vi=True on the fused path: gradients w.r.t. x and the distribution parameters equal those
+    of the materialised reparameterisation w = p0 + p1 * z (the reference's rsample path), with
+    nothing [E, D]-sized saved for the backward."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    from util import random_graph
+    rng = np.random.default_rng(7)
+    n, D = 150, 12
+    g = random_graph(n, 1100, seed=31, hub=160, device=dev)
+    E = g.number_of_edges()
+    shape = {"scalar": (), "per_channel": (D,), "per_edge1": (E, 1), "per_edge": (E, D)}[pmode]
+    a0 = torch.tensor(rng.uniform(0.5, 1.0, shape).astype(np.float32), device=dev)
+    b0 = torch.tensor(rng.uniform(0.3, 0.8, shape).astype(np.float32), device=dev)
+    if kind == "uniform":
+        b0 = a0 + b0 + 0.5          # high > low
+    x0 = torch.tensor(rng.standard_normal((n, D)).astype(np.float32), device=dev)
+    gout = torch.tensor(rng.standard_normal((n, D)).astype(np.float32), device=dev)
+    ss = torch.tensor(rng.uniform(0.5, 1.5, n).astype(np.float32), device=dev)
+    ds = torch.tensor(rng.uniform(0.5, 1.5, n).astype(np.float32), device=dev)
+    K = _lib.NOISE_NORMAL if kind == "normal" else _lib.NOISE_UNIFORM
+    shift = -0.9 if relu else 0.0   # push a good share of the weights below zero under relu
+
+    # fused
+    x, a, b = (t.clone().requires_grad_(True) for t in (x0, a0, b0))
+    noise = stag_amd.EdgeNoise(g, D, K, a + shift, b, relu=relu, seed=5, offset=2, differentiable=True)
+    out = ops.aggregate(g, x, noise, reduce="mean", src_scale=ss, dst_scale=ds, seg_len=32)
+    out.backward(gout)
+    # materialised reparameterisation with the same standard draw
+    std = stag_amd.EdgeNoise(g, D, K, 0.0, 1.0, seed=5, offset=2).materialize()
+    x2, a2, b2 = (t.clone().requires_grad_(True) for t in (x0, a0, b0))
+    w = (a2 + shift) + b2 * std if kind == "normal" else (a2 + shift) + (b2 - (a2 + shift)) * std
+    if relu:
+        w = w.relu()
+    out2 = ops.aggregate(g, x2, w.expand(E, D), reduce="mean", src_scale=ss, dst_scale=ds, seg_len=32)
+    out2.backward(gout)
+    assert_close(out, out2.detach().cpu().numpy(), what="forward")
+    assert_close(x.grad, x2.grad.cpu().numpy(), tol=2e-5, what="dx")
+    assert_close(a.grad, a2.grad.cpu().numpy(), tol=5e-5, what=f"d p0 {pmode}")
+    assert_close(b.grad, b2.grad.cpu().numpy(), tol=5e-5, what=f"d p1 {pmode}")
+    # and against the oracle's statement of dw/dp (per-edge modes)
+    if pmode == "per_edge":
+        og = oracle_graph(oracle, g)
+        gs = (gout * ds.unsqueeze(1) / g.in_degrees().clamp(min=1).unsqueeze(1)).cpu().numpy()
+        spec = oracle.make_spec(kind, (a0 + shift).cpu().numpy(), b0.cpu().numpy(), relu=relu, seed=5, offset=2,
+                                Dn=D, n_edges=E, deriv=2)
+        ref = oracle.agg_bwd_w(og, x0.cpu().numpy(), gs, src_scale=ss.cpu().numpy(), spec=spec)
+        assert_close(b.grad, ref, tol=5e-5, what="d p1 vs oracle")
+
+
+def test_vi_layer_trains_fused(dev):
+    """StagLayer(vi=True) on GCN keeps the EdgeNoise descriptor (no [E, D] tensor) and its
+    q_a parameters receive gradients; KL uses the closed form."""
+    import stag_amd
+    from util import random_graph
+    g = random_graph(200, 2000, seed=3, device=dev)
+    x = torch.randn(200, 16, device=dev)
+    layer = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(16, 8), q_a=torch.distributions.Normal(1.0, 0.4), vi=True).to(dev)
+    out = layer(g, x)
+    assert isinstance(layer._edge_weight_handle, stag_amd.EdgeNoise)
+    (out.square().mean() + layer.kl_divergence()).backward()
+    assert layer.q_a.loc.grad is not None and layer.q_a.log_scale.grad is not None
+    assert float(layer.q_a.log_scale.grad.abs()) > 0
+    rc = stag_amd.layers.StagLayer(stag_amd.zoo.GraphSAGE(16, 8), relu=True, vi=True,
+                                   q_a=torch.distributions.Normal(torch.ones(16), 0.5 * torch.ones(16))).to(dev)
+    rc(g, x).sum().backward()
+    assert rc.q_a.loc.grad.shape == (16,) and rc.q_a.log_scale.grad.shape == (16,)
