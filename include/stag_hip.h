@@ -106,7 +106,8 @@ typedef struct stag_noise_spec {
                       stag/layers.py:123-124) NORMAL / UNIFORM draw: 1: dw/dp0, 2: dw/dp1
                       (times 1[w > 0] under relu) — same counters, so the [E, Dn] noise is
                       regenerated, never stored.  Requires in_norm == 0.                  */
-  int32_t reserved;
+  int32_t group;   /* EXPLICIT only: channels sharing one weight column, p0 = w[E, D/group]
+                      (GAT: a[e,h] over the F features of head h); 0 or 1 = one per channel */
   uint64_t seed;
   uint64_t offset;
   int64_t pos_base; /* global CSR position of this shard's position 0 (multi-GPU) */
@@ -209,6 +210,18 @@ int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const float* el, co
                  const float* ft, int32_t H, int32_t F, float neg_slope,
                  const stag_noise_spec* spec, const float* norm_scale, float* out,
                  float* attn_out, void* stream);
+
+/* Per-edge part of the GAT backward (the rest is stag_agg_fwd on the transposed CSR):
+ *   da = <g[v,h,:], ft[u,h,:]>,  ds = a * (da - gdo[v,h]),  gdo[v,h] = <g[v,h,:], out[v,h,:]>
+ *   de[eid,h] = ds * w * lrelu'(el[u,h] + er[v,h])      sum over in-edges -> d er, over out-edges -> d el
+ *   dw[eid,h] = ds * lrelu(...) * norm_scale            (NULL: not wanted)
+ * d ft[u,h,:] = sum_{out-edges} a[e,h] * g[v,h,:]  is stag_agg_fwd on the transposed CSR with
+ * EXPLICIT weights a[E,H] and spec.group = F.  Requires F % 4 == 0, F/4 a power of two.  */
+int stag_gat_bwd_edge(const stag_csr* csr, const stag_plan* plan, const float* el,
+                      const float* er, const float* ft, const float* attn, const float* g,
+                      const float* gdo, int32_t H, int32_t F, float neg_slope,
+                      const stag_noise_spec* spec, const float* norm_scale, float* de, float* dw,
+                      void* stream);
 
 #ifdef __cplusplus
 }

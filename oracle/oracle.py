@@ -32,7 +32,7 @@ class NoiseSpec(C.Structure):
                 ("p0", _f32p), ("p1", _f32p),
                 ("p0_scalar", C.c_float), ("p1_scalar", C.c_float),
                 ("relu", C.c_int32), ("in_norm", C.c_int32), ("deriv", C.c_int32),
-                ("reserved", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64), ("pos_base", C.c_int64)]
+                ("group", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64), ("pos_base", C.c_int64)]
 
 
 def build(force=False):

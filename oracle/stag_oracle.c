@@ -131,8 +131,9 @@ static void edge_weights4(const stag_csr* csr, const stag_noise_spec* s,
   if (s->kind == STAG_NOISE_NONE) {
     for (int j = 0; j < 4; ++j) w[j] = 1.0f;
   } else if (s->kind == STAG_NOISE_EXPLICIT) {
+    int32_t grp = s->group > 1 ? s->group : 1;   /* one weight per `grp` channels */
     for (int j = 0; j < 4; ++j)
-      w[j] = (k0 + j < Dn) ? s->p0[eid * (int64_t)Dn + k0 + j] : 0.0f;
+      w[j] = (k0 + j < Dn) ? s->p0[eid * (int64_t)(Dn / grp) + (k0 + j) / grp] : 0.0f;
   } else {
     int64_t gpos = csr->nidx ? (int64_t)csr->nidx[p] : s->pos_base + p;
     uint32_t r[4];

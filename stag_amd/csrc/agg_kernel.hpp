@@ -51,6 +51,7 @@ struct AggArgs {
   float p0s, p1s;
   int32_t pmode;   // STAG_PARAM_*
   int32_t relu, in_norm;   // relu: noise flags = relu | deriv << 1 (noise.hpp)
+  int32_t wgroup;          // EXPLICIT: channels sharing one weight column (<= 1: one per channel)
   PhiloxKey key;
   uint32_t pos_lo, pos_hi;   // lo32 / hi32 of the shard's global position base
   // scaling / reduce
@@ -268,7 +269,13 @@ struct AggTeam {
         if constexpr (KIND == kNone) {
           w[0] = w[1] = w[2] = w[3] = 1.0f;
         } else if constexpr (KIND == kExplicit) {
-          loadrow4(row_at(a.p0, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, w);
+          if (a.wgroup > 1) {   // one weight per `wgroup` channels (GAT heads: a[e,h] over F)
+            const float* wr = a.p0 + (int64_t)I.ee[j] * (a.D / a.wgroup);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = (k0 + q < a.D) ? wr[(k0 + q) / a.wgroup] : 0.0f;
+          } else {
+            loadrow4(row_at(a.p0, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, w);
+          }
           if (a.relu & kFlagRelu) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) w[q] = fmaxf(w[q], 0.0f);

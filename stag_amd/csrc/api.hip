@@ -349,7 +349,7 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int
   {
     // 32-bit byte offsets + 24-bit multiplies when everything fits, else 64-bit addressing
     const uint64_t xbytes = (uint64_t)csr->n_src * (uint64_t)ldx * 4u;
-    const uint64_t wbytes = (uint64_t)csr->n_edges * (uint64_t)D * 4u;
+    const uint64_t wbytes = (uint64_t)csr->n_edges * (uint64_t)D * 4u;   // (upper bound when grouped)
     const bool x_narrow = xbytes < (1ull << 32) && csr->n_src < (1 << 24) && (uint64_t)ldx * 4u < (1u << 24);
     const bool w_narrow = wbytes < (1ull << 32) && csr->n_edges < (1 << 24) && (uint64_t)D * 4u < (1u << 24);
     a.wide = (x_narrow ? 0 : 1) | (w_narrow ? 0 : 2);
@@ -358,6 +358,8 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int
   a.p0 = spec->p0; a.p1 = spec->p1; a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar;
   a.pmode = spec->kind >= STAG_NOISE_NORMAL ? spec->param_mode : 0;
   a.relu = (spec->relu ? kFlagRelu : 0) | (spec->deriv << kDerivShift); a.in_norm = spec->in_norm;
+  a.wgroup = (spec->kind == STAG_NOISE_EXPLICIT && spec->group > 1) ? spec->group : 1;
+  if (a.wgroup > 1 && (D % a.wgroup != 0 || spec->in_norm)) return STAG_EINVAL;
   a.key = make_key(spec);
   a.pos_lo = (uint32_t)((uint64_t)spec->pos_base & 0xFFFFFFFFull);
   a.pos_hi = (uint32_t)((uint64_t)spec->pos_base >> 32);

@@ -321,6 +321,108 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatArgs a) {
   }
 }
 
+// ---- backward, per-edge part ---------------------------------------------------------------
+// Given G = dL/dout[v,h,:] and gdo[v,h] = <G[v,h,:], out[v,h,:]>:
+//     da[p,h] = <G[v,h,:], ft[u_p,h,:]>
+//     ds[p,h] = a[p,h] * (da[p,h] - gdo[v,h])                      softmax backward
+//     de[p,h] = ds[p,h] * w[p,h] * lrelu'(el[u_p,h] + er[v,h])     -> d el / d er by segment sums
+//     dw[p,h] = ds[p,h] * lrelu(el[u_p,h] + er[v,h]) * nscale      (explicit / materialised w)
+// Edges are independent, so segments need no merge.  Phase 1 (edge-parallel) regenerates the
+// weights and parks a, w*lrelu', lrelu in LDS; phase 2 (channel-parallel) gathers ft rows,
+// takes the dot with G, reduces it over the F/4 lanes of a head and lets the head's first
+// lane write.  Requires F % 4 == 0 and F/4 a power of two.
+struct GatBwdArgs {
+  GatArgs f;
+  const float* g;      // [n_rows, H*F]
+  const float* gdo;    // [n_rows, H]
+  float* de;           // [E, H] by edge id
+  float* dw;           // [E, H] by edge id, or null
+};
+
+template <int LPE>
+__global__ __launch_bounds__(256) void gat_bwd_edge_kernel(const GatBwdArgs ba) {
+  extern __shared__ __align__(16) float lds[];
+  const GatArgs& a = ba.f;
+  constexpr int TEAMS_PER_BLOCK = 256 / LPE;
+  const int H = a.H, F = a.F, HF = a.HF;
+  const int team = threadIdx.x / LPE;
+  const int c = threadIdx.x % LPE;
+  const int team_lane0 = (int)(threadIdx.x & 63) - c;
+  float* sa = lds + (size_t)team * (3 * LPE * H);   // [LPE][H] attention
+  float* sc1 = sa + LPE * H;                         // [LPE][H] w * nscale * lrelu'
+  float* sc2 = sc1 + LPE * H;                        // [LPE][H] lrelu * nscale
+  const int unit = blockIdx.x * TEAMS_PER_BLOCK + team;
+  if (unit >= a.n_units) return;
+
+  int v, b, len, slot = -1;
+  if (a.units) {
+    const int4 q = *reinterpret_cast<const int4*>(a.units + unit);
+    v = q.x; b = q.y; len = q.z; slot = q.w;
+  } else {
+    v = unit;
+    b = a.indptr[v];
+    len = a.indptr[v + 1] - b;
+  }
+  const int row = (slot >= 0) ? a.long_rows[v] : v;
+  const int k0 = c * 4;
+  const bool kin = k0 < HF;
+  const int hl = kin ? k0 / F : 0;
+  const int nchunk = (H + 3) / 4;
+  const int lanes_per_head = F / 4;
+
+  float gv[4] = {0.f, 0.f, 0.f, 0.f};
+  float gdo = 0.f;
+  if (kin) {
+    load4(ba.g + (int64_t)row * HF, k0, HF, true, gv);
+    gdo = ba.gdo[(int64_t)row * H + hl];
+  }
+
+  for (int i0 = 0; i0 < len; i0 += LPE) {
+    const int nb = min(LPE, len - i0);
+    wave_sync();
+    int u = 0, edl = 0;
+    if (c < nb) {
+      const int p = b + i0 + c;
+      u = a.indices[p];
+      const int64_t ed = a.eid ? a.eid[p] : p;
+      edl = (int)ed;
+      const uint32_t n = a.nidx ? (uint32_t)a.nidx[p] : a.pos_lo + (uint32_t)p;
+      for (int cc = 0; cc < nchunk; ++cc) {
+        float w[4];
+        head_w4(a, n, ed, (uint32_t)cc, w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int h = 4 * cc + j;
+          if (h < H) {
+            const float e = a.el[(int64_t)u * H + h] + a.er[(int64_t)row * H + h];
+            const float ns = a.nscale ? a.nscale[(int64_t)row * H + h] : 1.0f;
+            sa[c * H + h] = a.attn[ed * H + h];
+            sc1[c * H + h] = (w[j] * ns) * (e > 0.f ? 1.0f : a.neg_slope);
+            sc2[c * H + h] = (e > 0.f ? e : a.neg_slope * e) * ns;
+          }
+        }
+      }
+    }
+    wave_sync();
+    for (int i = 0; i < nb; ++i) {
+      const int ui = __builtin_amdgcn_ds_bpermute((team_lane0 + i) << 2, u);
+      const int ei = __builtin_amdgcn_ds_bpermute((team_lane0 + i) << 2, edl);
+      float dot = 0.f;
+      if (kin) {
+        float fv[4];
+        load4(a.ft + (int64_t)ui * HF, k0, HF, true, fv);
+        dot = (gv[0] * fv[0] + gv[1] * fv[1]) + (gv[2] * fv[2] + gv[3] * fv[3]);
+      }
+      for (int m = 1; m < lanes_per_head; m <<= 1) dot += __shfl_xor(dot, m);
+      if (kin && (k0 % F) == 0) {
+        const float ds = sa[i * H + hl] * (dot - gdo);
+        ba.de[(int64_t)ei * H + hl] = ds * sc1[i * H + hl];
+        if (ba.dw) ba.dw[(int64_t)ei * H + hl] = ds * sc2[i * H + hl];
+      }
+    }
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
@@ -413,5 +515,60 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
     default: STAG_GAT_LAUNCH(4); break;
   }
 #undef STAG_GAT_LAUNCH
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}
+
+extern "C" int stag_gat_bwd_edge(const stag_csr* csr, const stag_plan* plan, const float* el,
+                                 const float* er, const float* ft, const float* attn, const float* g,
+                                 const float* gdo, int32_t H, int32_t F, float neg_slope,
+                                 const stag_noise_spec* spec, const float* norm_scale, float* de,
+                                 float* dw, void* stream) {
+  if (!csr || !csr->indptr || csr->n_dst < 0 || csr->n_edges < 0) return STAG_EINVAL;
+  if (!spec || spec->kind < STAG_NOISE_NONE || spec->kind > STAG_NOISE_BERNOULLI || spec->deriv) return STAG_EINVAL;
+  if (!de || H <= 0 || F <= 0) return STAG_EINVAL;
+  const int64_t HF64 = (int64_t)H * F;
+  const int lph = F / 4;
+  if (H > 64 || HF64 > 256 || F % 4 != 0 || (lph & (lph - 1)) != 0) return STAG_ENOSYS;
+  if (spec->in_norm && !norm_scale) return STAG_EINVAL;
+  if (csr->n_dst == 0 || csr->n_edges == 0) return STAG_OK;
+  if (!csr->indices || !el || !er || !ft || !attn || !g || !gdo) return STAG_EINVAL;
+  if (!aligned16(ft) || !aligned16(g)) return STAG_EINVAL;
+  if (spec->kind == STAG_NOISE_EXPLICIT && !spec->p0) return STAG_EINVAL;
+  const int HF = (int)HF64;
+  GatBwdArgs ba{};
+  GatArgs& a = ba.f;
+  a.indptr = csr->indptr; a.indices = csr->indices; a.eid = csr->eid; a.nidx = csr->nidx;
+  a.n_rows = csr->n_dst; a.el = el; a.er = er; a.ft = ft;
+  a.nscale = spec->in_norm ? norm_scale : nullptr;
+  a.H = H; a.F = F; a.HF = HF; a.neg_slope = neg_slope;
+  a.kind = spec->kind; a.p0 = spec->p0; a.p1 = spec->p1; a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar;
+  a.pmode = spec->kind >= STAG_NOISE_NORMAL ? spec->param_mode : 0;
+  a.relu = spec->relu ? kFlagRelu : 0;
+  a.key.k0 = (uint32_t)(spec->seed & 0xFFFFFFFFull); a.key.k1 = (uint32_t)(spec->seed >> 32);
+  a.key.o0 = (uint32_t)(spec->offset & 0xFFFFFFFFull); a.key.o1 = (uint32_t)(spec->offset >> 32);
+  a.pos_lo = (uint32_t)((uint64_t)spec->pos_base & 0xFFFFFFFFull);
+  a.pos_hi = (uint32_t)((uint64_t)spec->pos_base >> 32);
+  a.attn = const_cast<float*>(attn);
+  a.n_units = csr->n_dst;
+  if (plan && plan->n_units > 0) {
+    if (!plan->units || !aligned16(plan->units)) return STAG_EINVAL;
+    if (plan->n_seg > 0 && !plan->long_rows) return STAG_EINVAL;
+    a.units = plan->units; a.n_units = plan->n_units; a.long_rows = plan->long_rows;
+  }
+  ba.g = g; ba.gdo = gdo; ba.de = de; ba.dw = dw;
+  const int nchunk = (HF + 3) / 4;
+  int lpe = 4;
+  while (lpe < nchunk) lpe <<= 1;
+  const int tpb = 256 / lpe;
+  const dim3 grid((a.n_units + tpb - 1) / tpb);
+  const size_t lds_bytes = (size_t)3 * 256 * H * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  switch (lpe) {
+    case 64: hipLaunchKernelGGL(gat_bwd_edge_kernel<64>, grid, dim3(256), lds_bytes, s, ba); break;
+    case 32: hipLaunchKernelGGL(gat_bwd_edge_kernel<32>, grid, dim3(256), lds_bytes, s, ba); break;
+    case 16: hipLaunchKernelGGL(gat_bwd_edge_kernel<16>, grid, dim3(256), lds_bytes, s, ba); break;
+    case 8: hipLaunchKernelGGL(gat_bwd_edge_kernel<8>, grid, dim3(256), lds_bytes, s, ba); break;
+    default: hipLaunchKernelGGL(gat_bwd_edge_kernel<4>, grid, dim3(256), lds_bytes, s, ba); break;
+  }
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }

@@ -60,9 +60,9 @@ class EdgeNoise:
             mode = max(_param_mode(p, E, dn) for p in ps)
             self.param_mode = mode
             if mode == _lib.PARAM_SCALAR:
-                self.p0_scalar = float(ps[0].reshape(()))
+                self.p0_scalar = float(ps[0].detach().reshape(()))
                 if p1 is not None:
-                    self.p1_scalar = float(ps[1].reshape(()))
+                    self.p1_scalar = float(ps[1].detach().reshape(()))
             else:
                 shape = {_lib.PARAM_PER_CHANNEL: (dn,), _lib.PARAM_PER_EDGE1: (E, 1),
                          _lib.PARAM_PER_EDGE: (E, dn)}[mode]

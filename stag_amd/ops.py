@@ -291,6 +291,17 @@ def segment_reduce(x, offsets, reduce="sum"):
     return _SegmentReduce.apply(x, offsets.to(torch.int32).contiguous(), _REDUCE[reduce])
 
 
+def _gat_norm_scale(csrv, noise, H, seg_len, dev):
+    """in-norm factor [N, H] of H-wide weights (stag/layers.py:8-36): row sums on the aggregation
+    kernel (a broadcast row of ones, same noise, in-norm off), then indeg / sum."""
+    s2 = noise.spec()
+    s2.in_norm = 0
+    ones = torch.ones(1, H, dtype=torch.float32, device=dev)
+    sums, _ = _agg_raw(csrv, ones, H, s2, _lib.REDUCE_SUM, None, None, seg_len, broadcast_x=True)
+    deg = csrv.degrees.to(torch.float32).unsqueeze(1)
+    return torch.where(sums != 0, deg / sums, torch.ones_like(sums)).contiguous()
+
+
 class _GatAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, el, er, ft, w, graph, noise, neg_slope, want_attn, seg_len):
@@ -305,18 +316,11 @@ class _GatAggregate(torch.autograd.Function):
             spec = _explicit_spec(w)
         else:
             spec = _none_spec()
-        nscale = None
-        if spec.in_norm:
-            # row sums of the H-wide weights first (stag/layers.py:8-36), on the same kernel:
-            # aggregate a broadcast row of ones with the same noise, in-norm off
-            s2 = noise.spec()
-            s2.in_norm = 0
-            ones = torch.ones(1, H, dtype=torch.float32, device=dev)
-            sums, _ = _agg_raw(csrv, ones, H, s2, _lib.REDUCE_SUM, None, None, seg_len, broadcast_x=True)
-            deg = csrv.degrees.to(torch.float32).unsqueeze(1)
-            nscale = torch.where(sums != 0, deg / sums, torch.ones_like(sums)).contiguous()
+        nscale = _gat_norm_scale(csrv, noise, H, seg_len, dev) if spec.in_norm else None
+        need_grad = any(ctx.needs_input_grad[:4])
         out = torch.empty((csrv.n_dst, H, F), dtype=torch.float32, device=dev)
-        attn = torch.empty((csrv.n_edges, H), dtype=torch.float32, device=dev) if want_attn else None
+        attn = (torch.empty((csrv.n_edges, H), dtype=torch.float32, device=dev)
+                if (want_attn or need_grad) else None)      # the backward needs a[E, H]
         plan_t = csrv.plan(seg_len)
         nbytes = _lib.lib().stag_gat_workspace_bytes(plan_t["n_seg"], H, F) if plan_t is not None else 0
         plan_c, _keep = _plan_struct(csrv, seg_len, 1, nbytes, dev)
@@ -327,13 +331,58 @@ class _GatAggregate(torch.autograd.Function):
                                          float(neg_slope), C.byref(spec), _lib.ptr(nscale),
                                          _lib.ptr(out), _lib.ptr(attn), _lib.stream_of(dev))
         _lib.check(rc, "stag_gat_fwd")
-        ctx.mark_non_differentiable(*([attn] if attn is not None else []))
-        return (out, attn) if want_attn else out
+        if need_grad:
+            ctx.graph, ctx.noise, ctx.neg_slope, ctx.seg_len = graph, noise, float(neg_slope), seg_len
+            ctx.save_for_backward(el, er, ft, w, attn, out, nscale)
+        if want_attn:
+            ctx.mark_non_differentiable(attn)
+            return out, attn
+        return out
 
     @staticmethod
-    def backward(ctx, *grads):
-        raise NotImplementedError(
-            "stag_gat_fwd has no backward kernel yet (DESIGN.md, 'next'): GAT is inference-only")
+    def backward(ctx, grad_out, *unused):
+        el, er, ft, w, attn, out, nscale = ctx.saved_tensors
+        graph, noise = ctx.graph, ctx.noise
+        H, F = ft.shape[1], ft.shape[2]
+        HF = H * F
+        csrv, csrt = graph.csr, graph.csr_t
+        dev = ft.device
+        G = _f32c(grad_out)
+        gdo = (G * out).sum(-1).contiguous()                       # <G, out> per (v, h)
+        if noise is not None:
+            spec = noise.spec()
+        elif w is not None:
+            spec = _explicit_spec(w)
+        else:
+            spec = _none_spec()
+        want_dw = w is not None and ctx.needs_input_grad[3]
+        de = torch.empty((csrv.n_edges, H), dtype=torch.float32, device=dev)
+        dw = torch.empty((csrv.n_edges, H), dtype=torch.float32, device=dev) if want_dw else None
+        plan_c, _keep = _plan_struct(csrv, ctx.seg_len, 1, 0, dev)
+        cs = csrv.struct()
+        with torch.cuda.device(dev):
+            rc = _lib.lib().stag_gat_bwd_edge(
+                C.byref(cs), C.byref(plan_c) if plan_c is not None else None, _lib.ptr(el),
+                _lib.ptr(er), _lib.ptr(ft), _lib.ptr(attn), _lib.ptr(G), _lib.ptr(gdo), H, F,
+                ctx.neg_slope, C.byref(spec), _lib.ptr(nscale), _lib.ptr(de), _lib.ptr(dw),
+                _lib.stream_of(dev))
+        if rc == -38:
+            raise NotImplementedError("GAT backward needs out_feats % 4 == 0 and out_feats / 4 a power of two")
+        _lib.check(rc, "stag_gat_bwd_edge")
+        ones = torch.ones(1, H, dtype=torch.float32, device=dev)
+        d_el = d_er = d_ft = None
+        if ctx.needs_input_grad[1]:      # d er[v,h] = sum over in-edges of de
+            d_er, _ = _agg_raw(csrv, ones, H, _explicit_spec(de), _lib.REDUCE_SUM, None, None,
+                               ctx.seg_len, broadcast_x=True)
+        if ctx.needs_input_grad[0]:      # d el[u,h] = sum over out-edges of de
+            d_el, _ = _agg_raw(csrt, ones, H, _explicit_spec(de), _lib.REDUCE_SUM, None, None,
+                               ctx.seg_len, broadcast_x=True)
+        if ctx.needs_input_grad[2]:      # d ft[u,h,:] = sum over out-edges of a[e,h] * G[v,h,:]
+            sa = _explicit_spec(attn)
+            sa.group = F
+            d_ft, _ = _agg_raw(csrt, G.reshape(-1, HF), HF, sa, _lib.REDUCE_SUM, None, None, ctx.seg_len)
+            d_ft = d_ft.reshape(-1, H, F)
+        return d_el, d_er, d_ft, dw, None, None, None, None, None
 
 
 def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False,

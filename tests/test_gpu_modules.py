@@ -161,7 +161,7 @@ def test_training_step_reduces_loss(dev):
         loss = model.loss(g, x, y, n_samples=2)
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(loss.item())
     assert losses[-1] < losses[0] - 0.05
     with torch.no_grad():
         p = model(g, x, n_samples=4, return_parameters=True)
@@ -318,3 +318,81 @@ def test_vi_layer_trains_fused(dev):
                                    q_a=torch.distributions.Normal(torch.ones(16), 0.5 * torch.ones(16))).to(dev)
     rc(g, x).sum().backward()
     assert rc.q_a.loc.grad.shape == (16,) and rc.q_a.log_scale.grad.shape == (16,)
+
+
+def _gat_torch_reference(src, dst, n, el, er, ft, w, neg_slope):
+    """Plain torch (autograd) statement of stag/zoo/gat.py:114-126 for the gradient check."""
+    e = torch.nn.functional.leaky_relu(el[src] + er[dst], neg_slope)
+    if w is not None:
+        e = w * e
+    H = e.shape[1]
+    idx = dst.unsqueeze(1).expand_as(e)
+    mx = torch.full((n, H), -float("inf"), device=e.device, dtype=e.dtype).scatter_reduce(0, idx, e, "amax")
+    ex = torch.exp(e - mx[dst])
+    den = torch.zeros((n, H), device=e.device, dtype=e.dtype).index_add_(0, dst, ex)
+    a = ex / den[dst]
+    return torch.zeros_like(ft).index_add_(0, dst, a.unsqueeze(-1) * ft[src])
+
+
+@pytest.mark.parametrize("H,F", [(8, 32), (3, 4), (2, 16)])
+@pytest.mark.parametrize("mode", ["none", "explicit", "noise", "noise_norm"])
+def test_gat_backward(dev, H, F, mode):
+    import stag_amd
+    from stag_amd import _lib, ops
+    from util import random_graph
+    rng = np.random.default_rng(H * 7 + F)
+    n = 120
+    g = random_graph(n, 900, seed=H + F, hub=200, device=dev)
+    src, dst = g.edges()
+    E = g.number_of_edges()
+    mk = lambda *shape: torch.tensor(rng.standard_normal(shape).astype(np.float32), device=dev)
+    el0, er0, ft0, G = mk(n, H), mk(n, H), mk(n, H, F), mk(n, H, F)
+    w0 = torch.tensor(rng.uniform(0.5, 1.5, (E, H)).astype(np.float32), device=dev)
+    if mode == "noise":
+        weight = stag_amd.EdgeNoise(g, H, _lib.NOISE_NORMAL, 1.0, 0.3, seed=3, offset=1)
+        w_ref = weight.materialize()
+    elif mode == "noise_norm":
+        weight = stag_amd.EdgeNoise(g, H, _lib.NOISE_BERNOULLI, 0.7, None, seed=3, offset=1, in_norm=True)
+        w_ref = weight.materialize()
+    elif mode == "explicit":
+        weight = w0.clone().requires_grad_(True)
+        w_ref = w0.clone().requires_grad_(True)
+    else:
+        weight = w_ref = None
+    el, er, ft = (t.clone().requires_grad_(True) for t in (el0, er0, ft0))
+    out = ops.gat_aggregate(g, el, er, ft, 0.2, weight, seg_len=32)
+    out.backward(G)
+    el2, er2, ft2 = (t.clone().requires_grad_(True) for t in (el0, er0, ft0))
+    ref = _gat_torch_reference(src, dst, n, el2, er2, ft2, w_ref, 0.2)
+    ref.backward(G)
+    assert_close(out, ref.detach().cpu().numpy(), tol=2e-5, what="gat forward")
+    assert_close(ft.grad, ft2.grad.cpu().numpy(), tol=5e-5, what="d ft")
+    assert_close(el.grad, el2.grad.cpu().numpy(), tol=1e-4, what="d el")
+    assert_close(er.grad, er2.grad.cpu().numpy(), tol=1e-4, what="d er")
+    if mode == "explicit":
+        assert_close(weight.grad, w_ref.grad.cpu().numpy(), tol=1e-4, what="d w")
+
+
+def test_gat_layer_trains(dev):
+    import stag_amd
+    from util import random_graph
+    torch.manual_seed(0)
+    g = random_graph(300, 3000, seed=2, hub=400, device=dev)
+    x = torch.randn(300, 16, device=dev)
+    y = torch.randint(0, 4, (300,), device=dev)
+    layers = torch.nn.ModuleList([
+        stag_amd.layers.StagLayer(stag_amd.zoo.GAT(16, 8, num_heads=4, activation=torch.nn.functional.elu),
+                                  q_a=torch.distributions.Normal(1.0, 0.2)),
+        stag_amd.layers.StagLayer(stag_amd.zoo.GAT(32, 4, num_heads=2, last=True,
+                                                   activation=lambda t: torch.softmax(t, -1)),
+                                  q_a=torch.distributions.Normal(1.0, 0.2))])
+    model = stag_amd.models.StagModel(layers=layers).to(dev)
+    opt = torch.optim.Adam(model.parameters(), 1e-2)
+    losses = []
+    for _ in range(25):
+        opt.zero_grad()
+        loss = model.loss(g, x, y)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0] - 0.03
