@@ -206,6 +206,14 @@ constexpr int kKahanMinLen = STAG_KAHAN_MIN_LEN;
 #ifndef STAG_BLOCK_THREADS
 #define STAG_BLOCK_THREADS 256
 #endif
+// LDS staging of the gathered rows (buffer_load ... lds): rows in flight cost no VGPRs, so a
+// team can have STAG_BLK_LDS rows outstanding at 8 waves per SIMD.
+#ifndef STAG_LDS_STAGE
+#define STAG_LDS_STAGE 0
+#endif
+#ifndef STAG_BLK_LDS
+#define STAG_BLK_LDS 2
+#endif
 
 // Register image of one block of BLK edges of a unit.
 template <int BLK>
@@ -226,7 +234,7 @@ struct AggTeam {
   const AggArgs& a;
   const int k0;
   const uint32_t koff, c1;
-  const int pend;
+  int pend;
   const __amdgpu_buffer_rsrc_t rx;
   const bool x_buf;
   float pa[4], pb[4];
@@ -259,12 +267,66 @@ struct AggTeam {
     }
   }
 
-  __device__ __forceinline__ void compute(EdgeRows<BLK>& R, const EdgeIdx<BLK>& I, int p0) {
-    // block sums go into fresh accumulators (small magnitudes => small rounding)
-    float t[4] = {0.f, 0.f, 0.f, 0.f};
+  // LDS-DMA form of fetch_rows: one `buffer_load_dwordx4 ... offen lds` per edge writes the
+  // wave's 64 x 16 B straight into LDS slot j (M0 = slot base, lane l lands at base + 16 l);
+  // nothing is held in VGPRs while the rows are in flight.
+  __device__ __forceinline__ void dma_rows(const EdgeIdx<BLK>& I, int p0, float* wave_lds) const {
 #pragma unroll
     for (int j = 0; j < BLK; ++j) {
       if (p0 + j < pend) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rx, (__attribute__((address_space(3))) void*)(wave_lds + j * 256), 16,
+            (int)(__umul24((uint32_t)I.u[j], a.ldxb) + koff), 0, 0, 0);
+      }
+    }
+  }
+
+  template <int N>
+  static __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  }
+
+  // LDS = nullptr: rows are in R.xv (register staging).  Else slot j of `lds` holds edge j's
+  // row; `full` (wave-uniform) says every active team issued all BLK DMAs, so counted waits
+  // are exact and edge j's draw overlaps the flight of edges j+1..BLK-1.
+  template <int N>
+  static __device__ __forceinline__ void wait_upto() {   // vmcnt(N), N clamped to what this build uses
+    if constexpr (N <= 0) wait_vmcnt<0>();
+    else if constexpr (N == 1) wait_vmcnt<1>();
+    else if constexpr (N == 2) wait_vmcnt<2>();
+    else if constexpr (N == 3) wait_vmcnt<3>();
+    else if constexpr (N == 4) wait_vmcnt<4>();
+    else if constexpr (N == 5) wait_vmcnt<5>();
+    else if constexpr (N == 6) wait_vmcnt<6>();
+    else wait_vmcnt<7>();
+  }
+
+  // lds = nullptr: rows are in R.xv (register staging).  Else slot j of `lds` holds edge j's
+  // row.  `full` (wave-uniform): every active team issued all BLK DMAs of this block, so the
+  // counted wait for slot j is exact: BLK-1-j younger DMAs of this block, plus BLK more when
+  // `next_full` says the next block's DMAs were issued behind them (software pipeline).
+  __device__ __forceinline__ void compute(EdgeRows<BLK>& R, const EdgeIdx<BLK>& I, int p0,
+                                          const float* lds = nullptr, bool full = false,
+                                          bool next_full = false) {
+    // block sums go into fresh accumulators (small magnitudes => small rounding)
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    if (lds && !full) wait_vmcnt<0>();
+#pragma unroll
+    for (int j = 0; j < BLK; ++j) {
+      if (lds && full) {
+        if (next_full) {
+          if (j == 0) wait_upto<2 * BLK - 1>(); else if (j == 1) wait_upto<2 * BLK - 2>();
+          else if (j == 2) wait_upto<2 * BLK - 3>(); else wait_upto<BLK>();
+        } else {
+          if (j == 0) wait_upto<BLK - 1>(); else if (j == 1) wait_upto<BLK - 2>();
+          else if (j == 2) wait_upto<BLK - 3>(); else wait_upto<0>();
+        }
+      }
+      if (p0 + j < pend) {
+        if (lds) {
+          const float4 xr = *reinterpret_cast<const float4*>(lds + j * 256 + (threadIdx.x & 63) * 4);
+          R.xv[j][0] = xr.x; R.xv[j][1] = xr.y; R.xv[j][2] = xr.z; R.xv[j][3] = xr.w;
+        }
         float w[4];
         if constexpr (KIND == kNone) {
           w[0] = w[1] = w[2] = w[3] = 1.0f;
@@ -325,18 +387,22 @@ struct AggTeam {
   }
 };
 
-template <int KIND, int LPE, bool VEC, bool PEDGE>
+// STAGE: gathered rows travel global -> LDS -> VGPR (buffer_load ... lds); needs VEC and the
+// narrow (buffer-descriptor) addressing form, decided on the host.
+template <int KIND, int LPE, bool VEC, bool PEDGE, bool STAGE>
 __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_kernel(const AggArgs a) {
   constexpr int TEAMS_PER_BLOCK = STAG_BLOCK_THREADS / LPE;
   // edges per block: the RNG kinds are VALU-bound and register-hungry, the others want
   // more rows in flight
-  constexpr int BLK = (KIND >= kNormal) ? STAG_BLK_RNG : STAG_BLK_MEM;
+  constexpr int BLK = STAGE ? STAG_BLK_LDS : ((KIND >= kNormal) ? STAG_BLK_RNG : STAG_BLK_MEM);
 
   const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
   const int unit = blockIdx.x * TEAMS_PER_BLOCK + threadIdx.x / LPE;
   const uint32_t chunk = blockIdx.y * LPE + c;
   const int k0 = (int)chunk * 4;
-  if (unit >= a.n_units || k0 >= a.D) return;   // teams never talk to each other: no barrier below
+  if (unit >= a.n_units) return;                  // teams never talk to each other: no barrier below
+  const bool kin = k0 < a.D;                      // lanes past the row's end still help fetch edge records
+  if (!STAGE && !kin) return;
 
   int v, b, len, slot = -1;
   if (a.units) {
@@ -367,7 +433,7 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
       {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f},
       len > kKahanMinLen};
   if constexpr (KIND >= kNormal) {
-    if (a.pmode == STAG_PARAM_PER_CHANNEL) {   // distribution parameters of this lane's 4 channels
+    if (a.pmode == STAG_PARAM_PER_CHANNEL && kin) {   // distribution parameters of this lane's 4 channels
       load4(a.p0, k0, a.D, VEC, T.pa);
       if (a.p1) load4(a.p1, k0, a.D, VEC, T.pb);
     }
@@ -380,10 +446,72 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
   const int pend = b + len;
   EdgeIdx<BLK> I;
   EdgeRows<BLK> R;
-  for (int p0 = b; p0 < pend; p0 += BLK) {
-    T.fetch_idx(I, p0);
-    T.fetch_rows(R, I, p0);
-    T.compute(R, I, p0);
+  if constexpr (STAGE) {
+    // Staged pipeline (VEC, narrow addressing).  Per chunk of LPE edges the team fetches its
+    // edge records with ONE coalesced load per field and parks them in LDS; after that a
+    // block costs no global round trip for ids.  Rows travel by LDS-DMA into 2 x BLK slots:
+    // the next block's rows are in flight while this block's noise is drawn, at no VGPR cost.
+    constexpr int NW = STAG_BLOCK_THREADS / 64;
+    constexpr bool NEED_EID = (KIND == kExplicit) || PEDGE;
+    __shared__ __attribute__((aligned(16))) float stage[NW][2 * BLK][256];
+    __shared__ int ubuf[NW][64];
+    __shared__ uint32_t nbuf[NW][64];
+    __shared__ int ebuf[NEED_EID ? NW : 1][64];
+    __shared__ float sbuf[NW][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tl0 = lane - c;
+    float* wl = &stage[wave][0][0];
+    const bool has_ss = a.src_scale != nullptr;
+
+    auto take = [&](EdgeIdx<BLK>& J, EdgeRows<BLK>& Q, int j0, int nb) {
+#pragma unroll
+      for (int j = 0; j < BLK; ++j) {
+        if (j0 + j < nb) {
+          J.u[j] = ubuf[wave][tl0 + j0 + j];
+          if constexpr (KIND >= kNormal) J.nn[j] = nbuf[wave][tl0 + j0 + j];
+          if constexpr (NEED_EID) J.ee[j] = ebuf[NEED_EID ? wave : 0][tl0 + j0 + j];
+          if (has_ss) Q.xs[j] = sbuf[wave][tl0 + j0 + j];
+        }
+      }
+    };
+
+    for (int i0 = 0; i0 < len; i0 += LPE) {
+      const int nb = min(LPE, len - i0);
+      const int pb = b + i0;
+      if (c < nb) {
+        const int p = pb + c;
+        const int uu = a.indices[p];
+        ubuf[wave][lane] = uu;
+        if constexpr (KIND >= kNormal) nbuf[wave][lane] = a.nidx ? (uint32_t)a.nidx[p] : a.pos_lo + (uint32_t)p;
+        if constexpr (NEED_EID) ebuf[NEED_EID ? wave : 0][lane] = a.eid ? a.eid[p] : p;
+        if (has_ss) sbuf[wave][lane] = a.src_scale[uu];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // same-wave LDS hand-off: order only
+      __builtin_amdgcn_wave_barrier();
+      T.pend = pb + nb;
+      if (!kin) continue;
+      // ONE rolled loop (a second copy of the body for an A/B register set costs 40 VGPRs):
+      // the slot pair alternates by address, the edge records are re-read from LDS.
+      take(I, R, 0, nb);
+      T.dma_rows(I, pb, wl);
+      int pair = 0;
+      for (int j0 = 0; j0 < nb; j0 += BLK) {
+        if (j0 + BLK < nb) {   // next block's rows into the other slot pair
+          take(I, R, j0 + BLK, nb);
+          T.dma_rows(I, pb + j0 + BLK, wl + (pair ^ 1) * (BLK * 256));
+        }
+        take(I, R, j0, nb);
+        T.compute(R, I, pb + j0, wl + pair * (BLK * 256), __all(j0 + BLK <= nb),
+                  __all(j0 + 2 * BLK <= nb));
+        pair ^= 1;
+      }
+    }
+    if (!kin) return;
+  } else {
+    for (int p0 = b; p0 < pend; p0 += BLK) {
+      T.fetch_idx(I, p0);
+      T.fetch_rows(R, I, p0);
+      T.compute(R, I, p0);
+    }
   }
 
   if (slot < 0) {
@@ -433,15 +561,25 @@ inline void agg_launch_shape(const AggArgs& a, bool vec, bool pedge, int tiles, 
   constexpr int TPB = STAG_BLOCK_THREADS / LPE;
   dim3 grid((a.n_units + TPB - 1) / TPB, tiles);
   if (grid.x == 0) return;
+  const dim3 block(STAG_BLOCK_THREADS);
+#if STAG_LDS_STAGE
+  if (vec && (a.wide & 1) == 0 && a.ldxb != 0) {   // staged form: dwordx4 rows behind a buffer descriptor
+    if constexpr (KIND >= kNormal) {
+      if (pedge) { hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, true, true>), grid, block, 0, s, a); return; }
+    }
+    hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, false, true>), grid, block, 0, s, a);
+    return;
+  }
+#endif
   if constexpr (KIND >= kNormal) {
     if (pedge) {
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, true>), grid, dim3(STAG_BLOCK_THREADS), 0, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, true>), grid, dim3(STAG_BLOCK_THREADS), 0, s, a);
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, true, false>), grid, block, 0, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, true, false>), grid, block, 0, s, a);
       return;
     }
   }
-  if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, false>), grid, dim3(STAG_BLOCK_THREADS), 0, s, a);
-  else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, false>), grid, dim3(STAG_BLOCK_THREADS), 0, s, a);
+  if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, false, false>), grid, block, 0, s, a);
+  else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, false, false>), grid, block, 0, s, a);
 }
 
 template <int KIND>
