@@ -196,17 +196,25 @@ def test_shard_equals_whole_graph(dev):
     whole = ops.aggregate(g, x, mk(g))
     sh = GraphShard(src, dst, n, 0, 1, device=dev)
     assert torch.equal(sh.aggregate(x, mk(sh)), whole)
-    parts = []
-    for r in range(2):
-        sh = GraphShard(src, dst, n, r, 2, device=dev)
-        buf = torch.zeros(2 * sh.max_rows, D, device=dev)      # what the all-gather would deliver
-        for q in range(2):
-            lo, hi = int(sh.bounds[q]), int(sh.bounds[q + 1])
-            buf[q * sh.max_rows:q * sh.max_rows + hi - lo] = x[lo:hi]
-        noise = mk(sh)
-        noise.pos_base = sh.pos_base
-        parts.append(ops.aggregate(sh, buf, noise))
-    assert torch.equal(torch.cat(parts, 0), whole)
+    for world in (2, 3):
+        parts, parts_halo = [], []
+        for r in range(world):
+            sh = GraphShard(src, dst, n, r, world, device=dev, exchange="allgather")
+            buf = torch.zeros(world * sh.max_rows, D, device=dev)      # what the all-gather would deliver
+            for q in range(world):
+                lo, hi = int(sh.bounds[q]), int(sh.bounds[q + 1])
+                buf[q * sh.max_rows:q * sh.max_rows + hi - lo] = x[lo:hi]
+            noise = mk(sh)
+            noise.pos_base = sh.pos_base
+            parts.append(ops.aggregate(sh, buf, noise))
+            hs = GraphShard(src, dst, n, r, world, device=dev, exchange="halo")
+            buf = torch.cat([x[hs.row_lo:hs.row_hi], x[torch.from_numpy(hs.recv_ids).to(dev)]], 0)   # all-to-all result
+            assert buf.shape[0] == hs.n_buf
+            noise = mk(hs)
+            noise.pos_base = hs.pos_base
+            parts_halo.append(ops.aggregate(hs, buf, noise))
+        assert torch.equal(torch.cat(parts, 0), whole)
+        assert torch.equal(torch.cat(parts_halo, 0), whole)
 
 
 def test_full_size_properties(dev):

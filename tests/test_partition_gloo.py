@@ -37,7 +37,29 @@ def _worker(rank, world, port, tmp):
         from oracle import oracle as O
         from stag_amd.partition import GraphShard
         src, dst, n, x = _graph()
-        sh = GraphShard(src, dst, n, rank, world)
+        # ---- exchange="halo": all-to-all of exactly the referenced remote rows ---------------------
+        hs = GraphShard(src, dst, n, rank, world, exchange="halo")
+        xl = torch.from_numpy(x[hs.row_lo:hs.row_hi]).requires_grad_(True)
+        xf = hs.halo_gather(xl)
+        assert xf.shape[0] == hs.n_buf == hs.n_rows + sum(hs.out_splits) < n + 1
+        og = O.CsrGraph(hs.local_indptr.numpy(), hs.local_indices.numpy(), n_src=hs.n_buf)
+        spec = O.make_spec("normal", 1.0, 0.5, seed=77, offset=5, pos_base=hs.pos_base, Dn=x.shape[1], n_edges=og.n_edges)
+        np.save(os.path.join(tmp, f"halo{rank}.npy"), O.agg_fwd(og, xf.detach().numpy(), spec))
+        # every buffer row holds the global row the remapped column id stands for
+        order = np.argsort(dst, kind="stable")
+        gsrc = src[order][hs.pos_base:hs.pos_base + og.n_edges]
+        assert np.array_equal(xf.detach().numpy()[hs.local_indices.numpy()], x[gsrc])
+        (xf * (rank + 1)).sum().backward()      # transposed exchange: each local row collects its users
+        cnt = np.ones(hs.n_rows) * (rank + 1)
+        for r in range(world):
+            if r != rank:
+                ids = np.unique(src[order][(np.searchsorted(hs.bounds, dst[order], side="right") - 1 == r)
+                                            & (src[order] >= hs.row_lo) & (src[order] < hs.row_hi)])
+                cnt[ids - hs.row_lo] += r + 1
+        assert np.allclose(xl.grad.numpy(), np.broadcast_to(cnt[:, None], xl.shape))
+
+        # ---- exchange="allgather" ----------------------------------------------------------------------
+        sh = GraphShard(src, dst, n, rank, world, exchange="allgather")
         # every rank owns a contiguous row range; the ranges tile [0, n)
         assert sh.bounds[0] == 0 and sh.bounds[-1] == n and (np.diff(sh.bounds) >= 0).all()
         x_local = torch.from_numpy(x[sh.row_lo:sh.row_hi]).requires_grad_(True)
@@ -77,9 +99,10 @@ def test_partition_two_ranks_matches_single(world, tmp_path, oracle):
     indptr, indices, eid, *_ = oracle.csr_build(src, dst, n, n)
     g = oracle.CsrGraph(indptr, indices, eid, n_src=n)
     ref = oracle.agg_fwd(g, x, oracle.make_spec("normal", 1.0, 0.5, seed=77, offset=5, Dn=x.shape[1], n_edges=len(src)))
-    got = np.concatenate([np.load(tmp_path / f"out{r}.npy") for r in range(world)], 0)
-    assert got.shape == ref.shape
-    assert np.array_equal(got, ref), "partitioned result must be bit-identical to the unpartitioned one"
+    for tag in ("out", "halo"):
+        got = np.concatenate([np.load(tmp_path / f"{tag}{r}.npy") for r in range(world)], 0)
+        assert got.shape == ref.shape
+        assert np.array_equal(got, ref), f"{tag}: partitioned result must be bit-identical to the unpartitioned one"
 
 
 def test_edge_balanced_bounds():
