@@ -153,6 +153,16 @@ int stag_plan_fill(const int32_t* indptr_host, int32_t n_dst, int32_t seg_len,
                    int32_t* long_seg_ptr_host);
 size_t stag_plan_workspace_bytes(int32_t n_seg, int32_t D, int32_t in_norm);
 
+/* ---- graph preprocessing on the device: COO -> stable destination-major CSR ----------------
+ * Position order inside a row = ascending original edge id (the order `graph.edata` frames
+ * and the Philox positions are defined against).  indptr[n_dst+1], indices[E], eid[E];
+ * out_deg[n_src] may be NULL; in-degrees are indptr differences.  Replaces the graph
+ * construction the reference leaves to DGL (scripts/arxiv_mle/gcn/run.py:53-55).          */
+size_t stag_csr_build_workspace_bytes(int32_t n_dst, int64_t n_edges);
+int stag_csr_build(const int32_t* src, const int32_t* dst, int32_t n_src, int32_t n_dst,
+                   int64_t n_edges, int32_t* indptr, int32_t* indices, int32_t* eid,
+                   int32_t* out_deg, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- test hook: raw Philox words, out[n_pos][n_chunk][4] ------------------ */
 int stag_philox_raw(uint64_t seed, uint64_t offset, int64_t pos0, int64_t n_pos,
                     int32_t n_chunk, uint32_t* out, void* stream);

@@ -80,6 +80,10 @@ def lib():
     l.stag_plan_fill.argtypes = [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]
     l.stag_plan_workspace_bytes.restype = C.c_size_t
     l.stag_plan_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    l.stag_csr_build_workspace_bytes.restype = C.c_size_t
+    l.stag_csr_build_workspace_bytes.argtypes = [C.c_int32, C.c_int64]
+    l.stag_csr_build.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp, _vp, _vp, _vp,
+                                 C.c_size_t, _vp]
     l.stag_philox_raw.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]
     l.stag_agg_fwd.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, C.c_int64, C.c_int32,
                                C.POINTER(NoiseSpec), C.c_int32, _vp, _vp, _vp, C.c_int64, _vp, _vp]

@@ -76,9 +76,24 @@ class CsrView:
 
 def build_csr(src, dst, n_src, n_dst):
     """Stable destination-major CSR from COO (position order inside a row = ascending
-    original edge id).  torch sort/bincount on whatever device the COO lives on."""
+    original edge id).  On a HIP device: stag_csr_build (rocPRIM radix sort + scan in the
+    library); on the CPU (host-logic tests, partition setup): torch sort/bincount."""
     E = int(src.shape[0])
     dev = src.device
+    if src.is_cuda and E > 0:
+        lib = _lib.lib()
+        src32, dst32 = src.to(torch.int32).contiguous(), dst.to(torch.int32).contiguous()
+        indptr = torch.empty(n_dst + 1, dtype=torch.int32, device=dev)
+        indices = torch.empty(E, dtype=torch.int32, device=dev)
+        eid = torch.empty(E, dtype=torch.int32, device=dev)
+        nbytes = lib.stag_csr_build_workspace_bytes(n_dst, E)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.stag_csr_build(_lib.ptr(src32), _lib.ptr(dst32), n_src, n_dst, E, _lib.ptr(indptr),
+                                    _lib.ptr(indices), _lib.ptr(eid), None, _lib.ptr(ws), nbytes,
+                                    _lib.stream_of(dev))
+        _lib.check(rc, "stag_csr_build")
+        return indptr, indices, eid
     if E == 0:
         z = torch.zeros(0, dtype=torch.int32, device=dev)
         return torch.zeros(n_dst + 1, dtype=torch.int32, device=dev), z, z.clone()

@@ -300,3 +300,22 @@ def test_gat_hub_rows_and_seg_len(dev, oracle):
     with pytest.raises(Exception):
         ops.gat_aggregate(g, torch.zeros(n, 8, device=dev), torch.zeros(n, 8, device=dev),
                           torch.zeros(n, 8, 64, device=dev))        # H*F > 256: STAG_ENOSYS
+
+
+def test_device_csr_build_full_size(dev, oracle):
+    """stag_csr_build (rocPRIM radix sort) at the BASELINE size == the oracle's counting sort."""
+    import stag_amd
+    from stag_amd import synthetic
+    src, dst = synthetic.arxiv_like(seed=1)
+    n = synthetic.ARXIV_NODES
+    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
+    indptr, indices, eid, ind, outd = oracle.csr_build(src, dst, n, n)
+    assert np.array_equal(g.csr.indptr.cpu().numpy(), indptr)
+    assert np.array_equal(g.csr.indices.cpu().numpy(), indices)
+    assert np.array_equal(g.csr.eid.cpu().numpy(), eid)
+    t = g.csr_t
+    indptr_t, indices_t, eid_t, *_ = oracle.csr_build(dst, src, n, n)
+    assert np.array_equal(t.indptr.cpu().numpy(), indptr_t) and np.array_equal(t.eid.cpu().numpy(), eid_t)
+    # one destination only / one edge
+    g1 = stag_amd.Graph(torch.arange(5), torch.zeros(5, dtype=torch.int64), 5, device=dev)
+    assert g1.csr.indptr.tolist() == [0, 5, 5, 5, 5, 5] and g1.csr.eid.tolist() == [0, 1, 2, 3, 4]
