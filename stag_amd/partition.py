@@ -222,3 +222,21 @@ class GraphShard:
         return ops.aggregate(self, x_full, weight, reduce=reduce, src_scale=src_scale,
                              dst_scale=dst_scale_local,
                              seg_len=DEFAULT_SEG_LEN if seg_len is None else seg_len)
+
+    def gat_aggregate(self, el_local, er_local, ft_local, neg_slope=0.2, weight=None, seg_len=None):
+        """Partitioned GAT layer-forward (BASELINE cfg5): ONE exchange carries [ft | el] of the
+        referenced source rows (H*F + H columns), then the single-GPU fused kernel runs on this
+        rank's rows.  `weight`: None or an EdgeNoise(dn=H) built on this shard."""
+        from . import ops
+        from .graph import DEFAULT_SEG_LEN
+        from .noise import EdgeNoise
+        n, H, F = ft_local.shape
+        packed = torch.cat([ft_local.reshape(n, H * F), el_local], 1)
+        full = self.halo_gather(packed)
+        ft_full = full[:, :H * F].reshape(-1, H, F)
+        el_full = full[:, H * F:]
+        er_rows = er_local
+        if isinstance(weight, EdgeNoise):
+            weight.pos_base = self.pos_base
+        return ops.gat_aggregate(self, el_full, er_rows, ft_full, neg_slope, weight,
+                                 seg_len=DEFAULT_SEG_LEN if seg_len is None else seg_len)

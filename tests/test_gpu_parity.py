@@ -319,3 +319,49 @@ def test_device_csr_build_full_size(dev, oracle):
     # one destination only / one edge
     g1 = stag_amd.Graph(torch.arange(5), torch.zeros(5, dtype=torch.int64), 5, device=dev)
     assert g1.csr.indptr.tolist() == [0, 5, 5, 5, 5, 5] and g1.csr.eid.tolist() == [0, 1, 2, 3, 4]
+
+
+def test_fuzz_agg_against_oracle(dev, oracle):
+    """Seeded sweep over shapes x kinds x parameter modes x flags x plans: every combination the
+    launcher can route (tiles, scalar tail lanes, per-edge parameters, segments, mean, scales)."""
+    from stag_amd import ops
+    rng = np.random.default_rng(20261003)
+    kinds = ["none", "explicit", "normal", "uniform", "bernoulli"]
+    for it in range(60):
+        n = int(rng.integers(1, 400))
+        e = int(rng.integers(0, 3000))
+        hub = int(rng.choice([0, 0, 70, 400]))
+        D = int(rng.choice([1, 2, 5, 8, 12, 31, 32, 64, 100, 128, 129, 200, 256, 260, 515]))
+        kind = kinds[it % 5]
+        seg_len = int(rng.choice([0, 8, 64, 64, 1000]))
+        reduce = "mean" if rng.random() < 0.3 else "sum"
+        g = random_graph(n, e, seed=1000 + it, hub=hub if n > 4 else 0, device=dev)
+        E = g.number_of_edges()
+        og = oracle_graph(oracle, g)
+        x = rng.standard_normal((n, D)).astype(np.float32)
+        ss = rng.uniform(0.5, 1.5, n).astype(np.float32) if rng.random() < 0.5 else None
+        ds = rng.uniform(0.5, 1.5, n).astype(np.float32) if rng.random() < 0.5 else None
+        relu = bool(rng.random() < 0.3)
+        if kind == "none":
+            w, spec = None, oracle.make_spec("none")
+        elif kind == "explicit":
+            wt = rng.uniform(-1, 2, (E, D)).astype(np.float32)
+            w, spec = torch.from_numpy(wt).to(dev), oracle.make_spec("explicit", wt)
+        else:
+            mode = PARAM_CASES[int(rng.integers(0, 4))]
+            p0, p1 = _params(mode, E, D, rng)
+            norm = False
+            if kind == "bernoulli":
+                p0, p1 = (p0 * 0.5 if torch.is_tensor(p0) else 0.6), None
+                norm = bool(rng.random() < 0.5)
+            elif kind == "uniform":
+                p1 = p0 + p1
+            kw = dict(relu=relu, in_norm=norm, seed=int(rng.integers(0, 2**40)), offset=int(rng.integers(0, 99)))
+            w = _noise(g, D, kind, p0, p1, **kw)
+            spec = _ospec(oracle, g, D, kind, p0, p1, **kw)
+        t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+        got = ops.aggregate(g, t(x), w, reduce=reduce, src_scale=t(ss), dst_scale=t(ds), seg_len=seg_len)
+        ref = oracle.agg_fwd(og, x, spec, reduce=oracle.REDUCE_MEAN if reduce == "mean" else oracle.REDUCE_SUM,
+                             src_scale=ss, dst_scale=ds)
+        assert_close(got, ref, tol=2 * TOL if seg_len in (0, 1000) else TOL,
+                     what=f"fuzz {it}: n={n} E={E} D={D} {kind} seg={seg_len} {reduce} relu={relu}")
