@@ -206,6 +206,12 @@ constexpr int kKahanMinLen = STAG_KAHAN_MIN_LEN;
 #ifndef STAG_BLOCK_THREADS
 #define STAG_BLOCK_THREADS 256
 #endif
+#ifndef STAG_LOAD_PRIO
+#define STAG_LOAD_PRIO 1
+#endif
+#ifndef STAG_PRIO_MIN_LEN
+#define STAG_PRIO_MIN_LEN 24
+#endif
 // LDS staging of the gathered rows (buffer_load ... lds): rows in flight cost no VGPRs, so a
 // team can have STAG_BLK_LDS rows outstanding at 8 waves per SIMD.
 #ifndef STAG_LDS_STAGE
@@ -417,9 +423,6 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
   // Long units are the critical path of the launch: a SIMD round-robins its waves, so a
   // 64-edge unit would take 8x its own issue time at 8 waves per SIMD.  They are dispatched
   // first (plan order) and run at raised priority; the short rows fill in behind them.
-#ifndef STAG_PRIO_MIN_LEN
-#define STAG_PRIO_MIN_LEN 24
-#endif
   if (len > STAG_PRIO_MIN_LEN) __builtin_amdgcn_s_setprio(2);
 
   AggTeam<KIND, LPE, VEC, PEDGE, BLK> T{
@@ -508,8 +511,14 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
     if (!kin) return;
   } else {
     for (int p0 = b; p0 < pend; p0 += BLK) {
+#if STAG_LOAD_PRIO
+      __builtin_amdgcn_s_setprio(3);   // get the loads out ahead of other waves' draws
+#endif
       T.fetch_idx(I, p0);
       T.fetch_rows(R, I, p0);
+#if STAG_LOAD_PRIO
+      if (len > STAG_PRIO_MIN_LEN) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#endif
       T.compute(R, I, p0);
     }
   }
