@@ -115,8 +115,9 @@ typedef struct stag_noise_spec {
 
 /* Launch plan, built once per graph on the host (stag_plan_count / stag_plan_fill).
  * The aggregation kernel walks UNITS: a unit is a whole destination row, or one
- * segment (<= seg_len edges) of a row longer than seg_len.  Units are sorted by
- * length, longest first: lanes that share a wave then run equal trip counts and the
+ * segment (<= seg_len edges, balanced) of a row longer than seg_len.  units[0, n_seg) are
+ * the segments (slot == index, hub rows first); units[n_seg, n_units) the whole rows sorted
+ * by length, longest first: lanes that share a wave then run equal trip counts and the
  * heavy units are dispatched first.  Segment sums go to `workspace`; the segment that
  * finishes last (an arrival counter per long row) adds them in segment order, in the
  * same launch, so the result does not depend on scheduling. */

@@ -68,6 +68,7 @@ struct AggArgs {
   const int32_t* long_rows;
   const int32_t* long_seg_ptr;
   int32_t n_long;
+  int32_t n_seg;           // units[0, n_seg) are segments, the rest whole rows
   int32_t* seg_counters;   // [n_long] arrival counters, zero between launches
   float* ws;               // [n_seg][ws_stride]: D partial sums, then D weight sums if in_norm
   int32_t ws_stride;
@@ -445,7 +446,9 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
   // One block at a time: ids -> rows -> draws.  Measured on MI355X (tools/ab_bench.py, cfg2,
   // Normal noise): this loop at 2 edges per block 113 us/step; 4 edges per block 126 us;
   // an A/B software pipeline that keeps the next block's rows in flight 133 us (the extra
-  // registers cost a wave per SIMD, and occupancy hides the gather latency better).
+  // registers cost a wave per SIMD, and occupancy hides the gather latency better);
+  // persistent teams striding over the unit list (grid = chip) 140-170 us, also without
+  // noise (104 vs 98 us): many short-lived waves beat few long-lived ones here.
   const int pend = b + len;
   EdgeIdx<BLK> I;
   EdgeRows<BLK> R;

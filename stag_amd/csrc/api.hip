@@ -286,41 +286,39 @@ int stag_plan_fill(const int32_t* indptr_host, int32_t n_dst, int32_t seg_len,
   if (!indptr_host || n_dst < 0 || seg_len <= 0 || seg_len > (1 << 20) || !long_seg_ptr_host)
     return STAG_EINVAL;
   if (n_dst > 0 && !units_host) return STAG_EINVAL;
-  // counting sort by length, longest first (every length is in [0, seg_len])
-  std::vector<int64_t> bucket((size_t)seg_len + 2, 0);
   std::vector<int32_t> longs;
+  std::vector<int64_t> bucket((size_t)seg_len + 2, 0);   // whole rows by length
   for (int32_t v = 0; v < n_dst; ++v) {
     const int32_t deg = indptr_host[v + 1] - indptr_host[v];
-    if (deg > seg_len) {
-      longs.push_back(v);
-      bucket[seg_len] += deg / seg_len;
-      if (deg % seg_len) bucket[deg % seg_len] += 1;
-    } else {
-      bucket[deg] += 1;
-    }
+    if (deg > seg_len) longs.push_back(v); else bucket[deg] += 1;
   }
   if (!longs.empty() && !long_rows_host) return STAG_EINVAL;
-  // hubs first: the row with the most segments gets the earliest blocks, so the segment
-  // that arrives last (and adds the partials) is done long before the launch ends
+  // Segments first — the row with the most segments gets the earliest blocks, so the segment
+  // that arrives last (and adds the partials) is done long before the launch ends — then the
+  // whole rows, longest first (counting sort; every length is in [0, seg_len]).
   std::stable_sort(longs.begin(), longs.end(), [&](int32_t x, int32_t y) {
     return indptr_host[x + 1] - indptr_host[x] > indptr_host[y + 1] - indptr_host[y];
   });
-  std::vector<int64_t> cursor((size_t)seg_len + 1, 0);
-  int64_t run = 0;
-  for (int32_t l = seg_len; l >= 0; --l) { cursor[l] = run; run += bucket[l]; }
   int32_t s = 0;
   long_seg_ptr_host[0] = 0;
   for (size_t r = 0; r < longs.size(); ++r) {
     const int32_t v = longs[r];
-    const int32_t b = indptr_host[v], e = indptr_host[v + 1];
+    const int32_t b = indptr_host[v], deg = indptr_host[v + 1] - b;
+    const int32_t nseg = (deg + seg_len - 1) / seg_len;
+    const int32_t base = deg / nseg, rem = deg % nseg;    // balanced: lengths differ by at most 1
     long_rows_host[r] = v;
-    for (int32_t p = b; p < e; p += seg_len) {
-      const int32_t l = (e - p < seg_len) ? (e - p) : seg_len;
-      units_host[cursor[l]++] = stag_unit{(int32_t)r, p, l, s};
+    int32_t p = b;
+    for (int32_t i = 0; i < nseg; ++i) {
+      const int32_t l = base + (i < rem ? 1 : 0);
+      units_host[s] = stag_unit{(int32_t)r, p, l, s};
+      p += l;
       ++s;
     }
     long_seg_ptr_host[r + 1] = s;
   }
+  std::vector<int64_t> cursor((size_t)seg_len + 1, 0);
+  int64_t run = s;
+  for (int32_t l = seg_len; l >= 0; --l) { cursor[l] = run; run += bucket[l]; }
   for (int32_t v = 0; v < n_dst; ++v) {
     const int32_t b = indptr_host[v], e = indptr_host[v + 1];
     if (e - b <= seg_len) units_host[cursor[e - b]++] = stag_unit{v, b, e - b, -1};
@@ -405,7 +403,7 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int
     const size_t need = stag_plan_workspace_bytes(plan->n_seg, D, spec->in_norm);
     if (need >= (1ull << 32)) return STAG_ENOSYS;   // partials go through a 32-bit buffer descriptor
     a.ws = plan->workspace; a.ws_stride = D * (spec->in_norm ? 2 : 1); a.ws_bytes = (uint32_t)need;
-    a.n_long = plan->n_long; a.seg_counters = plan->seg_counters;
+    a.n_long = plan->n_long; a.seg_counters = plan->seg_counters; a.n_seg = plan->n_seg;
   }
 
   // dwordx4 path needs 16-B aligned rows everywhere a float4 is formed

@@ -86,8 +86,12 @@ def test_plan_covers_every_edge_once(seg_len):
     indptr = g.csr.indptr.numpy()
     deg = np.diff(indptr)
     assert p["n_units"] == len(units) == (deg <= seg_len).sum() + p["n_seg"]
-    assert (np.diff(units[:, 2]) <= 0).all(), "units sorted by length, longest first"
+    ns = p["n_seg"]
+    assert (units[:ns, 3] == np.arange(ns)).all() and (units[ns:, 3] == -1).all(), "segments first"
+    assert (np.diff(units[ns:, 2]) <= 0).all(), "whole rows sorted by length, longest first"
     assert units[:, 2].max() <= seg_len
+    if ns:
+        assert units[:ns, 2].min() >= (seg_len + 1) // 2, "segments are balanced"
     covered = np.zeros(len(dst), np.int32)
     long_rows, lsp = p["long_rows"].numpy(), p["long_seg_ptr"].numpy()
     for row, start, ln, slot in units:
