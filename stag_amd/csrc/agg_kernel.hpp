@@ -172,8 +172,11 @@ __device__ __forceinline__ const float* row_at(const float* base, int idx, uint3
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void bufrow4(__amdgpu_buffer_rsrc_t rsrc, int idx, uint32_t stride_bytes,
                                         uint32_t koff, float (&v)[4]) {
+#ifndef STAG_X_AUX
+#define STAG_X_AUX 0   // cache-policy bits of the row gather (2 = nt, 16 = sc1, ...): A/B knob
+#endif
   const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(
-      rsrc, (int)(__umul24((uint32_t)idx, stride_bytes) + koff), 0, 0);
+      rsrc, (int)(__umul24((uint32_t)idx, stride_bytes) + koff), 0, STAG_X_AUX);
   v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y);
   v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
 }
