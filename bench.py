@@ -96,6 +96,26 @@ def cpu_baseline(src, dst, n, x, kind, budget_s):
     return out
 
 
+def measured_traffic(args, world):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same workload
+    (profiles/<round>/bench_n1_pmc_summary.json: FETCH_SIZE x2 per the gfx950 correction, plus
+    WRITE_SIZE); None when no profile of this exact workload is committed."""
+    if world != 1:
+        return None
+    key = f"{args.graph}/{args.noise}/D{args.feat}/seg{args.seg_len}"
+    best = None
+    for d in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        f = os.path.join(ROOT, "profiles", d, "bench_n1_pmc_summary.json")
+        if os.path.exists(f):
+            try:
+                t = json.load(open(f)).get("traffic", {})
+                if t.get("workload") == key:
+                    best = float(t["traffic_bytes_per_launch"])
+            except (ValueError, KeyError):
+                pass
+    return best
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -186,7 +206,7 @@ def main():
                                       f"dst-range partition x{world} + RCCL all-gather of x per step",
                        "seg_len": args.seg_len},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, world),
                          "algorithmic_bytes_per_step": b_alg, "bytes_per_edge": b_alg / E,
                          "device_ms_per_step": dev_ms,
                          "note": "one step = one stag_agg_fwd call = ONE kernel launch (agg_kernel); "

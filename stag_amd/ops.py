@@ -95,14 +95,11 @@ class _Aggregate(torch.autograd.Function):
         x = _f32c(x)
         D = x.shape[1]
         csrv = graph.csr
-        keep = []
         if noise is not None:
-            spec = noise.spec()
-            keep += [noise.p0, noise.p1]
+            spec = noise.spec()        # ctx.noise keeps the parameter tensors alive
         elif w is not None:
             w = _f32c(w)
             spec = _explicit_spec(w)
-            keep.append(w)
         else:
             spec = _none_spec()
         # the in-norm factor is only kept (one more [N, D] store) when a backward can follow
