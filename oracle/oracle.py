@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libstag_oracle.so")
+_SO = os.environ.get("STAG_ORACLE_SO") or os.path.join(_HERE, "_build", "libstag_oracle.so")
 
 NOISE_NONE, NOISE_EXPLICIT, NOISE_NORMAL, NOISE_UNIFORM, NOISE_BERNOULLI = range(5)
 PARAM_SCALAR, PARAM_PER_CHANNEL, PARAM_PER_EDGE1, PARAM_PER_EDGE = range(4)

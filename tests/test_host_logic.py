@@ -256,3 +256,68 @@ def test_synthetic_graph_shape():
     assert len(src) == 140000 and deg.max() > 1000 and 0.02 < (deg == 0).mean() < 0.25
     s2, d2 = synthetic.arxiv_like(n_nodes=20000, n_edges=140000, max_in_degree=1500, seed=1)
     assert np.array_equal(src, s2) and np.array_equal(dst, d2)
+
+
+def test_abi_argument_validation_without_gpu():
+    """Every entry point rejects bad arguments BEFORE touching the device (errno-style codes,
+    no exception across the ABI), so this runs without a GPU."""
+    import ctypes as C
+    from stag_amd import _lib
+    lib = _lib.lib()
+    EINVAL, ENOSYS = -22, -38
+    indptr = np.array([0, 1, 2], np.int32)
+    csr = _lib.Csr(2, 2, 2, indptr.ctypes.data, indptr.ctypes.data, None, None)   # never dereferenced
+    spec = _lib.NoiseSpec()
+    f = C.c_void_p(16)                       # a non-null, 16-B aligned dummy "device pointer"
+    ok_args = lambda: [C.byref(csr), None, f, 4, 4, C.byref(spec), 0, None, None, f, 4, None, None]
+    a = ok_args(); a[0] = None
+    assert lib.stag_agg_fwd(*a) == EINVAL                                   # no graph
+    a = ok_args(); a[9] = None
+    assert lib.stag_agg_fwd(*a) == EINVAL                                   # no output
+    a = ok_args(); a[3] = 2
+    assert lib.stag_agg_fwd(*a) == EINVAL                                   # ldx < D
+    a = ok_args(); a[6] = 7
+    assert lib.stag_agg_fwd(*a) == EINVAL                                   # unknown reduce
+    bad = _lib.NoiseSpec(); bad.kind = 9
+    a = ok_args(); a[5] = C.byref(bad)
+    assert lib.stag_agg_fwd(*a) == EINVAL                                   # unknown noise kind
+    bad = _lib.NoiseSpec(); bad.kind = _lib.NOISE_EXPLICIT
+    a = ok_args(); a[5] = C.byref(bad)
+    assert lib.stag_agg_fwd(*a) == EINVAL                                   # explicit weights without p0
+    bad = _lib.NoiseSpec(); bad.kind = _lib.NOISE_NORMAL; bad.param_mode = _lib.PARAM_PER_CHANNEL
+    a = ok_args(); a[5] = C.byref(bad)
+    assert lib.stag_agg_fwd(*a) == EINVAL                                   # per-channel params without pointers
+    bad = _lib.NoiseSpec(); bad.kind = _lib.NOISE_BERNOULLI; bad.deriv = 1
+    a = ok_args(); a[5] = C.byref(bad)
+    assert lib.stag_agg_fwd(*a) == EINVAL                                   # Bernoulli has no reparameterised gradient
+    bad = _lib.NoiseSpec(); bad.kind = _lib.NOISE_NORMAL; bad.deriv = 2; bad.in_norm = 1
+    a = ok_args(); a[5] = C.byref(bad)
+    assert lib.stag_agg_fwd(*a) == EINVAL                                   # in-norm is not differentiated
+    bad = _lib.NoiseSpec(); bad.kind = _lib.NOISE_NORMAL; bad.pos_base = (1 << 32) - 1
+    a = ok_args(); a[5] = C.byref(bad)
+    assert lib.stag_agg_fwd(*a) == ENOSYS                                   # launch would straddle 2^32 positions
+    plan = _lib.Plan(64, 2, 1, 2, None, None, None, None, None, 0)
+    a = ok_args(); a[1] = C.byref(plan)
+    assert lib.stag_agg_fwd(*a) == EINVAL                                   # plan without units
+    # GAT limits
+    g = [C.byref(csr), None, f, f, f, 65, 2, 0.2, C.byref(spec), None, f, None, None]
+    assert lib.stag_gat_fwd(*g) == ENOSYS                                   # H > 64
+    g[5], g[6] = 8, 64
+    assert lib.stag_gat_fwd(*g) == ENOSYS                                   # H*F > 256
+    g[5], g[6] = 0, 4
+    assert lib.stag_gat_fwd(*g) == EINVAL
+    ns = _lib.NoiseSpec(); ns.in_norm = 1
+    g = [C.byref(csr), None, f, f, f, 2, 4, 0.2, C.byref(ns), None, f, None, None]
+    assert lib.stag_gat_fwd(*g) == EINVAL                                   # in-norm needs norm_scale
+    # planning on host arrays
+    nu, nl, nsg = C.c_int32(), C.c_int32(), C.c_int32()
+    assert lib.stag_plan_count(None, 2, 64, C.byref(nu), C.byref(nl), C.byref(nsg)) == EINVAL
+    assert lib.stag_plan_count(indptr.ctypes.data, 2, 0, C.byref(nu), C.byref(nl), C.byref(nsg)) == EINVAL
+    dec = np.array([0, 3, 1], np.int32)
+    assert lib.stag_plan_count(dec.ctypes.data, 2, 64, C.byref(nu), C.byref(nl), C.byref(nsg)) == EINVAL   # decreasing indptr
+    assert lib.stag_plan_count(indptr.ctypes.data, 2, 64, C.byref(nu), C.byref(nl), C.byref(nsg)) == 0 and nu.value == 2
+    assert lib.stag_plan_workspace_bytes(0, 128, 0) == 0 and lib.stag_plan_workspace_bytes(3, 128, 1) == 3 * 128 * 2 * 4
+    assert lib.stag_csr_build(None, None, 2, 2, 5, indptr.ctypes.data, None, None, None, None, 0, None) == EINVAL
+    assert lib.stag_segment_reduce(f, 4, 4, None, 2, 0, f, 4, None) == EINVAL
+    assert lib.stag_noise_materialize(C.byref(csr), C.byref(spec), 0, f, 4, None) == EINVAL
+    assert lib.stag_philox_raw(0, 0, 0, 4, 0, f, None) == EINVAL
