@@ -7,7 +7,8 @@ A "step" = one pass of the hot path: `ops.aggregate(graph, x, EdgeNoise)` =
 noise draw + gather + weighted segmented sum, fresh Philox offset per step.  Inputs
 are resident in HBM before the timed region.  With --gpus N > 1 the same graph is
 node-range partitioned over N ranks (stag_amd.partition) and a step is the halo
-all-gather (RCCL) + the local kernel: total work fixed => "strong" scaling.
+exchange (RCCL) + the local kernel: total work fixed => "strong" scaling.
+(--partition channels: the exchange-free alternative for graphs that fit one GPU.)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
 objects: `roofline` (algorithmic bytes / device time of the op, measured with HIP
@@ -41,6 +42,16 @@ def parse():
                     help="arxiv: the 1,166,243-edge directed CSR; arxiv_sym: the script's "
                          "self-loop + reverse-edge variant (scripts/arxiv_mle/gcn/run.py:53-55)")
     ap.add_argument("--seg-len", type=int, default=64)
+    ap.add_argument("--partition", default="auto", choices=["auto", "nodes", "channels"],
+                    help="N>1 only. nodes: dst-range shards + RCCL exchange of the referenced source "
+                         "rows per step (BASELINE north_star: graphs larger than one GPU). channels: "
+                         "every rank keeps the whole CSR and D/N channels; the step has no exchange "
+                         "(partition.ChannelShard). auto: channels when the whole graph fits one GPU "
+                         "(it does for the arxiv CSR), else nodes")
+    ap.add_argument("--no-alt", action="store_true",
+                    help="N>1: skip the second, shorter timed loop over the partition NOT chosen "
+                         "(reported as `alt_partition` in the same JSON line)")
+    ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     return ap.parse_args()
@@ -125,12 +136,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the stochastic-aggregation path has no CPU fallback")
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl") always in a real run; STAG_BENCH_BACKEND=gloo only rehearses the N>1 code
+        # path with several ranks sharing one card (RCCL refuses two ranks on one device)
+        backend = os.environ.get("STAG_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import stag_amd
     from stag_amd import ops, synthetic
@@ -143,50 +161,79 @@ def main():
     E, D = len(src), args.feat
     x_host = torch.randn(n, D, generator=torch.Generator().manual_seed(0))
 
-    if world == 1:
-        graph = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
-        graph.csr.plan(args.seg_len)
-        x = x_host.to(dev)
-
-        def step(i):
-            return ops.aggregate(graph, x, make_noise(stag_amd, graph, D, args.noise, i),
-                                 seg_len=args.seg_len)
-    else:
-        graph = GraphShard(src, dst, n, rank, world, device=dev)
-        graph.csr.plan(args.seg_len)
-        x = x_host[graph.row_lo:graph.row_hi].to(dev)
-
-        def step(i):
-            return graph.aggregate(x, make_noise(stag_amd, graph, D, args.noise, i),
-                                   seg_len=args.seg_len)
-
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for i in range(args.warmup):
-            step(i)
-        # one HIP event pair brackets the K steps on the launch stream (an event pair per step
-        # adds ~14 us of queue bubbles per step and would be charged to the kernel)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        fence()
-        t0 = time.perf_counter()
-        ev0.record()
-        for i in range(args.steps):
-            out = step(args.warmup + i)
-        ev1.record()
-        fence()
-        t1 = time.perf_counter()
-    wall = t1 - t0
-    dev_ms = ev0.elapsed_time(ev1) / args.steps
-    if world > 1:
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, dev_ms = float(t[0]), float(t[1])
-    assert torch.isfinite(out).all()
+    def make_step(partition):
+        """-> (step(i), description).  All inputs end up resident in HBM here."""
+        if world == 1:
+            graph = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
+            graph.csr.plan(args.seg_len)
+            x = x_host.to(dev)
+            return (lambda i: ops.aggregate(graph, x, make_noise(stag_amd, graph, D, args.noise, i),
+                                            seg_len=args.seg_len)), "single GPU"
+        if partition == "channels":
+            from stag_amd.partition import ChannelShard
+            whole = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
+            whole.csr.plan(args.seg_len)
+            shard = ChannelShard(whole, D, rank, world)
+            x = shard.scatter_cols(x_host).to(dev)
+            return (lambda i: shard.aggregate(x, make_noise(stag_amd, whole, shard.dn, args.noise, i),
+                                              seg_len=args.seg_len)), (
+                f"channel shards x{world}: whole CSR per rank, D/{world} channels each, "
+                f"no exchange in the step")
+        shard = GraphShard(src, dst, n, rank, world, device=dev, exchange=args.exchange)
+        shard.csr.plan(args.seg_len)
+        x = x_host[shard.row_lo:shard.row_hi].to(dev)
+        return (lambda i: shard.aggregate(x, make_noise(stag_amd, shard, D, args.noise, i),
+                                          seg_len=args.seg_len)), (
+            f"dst-range partition x{world} + RCCL {args.exchange} exchange of the referenced "
+            f"source rows per step")
+
+    def timed(step, steps, warmup):
+        """-> (wall seconds, device ms per step), MAX over ranks; barrier + sync both sides."""
+        with torch.no_grad():
+            for i in range(warmup):
+                step(i)
+            # one HIP event pair brackets the K steps on the launch stream (an event pair per step
+            # adds ~14 us of queue bubbles per step and would be charged to the kernel)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fence()
+            t0 = time.perf_counter()
+            ev0.record()
+            for i in range(steps):
+                out = step(warmup + i)
+            ev1.record()
+            fence()
+            t1 = time.perf_counter()
+        wall, dev_ms = t1 - t0, ev0.elapsed_time(ev1) / steps
+        if world > 1:
+            t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall, dev_ms = float(t[0]), float(t[1])
+        assert torch.isfinite(out).all()
+        return wall, dev_ms
+
+    # the arxiv CSR (5 MB) and x (87 MB) fit any GPU: auto => channel shards
+    fits = (4 * (n + 1) + 8 * E + 8 * n * D) < 0.5 * torch.cuda.get_device_properties(dev).total_memory
+    partition = args.partition if args.partition != "auto" else ("channels" if fits else "nodes")
+    step, parallelism = make_step(partition)
+    wall, dev_ms = timed(step, args.steps, args.warmup)
+
+    alt = None
+    if world > 1 and not args.no_alt:
+        other = "nodes" if partition == "channels" else "channels"
+        try:
+            step2, par2 = make_step(other)
+            k2 = max(1, min(args.steps, 50))
+            w2, d2 = timed(step2, k2, min(args.warmup, 5))
+            alt = {"partition": other, "parallelism": par2, "steps": k2, "ms_per_step": w2 / k2 * 1e3,
+                   "value": E / (w2 / k2), "unit": "edges/s", "device_ms_per_step": d2}
+        except Exception as exc:   # the headline partition's numbers stand on their own
+            alt = {"partition": other, "error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3
@@ -202,11 +249,11 @@ def main():
                                    f"({args.graph}), N={n}, E={E}, D={D}, fp32, int32 CSR, "
                                    f"noise={args.noise}(per edge, per channel, Philox4x32-10), "
                                    f"1 layer-forward, 1 MC sample",
-                       "parallelism": "single GPU" if world == 1 else
-                                      f"dst-range partition x{world} + RCCL all-gather of x per step",
+                       "parallelism": parallelism,
                        "seg_len": args.seg_len},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, world),
+            # N > 1: whole-job algorithmic bytes over the slowest rank's device time, against N x 8 TB/s
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                         "frac": achieved / (HBM_PEAK_GBS * world), "traffic": measured_traffic(args, world),
                          "algorithmic_bytes_per_step": b_alg, "bytes_per_edge": b_alg / E,
                          "device_ms_per_step": dev_ms,
                          "note": "one step = one stag_agg_fwd call = ONE kernel launch (agg_kernel); "
@@ -218,6 +265,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(src, dst, n, x_host.numpy(), args.noise, args.cpu_budget_s)
         else:
             line["cpu_baseline"] = None
+        if alt is not None:
+            line["alt_partition"] = alt
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 2
+#define STAG_ABI_VERSION 3
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -110,7 +110,10 @@ typedef struct stag_noise_spec {
                       (GAT: a[e,h] over the F features of head h); 0 or 1 = one per channel */
   uint64_t seed;
   uint64_t offset;
-  int64_t pos_base; /* global CSR position of this shard's position 0 (multi-GPU) */
+  int64_t pos_base; /* global CSR position of this shard's position 0 (node-range shards) */
+  int32_t chunk_base; /* first global channel / 4 of this shard's channel 0 (channel shards:
+                         every GPU holds the whole CSR and D/P of the channels, no exchange) */
+  int32_t reserved;
 } stag_noise_spec;
 
 /* Launch plan, built once per graph on the host (stag_plan_count / stag_plan_fill).

@@ -32,7 +32,8 @@ class NoiseSpec(C.Structure):
                 ("p0", _f32p), ("p1", _f32p),
                 ("p0_scalar", C.c_float), ("p1_scalar", C.c_float),
                 ("relu", C.c_int32), ("in_norm", C.c_int32), ("deriv", C.c_int32),
-                ("group", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64), ("pos_base", C.c_int64)]
+                ("group", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64), ("pos_base", C.c_int64),
+                ("chunk_base", C.c_int32), ("reserved", C.c_int32)]
 
 
 def build(force=False):
@@ -148,13 +149,13 @@ def csr_build(src, dst, n_src, n_dst):
 
 
 def make_spec(kind="none", p0=None, p1=None, relu=False, in_norm=False, seed=0, offset=0,
-              pos_base=0, Dn=None, n_edges=None, deriv=0):
+              pos_base=0, Dn=None, n_edges=None, deriv=0, chunk_base=0):
     """Build a NoiseSpec; p0/p1 may be python floats or arrays ([Dn], [E,1], [E,Dn])."""
     k = KIND[kind] if isinstance(kind, str) else int(kind)
     keep = []
     s = NoiseSpec()
     s.kind, s.relu, s.in_norm, s.deriv = k, int(relu), int(in_norm), int(deriv)
-    s.seed, s.offset, s.pos_base = int(seed), int(offset), int(pos_base)
+    s.seed, s.offset, s.pos_base, s.chunk_base = int(seed), int(offset), int(pos_base), int(chunk_base)
     s.param_mode = PARAM_SCALAR
 
     def classify(a):

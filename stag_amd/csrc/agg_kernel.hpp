@@ -54,6 +54,7 @@ struct AggArgs {
   int32_t wgroup;          // EXPLICIT: channels sharing one weight column (<= 1: one per channel)
   PhiloxKey key;
   uint32_t pos_lo, pos_hi;   // lo32 / hi32 of the shard's global position base
+  uint32_t chunk_base;       // global chunk (channel / 4) of this shard's channel 0
   // scaling / reduce
   const float* src_scale;
   const float* dst_scale;
@@ -224,6 +225,23 @@ constexpr int kKahanMinLen = STAG_KAHAN_MIN_LEN;
 #ifndef STAG_BLK_LDS
 #define STAG_BLK_LDS 2
 #endif
+// blocks fetched together, by lanes per unit (LPE 4: D <= 16; 8: D <= 32; 16: D <= 64; wider);
+// the gather-bound kinds (none, explicit) take twice the RNG kinds' depth at LPE 8 and 16
+#ifndef STAG_IDX_PREFETCH
+#define STAG_IDX_PREFETCH 1
+#endif
+#ifndef STAG_MULT_LPE4
+#define STAG_MULT_LPE4 8
+#endif
+#ifndef STAG_MULT_LPE8
+#define STAG_MULT_LPE8 4
+#endif
+#ifndef STAG_MULT_LPE16
+#define STAG_MULT_LPE16 2
+#endif
+#ifndef STAG_MULT_WIDE
+#define STAG_MULT_WIDE 1
+#endif
 
 // Register image of one block of BLK edges of a unit.
 template <int BLK>
@@ -238,8 +256,11 @@ struct EdgeRows {       // what the row fetch brings in
   float xs[BLK];
 };
 
-template <int KIND, int LPE, bool VEC, bool PEDGE, int BLK>
+// BLK: edges per arithmetic block (fixes the summation order, so the same for every shape);
+// MULT: blocks fetched together (BLK * MULT rows in flight per team; no effect on the sums).
+template <int KIND, int LPE, bool VEC, bool PEDGE, int BLK, int MULT = 1>
 struct AggTeam {
+  static constexpr int NB = BLK * MULT;
   static constexpr bool NEED_EID = (KIND == kExplicit) || PEDGE;
   const AggArgs& a;
   const int k0;
@@ -254,9 +275,9 @@ struct AggTeam {
 
   // every lane of the team reads the same BLK column ids: broadcast dword loads with
   // immediate offsets, no per-edge vector arithmetic
-  __device__ __forceinline__ void fetch_idx(EdgeIdx<BLK>& I, int p0) const {
+  __device__ __forceinline__ void fetch_idx(EdgeIdx<NB>& I, int p0) const {
 #pragma unroll
-    for (int j = 0; j < BLK; ++j) {
+    for (int j = 0; j < NB; ++j) {
       const int p = p0 + j;
       if (p < pend) {
         I.u[j] = a.indices[p];
@@ -266,9 +287,9 @@ struct AggTeam {
     }
   }
 
-  __device__ __forceinline__ void fetch_rows(EdgeRows<BLK>& R, const EdgeIdx<BLK>& I, int p0) const {
+  __device__ __forceinline__ void fetch_rows(EdgeRows<NB>& R, const EdgeIdx<NB>& I, int p0) const {
 #pragma unroll
-    for (int j = 0; j < BLK; ++j) {
+    for (int j = 0; j < NB; ++j) {
       if (p0 + j < pend) {
         if (x_buf) bufrow4(rx, I.u[j], a.ldxb, koff, R.xv[j]);
         else loadrow4(row_at(a.x, I.u[j], a.ldxb, koff, (a.wide & 1) != 0), k0, a.D, VEC, R.xv[j]);
@@ -280,7 +301,7 @@ struct AggTeam {
   // LDS-DMA form of fetch_rows: one `buffer_load_dwordx4 ... offen lds` per edge writes the
   // wave's 64 x 16 B straight into LDS slot j (M0 = slot base, lane l lands at base + 16 l);
   // nothing is held in VGPRs while the rows are in flight.
-  __device__ __forceinline__ void dma_rows(const EdgeIdx<BLK>& I, int p0, float* wave_lds) const {
+  __device__ __forceinline__ void dma_rows(const EdgeIdx<NB>& I, int p0, float* wave_lds) const {
 #pragma unroll
     for (int j = 0; j < BLK; ++j) {
       if (p0 + j < pend) {
@@ -315,14 +336,17 @@ struct AggTeam {
   // row.  `full` (wave-uniform): every active team issued all BLK DMAs of this block, so the
   // counted wait for slot j is exact: BLK-1-j younger DMAs of this block, plus BLK more when
   // `next_full` says the next block's DMAs were issued behind them (software pipeline).
-  __device__ __forceinline__ void compute(EdgeRows<BLK>& R, const EdgeIdx<BLK>& I, int p0,
+  __device__ __forceinline__ void compute(EdgeRows<NB>& R, const EdgeIdx<NB>& I, int p0,
                                           const float* lds = nullptr, bool full = false,
                                           bool next_full = false) {
-    // block sums go into fresh accumulators (small magnitudes => small rounding)
-    float t[4] = {0.f, 0.f, 0.f, 0.f};
     if (lds && !full) wait_vmcnt<0>();
 #pragma unroll
-    for (int j = 0; j < BLK; ++j) {
+    for (int m = 0; m < MULT; ++m) {
+    if (m > 0 && p0 + m * BLK >= pend) break;   // an empty block must not touch the Kahan state
+    // block sums go into fresh accumulators (small magnitudes => small rounding)
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = m * BLK; j < (m + 1) * BLK; ++j) {
       if (lds && full) {
         if (next_full) {
           if (j == 0) wait_upto<2 * BLK - 1>(); else if (j == 1) wait_upto<2 * BLK - 2>();
@@ -394,6 +418,7 @@ struct AggTeam {
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[q] += t[q];
     }
+    }   // m
   }
 };
 
@@ -405,6 +430,16 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
   // edges per block: the RNG kinds are VALU-bound and register-hungry, the others want
   // more rows in flight
   constexpr int BLK = STAGE ? STAG_BLK_LDS : ((KIND >= kNormal) ? STAG_BLK_RNG : STAG_BLK_MEM);
+  // Narrow rows (few lanes per unit) leave a team's 64-edge segment as the launch's critical
+  // path: 32 dependent round trips at 2 rows in flight.  They fetch MULT blocks at a time.
+  // Measured (tools/ab_bench.py, arxiv CSR): D=16 8 blocks, D=32 4 (RNG kinds) | 8, D=64 2 | 4.
+  constexpr bool RNG = KIND >= kNormal;
+  constexpr int MULT = STAGE ? 1
+                       : LPE <= 4 ? STAG_MULT_LPE4
+                       : LPE == 8 ? (RNG ? STAG_MULT_LPE8 : 2 * STAG_MULT_LPE8)
+                       : LPE == 16 ? (RNG ? STAG_MULT_LPE16 : 2 * STAG_MULT_LPE16)
+                                   : STAG_MULT_WIDE;
+  constexpr int NB = BLK * MULT;
 
   const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
   const int unit = blockIdx.x * TEAMS_PER_BLOCK + threadIdx.x / LPE;
@@ -428,10 +463,21 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
   // 64-edge unit would take 8x its own issue time at 8 waves per SIMD.  They are dispatched
   // first (plan order) and run at raised priority; the short rows fill in behind them.
   if (len > STAG_PRIO_MIN_LEN) __builtin_amdgcn_s_setprio(2);
+#ifdef STAG_TRACE   // tools/trace_units.py: per-unit timestamps (100 MHz) into the norm-scale buffer
+  uint64_t* trace = (!a.in_norm && a.norm_scale_out && blockIdx.y == 0 && c == 0)
+                        ? reinterpret_cast<uint64_t*>(a.norm_scale_out) + (int64_t)unit * 4 : nullptr;
+  if (trace) { trace[0] = wall_clock64(); trace[1] = trace[2] = trace[3] = 0; }
+#endif
+#if defined(STAG_PROBE) && STAG_PROBE == 2     // timing probe only: segments do nothing
+  if (slot >= 0) return;
+#endif
+#if defined(STAG_PROBE) && STAG_PROBE == 3     // timing probe only: whole rows do nothing
+  if (slot < 0) return;
+#endif
 
-  AggTeam<KIND, LPE, VEC, PEDGE, BLK> T{
+  AggTeam<KIND, LPE, VEC, PEDGE, BLK, MULT> T{
       a, k0, (uint32_t)k0 * 4u,
-      chunk | (a.pos_hi << 20),           // Philox counter word 1: a per-lane constant
+      (chunk + a.chunk_base) | (a.pos_hi << 20),   // Philox counter word 1: a per-lane constant
       b + len,
       // descriptor of x for the narrow (< 4 GB, ids < 2^24) case; kernel arguments only
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000),
@@ -453,8 +499,8 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
   // persistent teams striding over the unit list (grid = chip) 140-170 us, also without
   // noise (104 vs 98 us): many short-lived waves beat few long-lived ones here.
   const int pend = b + len;
-  EdgeIdx<BLK> I;
-  EdgeRows<BLK> R;
+  EdgeIdx<NB> I;
+  EdgeRows<NB> R;
   if constexpr (STAGE) {
     // Staged pipeline (VEC, narrow addressing).  Per chunk of LPE edges the team fetches its
     // edge records with ONE coalesced load per field and parks them in LDS; after that a
@@ -516,7 +562,28 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
     }
     if (!kin) return;
   } else {
-    for (int p0 = b; p0 < pend; p0 += BLK) {
+    // the next block's edge records are fetched while this block's rows are in flight: one
+    // round trip per block on the unit's critical path instead of two.  Narrow shapes only
+    // (their launch is latency-bound: -2..3 us); at LPE >= 32 the extra registers would cost
+    // the RNG kinds their 8th wave per SIMD for no gain.
+    constexpr bool PREFETCH = STAG_IDX_PREFETCH && LPE <= 16;
+    if constexpr (PREFETCH) {
+    EdgeIdx<NB> In;
+    T.fetch_idx(I, b);
+    for (int p0 = b; p0 < pend; p0 += NB) {
+#if STAG_LOAD_PRIO
+      __builtin_amdgcn_s_setprio(3);   // get the loads out ahead of other waves' draws
+#endif
+      T.fetch_rows(R, I, p0);
+      if (p0 + NB < pend) T.fetch_idx(In, p0 + NB);
+#if STAG_LOAD_PRIO
+      if (len > STAG_PRIO_MIN_LEN) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#endif
+      T.compute(R, I, p0);
+      I = In;
+    }
+    } else {
+    for (int p0 = b; p0 < pend; p0 += NB) {
 #if STAG_LOAD_PRIO
       __builtin_amdgcn_s_setprio(3);   // get the loads out ahead of other waves' draws
 #endif
@@ -527,10 +594,17 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
 #endif
       T.compute(R, I, p0);
     }
+    }
   }
 
+#ifdef STAG_TRACE
+  if (trace) trace[1] = wall_clock64();
+#endif
   if (slot < 0) {
     agg_epilogue(a, v, len, k0, VEC, T.acc, T.wsum);
+#ifdef STAG_TRACE
+    if (trace) trace[3] = wall_clock64();
+#endif
     return;
   }
   // ---- segment of a long row: publish the partial, the last arriver sums the row ----------
@@ -541,6 +615,9 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
   const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)a.ws_bytes, 0x00020000);
   const uint32_t woff = (uint32_t)slot * ((uint32_t)a.ws_stride * 4u) + (uint32_t)k0 * 4u;
   store4_sc1(rws, woff, k0, a.D, VEC, T.acc);
+#if defined(STAG_PROBE) && STAG_PROBE == 1     // timing probe only: no ticket, no combine
+  return;
+#endif
   if (a.in_norm) store4_sc1(rws, woff + (uint32_t)a.D * 4u, k0, a.D, VEC, T.wsum);
   const int s0 = a.long_seg_ptr[r], s1 = a.long_seg_ptr[r + 1];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -549,6 +626,9 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
   if (c == 0)
     ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   ticket = __builtin_amdgcn_ds_bpermute(((int)(threadIdx.x & 63) - c) << 2, ticket);
+#ifdef STAG_TRACE
+  if (trace) trace[2] = wall_clock64();
+#endif
   if (ticket != (s1 - s0) - 1) return;
   // consumer side: this team drew the last ticket; acquire, then plain loads
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -559,11 +639,17 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
   // Sum the row's partials in segment order with compensated (Kahan) fp32 adds: a hub row has
   // hundreds of them.  NF partials are in flight at a time; the tail is written to stay under
   // the hot loop's register count (fp64 accumulators or a wider NF cost a wave per SIMD).
-  constexpr int NF = 8;
+#ifndef STAG_COMBINE_NF
+#define STAG_COMBINE_NF 8
+#endif
+  constexpr int NF = STAG_COMBINE_NF;
   float facc[4], fws[4] = {0.f, 0.f, 0.f, 0.f};
   kahan_sum_partials<NF, VEC>(a.ws, a.ws_stride, s0, s1, k0, a.D, facc);
   if (a.in_norm) kahan_sum_partials<NF, VEC>(a.ws + a.D, a.ws_stride, s0, s1, k0, a.D, fws);
   agg_epilogue(a, row, deg, k0, VEC, facc, fws);
+#ifdef STAG_TRACE
+  if (trace) trace[3] = wall_clock64();
+#endif
 }
 
 // Launch one (KIND, PEDGE) family; defined per kind in agg_<kind>.hip so the

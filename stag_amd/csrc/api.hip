@@ -23,7 +23,7 @@ int check_spec(const stag_noise_spec* s) {
   if (!s) return STAG_EINVAL;
   if (s->kind < STAG_NOISE_NONE || s->kind > STAG_NOISE_BERNOULLI) return STAG_EINVAL;
   if (s->kind == STAG_NOISE_EXPLICIT && !s->p0) return STAG_EINVAL;
-  if (s->deriv < 0 || s->deriv > 2) return STAG_EINVAL;
+  if (s->deriv < 0 || s->deriv > 2 || s->chunk_base < 0 || s->chunk_base >= (1 << 20)) return STAG_EINVAL;
   if (s->deriv != 0 && (s->in_norm || (s->kind != STAG_NOISE_NORMAL && s->kind != STAG_NOISE_UNIFORM)))
     return STAG_EINVAL;   // only reparameterised draws have a derivative; in-norm is not differentiated here
   if (s->kind >= STAG_NOISE_NORMAL) {
@@ -77,6 +77,7 @@ struct NoiseArgs {
   int32_t pmode, nflags, in_norm;   // nflags: relu | deriv << 1 (noise.hpp)
   PhiloxKey key;
   int64_t pos_base;
+  uint32_t chunk_base;
   float* w;
   int64_t ldw;
 };
@@ -96,6 +97,7 @@ __device__ __forceinline__ void edge_w4(const NoiseArgs& a, int p, int64_t ed, u
     pa[j] = q0; pb[j] = q1;
   }
   const int64_t gpos = a.nidx ? (int64_t)a.nidx[p] : a.pos_base + p;
+  chunk += a.chunk_base;   // global channel group (channel shards)
   switch (a.kind) {
     case kNormal: draw4<kNormal>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.nflags, w); break;
     case kUniform: draw4<kUniform>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.nflags, w); break;
@@ -378,6 +380,7 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int
   a.key = make_key(spec);
   a.pos_lo = (uint32_t)((uint64_t)spec->pos_base & 0xFFFFFFFFull);
   a.pos_hi = (uint32_t)((uint64_t)spec->pos_base >> 32);
+  a.chunk_base = (uint32_t)spec->chunk_base;
   // one launch must not straddle a 2^32 boundary of the global position space (the kernel
   // keeps hi32 in a scalar): shards are < 2^31 edges, so split the call at the boundary
   if (spec->kind >= STAG_NOISE_NORMAL && !csr->nidx &&
@@ -443,7 +446,8 @@ int stag_noise_materialize(const stag_csr* csr, const stag_noise_spec* spec, int
   a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar;
   a.pmode = spec->kind >= STAG_NOISE_NORMAL ? spec->param_mode : 0;
   a.nflags = (spec->relu ? kFlagRelu : 0) | (spec->deriv << kDerivShift); a.in_norm = spec->in_norm;
-  a.key = make_key(spec); a.pos_base = spec->pos_base; a.w = w; a.ldw = ldw;
+  a.key = make_key(spec); a.pos_base = spec->pos_base; a.chunk_base = (uint32_t)spec->chunk_base;
+  a.w = w; a.ldw = ldw;
   const int nchunk = (Dn + 3) / 4;
   int lpe = 1;
   while (lpe < nchunk && lpe < 64) lpe <<= 1;
@@ -477,7 +481,7 @@ int stag_agg_bwd_w(const stag_csr* csr, const float* x, int64_t ldx, const float
     a.kind = spec->kind; a.p0 = spec->p0; a.p1 = spec->p1;
     a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar; a.pmode = spec->param_mode;
     a.nflags = (spec->relu ? kFlagRelu : 0) | (spec->deriv << kDerivShift);
-    a.key = make_key(spec); a.pos_base = spec->pos_base;
+    a.key = make_key(spec); a.pos_base = spec->pos_base; a.chunk_base = (uint32_t)spec->chunk_base;
   }
   a.w = dw; a.ldw = ldw;
   b.indices = csr->indices; b.x = x; b.ldx = ldx; b.g = g; b.ldg = ldg; b.src_scale = src_scale;

@@ -441,6 +441,7 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
   if (!out || H <= 0 || F <= 0) return STAG_EINVAL;
   const int64_t HF64 = (int64_t)H * F;
   if (H > 64 || HF64 > 256) return STAG_ENOSYS;   // one wave spans the H*F row; LDS tile is [64][H]
+  if (spec->chunk_base != 0) return STAG_ENOSYS;  // heads are not channel-sharded
   if (spec->in_norm && !norm_scale) return STAG_EINVAL;   // the caller runs the row-sum pass first
   if (csr->n_dst == 0) return STAG_OK;
   if (csr->n_edges > 0 && (!csr->indices || !el || !er || !ft)) return STAG_EINVAL;
@@ -529,6 +530,7 @@ extern "C" int stag_gat_bwd_edge(const stag_csr* csr, const stag_plan* plan, con
   const int64_t HF64 = (int64_t)H * F;
   const int lph = F / 4;
   if (H > 64 || HF64 > 256 || F % 4 != 0 || (lph & (lph - 1)) != 0) return STAG_ENOSYS;
+  if (spec->chunk_base != 0) return STAG_ENOSYS;
   if (spec->in_norm && !norm_scale) return STAG_EINVAL;
   if (csr->n_dst == 0 || csr->n_edges == 0) return STAG_OK;
   if (!csr->indices || !el || !er || !ft || !attn || !g || !gdo) return STAG_EINVAL;

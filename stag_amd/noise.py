@@ -40,7 +40,7 @@ def _param_mode(p, n_edges, dn):
 
 class EdgeNoise:
     def __init__(self, graph, dn, kind, p0, p1=None, relu=False, in_norm=False, seed=0, offset=0,
-                 pos_base=0, differentiable=False):
+                 pos_base=0, differentiable=False, chunk_base=0):
         self.graph, self.dn, self.kind = graph, int(dn), int(kind)
         # vi=True: keep the live parameter tensors so ops.aggregate can return their gradients
         # (reparameterised draw; the backward regenerates the noise with spec.deriv = 1 | 2)
@@ -50,6 +50,8 @@ class EdgeNoise:
         self.deriv = 0
         self.relu, self.in_norm = bool(relu), bool(in_norm)
         self.seed, self.offset, self.pos_base = int(seed), int(offset), int(pos_base)
+        # channel shards (partition.ChannelShard): this tensor's channel 0 is global channel 4*chunk_base
+        self.chunk_base = int(chunk_base)
         E = graph.number_of_edges()
         dev = graph.device
         self.param_mode = _lib.PARAM_SCALAR
@@ -94,6 +96,7 @@ class EdgeNoise:
         s.p0_scalar, s.p1_scalar = self.p0_scalar, self.p1_scalar
         s.relu, s.in_norm, s.deriv = int(self.relu), int(self.in_norm), int(self.deriv)
         s.seed, s.offset, s.pos_base = self.seed, self.offset, self.pos_base
+        s.chunk_base = self.chunk_base
         return s
 
     def materialize(self):

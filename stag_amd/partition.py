@@ -15,6 +15,15 @@ new functionality — the reference is single-process).
     Philox counters are keyed by the GLOBAL CSR position (`pos_base` = first global
     position of the shard), so 1/2/4/8-GPU outputs are bit-identical;
     backward = the transposed exchange (reduce-scatter of dx).
+
+Channel sharding (`ChannelShard`) is the alternative for graphs that FIT one GPU (arxiv: 5 MB
+of CSR): every rank keeps the whole CSR and D/P of the feature channels.  The channels of the
+aggregation are independent, so the step needs NO exchange at all, and the only traffic of a
+GCN layer is the all-to-all that turns the channel-sharded result into row shards for the
+dense transform (`to_row_shards`, N*D/P floats per rank; the halo exchange moves up to
+N*D*(P-1)/P).  What does not shrink with P is the per-edge part (index loads, address
+arithmetic), so this mode stops scaling at about D/P = 32.  Philox
+counters are keyed by the GLOBAL channel (`chunk_base`), so outputs are again bit-identical.
 """
 import numpy as np
 import torch
@@ -240,3 +249,76 @@ class GraphShard:
             weight.pos_base = self.pos_base
         return ops.gat_aggregate(self, el_full, er_rows, ft_full, neg_slope, weight,
                                  seg_len=DEFAULT_SEG_LEN if seg_len is None else seg_len)
+
+
+# ------------------------------------------------------------------------------------- #
+def channel_bounds(D, world):
+    """Column cut points [world+1], multiples of 4 (one Philox block = 4 channels), as even
+    as that allows."""
+    blocks = (D + 3) // 4
+    cuts = [min(D, 4 * ((blocks * r) // world)) for r in range(world)] + [D]
+    return cuts
+
+
+class ChannelShard:
+    """Rank `rank`'s channels [c_lo, c_hi) of a graph every rank holds whole.
+
+    shard.aggregate(x_cols, noise) == ops.aggregate(graph, x, noise)[:, c_lo:c_hi] bit for bit;
+    `noise` is an EdgeNoise of dn = c_hi - c_lo built on `graph` (per-channel / per-edge
+    parameters are the shard's own columns)."""
+
+    def __init__(self, graph, D, rank, world, group=None):
+        self.graph, self.D, self.rank, self.world, self.group = graph, int(D), int(rank), int(world), group
+        self.bounds = channel_bounds(self.D, self.world)
+        self.c_lo, self.c_hi = self.bounds[rank], self.bounds[rank + 1]
+        self.dn = self.c_hi - self.c_lo
+
+    def scatter_cols(self, x_global):
+        return x_global[:, self.c_lo:self.c_hi].contiguous()
+
+    def aggregate(self, x_cols, weight=None, reduce="sum", src_scale=None, dst_scale=None, seg_len=None):
+        from . import ops
+        from .graph import DEFAULT_SEG_LEN
+        from .noise import EdgeNoise
+        if x_cols.shape[1] != self.dn:
+            raise ValueError(f"rank {self.rank} owns {self.dn} channels, got {x_cols.shape[1]}")
+        if isinstance(weight, EdgeNoise):
+            weight.chunk_base = self.c_lo // 4
+        return ops.aggregate(self.graph, x_cols, weight, reduce=reduce, src_scale=src_scale,
+                             dst_scale=dst_scale,
+                             seg_len=DEFAULT_SEG_LEN if seg_len is None else seg_len)
+
+    # ---- layout exchange for the dense transform that follows --------------------------
+    def row_bounds(self):
+        n = self.graph.number_of_dst_nodes() if hasattr(self.graph, "number_of_dst_nodes") else self.graph.number_of_nodes()
+        return [(n * r) // self.world for r in range(self.world + 1)]
+
+    def to_row_shards(self, out_cols):
+        """[N, dn] channel shard -> [N/P, D] row shard: ONE all-to-all (RCCL over xGMI)."""
+        if self.world == 1:
+            return out_cols
+        rb = self.row_bounds()
+        n_mine = rb[self.rank + 1] - rb[self.rank]
+        widths = [self.bounds[r + 1] - self.bounds[r] for r in range(self.world)]
+        in_splits = [(rb[r + 1] - rb[r]) * self.dn for r in range(self.world)]
+        out_splits = [n_mine * w for w in widths]
+        recv = torch.empty(sum(out_splits), dtype=out_cols.dtype, device=out_cols.device)
+        dist.all_to_all_single(recv, out_cols.contiguous().reshape(-1), out_splits, in_splits,
+                               group=self.group)
+        parts = recv.split(out_splits)
+        return torch.cat([p.reshape(n_mine, w) for p, w in zip(parts, widths)], 1)
+
+    def to_channel_shards(self, y_rows):
+        """[N/P, D] row shard -> [N, dn] channel shard: the inverse all-to-all."""
+        if self.world == 1:
+            return y_rows
+        rb = self.row_bounds()
+        n_mine = rb[self.rank + 1] - rb[self.rank]
+        widths = [self.bounds[r + 1] - self.bounds[r] for r in range(self.world)]
+        send = torch.cat([y_rows[:, self.bounds[r]:self.bounds[r + 1]].reshape(-1)
+                          for r in range(self.world)])
+        in_splits = [n_mine * w for w in widths]
+        out_splits = [(rb[r + 1] - rb[r]) * self.dn for r in range(self.world)]
+        recv = torch.empty(sum(out_splits), dtype=y_rows.dtype, device=y_rows.device)
+        dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group)
+        return recv.reshape(-1, self.dn)

@@ -215,6 +215,24 @@ def test_shard_equals_whole_graph(dev):
             parts_halo.append(ops.aggregate(hs, buf, noise))
         assert torch.equal(torch.cat(parts, 0), whole)
         assert torch.equal(torch.cat(parts_halo, 0), whole)
+    # channel shards: whole CSR on every rank, D/P channels each, no exchange; per-channel params follow
+    from stag_amd.partition import ChannelShard
+    loc, scale = torch.rand(D, device=dev) + 0.5, torch.rand(D, device=dev) * 0.5 + 0.1
+    whole_pc = ops.aggregate(g, x, stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, loc, scale, seed=8, offset=3, relu=True))
+    whole_bn = ops.aggregate(g, x, stag_amd.EdgeNoise(g, D, _lib.NOISE_BERNOULLI, 0.6, seed=8, offset=3, in_norm=True))
+    for world in (2, 8, 3):
+        cols, cols_pc, cols_bn = [], [], []
+        for r in range(world):
+            cs = ChannelShard(g, D, r, world)
+            xc = cs.scatter_cols(x)
+            cols.append(cs.aggregate(xc, stag_amd.EdgeNoise(g, cs.dn, _lib.NOISE_NORMAL, 1.0, 0.5, seed=8, offset=3)))
+            cols_pc.append(cs.aggregate(xc, stag_amd.EdgeNoise(g, cs.dn, _lib.NOISE_NORMAL, loc[cs.c_lo:cs.c_hi],
+                                                                 scale[cs.c_lo:cs.c_hi], seed=8, offset=3, relu=True)))
+            cols_bn.append(cs.aggregate(xc, stag_amd.EdgeNoise(g, cs.dn, _lib.NOISE_BERNOULLI, 0.6, seed=8, offset=3,
+                                                                 in_norm=True)))
+        assert torch.equal(torch.cat(cols, 1), whole)
+        assert torch.equal(torch.cat(cols_pc, 1), whole_pc)
+        assert torch.equal(torch.cat(cols_bn, 1), whole_bn)
     # partitioned GAT (cfg5 shape of the exchange: [ft | el] in one buffer), 2 emulated ranks
     H, F = 8, 16
     el, er, ft = torch.randn(n, H, device=dev), torch.randn(n, H, device=dev), torch.randn(n, H, F, device=dev)

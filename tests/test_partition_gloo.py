@@ -2,7 +2,8 @@
 
 What is checked: the node-range partition (edge-balanced bounds, local CSR, column ids
 remapped into the all-gathered buffer, global Philox positions) and the halo exchange
-(all_gather forward, reduce_scatter backward).  The aggregation kernel itself cannot run
+(all_gather forward, reduce_scatter backward), and the channel shards
+(`ChannelShard`: no exchange in the step; the layout all-to-all either side of the dense transform).  The aggregation kernel itself cannot run
 here (no CPU fallback by design); the oracle — the checker — stands in for it on each
 rank's shard, and the concatenation of the shards' results must equal the single-process
 oracle result BIT FOR BIT (same noise per edge whatever the partition).
@@ -83,6 +84,25 @@ def _worker(rank, world, port, tmp):
         t = sh.csr_t
         assert t.n_dst == sh.n_buf and t.n_src == sh.n_rows
         assert int(t.nidx.min()) >= sh.pos_base and int(t.nidx.max()) < sh.pos_base + E_loc
+        # ---- channel shards: whole CSR everywhere, D/P channels each, no exchange in the step ---------
+        from stag_amd.partition import ChannelShard
+
+        class _G:                       # the only thing ChannelShard asks of a graph on this path
+            def number_of_nodes(self):
+                return n
+        D = x.shape[1]
+        cs = ChannelShard(_G(), D, rank, world)
+        assert cs.bounds[0] == 0 and cs.bounds[-1] == D and all(b % 4 == 0 for b in cs.bounds[:-1])
+        indptr, indices, eid, *_ = O.csr_build(src, dst, n, n)
+        wg = O.CsrGraph(indptr, indices, eid, n_src=n)
+        spec = O.make_spec("normal", 1.0, 0.5, seed=77, offset=5, Dn=cs.dn, n_edges=len(src), chunk_base=cs.c_lo // 4)
+        cols = torch.from_numpy(O.agg_fwd(wg, np.ascontiguousarray(x[:, cs.c_lo:cs.c_hi]), spec))
+        np.save(os.path.join(tmp, f"chan{rank}.npy"), cols.numpy())
+        rows = cs.to_row_shards(cols)                            # one all-to-all: [N, D/P] -> [N/P, D]
+        rb = cs.row_bounds()
+        assert rows.shape == (rb[rank + 1] - rb[rank], D)
+        np.save(os.path.join(tmp, f"rows{rank}.npy"), rows.numpy())
+        assert torch.equal(cs.to_channel_shards(rows), cols)     # and back
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -103,6 +123,10 @@ def test_partition_two_ranks_matches_single(world, tmp_path, oracle):
         got = np.concatenate([np.load(tmp_path / f"{tag}{r}.npy") for r in range(world)], 0)
         assert got.shape == ref.shape
         assert np.array_equal(got, ref), f"{tag}: partitioned result must be bit-identical to the unpartitioned one"
+    chan = np.concatenate([np.load(tmp_path / f"chan{r}.npy") for r in range(world)], 1)
+    assert np.array_equal(chan, ref), "channel shards: global Philox channel => bit-identical columns"
+    rows = np.concatenate([np.load(tmp_path / f"rows{r}.npy") for r in range(world)], 0)
+    assert np.array_equal(rows, ref), "to_row_shards must deliver every rank its rows of the full-width result"
 
 
 def test_edge_balanced_bounds():
