@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 3
+#define STAG_ABI_VERSION 4
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -144,14 +144,20 @@ typedef struct stag_plan {
   float* workspace;            /* >= stag_plan_workspace_bytes(); one call at a
                                   time may use a plan's workspace and counters     */
   size_t workspace_bytes;
+  int32_t n_heavy;             /* units[0, n_heavy): all segments, then the whole rows longer
+                                  than STAG_HEAVY_LEN edges (stag_plan_count reports it); the
+                                  kernel spreads each of them over more lanes.  0 is valid.  */
+  int32_t reserved;
 } stag_plan;
 
 int stag_abi_version(void);
 const char* stag_strerror(int code);
 
 /* ---- host-side planning (plain C++ on host arrays, no GPU call) ---------- */
+#define STAG_HEAVY_LEN 16
 int stag_plan_count(const int32_t* indptr_host, int32_t n_dst, int32_t seg_len,
-                    int32_t* n_units_out, int32_t* n_long_out, int32_t* n_seg_out);
+                    int32_t* n_units_out, int32_t* n_long_out, int32_t* n_seg_out,
+                    int32_t* n_heavy_out /* may be NULL */);
 int stag_plan_fill(const int32_t* indptr_host, int32_t n_dst, int32_t seg_len,
                    stag_unit* units_host, int32_t* long_rows_host,
                    int32_t* long_seg_ptr_host);

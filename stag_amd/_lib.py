@@ -37,7 +37,8 @@ class NoiseSpec(C.Structure):
 class Plan(C.Structure):
     _fields_ = [("seg_len", C.c_int32), ("n_units", C.c_int32), ("n_long", C.c_int32),
                 ("n_seg", C.c_int32), ("units", _vp), ("long_rows", _vp), ("long_seg_ptr", _vp),
-                ("seg_counters", _vp), ("workspace", _vp), ("workspace_bytes", C.c_size_t)]
+                ("seg_counters", _vp), ("workspace", _vp), ("workspace_bytes", C.c_size_t),
+                ("n_heavy", C.c_int32), ("reserved", C.c_int32)]
 
 
 class StagHipError(RuntimeError):
@@ -77,7 +78,7 @@ def lib():
     l.stag_abi_version.restype = C.c_int
     l.stag_strerror.restype = C.c_char_p
     l.stag_strerror.argtypes = [C.c_int]
-    l.stag_plan_count.argtypes = [_vp, C.c_int32, C.c_int32, ip, ip, ip]
+    l.stag_plan_count.argtypes = [_vp, C.c_int32, C.c_int32, ip, ip, ip, ip]
     l.stag_plan_fill.argtypes = [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]
     l.stag_plan_workspace_bytes.restype = C.c_size_t
     l.stag_plan_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
@@ -101,7 +102,7 @@ def lib():
     l.stag_gat_bwd_edge.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp, _vp, _vp, _vp,
                                     C.c_int32, C.c_int32, C.c_float, C.POINTER(NoiseSpec), _vp, _vp,
                                     _vp, _vp]
-    if l.stag_abi_version() != 3:
+    if l.stag_abi_version() != 4:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     _lib = l
     return l

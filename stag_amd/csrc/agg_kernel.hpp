@@ -55,6 +55,8 @@ struct AggArgs {
   PhiloxKey key;
   uint32_t pos_lo, pos_hi;   // lo32 / hi32 of the shard's global position base
   uint32_t chunk_base;       // global chunk (channel / 4) of this shard's channel 0
+  int32_t n_heavy;           // leading units of the plan longer than STAG_HEAVY_LEN edges
+  int32_t n_heavy_blocks;    // blocks that serve them (set per launch shape)
   // scaling / reduce
   const float* src_scale;
   const float* dst_scale;
@@ -135,6 +137,39 @@ __device__ __forceinline__ void kahan_sum_partials(const float* ws, int ws_strid
         comp[q] = (n - sum[q]) - y;
         sum[q] = n;
       }
+  }
+}
+
+// Two-level form: Kahan sums of groups of kGroup partials, then a Kahan sum of the group sums in
+// group order.  SLOTS edge slots of the unit take one group each per round and exchange the group
+// sums (ds_bpermute; slot0 = byte address of slot 0's lane with my channels): same arithmetic
+// for every SLOTS.
+constexpr int kCombineGroup = 16;
+template <int NF, bool VEC, int LPE, int SLOTS>
+__device__ __forceinline__ void two_level_sum(const float* ws, int ws_stride, int s0, int s1, int k0,
+                                              int D, int sl, int slot0, float (&sum)[4]) {
+  float comp[4] = {0.f, 0.f, 0.f, 0.f};
+  sum[0] = sum[1] = sum[2] = sum[3] = 0.f;
+#pragma unroll 1
+  for (int g0 = s0; g0 < s1; g0 += kCombineGroup * SLOTS) {
+    const int gs = g0 + sl * kCombineGroup;
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+    if (gs < s1) kahan_sum_partials<NF, VEC>(ws, ws_stride, gs, min(gs + kCombineGroup, s1), k0, D, gsum);
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+      if (g0 + j * kCombineGroup < s1) {            // uniform over the unit's lanes
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float gj = SLOTS > 1 ? __int_as_float(__builtin_amdgcn_ds_bpermute(
+                                           slot0 + j * (LPE << 2), __float_as_int(gsum[q])))
+                                     : gsum[q];
+          const float y = gj - comp[q];
+          const float n = sum[q] + y;
+          comp[q] = (n - sum[q]) - y;
+          sum[q] = n;
+        }
+      }
+    }
   }
 }
 
@@ -225,19 +260,35 @@ constexpr int kKahanMinLen = STAG_KAHAN_MIN_LEN;
 #ifndef STAG_BLK_LDS
 #define STAG_BLK_LDS 2
 #endif
-// blocks fetched together, by lanes per unit (LPE 4: D <= 16; 8: D <= 32; 16: D <= 64; wider);
-// the gather-bound kinds (none, explicit) take twice the RNG kinds' depth at LPE 8 and 16
+// blocks fetched together by a light unit, by lanes per unit (LPE 4: D <= 16; 8: D <= 32; 16: D <= 64;
+// wider); values are for the RNG kinds, mult_of() scales them for the gather-bound kinds
 #ifndef STAG_IDX_PREFETCH
 #define STAG_IDX_PREFETCH 1
 #endif
+// Edge slots: a narrow unit is spread over SLOTS x LPE lanes; slot s takes the s-th run of
+// BLK * MULT edges of every round, so SLOTS x as many rows and draws are in flight per unit,
+// and the block sums are folded in the SAME order as the one-slot loop (bit-identical sums).
+#ifndef STAG_SLOTS_LPE4
+#define STAG_SLOTS_LPE4 1
+#endif
+#ifndef STAG_SLOTS_LPE8
+#define STAG_SLOTS_LPE8 1
+#endif
+#ifndef STAG_SLOTS_LPE16
+#define STAG_SLOTS_LPE16 1
+#endif
+template <int LPE, bool STAGE>
+constexpr int slots_of() {
+  return STAGE ? 1 : LPE <= 4 ? STAG_SLOTS_LPE4 : LPE == 8 ? STAG_SLOTS_LPE8 : LPE == 16 ? STAG_SLOTS_LPE16 : 1;
+}
 #ifndef STAG_MULT_LPE4
-#define STAG_MULT_LPE4 8
+#define STAG_MULT_LPE4 4
 #endif
 #ifndef STAG_MULT_LPE8
-#define STAG_MULT_LPE8 4
+#define STAG_MULT_LPE8 1
 #endif
 #ifndef STAG_MULT_LPE16
-#define STAG_MULT_LPE16 2
+#define STAG_MULT_LPE16 1
 #endif
 #ifndef STAG_MULT_WIDE
 #define STAG_MULT_WIDE 1
@@ -362,34 +413,7 @@ struct AggTeam {
           R.xv[j][0] = xr.x; R.xv[j][1] = xr.y; R.xv[j][2] = xr.z; R.xv[j][3] = xr.w;
         }
         float w[4];
-        if constexpr (KIND == kNone) {
-          w[0] = w[1] = w[2] = w[3] = 1.0f;
-        } else if constexpr (KIND == kExplicit) {
-          if (a.wgroup > 1) {   // one weight per `wgroup` channels (GAT heads: a[e,h] over F)
-            const float* wr = a.p0 + (int64_t)I.ee[j] * (a.D / a.wgroup);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) w[q] = (k0 + q < a.D) ? wr[(k0 + q) / a.wgroup] : 0.0f;
-          } else {
-            loadrow4(row_at(a.p0, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, w);
-          }
-          if (a.relu & kFlagRelu) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) w[q] = fmaxf(w[q], 0.0f);
-          }
-        } else {
-          if constexpr (PEDGE) {
-            if (a.pmode == STAG_PARAM_PER_EDGE1) {
-              const float q0 = a.p0[I.ee[j]];
-              const float q1 = a.p1 ? a.p1[I.ee[j]] : 0.0f;
-#pragma unroll
-              for (int q = 0; q < 4; ++q) { pa[q] = q0; pb[q] = q1; }
-            } else {
-              loadrow4(row_at(a.p0, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, pa);
-              if (a.p1) loadrow4(row_at(a.p1, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, pb);
-            }
-          }
-          draw4<KIND>(I.nn[j], c1, a.key, pa, pb, a.relu, w);
-        }
+        edge_weight(I, j, w);
         if (a.src_scale) {
           asm volatile("" ::: "memory");   // keep this a branch: as selects it costs 6 VALU ops per edge
 #pragma unroll
@@ -400,12 +424,17 @@ struct AggTeam {
         if (a.in_norm) {
           asm volatile("" ::: "memory");
 #pragma unroll
-          for (int q = 0; q < 4; ++q) wsum[q] += w[q];   // 0/1 draws (Bernoulli + norm): exact
+          for (int q = 0; q < 4; ++q) wsum[q] += w[q];   // edge order; 0/1 draws (Bernoulli + norm): exact
         }
       }
     }
-    // fold the block into the unit's sum; compensated (Kahan) once a unit is long enough for
-    // the running sum to dwarf a block, so a 13k-edge hub row keeps ~1e-6 relative accuracy
+    fold(t);
+    }   // m
+  }
+
+  // fold one block into the unit's sum; compensated (Kahan) once a unit is long enough for
+  // the running sum to dwarf a block, so a 13k-edge hub row keeps ~1e-6 relative accuracy
+  __device__ __forceinline__ void fold(const float (&t)[4]) {
     if (kahan) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -418,34 +447,81 @@ struct AggTeam {
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[q] += t[q];
     }
-    }   // m
+  }
+
+  // Block sums only (register staging), for the slotted loop: t[m] of this lane's MULT blocks
+  // starting at p0 and the weights we[j] of its NB edges (in-norm sums them in edge order);
+  // blocks past the unit's end stay zero and are never folded.
+  __device__ __forceinline__ void block_sums(EdgeRows<NB>& R, const EdgeIdx<NB>& I, int p0,
+                                             float (&t)[MULT][4], float (&we)[NB][4]) {
+#pragma unroll
+    for (int m = 0; m < MULT; ++m) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t[m][q] = 0.f;
+#pragma unroll
+      for (int j = m * BLK; j < (m + 1) * BLK; ++j) {
+        if (p0 + j < pend) {
+          float w[4];
+          edge_weight(I, j, w);
+          if (a.src_scale) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) R.xv[j][q] *= R.xs[j];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t[m][q] = __builtin_fmaf(w[q], R.xv[j][q], t[m][q]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) we[j][q] = w[q];
+        }
+      }
+    }
+  }
+
+  // w[0..3]: the multiplicative weight of edge j of the fetched set on this lane's channels
+  __device__ __forceinline__ void edge_weight(const EdgeIdx<NB>& I, int j, float (&w)[4]) {
+    if constexpr (KIND == kNone) {
+      w[0] = w[1] = w[2] = w[3] = 1.0f;
+    } else if constexpr (KIND == kExplicit) {
+      if (a.wgroup > 1) {   // one weight per `wgroup` channels (GAT heads: a[e,h] over F)
+        const float* wr = a.p0 + (int64_t)I.ee[j] * (a.D / a.wgroup);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = (k0 + q < a.D) ? wr[(k0 + q) / a.wgroup] : 0.0f;
+      } else {
+        loadrow4(row_at(a.p0, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, w);
+      }
+      if (a.relu & kFlagRelu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = fmaxf(w[q], 0.0f);
+      }
+    } else {
+      if constexpr (PEDGE) {
+        if (a.pmode == STAG_PARAM_PER_EDGE1) {
+          const float q0 = a.p0[I.ee[j]];
+          const float q1 = a.p1 ? a.p1[I.ee[j]] : 0.0f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { pa[q] = q0; pb[q] = q1; }
+        } else {
+          loadrow4(row_at(a.p0, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, pa);
+          if (a.p1) loadrow4(row_at(a.p1, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, pb);
+        }
+      }
+      draw4<KIND>(I.nn[j], c1, a.key, pa, pb, a.relu, w);
+    }
   }
 };
 
-// STAGE: gathered rows travel global -> LDS -> VGPR (buffer_load ... lds); needs VEC and the
-// narrow (buffer-descriptor) addressing form, decided on the host.
-template <int KIND, int LPE, bool VEC, bool PEDGE, bool STAGE>
-__global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_kernel(const AggArgs a) {
-  constexpr int TEAMS_PER_BLOCK = STAG_BLOCK_THREADS / LPE;
+// One unit (a whole row or a segment of a long row) on LPE x SLOTS lanes of a wave:
+// c = this lane's chunk (4 channels) of the channel tile, sl = its edge slot.
+template <int KIND, int LPE, bool VEC, bool PEDGE, bool STAGE, int SLOTS, int MULT>
+__device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const int c, const int sl) {
+  static_assert(LPE * SLOTS <= 64 && 64 % (LPE * SLOTS) == 0, "a unit's lanes stay inside one wave");
   // edges per block: the RNG kinds are VALU-bound and register-hungry, the others want
   // more rows in flight
   constexpr int BLK = STAGE ? STAG_BLK_LDS : ((KIND >= kNormal) ? STAG_BLK_RNG : STAG_BLK_MEM);
-  // Narrow rows (few lanes per unit) leave a team's 64-edge segment as the launch's critical
-  // path: 32 dependent round trips at 2 rows in flight.  They fetch MULT blocks at a time.
-  // Measured (tools/ab_bench.py, arxiv CSR): D=16 8 blocks, D=32 4 (RNG kinds) | 8, D=64 2 | 4.
-  constexpr bool RNG = KIND >= kNormal;
-  constexpr int MULT = STAGE ? 1
-                       : LPE <= 4 ? STAG_MULT_LPE4
-                       : LPE == 8 ? (RNG ? STAG_MULT_LPE8 : 2 * STAG_MULT_LPE8)
-                       : LPE == 16 ? (RNG ? STAG_MULT_LPE16 : 2 * STAG_MULT_LPE16)
-                                   : STAG_MULT_WIDE;
   constexpr int NB = BLK * MULT;
 
-  const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
-  const int unit = blockIdx.x * TEAMS_PER_BLOCK + threadIdx.x / LPE;
   const uint32_t chunk = blockIdx.y * LPE + c;
   const int k0 = (int)chunk * 4;
-  if (unit >= a.n_units) return;                  // teams never talk to each other: no barrier below
   const bool kin = k0 < a.D;                      // lanes past the row's end still help fetch edge records
   if (!STAGE && !kin) return;
 
@@ -464,7 +540,7 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
   // first (plan order) and run at raised priority; the short rows fill in behind them.
   if (len > STAG_PRIO_MIN_LEN) __builtin_amdgcn_s_setprio(2);
 #ifdef STAG_TRACE   // tools/trace_units.py: per-unit timestamps (100 MHz) into the norm-scale buffer
-  uint64_t* trace = (!a.in_norm && a.norm_scale_out && blockIdx.y == 0 && c == 0)
+  uint64_t* trace = (!a.in_norm && a.norm_scale_out && blockIdx.y == 0 && c == 0 && sl == 0)
                         ? reinterpret_cast<uint64_t*>(a.norm_scale_out) + (int64_t)unit * 4 : nullptr;
   if (trace) { trace[0] = wall_clock64(); trace[1] = trace[2] = trace[3] = 0; }
 #endif
@@ -567,7 +643,50 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
     // (their launch is latency-bound: -2..3 us); at LPE >= 32 the extra registers would cost
     // the RNG kinds their 8th wave per SIMD for no gain.
     constexpr bool PREFETCH = STAG_IDX_PREFETCH && LPE <= 16;
-    if constexpr (PREFETCH) {
+    if constexpr (SLOTS > 1) {
+      constexpr int RB = SLOTS * NB;               // edges of the unit per round
+      const int base = ((int)(threadIdx.x & 63) - sl * LPE) << 2;   // slot 0's lane of my channels (bpermute address)
+      for (int r0 = b; r0 < pend; r0 += RB) {
+        const int p0 = r0 + sl * NB;
+#if STAG_LOAD_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        T.fetch_idx(I, p0);
+        T.fetch_rows(R, I, p0);
+#if STAG_LOAD_PRIO
+        if (len > STAG_PRIO_MIN_LEN) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#endif
+        float t[MULT][4], we[NB][4];
+        T.block_sums(R, I, p0, t, we);
+        // every slot folds all the round's blocks in block order: the same sequence of adds as
+        // the one-slot loop, and every slot ends with the unit's sum
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+#pragma unroll
+          for (int m = 0; m < MULT; ++m) {
+            const int pb = r0 + (j * MULT + m) * BLK;     // first edge of slot j's block m
+            if (pb < pend) {                              // uniform over the unit's lanes
+              float tj[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                tj[q] = __int_as_float(__builtin_amdgcn_ds_bpermute(base + j * (LPE << 2), __float_as_int(t[m][q])));
+              T.fold(tj);
+              if (a.in_norm) {
+#pragma unroll
+                for (int e = 0; e < BLK; ++e) {
+                  if (pb + e < pend) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                      T.wsum[q] += __int_as_float(__builtin_amdgcn_ds_bpermute(
+                          base + j * (LPE << 2), __float_as_int(we[m * BLK + e][q])));
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+    } else if constexpr (PREFETCH) {
     EdgeIdx<NB> In;
     T.fetch_idx(I, b);
     for (int p0 = b; p0 < pend; p0 += NB) {
@@ -601,6 +720,7 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
   if (trace) trace[1] = wall_clock64();
 #endif
   if (slot < 0) {
+    if (sl != 0) return;                // every slot holds the row's sum; slot 0 writes it
     agg_epilogue(a, v, len, k0, VEC, T.acc, T.wsum);
 #ifdef STAG_TRACE
     if (trace) trace[3] = wall_clock64();
@@ -614,18 +734,21 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
   // storing wave drains its stores, then one lane per team takes a ticket.
   const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)a.ws_bytes, 0x00020000);
   const uint32_t woff = (uint32_t)slot * ((uint32_t)a.ws_stride * 4u) + (uint32_t)k0 * 4u;
-  store4_sc1(rws, woff, k0, a.D, VEC, T.acc);
+  if (sl == 0) {
+    store4_sc1(rws, woff, k0, a.D, VEC, T.acc);
+    if (a.in_norm) store4_sc1(rws, woff + (uint32_t)a.D * 4u, k0, a.D, VEC, T.wsum);
+  }
 #if defined(STAG_PROBE) && STAG_PROBE == 1     // timing probe only: no ticket, no combine
   return;
 #endif
-  if (a.in_norm) store4_sc1(rws, woff + (uint32_t)a.D * 4u, k0, a.D, VEC, T.wsum);
   const int s0 = a.long_seg_ptr[r], s1 = a.long_seg_ptr[r + 1];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int ticket = 0;
   int32_t* counter = a.seg_counters + (int64_t)blockIdx.y * a.n_long + r;   // per channel tile
-  if (c == 0)
+  if (c == 0 && sl == 0)
     ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  ticket = __builtin_amdgcn_ds_bpermute(((int)(threadIdx.x & 63) - c) << 2, ticket);
+  const int lane0 = ((int)(threadIdx.x & 63) - c - sl * LPE) << 2;   // the unit's first lane
+  ticket = __builtin_amdgcn_ds_bpermute(lane0, ticket);
 #ifdef STAG_TRACE
   if (trace) trace[2] = wall_clock64();
 #endif
@@ -633,23 +756,87 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
   // consumer side: this team drew the last ticket; acquire, then plain loads
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (c == 0) *counter = 0;             // leave the counter ready for the next call
+  if (c == 0 && sl == 0) *counter = 0;  // leave the counter ready for the next call
   const int row = a.long_rows[r];
   const int deg = a.indptr[row + 1] - a.indptr[row];
-  // Sum the row's partials in segment order with compensated (Kahan) fp32 adds: a hub row has
-  // hundreds of them.  NF partials are in flight at a time; the tail is written to stay under
-  // the hot loop's register count (fp64 accumulators or a wider NF cost a wave per SIMD).
+  // Sum the row's partials with compensated (Kahan) fp32 adds, two levels: groups of 16
+  // partials in segment order, then the group sums in group order — a hub row has hundreds of
+  // partials and the unit's slots take a group each (the sum is the same for any slot count).
+  // NF partials are in flight at a time; the tail is written to stay under the hot loop's
+  // register count (fp64 accumulators or a wider NF cost a wave per SIMD).
 #ifndef STAG_COMBINE_NF
 #define STAG_COMBINE_NF 8
 #endif
   constexpr int NF = STAG_COMBINE_NF;
   float facc[4], fws[4] = {0.f, 0.f, 0.f, 0.f};
-  kahan_sum_partials<NF, VEC>(a.ws, a.ws_stride, s0, s1, k0, a.D, facc);
-  if (a.in_norm) kahan_sum_partials<NF, VEC>(a.ws + a.D, a.ws_stride, s0, s1, k0, a.D, fws);
+  const int slot0 = lane0 + (c << 2);   // slot 0's lane of my channels
+  two_level_sum<NF, VEC, LPE, SLOTS>(a.ws, a.ws_stride, s0, s1, k0, a.D, sl, slot0, facc);
+  if (a.in_norm) two_level_sum<NF, VEC, LPE, SLOTS>(a.ws + a.D, a.ws_stride, s0, s1, k0, a.D, sl, slot0, fws);
+  if (sl != 0) return;
   agg_epilogue(a, row, deg, k0, VEC, facc, fws);
 #ifdef STAG_TRACE
   if (trace) trace[3] = wall_clock64();
 #endif
+}
+
+// Lanes per unit.  Light units (the many short rows) take LPE lanes; HEAVY units — the first
+// a.n_heavy of the plan, every unit longer than STAG_HEAVY_LEN edges: segments of long rows and
+// the longest whole rows — are the launch's critical path when rows are narrow (D <= 64: the
+// launch is latency-bound, tools/trace_units.py) and take LPE x heavy_slots lanes.
+template <int KIND, int LPE, bool STAGE>
+constexpr int mult_of() {
+  // blocks a LIGHT unit fetches together.  Measured with heavy slots on (tools/ab_bench.py, arxiv
+  // CSR, us per launch none | normal): D=16 8 | 4 (42 | 47), D=32 4 | 1 (46 | 51), D=64 2 | 1
+  // (59 | 81); deeper costs the RNG kinds their occupancy, shallower the others their overlap.
+  constexpr bool RNG = KIND >= kNormal;
+  return STAGE ? 1
+         : LPE <= 4 ? (RNG ? STAG_MULT_LPE4 : 2 * STAG_MULT_LPE4)
+         : LPE == 8 ? (RNG ? STAG_MULT_LPE8 : 4 * STAG_MULT_LPE8)
+         : LPE == 16 ? (RNG ? STAG_MULT_LPE16 : 2 * STAG_MULT_LPE16)
+                     : STAG_MULT_WIDE;
+}
+#ifndef STAG_HSLOTS_LPE4
+#define STAG_HSLOTS_LPE4 4
+#endif
+#ifndef STAG_HSLOTS_LPE8
+#define STAG_HSLOTS_LPE8 4
+#endif
+#ifndef STAG_HSLOTS_LPE16
+#define STAG_HSLOTS_LPE16 2
+#endif
+#ifndef STAG_HSLOTS_LPE32
+#define STAG_HSLOTS_LPE32 1
+#endif
+#ifndef STAG_HMULT
+#define STAG_HMULT 1
+#endif
+template <int LPE, bool STAGE>
+constexpr int heavy_slots_of() {
+  return STAGE ? 1 : LPE <= 4 ? STAG_HSLOTS_LPE4 : LPE == 8 ? STAG_HSLOTS_LPE8
+         : LPE == 16 ? STAG_HSLOTS_LPE16 : LPE == 32 ? STAG_HSLOTS_LPE32 : 1;
+}
+
+// STAGE: gathered rows travel global -> LDS -> VGPR (buffer_load ... lds); needs VEC and the
+// narrow (buffer-descriptor) addressing form, decided on the host.
+template <int KIND, int LPE, bool VEC, bool PEDGE, bool STAGE>
+__global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_kernel(const AggArgs a) {
+  constexpr int SL = slots_of<LPE, STAGE>();
+  constexpr int HS = heavy_slots_of<LPE, STAGE>();
+  const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
+  int first = 0, blk = blockIdx.x;
+  if constexpr (HS > 1) {
+    if (blk < a.n_heavy_blocks) {                 // block-uniform
+      const int unit = blk * (STAG_BLOCK_THREADS / (LPE * HS)) + threadIdx.x / (LPE * HS);
+      if (unit >= a.n_heavy) return;              // teams never talk to each other: no barrier below
+      agg_unit<KIND, LPE, VEC, PEDGE, STAGE, HS, STAG_HMULT>(a, unit, c, (threadIdx.x / LPE) % HS);
+      return;
+    }
+    first = a.n_heavy;
+    blk -= a.n_heavy_blocks;
+  }
+  const int unit = first + blk * (STAG_BLOCK_THREADS / (LPE * SL)) + threadIdx.x / (LPE * SL);
+  if (unit >= a.n_units) return;
+  agg_unit<KIND, LPE, VEC, PEDGE, STAGE, SL, mult_of<KIND, LPE, STAGE>()>(a, unit, c, (threadIdx.x / LPE) % SL);
 }
 
 // Launch one (KIND, PEDGE) family; defined per kind in agg_<kind>.hip so the
@@ -658,17 +845,23 @@ template <int KIND>
 hipError_t agg_launch(const AggArgs& a, bool vec, hipStream_t stream);
 
 template <int KIND, int LPE>
-inline void agg_launch_shape(const AggArgs& a, bool vec, bool pedge, int tiles, hipStream_t s) {
-  constexpr int TPB = STAG_BLOCK_THREADS / LPE;
-  dim3 grid((a.n_units + TPB - 1) / TPB, tiles);
+inline void agg_launch_shape(const AggArgs& a_in, bool vec, bool pedge, int tiles, hipStream_t s) {
+  AggArgs a = a_in;
+  constexpr int TPB = STAG_BLOCK_THREADS / (LPE * slots_of<LPE, false>());
+  constexpr int HS = heavy_slots_of<LPE, false>();
+  constexpr int TPBH = STAG_BLOCK_THREADS / (LPE * HS);
+  if (HS == 1 || STAG_LDS_STAGE) a.n_heavy = 0;
+  a.n_heavy_blocks = (a.n_heavy + TPBH - 1) / TPBH;
+  dim3 grid(a.n_heavy_blocks + (a.n_units - a.n_heavy + TPB - 1) / TPB, tiles);
   if (grid.x == 0) return;
   const dim3 block(STAG_BLOCK_THREADS);
 #if STAG_LDS_STAGE
   if (vec && (a.wide & 1) == 0 && a.ldxb != 0) {   // staged form: dwordx4 rows behind a buffer descriptor
+    const dim3 gs((a.n_units + STAG_BLOCK_THREADS / LPE - 1) / (STAG_BLOCK_THREADS / LPE), tiles);   // one slot
     if constexpr (KIND >= kNormal) {
-      if (pedge) { hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, true, true>), grid, block, 0, s, a); return; }
+      if (pedge) { hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, true, true>), gs, block, 0, s, a); return; }
     }
-    hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, false, true>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, false, true>), gs, block, 0, s, a);
     return;
   }
 #endif

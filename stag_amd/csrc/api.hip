@@ -266,15 +266,18 @@ const char* stag_strerror(int code) {
 }
 
 int stag_plan_count(const int32_t* indptr_host, int32_t n_dst, int32_t seg_len,
-                    int32_t* n_units_out, int32_t* n_long_out, int32_t* n_seg_out) {
+                    int32_t* n_units_out, int32_t* n_long_out, int32_t* n_seg_out,
+                    int32_t* n_heavy_out) {
   if (!indptr_host || n_dst < 0 || seg_len <= 0 || seg_len > (1 << 20) || !n_units_out || !n_long_out || !n_seg_out)
     return STAG_EINVAL;
-  int64_t nl = 0, ns = 0;
+  int64_t nl = 0, ns = 0, nh = 0;
   for (int32_t v = 0; v < n_dst; ++v) {
     const int32_t deg = indptr_host[v + 1] - indptr_host[v];
     if (deg < 0) return STAG_EINVAL;
     if (deg > seg_len) { ++nl; ns += (deg + seg_len - 1) / seg_len; }
+    else if (deg > STAG_HEAVY_LEN) ++nh;
   }
+  if (n_heavy_out) *n_heavy_out = (int32_t)std::min<int64_t>(ns + nh, 0x7FFFFFFFll);
   const int64_t nu = (int64_t)n_dst - nl + ns;
   if (nu > 0x7FFFFFFFll) return STAG_EINVAL;
   *n_units_out = (int32_t)nu;
@@ -396,6 +399,8 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int
     if (!plan->units || !aligned16(plan->units)) return STAG_EINVAL;
     a.units = static_cast<const stag_unit*>(plan->units);
     a.n_units = plan->n_units;
+    if (plan->n_heavy < 0 || plan->n_heavy > plan->n_units) return STAG_EINVAL;
+    a.n_heavy = plan->n_heavy;
   }
   if (has_segs) {
     if (!plan->long_rows || !plan->long_seg_ptr || !plan->workspace || !plan->seg_counters)

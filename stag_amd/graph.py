@@ -54,10 +54,10 @@ class CsrView:
         if seg_len not in self._plans:
             lib = _lib.lib()
             indptr_h = np.ascontiguousarray(self.indptr.detach().cpu().numpy(), dtype=np.int32)
-            nu, nl, ns = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+            nu, nl, ns, nh = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
             _lib.check(lib.stag_plan_count(indptr_h.ctypes.data, self.n_dst, seg_len, C.byref(nu),
-                                           C.byref(nl), C.byref(ns)), "stag_plan_count")
-            nu, nl, ns = nu.value, nl.value, ns.value
+                                           C.byref(nl), C.byref(ns), C.byref(nh)), "stag_plan_count")
+            nu, nl, ns, nh = nu.value, nl.value, ns.value, nh.value
             units = np.zeros((max(nu, 1), 4), np.int32)
             long_rows = np.zeros(max(nl, 1), np.int32)
             long_seg_ptr = np.zeros(nl + 1, np.int32)
@@ -66,7 +66,7 @@ class CsrView:
                                           long_seg_ptr.ctypes.data), "stag_plan_fill")
             dev = self.indptr.device
             self._plans[seg_len] = dict(
-                seg_len=seg_len, n_units=nu, n_long=nl, n_seg=ns,
+                seg_len=seg_len, n_units=nu, n_long=nl, n_seg=ns, n_heavy=nh,
                 units=torch.from_numpy(units).to(dev),
                 long_rows=torch.from_numpy(long_rows).to(dev),
                 long_seg_ptr=torch.from_numpy(long_seg_ptr).to(dev),

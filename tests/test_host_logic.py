@@ -20,7 +20,7 @@ def test_abi_exports_every_declared_symbol():
     assert {"stag_agg_fwd", "stag_noise_materialize", "stag_gat_fwd", "stag_plan_fill"} <= names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/stag_hip.h but not exported"
-    assert lib.stag_abi_version() == 3
+    assert lib.stag_abi_version() == 4
     assert lib.stag_strerror(-22) == b"invalid argument"
 
 
@@ -28,7 +28,7 @@ def test_abi_struct_layouts_match_header():
     from stag_amd import _lib
     assert ctypes.sizeof(_lib.Csr) == 48
     assert ctypes.sizeof(_lib.NoiseSpec) == 80
-    assert ctypes.sizeof(_lib.Plan) == 64
+    assert ctypes.sizeof(_lib.Plan) == 72
     assert _lib.NoiseSpec.deriv.offset == 40 and _lib.NoiseSpec.seed.offset == 48 and _lib.NoiseSpec.pos_base.offset == 64
 
 
@@ -311,11 +311,11 @@ def test_abi_argument_validation_without_gpu():
     assert lib.stag_gat_fwd(*g) == EINVAL                                   # in-norm needs norm_scale
     # planning on host arrays
     nu, nl, nsg = C.c_int32(), C.c_int32(), C.c_int32()
-    assert lib.stag_plan_count(None, 2, 64, C.byref(nu), C.byref(nl), C.byref(nsg)) == EINVAL
-    assert lib.stag_plan_count(indptr.ctypes.data, 2, 0, C.byref(nu), C.byref(nl), C.byref(nsg)) == EINVAL
+    assert lib.stag_plan_count(None, 2, 64, C.byref(nu), C.byref(nl), C.byref(nsg), None) == EINVAL
+    assert lib.stag_plan_count(indptr.ctypes.data, 2, 0, C.byref(nu), C.byref(nl), C.byref(nsg), None) == EINVAL
     dec = np.array([0, 3, 1], np.int32)
-    assert lib.stag_plan_count(dec.ctypes.data, 2, 64, C.byref(nu), C.byref(nl), C.byref(nsg)) == EINVAL   # decreasing indptr
-    assert lib.stag_plan_count(indptr.ctypes.data, 2, 64, C.byref(nu), C.byref(nl), C.byref(nsg)) == 0 and nu.value == 2
+    assert lib.stag_plan_count(dec.ctypes.data, 2, 64, C.byref(nu), C.byref(nl), C.byref(nsg), None) == EINVAL   # decreasing indptr
+    assert lib.stag_plan_count(indptr.ctypes.data, 2, 64, C.byref(nu), C.byref(nl), C.byref(nsg), None) == 0 and nu.value == 2
     assert lib.stag_plan_workspace_bytes(0, 128, 0) == 0 and lib.stag_plan_workspace_bytes(3, 128, 1) == 3 * 128 * 2 * 4
     assert lib.stag_csr_build(None, None, 2, 2, 5, indptr.ctypes.data, None, None, None, None, 0, None) == EINVAL
     assert lib.stag_segment_reduce(f, 4, 4, None, 2, 0, f, 4, None) == EINVAL

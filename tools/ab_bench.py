@@ -77,6 +77,9 @@ def run(argv):
                 ref = out.clone()
             elif not torch.allclose(out, ref, rtol=1e-4, atol=1e-4):
                 print(f"WARNING: variant {name} output differs from the first variant")
+            elif r == 0 and not torch.equal(out, ref):
+                print(f"note: variant {name} is not bit-identical to the first variant "
+                      f"(max abs diff {(out - ref).abs().max().item():.3g})")
     for name, t in sorted(times.items(), key=lambda kv: np.median(kv[1])):
         print(f"{name:28s} median {np.median(t):8.2f} us   min {np.min(t):8.2f} us   ({args.noise}, {len(t)} rounds x {args.steps} steps)")
 
