@@ -8,22 +8,30 @@
 // Work decomposition (wave = 64 lanes)
 //   The launch walks a list of UNITS (stag_plan): a unit is a whole destination row,
 //   or one segment (<= seg_len edges) of a long row.  Units are sorted by length,
-//   longest first, so (a) the teams that share a wave have equal trip counts and
+//   longest first, so (a) the units that share a wave have equal trip counts and
 //   (b) the heavy units are dispatched first (no hub-row tail).
-//   A TEAM of LPE lanes owns one unit: lane c holds channels [4c, 4c+4) of the
-//   channel tile — one dwordx4 of the gathered row, one Philox block of noise, four
+//   LPE lanes cover a unit's channels: lane c holds channels [4c, 4c+4) of the channel
+//   tile — one dwordx4 of the gathered row, one Philox block of noise, four
 //   accumulators.  D = 128 -> LPE = 32, two rows per wave; D = 256 -> one row per
-//   wave; D = 16 -> sixteen rows per wave.  Nothing is reduced across lanes.
-//   The kernel is VALU(RNG)-bound at D = 128, so the loop is built to add as few
-//   vector instructions as possible around draw4(): column ids are broadcast loads
-//   with immediate offsets (ds_bpermute costs ~22 cycles per wave-op here), row
-//   addresses are 32-bit offsets from a scalar base (64-bit vector adds are quarter
-//   rate), rows are fetched four edges at a time, optional work hides behind
-//   wave-uniform branches.
+//   wave; D = 16 -> sixteen rows per wave.  Nothing is reduced across channel lanes.
+//   Summation order is fixed: edges are taken in BLOCKS of 2, a block's products are
+//   summed from zero and the block sums are folded into the unit's sum in order
+//   (compensated once the unit is longer than 16 edges).  Everything below that changes
+//   how much is in flight (blocks fetched together, edge slots) keeps exactly this
+//   order, so a result does not depend on D, on the launch shape or on scheduling —
+//   which is what lets channel shards reproduce the whole-width result bit for bit.
+//   D = 128 is VALU(RNG)- and gather-bound, so the loop adds as few vector
+//   instructions as possible around draw4(): column ids are broadcast loads with
+//   immediate offsets, row addresses are 32-bit offsets behind a buffer descriptor
+//   (64-bit vector adds are quarter rate), optional work hides behind wave-uniform
+//   branches.  D <= 64 is latency-bound (tools/trace_units.py): the heavy units (all
+//   segments and the whole rows longer than STAG_HEAVY_LEN edges; the first n_heavy of
+//   the plan) are spread over 2-4 EDGE SLOTS of LPE lanes each, which draw and gather
+//   side by side and exchange block sums by ds_bpermute.
 //   Segment partials go to a workspace; the segment of a row that finishes LAST
-//   (agent-scope release / counter / acquire, cdna_hip_programming.md Guideline 16) adds
-//   them in segment order in fp64, so results do not depend on scheduling and there is
-//   no second launch.
+//   (write-through stores / arrival counter / acquire, cdna_hip_programming.md
+//   Guideline 16) adds them — Kahan sums of groups of 16 in segment order, then of the
+//   group sums — so there is no second launch.
 #pragma once
 #include "../../include/stag_hip.h"
 #include "noise.hpp"
@@ -252,35 +260,11 @@ constexpr int kKahanMinLen = STAG_KAHAN_MIN_LEN;
 #ifndef STAG_PRIO_MIN_LEN
 #define STAG_PRIO_MIN_LEN 24
 #endif
-// LDS staging of the gathered rows (buffer_load ... lds): rows in flight cost no VGPRs, so a
-// team can have STAG_BLK_LDS rows outstanding at 8 waves per SIMD.
-#ifndef STAG_LDS_STAGE
-#define STAG_LDS_STAGE 0
-#endif
-#ifndef STAG_BLK_LDS
-#define STAG_BLK_LDS 2
-#endif
 // blocks fetched together by a light unit, by lanes per unit (LPE 4: D <= 16; 8: D <= 32; 16: D <= 64;
 // wider); values are for the RNG kinds, mult_of() scales them for the gather-bound kinds
 #ifndef STAG_IDX_PREFETCH
 #define STAG_IDX_PREFETCH 1
 #endif
-// Edge slots: a narrow unit is spread over SLOTS x LPE lanes; slot s takes the s-th run of
-// BLK * MULT edges of every round, so SLOTS x as many rows and draws are in flight per unit,
-// and the block sums are folded in the SAME order as the one-slot loop (bit-identical sums).
-#ifndef STAG_SLOTS_LPE4
-#define STAG_SLOTS_LPE4 1
-#endif
-#ifndef STAG_SLOTS_LPE8
-#define STAG_SLOTS_LPE8 1
-#endif
-#ifndef STAG_SLOTS_LPE16
-#define STAG_SLOTS_LPE16 1
-#endif
-template <int LPE, bool STAGE>
-constexpr int slots_of() {
-  return STAGE ? 1 : LPE <= 4 ? STAG_SLOTS_LPE4 : LPE == 8 ? STAG_SLOTS_LPE8 : LPE == 16 ? STAG_SLOTS_LPE16 : 1;
-}
 #ifndef STAG_MULT_LPE4
 #define STAG_MULT_LPE4 4
 #endif
@@ -349,48 +333,8 @@ struct AggTeam {
     }
   }
 
-  // LDS-DMA form of fetch_rows: one `buffer_load_dwordx4 ... offen lds` per edge writes the
-  // wave's 64 x 16 B straight into LDS slot j (M0 = slot base, lane l lands at base + 16 l);
-  // nothing is held in VGPRs while the rows are in flight.
-  __device__ __forceinline__ void dma_rows(const EdgeIdx<NB>& I, int p0, float* wave_lds) const {
-#pragma unroll
-    for (int j = 0; j < BLK; ++j) {
-      if (p0 + j < pend) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rx, (__attribute__((address_space(3))) void*)(wave_lds + j * 256), 16,
-            (int)(__umul24((uint32_t)I.u[j], a.ldxb) + koff), 0, 0, 0);
-      }
-    }
-  }
-
-  template <int N>
-  static __device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-  }
-
-  // LDS = nullptr: rows are in R.xv (register staging).  Else slot j of `lds` holds edge j's
-  // row; `full` (wave-uniform) says every active team issued all BLK DMAs, so counted waits
-  // are exact and edge j's draw overlaps the flight of edges j+1..BLK-1.
-  template <int N>
-  static __device__ __forceinline__ void wait_upto() {   // vmcnt(N), N clamped to what this build uses
-    if constexpr (N <= 0) wait_vmcnt<0>();
-    else if constexpr (N == 1) wait_vmcnt<1>();
-    else if constexpr (N == 2) wait_vmcnt<2>();
-    else if constexpr (N == 3) wait_vmcnt<3>();
-    else if constexpr (N == 4) wait_vmcnt<4>();
-    else if constexpr (N == 5) wait_vmcnt<5>();
-    else if constexpr (N == 6) wait_vmcnt<6>();
-    else wait_vmcnt<7>();
-  }
-
-  // lds = nullptr: rows are in R.xv (register staging).  Else slot j of `lds` holds edge j's
-  // row.  `full` (wave-uniform): every active team issued all BLK DMAs of this block, so the
-  // counted wait for slot j is exact: BLK-1-j younger DMAs of this block, plus BLK more when
-  // `next_full` says the next block's DMAs were issued behind them (software pipeline).
-  __device__ __forceinline__ void compute(EdgeRows<NB>& R, const EdgeIdx<NB>& I, int p0,
-                                          const float* lds = nullptr, bool full = false,
-                                          bool next_full = false) {
-    if (lds && !full) wait_vmcnt<0>();
+  // the blocks fetched at p0: draw, multiply, fold — one block (BLK edges) at a time
+  __device__ __forceinline__ void compute(EdgeRows<NB>& R, const EdgeIdx<NB>& I, int p0) {
 #pragma unroll
     for (int m = 0; m < MULT; ++m) {
     if (m > 0 && p0 + m * BLK >= pend) break;   // an empty block must not touch the Kahan state
@@ -398,20 +342,7 @@ struct AggTeam {
     float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = m * BLK; j < (m + 1) * BLK; ++j) {
-      if (lds && full) {
-        if (next_full) {
-          if (j == 0) wait_upto<2 * BLK - 1>(); else if (j == 1) wait_upto<2 * BLK - 2>();
-          else if (j == 2) wait_upto<2 * BLK - 3>(); else wait_upto<BLK>();
-        } else {
-          if (j == 0) wait_upto<BLK - 1>(); else if (j == 1) wait_upto<BLK - 2>();
-          else if (j == 2) wait_upto<BLK - 3>(); else wait_upto<0>();
-        }
-      }
       if (p0 + j < pend) {
-        if (lds) {
-          const float4 xr = *reinterpret_cast<const float4*>(lds + j * 256 + (threadIdx.x & 63) * 4);
-          R.xv[j][0] = xr.x; R.xv[j][1] = xr.y; R.xv[j][2] = xr.z; R.xv[j][3] = xr.w;
-        }
         float w[4];
         edge_weight(I, j, w);
         if (a.src_scale) {
@@ -512,18 +443,17 @@ struct AggTeam {
 
 // One unit (a whole row or a segment of a long row) on LPE x SLOTS lanes of a wave:
 // c = this lane's chunk (4 channels) of the channel tile, sl = its edge slot.
-template <int KIND, int LPE, bool VEC, bool PEDGE, bool STAGE, int SLOTS, int MULT>
+template <int KIND, int LPE, bool VEC, bool PEDGE, int SLOTS, int MULT>
 __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const int c, const int sl) {
   static_assert(LPE * SLOTS <= 64 && 64 % (LPE * SLOTS) == 0, "a unit's lanes stay inside one wave");
   // edges per block: the RNG kinds are VALU-bound and register-hungry, the others want
   // more rows in flight
-  constexpr int BLK = STAGE ? STAG_BLK_LDS : ((KIND >= kNormal) ? STAG_BLK_RNG : STAG_BLK_MEM);
+  constexpr int BLK = (KIND >= kNormal) ? STAG_BLK_RNG : STAG_BLK_MEM;
   constexpr int NB = BLK * MULT;
 
   const uint32_t chunk = blockIdx.y * LPE + c;
   const int k0 = (int)chunk * 4;
-  const bool kin = k0 < a.D;                      // lanes past the row's end still help fetch edge records
-  if (!STAGE && !kin) return;
+  if (k0 >= a.D) return;                          // lanes past the row's end (units never talk: no barrier below)
 
   int v, b, len, slot = -1;
   if (a.units) {
@@ -544,12 +474,6 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
                         ? reinterpret_cast<uint64_t*>(a.norm_scale_out) + (int64_t)unit * 4 : nullptr;
   if (trace) { trace[0] = wall_clock64(); trace[1] = trace[2] = trace[3] = 0; }
 #endif
-#if defined(STAG_PROBE) && STAG_PROBE == 2     // timing probe only: segments do nothing
-  if (slot >= 0) return;
-#endif
-#if defined(STAG_PROBE) && STAG_PROBE == 3     // timing probe only: whole rows do nothing
-  if (slot < 0) return;
-#endif
 
   AggTeam<KIND, LPE, VEC, PEDGE, BLK, MULT> T{
       a, k0, (uint32_t)k0 * 4u,
@@ -562,7 +486,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
       {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f},
       len > kKahanMinLen};
   if constexpr (KIND >= kNormal) {
-    if (a.pmode == STAG_PARAM_PER_CHANNEL && kin) {   // distribution parameters of this lane's 4 channels
+    if (a.pmode == STAG_PARAM_PER_CHANNEL) {   // distribution parameters of this lane's 4 channels
       load4(a.p0, k0, a.D, VEC, T.pa);
       if (a.p1) load4(a.p1, k0, a.D, VEC, T.pb);
     }
@@ -577,67 +501,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   const int pend = b + len;
   EdgeIdx<NB> I;
   EdgeRows<NB> R;
-  if constexpr (STAGE) {
-    // Staged pipeline (VEC, narrow addressing).  Per chunk of LPE edges the team fetches its
-    // edge records with ONE coalesced load per field and parks them in LDS; after that a
-    // block costs no global round trip for ids.  Rows travel by LDS-DMA into 2 x BLK slots:
-    // the next block's rows are in flight while this block's noise is drawn, at no VGPR cost.
-    constexpr int NW = STAG_BLOCK_THREADS / 64;
-    constexpr bool NEED_EID = (KIND == kExplicit) || PEDGE;
-    __shared__ __attribute__((aligned(16))) float stage[NW][2 * BLK][256];
-    __shared__ int ubuf[NW][64];
-    __shared__ uint32_t nbuf[NW][64];
-    __shared__ int ebuf[NEED_EID ? NW : 1][64];
-    __shared__ float sbuf[NW][64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tl0 = lane - c;
-    float* wl = &stage[wave][0][0];
-    const bool has_ss = a.src_scale != nullptr;
-
-    auto take = [&](EdgeIdx<BLK>& J, EdgeRows<BLK>& Q, int j0, int nb) {
-#pragma unroll
-      for (int j = 0; j < BLK; ++j) {
-        if (j0 + j < nb) {
-          J.u[j] = ubuf[wave][tl0 + j0 + j];
-          if constexpr (KIND >= kNormal) J.nn[j] = nbuf[wave][tl0 + j0 + j];
-          if constexpr (NEED_EID) J.ee[j] = ebuf[NEED_EID ? wave : 0][tl0 + j0 + j];
-          if (has_ss) Q.xs[j] = sbuf[wave][tl0 + j0 + j];
-        }
-      }
-    };
-
-    for (int i0 = 0; i0 < len; i0 += LPE) {
-      const int nb = min(LPE, len - i0);
-      const int pb = b + i0;
-      if (c < nb) {
-        const int p = pb + c;
-        const int uu = a.indices[p];
-        ubuf[wave][lane] = uu;
-        if constexpr (KIND >= kNormal) nbuf[wave][lane] = a.nidx ? (uint32_t)a.nidx[p] : a.pos_lo + (uint32_t)p;
-        if constexpr (NEED_EID) ebuf[NEED_EID ? wave : 0][lane] = a.eid ? a.eid[p] : p;
-        if (has_ss) sbuf[wave][lane] = a.src_scale[uu];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // same-wave LDS hand-off: order only
-      __builtin_amdgcn_wave_barrier();
-      T.pend = pb + nb;
-      if (!kin) continue;
-      // ONE rolled loop (a second copy of the body for an A/B register set costs 40 VGPRs):
-      // the slot pair alternates by address, the edge records are re-read from LDS.
-      take(I, R, 0, nb);
-      T.dma_rows(I, pb, wl);
-      int pair = 0;
-      for (int j0 = 0; j0 < nb; j0 += BLK) {
-        if (j0 + BLK < nb) {   // next block's rows into the other slot pair
-          take(I, R, j0 + BLK, nb);
-          T.dma_rows(I, pb + j0 + BLK, wl + (pair ^ 1) * (BLK * 256));
-        }
-        take(I, R, j0, nb);
-        T.compute(R, I, pb + j0, wl + pair * (BLK * 256), __all(j0 + BLK <= nb),
-                  __all(j0 + 2 * BLK <= nb));
-        pair ^= 1;
-      }
-    }
-    if (!kin) return;
-  } else {
+  {
     // the next block's edge records are fetched while this block's rows are in flight: one
     // round trip per block on the unit's critical path instead of two.  Narrow shapes only
     // (their launch is latency-bound: -2..3 us); at LPE >= 32 the extra registers would cost
@@ -738,9 +602,6 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
     store4_sc1(rws, woff, k0, a.D, VEC, T.acc);
     if (a.in_norm) store4_sc1(rws, woff + (uint32_t)a.D * 4u, k0, a.D, VEC, T.wsum);
   }
-#if defined(STAG_PROBE) && STAG_PROBE == 1     // timing probe only: no ticket, no combine
-  return;
-#endif
   const int s0 = a.long_seg_ptr[r], s1 = a.long_seg_ptr[r + 1];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int ticket = 0;
@@ -783,14 +644,13 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
 // a.n_heavy of the plan, every unit longer than STAG_HEAVY_LEN edges: segments of long rows and
 // the longest whole rows — are the launch's critical path when rows are narrow (D <= 64: the
 // launch is latency-bound, tools/trace_units.py) and take LPE x heavy_slots lanes.
-template <int KIND, int LPE, bool STAGE>
+template <int KIND, int LPE>
 constexpr int mult_of() {
   // blocks a LIGHT unit fetches together.  Measured with heavy slots on (tools/ab_bench.py, arxiv
   // CSR, us per launch none | normal): D=16 8 | 4 (42 | 47), D=32 4 | 1 (46 | 51), D=64 2 | 1
   // (59 | 81); deeper costs the RNG kinds their occupancy, shallower the others their overlap.
   constexpr bool RNG = KIND >= kNormal;
-  return STAGE ? 1
-         : LPE <= 4 ? (RNG ? STAG_MULT_LPE4 : 2 * STAG_MULT_LPE4)
+  return LPE <= 4 ? (RNG ? STAG_MULT_LPE4 : 2 * STAG_MULT_LPE4)
          : LPE == 8 ? (RNG ? STAG_MULT_LPE8 : 4 * STAG_MULT_LPE8)
          : LPE == 16 ? (RNG ? STAG_MULT_LPE16 : 2 * STAG_MULT_LPE16)
                      : STAG_MULT_WIDE;
@@ -810,33 +670,30 @@ constexpr int mult_of() {
 #ifndef STAG_HMULT
 #define STAG_HMULT 1
 #endif
-template <int LPE, bool STAGE>
+template <int LPE>
 constexpr int heavy_slots_of() {
-  return STAGE ? 1 : LPE <= 4 ? STAG_HSLOTS_LPE4 : LPE == 8 ? STAG_HSLOTS_LPE8
+  return LPE <= 4 ? STAG_HSLOTS_LPE4 : LPE == 8 ? STAG_HSLOTS_LPE8
          : LPE == 16 ? STAG_HSLOTS_LPE16 : LPE == 32 ? STAG_HSLOTS_LPE32 : 1;
 }
 
-// STAGE: gathered rows travel global -> LDS -> VGPR (buffer_load ... lds); needs VEC and the
-// narrow (buffer-descriptor) addressing form, decided on the host.
-template <int KIND, int LPE, bool VEC, bool PEDGE, bool STAGE>
+template <int KIND, int LPE, bool VEC, bool PEDGE>
 __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_kernel(const AggArgs a) {
-  constexpr int SL = slots_of<LPE, STAGE>();
-  constexpr int HS = heavy_slots_of<LPE, STAGE>();
+  constexpr int HS = heavy_slots_of<LPE>();
   const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
   int first = 0, blk = blockIdx.x;
   if constexpr (HS > 1) {
     if (blk < a.n_heavy_blocks) {                 // block-uniform
       const int unit = blk * (STAG_BLOCK_THREADS / (LPE * HS)) + threadIdx.x / (LPE * HS);
       if (unit >= a.n_heavy) return;              // teams never talk to each other: no barrier below
-      agg_unit<KIND, LPE, VEC, PEDGE, STAGE, HS, STAG_HMULT>(a, unit, c, (threadIdx.x / LPE) % HS);
+      agg_unit<KIND, LPE, VEC, PEDGE, HS, STAG_HMULT>(a, unit, c, (threadIdx.x / LPE) % HS);
       return;
     }
     first = a.n_heavy;
     blk -= a.n_heavy_blocks;
   }
-  const int unit = first + blk * (STAG_BLOCK_THREADS / (LPE * SL)) + threadIdx.x / (LPE * SL);
+  const int unit = first + blk * (STAG_BLOCK_THREADS / LPE) + threadIdx.x / LPE;
   if (unit >= a.n_units) return;
-  agg_unit<KIND, LPE, VEC, PEDGE, STAGE, SL, mult_of<KIND, LPE, STAGE>()>(a, unit, c, (threadIdx.x / LPE) % SL);
+  agg_unit<KIND, LPE, VEC, PEDGE, 1, mult_of<KIND, LPE>()>(a, unit, c, 0);
 }
 
 // Launch one (KIND, PEDGE) family; defined per kind in agg_<kind>.hip so the
@@ -847,33 +704,23 @@ hipError_t agg_launch(const AggArgs& a, bool vec, hipStream_t stream);
 template <int KIND, int LPE>
 inline void agg_launch_shape(const AggArgs& a_in, bool vec, bool pedge, int tiles, hipStream_t s) {
   AggArgs a = a_in;
-  constexpr int TPB = STAG_BLOCK_THREADS / (LPE * slots_of<LPE, false>());
-  constexpr int HS = heavy_slots_of<LPE, false>();
+  constexpr int TPB = STAG_BLOCK_THREADS / LPE;
+  constexpr int HS = heavy_slots_of<LPE>();
   constexpr int TPBH = STAG_BLOCK_THREADS / (LPE * HS);
-  if (HS == 1 || STAG_LDS_STAGE) a.n_heavy = 0;
+  if (HS == 1) a.n_heavy = 0;
   a.n_heavy_blocks = (a.n_heavy + TPBH - 1) / TPBH;
   dim3 grid(a.n_heavy_blocks + (a.n_units - a.n_heavy + TPB - 1) / TPB, tiles);
   if (grid.x == 0) return;
   const dim3 block(STAG_BLOCK_THREADS);
-#if STAG_LDS_STAGE
-  if (vec && (a.wide & 1) == 0 && a.ldxb != 0) {   // staged form: dwordx4 rows behind a buffer descriptor
-    const dim3 gs((a.n_units + STAG_BLOCK_THREADS / LPE - 1) / (STAG_BLOCK_THREADS / LPE), tiles);   // one slot
-    if constexpr (KIND >= kNormal) {
-      if (pedge) { hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, true, true>), gs, block, 0, s, a); return; }
-    }
-    hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, false, true>), gs, block, 0, s, a);
-    return;
-  }
-#endif
   if constexpr (KIND >= kNormal) {
     if (pedge) {
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, true, false>), grid, block, 0, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, true, false>), grid, block, 0, s, a);
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, true>), grid, block, 0, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, true>), grid, block, 0, s, a);
       return;
     }
   }
-  if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, false, false>), grid, block, 0, s, a);
-  else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, false, false>), grid, block, 0, s, a);
+  if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, false>), grid, block, 0, s, a);
+  else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, false>), grid, block, 0, s, a);
 }
 
 template <int KIND>
