@@ -1,0 +1,137 @@
+#!/usr/bin/env python
+"""Regenerate the profiles/<round>/ files for the bench workload into gpurun_out/profiles/<round>/
+(run on the GPU box, from the repo root; copy them into profiles/<round>/ afterwards):
+
+    python tools/profile_bench.py --round r01 [--noise normal] [--feat 128]
+
+Passes (each its own process; counters never share a run with a trace domain):
+  1. rocprofv3 --kernel-trace --stats   -> bench_n1_kernel_stats.csv + the bench line (bench_n1.json)
+  2. rocprofv3 --pmc FETCH_SIZE         |
+  3. rocprofv3 --pmc WRITE_SIZE         |-> bench_n1_pmc_summary.json (per-dispatch averages of the
+  4. rocprofv3 --pmc <SQ counters>      |   aggregation kernel, gfx950 FETCH_SIZE correction spelled out)
+This script never touches the GPU itself; the profiled program is `python3 bench.py ...` directly
+after `--`.
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SQ = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU",
+      "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"]
+
+
+def run_prof(tag, prof_args, bench_args, scratch):
+    out = os.path.join(scratch, tag)
+    cmd = ["rocprofv3", *prof_args, "-d", out, "-o", tag, "--output-format", "csv", "--",
+           "python3", "bench.py", *bench_args]
+    print("+", " ".join(cmd), flush=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout[-2000:] + r.stderr[-4000:])
+        raise SystemExit(f"{tag}: rocprofv3 exited {r.returncode}")
+    line = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    return out, (json.loads(line[-1]) if line else None)
+
+
+def find(out, suffix):
+    hits = glob.glob(os.path.join(out, "**", f"*{suffix}"), recursive=True)
+    if not hits:
+        raise SystemExit(f"no *{suffix} under {out}")
+    return hits[0]
+
+
+def counters(out, kernel_sub):
+    """Per-dispatch averages of each counter for dispatches of the aggregation kernel."""
+    f = find(out, "counter_collection.csv")
+    per = {}
+    disp = set()
+    name = None
+    for row in csv.DictReader(open(f)):
+        if kernel_sub not in row["Kernel_Name"]:
+            continue
+        name = row["Kernel_Name"]
+        disp.add(row["Dispatch_Id"])
+        per.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    n = max(len(disp), 1)
+    # a counter can appear once per dimension instance (XCD, SE ...): sum instances, average dispatches
+    return name, len(disp), {k: sum(v) / n for k, v in per.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--round", default="r01")
+    ap.add_argument("--noise", default="normal")
+    ap.add_argument("--feat", type=int, default=128)
+    ap.add_argument("--graph", default="arxiv")
+    ap.add_argument("--seg-len", type=int, default=64)
+    ap.add_argument("--summarize-only", action="store_true",
+                    help="rebuild the summaries from the CSVs already under gpurun_out/prof/ (no GPU needed)")
+    args = ap.parse_args()
+    if args.summarize_only:
+        global run_prof
+        run_prof = lambda tag, prof_args, bench_args, scratch: (os.path.join(scratch, tag), None)
+    scratch = os.path.join(ROOT, "gpurun_out", "prof")
+    # only gpurun_out/ travels back from the GPU box: copy the result into profiles/<round>/ afterwards
+    dst = os.path.join(ROOT, "gpurun_out", "profiles", args.round)
+    os.makedirs(dst, exist_ok=True)
+    common = ["--noise", args.noise, "--feat", str(args.feat), "--graph", args.graph,
+              "--seg-len", str(args.seg_len), "--no-cpu-baseline"]
+    kernel_sub = "agg_kernel"
+
+    out, line = run_prof("stats", ["--kernel-trace", "--stats"], ["--steps", "200", "--warmup", "20", *common], scratch)
+    stats = find(out, "kernel_stats.csv")
+    rows = list(csv.DictReader(open(stats)))
+    with open(os.path.join(dst, "bench_n1_kernel_stats.csv"), "w") as f:
+        f.write(open(stats).read())
+    agg = [r for r in rows if kernel_sub in r["Name"]]
+    print("kernel stats:", [(r["Name"][:60], r["Calls"], r["AverageNs"]) for r in agg])
+    if line:
+        with open(os.path.join(dst, "bench_n1.json"), "w") as f:
+            json.dump(line, f, indent=1)
+            f.write("\n")
+
+    summary = {}
+    short = ["--steps", "20", "--warmup", "5", *common]
+    for tag, ctrs in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_sq", SQ)):
+        out, _ = run_prof(tag, ["--pmc", *ctrs], short, scratch)
+        name, nd, avg = counters(out, kernel_sub)
+        summary[tag] = {"kernel": name, "dispatches": nd, "counters_avg_per_dispatch": avg}
+    fetch_kb = summary["pmc_fetch"]["counters_avg_per_dispatch"]["FETCH_SIZE"]
+    write_kb = summary["pmc_write"]["counters_avg_per_dispatch"]["WRITE_SIZE"]
+    summary["traffic"] = {
+        "workload": f"{args.graph}/{args.noise}/D{args.feat}/seg{args.seg_len}",
+        "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
+        "correction": "gfx950: FETCH_SIZE counts 128-B fabric read requests at 64 B => x2 for 16-B-per-lane "
+                      "loads (MI355X_MICROARCH.md HBM); WRITE_SIZE exact for 16-B-per-lane stores",
+        "traffic_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
+        "note": "counters sit on the fabric side of L2 and include Infinity-Cache hits: x (86.7 MB) stays "
+                "resident in the 256 MB Infinity Cache (an nt gather, which bypasses it, is 36 % slower), so "
+                "this is L2-miss traffic, an upper bound on HBM bytes"}
+    sq = summary["pmc_sq"]["counters_avg_per_dispatch"]
+    if agg and sq.get("SQ_BUSY_CYCLES"):
+        dur_us = float(agg[0]["AverageNs"]) / 1e3
+        xcd_cycles = sq["GRBM_GUI_ACTIVE"] / 8.0          # the counter is summed over the 8 XCDs
+        summary["derived"] = {
+            "kernel_avg_us_from_stats_pass": dur_us,
+            "clock_ghz_est": xcd_cycles / (dur_us * 1e3),
+            # SQ_ACTIVE_INST_VALU counts quad-cycles: x4 = SIMD cycles spent issuing VALU; 1024 SIMDs
+            "valu_busy_frac": sq["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * xcd_cycles),
+            "valu_insts_per_wave": sq["SQ_INSTS_VALU"] / max(sq["SQ_WAVES"], 1.0),
+            "cycles_per_valu_inst": sq["SQ_ACTIVE_INST_VALU"] * 4.0 / max(sq["SQ_INSTS_VALU"], 1.0),
+            "avg_waves_per_simd": sq["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * xcd_cycles),
+            "wait_frac_of_wave_life": sq["SQ_WAIT_ANY"] / max(sq["SQ_WAVE_CYCLES"], 1.0),
+        }
+    with open(os.path.join(dst, "bench_n1_pmc_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+        f.write("\n")
+    print(json.dumps(summary["traffic"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
