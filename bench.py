@@ -34,8 +34,11 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # 2000 x ~115 us: a quarter of a second.  The first ~15 launches after any host sync run at
+    # ~140 us and the clocks keep rising for ~25 ms of sustained load (rocprofv3 kernel trace:
+    # 121 -> 112.5 us over 200 launches), so a 200-step run reads 121 us, 1000+ steps 113 us.
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--feat", type=int, default=128)
     ap.add_argument("--noise", default="normal", choices=["normal", "uniform", "bernoulli", "none"])
     ap.add_argument("--graph", default="arxiv", choices=["arxiv", "arxiv_sym"],
