@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 4
+#define STAG_ABI_VERSION 5
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -195,6 +195,24 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x,
                  int32_t reduce, const float* src_scale, const float* dst_scale,
                  float* out, int64_t ldo, float* norm_scale_out, void* stream);
 
+/* Backward of stag_agg_fwd with respect to x and to the noise parameters, ONE pass over the
+ * source-major CSR (csr_t: rows = source nodes, indices = destination rows, nidx = the forward
+ * CSR position of each edge, so the forward's noise is redrawn from its counters):
+ *     dx[u,:]       = row_scale[u] * sum_{p: src_p = u} w[p,:]        * g_scale[v_p] * g[v_p,:]
+ *     dp0_rows[u,:] = row_scale[u] * sum_{p: src_p = u} dw/dp0[p,:]   * g_scale[v_p] * g[v_p,:]
+ *     dp1_rows[u,:] = ...          dw/dp1 ...
+ * (dw/dp = 1 | z for Normal, 1-u | u for Uniform, times 1[w > 0] under relu; the reference gets
+ * them from autograd through `rsample`, stag/layers.py:123-124.)  The gradient of a per-channel
+ * parameter is then  dp[k] = sum_u x[u,k] * dp_rows[u,k]  (a column sum the caller does); for a
+ * scalar parameter sum over k as well.  dp0_rows == dp1_rows == NULL: dx only (= stag_agg_fwd on
+ * csr_t).  With the dp outputs: kind NORMAL | UNIFORM, param_mode SCALAR | PER_CHANNEL, in_norm 0;
+ * the plan's workspace must hold stag_plan_workspace_bytes(n_seg, 3 * D, 0) bytes.
+ * Replaces the three autograd passes over [E, D] tensors of the reference's backward.        */
+int stag_agg_bwd(const stag_csr* csr_t, const stag_plan* plan_t, const float* g, int64_t ldg,
+                 int32_t D, const stag_noise_spec* spec, const float* g_scale,
+                 const float* row_scale, float* dx, float* dp0_rows, float* dp1_rows,
+                 int64_t ldo, void* stream);
+
 /* w[eid, k] for every edge of the shard: what the reference keeps in
  * `self._edge_weight_sample` (stag/layers.py:107). relu and in_norm applied.   */
 int stag_noise_materialize(const stag_csr* csr, const stag_noise_spec* spec,
@@ -215,6 +233,15 @@ int stag_agg_bwd_w(const stag_csr* csr, const float* x, int64_t ldx,
 int stag_segment_reduce(const float* x, int64_t ldx, int32_t D,
                         const int32_t* offsets, int32_t n_seg, int32_t reduce,
                         float* out, int64_t ldo, void* stream);
+
+/* Column dots  out_i[k] = sum_n x[n,k] * t_i[n,k]  (i = 0, and 1 when t1/out1 are given): the
+ * last step of a per-channel parameter gradient, dp_i[k] = sum_u x[u,k] * dp_i_rows[u,k]
+ * (stag_agg_bwd).  Two launches, fixed summation order.  workspace: device memory of
+ * stag_coldot_workspace_bytes(D) bytes.                                                      */
+size_t stag_coldot_workspace_bytes(int32_t D);
+int stag_coldot(const float* x, int64_t ldx, const float* t0, const float* t1, int64_t ldt,
+                int64_t n_rows, int32_t D, float* out0, float* out1, void* workspace,
+                size_t workspace_bytes, void* stream);
 
 /* GAT edge attention with noisy logits + softmax + aggregation, one launch:
  *   e[p,h]  = w[p,h] * leaky_relu(el[u_p,h] + er[v,h])     stag/zoo/gat.py:114-119

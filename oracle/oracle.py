@@ -276,3 +276,10 @@ def gat_fwd(g, el, er, ft, neg_slope, spec, want_attn=False):
                                   float(neg_slope), C.byref(spec), _p(out, _f32p),
                                   _p(attn, _f32p)), "gat_fwd")
     return (out, attn) if want_attn else out
+
+
+def coldot(x, t0, t1=None):
+    """CPU twin of stag_coldot: out_i[k] = sum_n x[n,k] * t_i[n,k], accumulated in fp64."""
+    x64 = np.asarray(x, dtype=np.float64)
+    o0 = (x64 * np.asarray(t0, dtype=np.float64)).sum(0)
+    return o0, (None if t1 is None else (x64 * np.asarray(t1, dtype=np.float64)).sum(0))

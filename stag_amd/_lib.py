@@ -93,6 +93,12 @@ def lib():
                                          C.c_int64, _vp]
     l.stag_agg_bwd_w.argtypes = [C.POINTER(Csr), _vp, C.c_int64, _vp, C.c_int64, C.c_int32, _vp,
                                  C.POINTER(NoiseSpec), C.c_int32, _vp, C.c_int64, _vp]
+    l.stag_agg_bwd.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, C.c_int64, C.c_int32,
+                               C.POINTER(NoiseSpec), _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]
+    l.stag_coldot_workspace_bytes.restype = C.c_size_t
+    l.stag_coldot_workspace_bytes.argtypes = [C.c_int32]
+    l.stag_coldot.argtypes = [_vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, _vp,
+                              C.c_size_t, _vp]
     l.stag_segment_reduce.argtypes = [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, C.c_int32, _vp,
                                       C.c_int64, _vp]
     l.stag_gat_workspace_bytes.restype = C.c_size_t
@@ -102,7 +108,7 @@ def lib():
     l.stag_gat_bwd_edge.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp, _vp, _vp, _vp,
                                     C.c_int32, C.c_int32, C.c_float, C.POINTER(NoiseSpec), _vp, _vp,
                                     _vp, _vp]
-    if l.stag_abi_version() != 4:
+    if l.stag_abi_version() != 5:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     _lib = l
     return l

@@ -71,6 +71,7 @@ struct AggArgs {
   int32_t mean;
   // output
   float* out;
+  float* outx[2];          // stag_agg_bwd: the two parameter-derivative aggregates, or null
   int64_t ldo;
   float* norm_scale_out;   // [n_rows, D] or null
   // plan
@@ -148,7 +149,11 @@ __device__ __forceinline__ void kahan_sum_partials(const float* ws, int ws_strid
   }
 }
 
-// Two-level form: Kahan sums of groups of kGroup partials, then a Kahan sum of the group sums in
+// a derivative aggregate: same row scale as the main output, no in-norm
+__device__ __forceinline__ void agg_epilogue_extra(const AggArgs& a, float* out, int v, int deg, int k0,
+                                                   bool vec, float (&acc)[4]);
+
+// Two-level form: Kahan sums of groups of kCombineGroup partials, then a Kahan sum of the group sums in
 // group order.  SLOTS edge slots of the unit take one group each per round and exchange the group
 // sums (ds_bpermute; slot0 = byte address of slot 0's lane with my channels): same arithmetic
 // for every SLOTS.
@@ -199,6 +204,15 @@ __device__ __forceinline__ void agg_epilogue(const AggArgs& a, int v, int deg, i
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] *= dv;
   store4(a.out + (int64_t)v * a.ldo, k0, a.D, vec, acc);
+}
+
+__device__ __forceinline__ void agg_epilogue_extra(const AggArgs& a, float* out, int v, int deg, int k0,
+                                                   bool vec, float (&acc)[4]) {
+  float dv = a.dst_scale ? a.dst_scale[v] : 1.0f;
+  if (a.mean) dv *= __builtin_amdgcn_rcpf((float)(deg > 1 ? deg : 1));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] *= dv;
+  store4(out + (int64_t)v * a.ldo, k0, a.D, vec, acc);
 }
 
 // row `idx` of a row-major fp32 matrix, `koff` bytes into the row.  Narrow form: one
@@ -293,9 +307,20 @@ struct EdgeRows {       // what the row fetch brings in
 
 // BLK: edges per arithmetic block (fixes the summation order, so the same for every shape);
 // MULT: blocks fetched together (BLK * MULT rows in flight per team; no effect on the sums).
-template <int KIND, int LPE, bool VEC, bool PEDGE, int BLK, int MULT = 1>
+// accumulators of the extra outputs; nothing at all when there are none
+template <int NX>
+struct ExtraAcc {
+  float acc[NX][4] = {}, comp[NX][4] = {};
+};
+template <>
+struct ExtraAcc<0> {};
+
+// NOUT: 1, or 3 = the weight and its two parameter derivatives side by side (stag_agg_bwd).
+template <int KIND, int LPE, bool VEC, bool PEDGE, int BLK, int MULT = 1, int NOUT = 1>
 struct AggTeam {
   static constexpr int NB = BLK * MULT;
+  static constexpr int NX = NOUT - 1;              // extra outputs
+  static_assert(NOUT == 1 || ((KIND == kNormal || KIND == kUniform) && !PEDGE), "derivatives: reparameterised, per-channel");
   static constexpr bool NEED_EID = (KIND == kExplicit) || PEDGE;
   const AggArgs& a;
   const int k0;
@@ -307,6 +332,7 @@ struct AggTeam {
   float acc[4] = {0.f, 0.f, 0.f, 0.f}, comp[4] = {0.f, 0.f, 0.f, 0.f};
   float wsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool kahan;
+  ExtraAcc<NX> X;
 
   // every lane of the team reads the same BLK column ids: broadcast dword loads with
   // immediate offsets, no per-edge vector arithmetic
@@ -340,11 +366,14 @@ struct AggTeam {
     if (m > 0 && p0 + m * BLK >= pend) break;   // an empty block must not touch the Kahan state
     // block sums go into fresh accumulators (small magnitudes => small rounding)
     float t[4] = {0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] ExtraAcc<NX> TX;              // block sums of the extra outputs (acc only)
 #pragma unroll
     for (int j = m * BLK; j < (m + 1) * BLK; ++j) {
       if (p0 + j < pend) {
         float w[4];
-        edge_weight(I, j, w);
+        [[maybe_unused]] ExtraAcc<NX> dd;          // dd.acc[o] = derivative o of this edge's draw
+        if constexpr (NX == 0) edge_weight(I, j, w);
+        else draw4_grad<KIND>(I.nn[j], c1, a.key, pa, pb, a.relu, w, dd.acc[0], dd.acc[1]);
         if (a.src_scale) {
           asm volatile("" ::: "memory");   // keep this a branch: as selects it costs 6 VALU ops per edge
 #pragma unroll
@@ -352,6 +381,12 @@ struct AggTeam {
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) t[q] = __builtin_fmaf(w[q], R.xv[j][q], t[q]);
+        if constexpr (NX > 0) {
+#pragma unroll
+          for (int o = 0; o < NX; ++o)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) TX.acc[o][q] = __builtin_fmaf(dd.acc[o][q], R.xv[j][q], TX.acc[o][q]);
+        }
         if (a.in_norm) {
           asm volatile("" ::: "memory");
 #pragma unroll
@@ -360,23 +395,28 @@ struct AggTeam {
       }
     }
     fold(t);
+    if constexpr (NX > 0) {
+#pragma unroll
+      for (int o = 0; o < NX; ++o) fold_into(X.acc[o], X.comp[o], TX.acc[o]);
+    }
     }   // m
   }
 
   // fold one block into the unit's sum; compensated (Kahan) once a unit is long enough for
   // the running sum to dwarf a block, so a 13k-edge hub row keeps ~1e-6 relative accuracy
-  __device__ __forceinline__ void fold(const float (&t)[4]) {
+  __device__ __forceinline__ void fold(const float (&t)[4]) { fold_into(acc, comp, t); }
+  __device__ __forceinline__ void fold_into(float (&s)[4], float (&cmp)[4], const float (&t)[4]) const {
     if (kahan) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float y = t[q] - comp[q];
-        const float sum = acc[q] + y;
-        comp[q] = (sum - acc[q]) - y;
-        acc[q] = sum;
+        const float y = t[q] - cmp[q];
+        const float sum = s[q] + y;
+        cmp[q] = (sum - s[q]) - y;
+        s[q] = sum;
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] += t[q];
+      for (int q = 0; q < 4; ++q) s[q] += t[q];
     }
   }
 
@@ -443,9 +483,10 @@ struct AggTeam {
 
 // One unit (a whole row or a segment of a long row) on LPE x SLOTS lanes of a wave:
 // c = this lane's chunk (4 channels) of the channel tile, sl = its edge slot.
-template <int KIND, int LPE, bool VEC, bool PEDGE, int SLOTS, int MULT>
+template <int KIND, int LPE, bool VEC, bool PEDGE, int SLOTS, int MULT, int NOUT = 1>
 __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const int c, const int sl) {
   static_assert(LPE * SLOTS <= 64 && 64 % (LPE * SLOTS) == 0, "a unit's lanes stay inside one wave");
+  static_assert(NOUT == 1 || SLOTS == 1, "the derivative outputs take the one-slot loop");
   // edges per block: the RNG kinds are VALU-bound and register-hungry, the others want
   // more rows in flight
   constexpr int BLK = (KIND >= kNormal) ? STAG_BLK_RNG : STAG_BLK_MEM;
@@ -475,7 +516,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   if (trace) { trace[0] = wall_clock64(); trace[1] = trace[2] = trace[3] = 0; }
 #endif
 
-  AggTeam<KIND, LPE, VEC, PEDGE, BLK, MULT> T{
+  AggTeam<KIND, LPE, VEC, PEDGE, BLK, MULT, NOUT> T{
       a, k0, (uint32_t)k0 * 4u,
       (chunk + a.chunk_base) | (a.pos_hi << 20),   // Philox counter word 1: a per-lane constant
       b + len,
@@ -586,6 +627,10 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   if (slot < 0) {
     if (sl != 0) return;                // every slot holds the row's sum; slot 0 writes it
     agg_epilogue(a, v, len, k0, VEC, T.acc, T.wsum);
+    if constexpr (NOUT > 1) {
+#pragma unroll
+      for (int o = 0; o < NOUT - 1; ++o) agg_epilogue_extra(a, a.outx[o], v, len, k0, VEC, T.X.acc[o]);
+    }
 #ifdef STAG_TRACE
     if (trace) trace[3] = wall_clock64();
 #endif
@@ -601,6 +646,11 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   if (sl == 0) {
     store4_sc1(rws, woff, k0, a.D, VEC, T.acc);
     if (a.in_norm) store4_sc1(rws, woff + (uint32_t)a.D * 4u, k0, a.D, VEC, T.wsum);
+    if constexpr (NOUT > 1) {
+#pragma unroll
+      for (int o = 0; o < NOUT - 1; ++o)
+        store4_sc1(rws, woff + (uint32_t)(o + 1) * (uint32_t)a.D * 4u, k0, a.D, VEC, T.X.acc[o]);
+    }
   }
   const int s0 = a.long_seg_ptr[r], s1 = a.long_seg_ptr[r + 1];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -635,6 +685,11 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   if (a.in_norm) two_level_sum<NF, VEC, LPE, SLOTS>(a.ws + a.D, a.ws_stride, s0, s1, k0, a.D, sl, slot0, fws);
   if (sl != 0) return;
   agg_epilogue(a, row, deg, k0, VEC, facc, fws);
+#pragma unroll
+  for (int o = 0; o < NOUT - 1; ++o) {
+    two_level_sum<NF, VEC, LPE, SLOTS>(a.ws + (o + 1) * a.D, a.ws_stride, s0, s1, k0, a.D, sl, slot0, facc);
+    agg_epilogue_extra(a, a.outx[o], row, deg, k0, VEC, facc);
+  }
 #ifdef STAG_TRACE
   if (trace) trace[3] = wall_clock64();
 #endif
@@ -676,9 +731,9 @@ constexpr int heavy_slots_of() {
          : LPE == 16 ? STAG_HSLOTS_LPE16 : LPE == 32 ? STAG_HSLOTS_LPE32 : 1;
 }
 
-template <int KIND, int LPE, bool VEC, bool PEDGE>
+template <int KIND, int LPE, bool VEC, bool PEDGE, int NOUT = 1>
 __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_kernel(const AggArgs a) {
-  constexpr int HS = heavy_slots_of<LPE>();
+  constexpr int HS = NOUT == 1 ? heavy_slots_of<LPE>() : 1;
   const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
   int first = 0, blk = blockIdx.x;
   if constexpr (HS > 1) {
@@ -693,7 +748,7 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
   }
   const int unit = first + blk * (STAG_BLOCK_THREADS / LPE) + threadIdx.x / LPE;
   if (unit >= a.n_units) return;
-  agg_unit<KIND, LPE, VEC, PEDGE, 1, mult_of<KIND, LPE>()>(a, unit, c, 0);
+  agg_unit<KIND, LPE, VEC, PEDGE, 1, NOUT == 1 ? mult_of<KIND, LPE>() : 1, NOUT>(a, unit, c, 0);
 }
 
 // Launch one (KIND, PEDGE) family; defined per kind in agg_<kind>.hip so the
@@ -707,11 +762,18 @@ inline void agg_launch_shape(const AggArgs& a_in, bool vec, bool pedge, int tile
   constexpr int TPB = STAG_BLOCK_THREADS / LPE;
   constexpr int HS = heavy_slots_of<LPE>();
   constexpr int TPBH = STAG_BLOCK_THREADS / (LPE * HS);
-  if (HS == 1) a.n_heavy = 0;
+  if (HS == 1 || a.outx[0]) a.n_heavy = 0;
   a.n_heavy_blocks = (a.n_heavy + TPBH - 1) / TPBH;
   dim3 grid(a.n_heavy_blocks + (a.n_units - a.n_heavy + TPB - 1) / TPB, tiles);
   if (grid.x == 0) return;
   const dim3 block(STAG_BLOCK_THREADS);
+  if constexpr (KIND == kNormal || KIND == kUniform) {
+    if (a.outx[0]) {        // weight + both parameter derivatives in one pass (validated on the host: !pedge)
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, false, 3>), grid, block, 0, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, false, 3>), grid, block, 0, s, a);
+      return;
+    }
+  }
   if constexpr (KIND >= kNormal) {
     if (pedge) {
       if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, true>), grid, block, 0, s, a);

@@ -247,6 +247,96 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const float* x, int
   store4(out + (int64_t)s * ldo, k0, D, VEC, acc);
 }
 
+
+// ---- column dots: out_i[k] = sum_n x[n,k] * t_i[n,k]  (the last step of a per-channel
+//      parameter gradient: dp_i[k] = sum_u x[u,k] * dp_i_rows[u,k]; stag_agg_bwd) ------------
+// Stage 1: block b walks rows b*R, b*R+1, ... (R rows side by side), CW lanes across the
+// columns; the R row-lanes of a column are added through LDS; one partial row per block.
+// Stage 2: the partials of a column are added in a fixed two-level order.  Deterministic.
+constexpr int kColdotBlocks = 1024;
+template <int W>   // W = 4: dwordx4 columns, W = 1: scalar
+__global__ __launch_bounds__(256) void coldot_partial_kernel(const float* x, int64_t ldx, const float* t0,
+                                                             const float* t1, int64_t ldt, int64_t n_rows,
+                                                             int D, int cw, float* part) {
+  __shared__ float red[2][256][W];
+  const int tx = threadIdx.x % cw, ty = threadIdx.x / cw, R = 256 / cw;
+  const int col = (blockIdx.y * cw + tx) * W;
+  float a0[W], a1[W];
+#pragma unroll
+  for (int q = 0; q < W; ++q) a0[q] = a1[q] = 0.f;
+  if (col < D) {
+    for (int64_t n = (int64_t)blockIdx.x * R + ty; n < n_rows; n += (int64_t)gridDim.x * R) {
+      float xv[W], u0[W], u1[W];
+      if constexpr (W == 4) {
+        const float4 xx = *reinterpret_cast<const float4*>(x + n * ldx + col);
+        const float4 aa = *reinterpret_cast<const float4*>(t0 + n * ldt + col);
+        xv[0] = xx.x; xv[1] = xx.y; xv[2] = xx.z; xv[3] = xx.w;
+        u0[0] = aa.x; u0[1] = aa.y; u0[2] = aa.z; u0[3] = aa.w;
+        if (t1) {
+          const float4 bb = *reinterpret_cast<const float4*>(t1 + n * ldt + col);
+          u1[0] = bb.x; u1[1] = bb.y; u1[2] = bb.z; u1[3] = bb.w;
+        }
+      } else {
+        xv[0] = x[n * ldx + col]; u0[0] = t0[n * ldt + col];
+        if (t1) u1[0] = t1[n * ldt + col];
+      }
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        a0[q] = __builtin_fmaf(xv[q], u0[q], a0[q]);
+        if (t1) a1[q] = __builtin_fmaf(xv[q], u1[q], a1[q]);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < W; ++q) { red[0][threadIdx.x][q] = a0[q]; red[1][threadIdx.x][q] = a1[q]; }
+  __syncthreads();
+  if (ty == 0 && col < D) {
+    for (int o = 0; o < (t1 ? 2 : 1); ++o)
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += red[o][r * cw + tx][q];
+        if (col + q < D) part[((int64_t)blockIdx.x * 2 + o) * D + col + q] = s;
+      }
+  }
+}
+
+// 16 columns x 16 groups per block: group y adds partials y*G .. y*G+G-1 (Kahan, loads batched 8
+// at a time), then thread (column, 0) adds the 16 group sums in group order.
+__global__ __launch_bounds__(256) void coldot_final_kernel(const float* part, int n_blocks, int D,
+                                                           float* out0, float* out1) {
+  __shared__ float red[2][16][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + tx;
+  const int G = (n_blocks + 15) / 16;
+  const int b0 = ty * G, b1 = min(b0 + G, n_blocks);
+  float s0 = 0.f, c0 = 0.f, s1 = 0.f, c1 = 0.f;
+  if (k < D) {
+    for (int b = b0; b < b1; b += 8) {
+      float v0[8], v1[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool in = b + i < b1;
+        v0[i] = in ? part[((int64_t)(b + i) * 2) * D + k] : 0.f;
+        v1[i] = (in && out1) ? part[((int64_t)(b + i) * 2 + 1) * D + k] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float y0 = v0[i] - c0; const float n0 = s0 + y0; c0 = (n0 - s0) - y0; s0 = n0;
+        const float y1 = v1[i] - c1; const float n1 = s1 + y1; c1 = (n1 - s1) - y1; s1 = n1;
+      }
+    }
+  }
+  red[0][ty][tx] = s0; red[1][ty][tx] = s1;
+  __syncthreads();
+  if (ty == 0 && k < D) {
+    float a = 0.f, b = 0.f;
+    for (int y = 0; y < 16; ++y) { a += red[0][y][tx]; b += red[1][y][tx]; }
+    out0[k] = a;
+    if (out1) out1[k] = b;
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------- //
@@ -348,10 +438,12 @@ int stag_philox_raw(uint64_t seed, uint64_t offset, int64_t pos0, int64_t n_pos,
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }
 
-int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int64_t ldx,
-                 int32_t D, const stag_noise_spec* spec, int32_t reduce, const float* src_scale,
-                 const float* dst_scale, float* out, int64_t ldo, float* norm_scale_out,
-                 void* stream) {
+// one aggregation launch; out1/out2 non-null: the two parameter-derivative aggregates ride along
+static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x, int64_t ldx,
+                      int32_t D, const stag_noise_spec* spec, int32_t reduce, const float* src_scale,
+                      const float* dst_scale, float* out, int64_t ldo, float* norm_scale_out,
+                      float* out1, float* out2, void* stream) {
+  const int nout = out1 ? 3 : 1;
   int rc = check_csr(csr);
   if (rc) return rc;
   rc = check_spec(spec);
@@ -391,6 +483,7 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int
     return STAG_ENOSYS;
   a.src_scale = src_scale; a.dst_scale = dst_scale; a.mean = (reduce == STAG_REDUCE_MEAN);
   a.out = out; a.ldo = ldo; a.norm_scale_out = norm_scale_out;
+  a.outx[0] = out1; a.outx[1] = out2;
 
   const bool use_plan = plan && plan->n_units > 0;
   const bool has_segs = use_plan && plan->n_seg > 0;
@@ -405,18 +498,20 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int
   if (has_segs) {
     if (!plan->long_rows || !plan->long_seg_ptr || !plan->workspace || !plan->seg_counters)
       return STAG_EINVAL;
-    if (plan->workspace_bytes < stag_plan_workspace_bytes(plan->n_seg, D, spec->in_norm))
-      return STAG_ENOMEM;
+    // partial rows: [D sums | D weight sums if in-norm], or [3 x D] with the derivative aggregates
+    const size_t need = nout == 3 ? stag_plan_workspace_bytes(plan->n_seg, 3 * D, 0)
+                                  : stag_plan_workspace_bytes(plan->n_seg, D, spec->in_norm);
+    if (plan->workspace_bytes < need) return STAG_ENOMEM;
     a.long_rows = plan->long_rows; a.long_seg_ptr = plan->long_seg_ptr;
-    const size_t need = stag_plan_workspace_bytes(plan->n_seg, D, spec->in_norm);
     if (need >= (1ull << 32)) return STAG_ENOSYS;   // partials go through a 32-bit buffer descriptor
-    a.ws = plan->workspace; a.ws_stride = D * (spec->in_norm ? 2 : 1); a.ws_bytes = (uint32_t)need;
+    a.ws = plan->workspace; a.ws_stride = D * (nout == 3 ? 3 : (spec->in_norm ? 2 : 1)); a.ws_bytes = (uint32_t)need;
     a.n_long = plan->n_long; a.seg_counters = plan->seg_counters; a.n_seg = plan->n_seg;
   }
 
   // dwordx4 path needs 16-B aligned rows everywhere a float4 is formed
   bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) && aligned16(out);
   if (norm_scale_out) vec = vec && aligned16(norm_scale_out);
+  if (out1) vec = vec && aligned16(out1) && aligned16(out2);
   if (spec->kind == STAG_NOISE_EXPLICIT) vec = vec && aligned16(spec->p0);
   if (spec->kind >= STAG_NOISE_NORMAL && spec->param_mode != STAG_PARAM_SCALAR &&
       spec->param_mode != STAG_PARAM_PER_EDGE1)
@@ -435,6 +530,31 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int
   };
   if (launch(a) != hipSuccess) return STAG_EIO;
   return STAG_OK;
+}
+
+int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int64_t ldx,
+                 int32_t D, const stag_noise_spec* spec, int32_t reduce, const float* src_scale,
+                 const float* dst_scale, float* out, int64_t ldo, float* norm_scale_out,
+                 void* stream) {
+  return agg_common(csr, plan, x, ldx, D, spec, reduce, src_scale, dst_scale, out, ldo, norm_scale_out,
+                    nullptr, nullptr, stream);
+}
+
+int stag_agg_bwd(const stag_csr* csr_t, const stag_plan* plan_t, const float* g, int64_t ldg,
+                 int32_t D, const stag_noise_spec* spec, const float* g_scale, const float* row_scale,
+                 float* dx, float* dp0_rows, float* dp1_rows, int64_t ldo, void* stream) {
+  if (!spec) return STAG_EINVAL;
+  if ((dp0_rows == nullptr) != (dp1_rows == nullptr)) return STAG_EINVAL;
+  if (spec->in_norm || spec->deriv) return STAG_EINVAL;      // in-norm is not differentiated here
+  if (dp0_rows) {
+    // parameter derivatives exist for the reparameterised kinds with scalar / per-channel
+    // parameters; per-edge (amortised) parameters take their gradients from stag_agg_bwd_w
+    if (spec->kind != STAG_NOISE_NORMAL && spec->kind != STAG_NOISE_UNIFORM) return STAG_EINVAL;
+    if (spec->param_mode != STAG_PARAM_SCALAR && spec->param_mode != STAG_PARAM_PER_CHANNEL) return STAG_EINVAL;
+    if (csr_t && csr_t->n_edges > 0 && !csr_t->nidx) return STAG_EINVAL;   // must redraw the FORWARD's noise
+  }
+  return agg_common(csr_t, plan_t, g, ldg, D, spec, STAG_REDUCE_SUM, g_scale, row_scale, dx, ldo, nullptr,
+                    dp0_rows, dp1_rows, stream);
 }
 
 int stag_noise_materialize(const stag_csr* csr, const stag_noise_spec* spec, int32_t Dn, float* w,
@@ -538,6 +658,32 @@ int stag_segment_reduce(const float* x, int64_t ldx, int32_t D, const int32_t* o
     default: STAG_SEG_LAUNCH(1); break;
   }
 #undef STAG_SEG_LAUNCH
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}
+
+size_t stag_coldot_workspace_bytes(int32_t D) {
+  return D > 0 ? (size_t)kColdotBlocks * 2u * (size_t)D * sizeof(float) : 0;
+}
+
+int stag_coldot(const float* x, int64_t ldx, const float* t0, const float* t1, int64_t ldt,
+                int64_t n_rows, int32_t D, float* out0, float* out1, void* workspace,
+                size_t workspace_bytes, void* stream) {
+  if (D <= 0 || n_rows < 0 || ldx < D || ldt < D || !out0 || (t1 != nullptr) != (out1 != nullptr)) return STAG_EINVAL;
+  if (n_rows > 0 && (!x || !t0)) return STAG_EINVAL;
+  if (!workspace || workspace_bytes < stag_coldot_workspace_bytes(D)) return STAG_ENOMEM;
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ldt % 4 == 0) && aligned16(x) && aligned16(t0) &&
+                   (!t1 || aligned16(t1));
+  const int elems = vec ? D / 4 : D;
+  int cw = 1;
+  while (cw < elems && cw < 256) cw <<= 1;
+  const int R = 256 / cw;
+  const int nb = (int)std::min<int64_t>(kColdotBlocks, std::max<int64_t>(1, (n_rows + R - 1) / R));
+  const dim3 grid(nb, (elems + cw - 1) / cw);
+  float* part = static_cast<float*>(workspace);
+  if (vec) hipLaunchKernelGGL((coldot_partial_kernel<4>), grid, dim3(256), 0, s, x, ldx, t0, t1, ldt, n_rows, D, cw, part);
+  else     hipLaunchKernelGGL((coldot_partial_kernel<1>), grid, dim3(256), 0, s, x, ldx, t0, t1, ldt, n_rows, D, cw, part);
+  hipLaunchKernelGGL(coldot_final_kernel, dim3((D + 15) / 16), dim3(256), 0, s, part, nb, D, out0, out1);
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }
 

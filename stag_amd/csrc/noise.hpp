@@ -124,4 +124,33 @@ __device__ __forceinline__ void draw4(uint32_t c0, uint32_t c1, const PhiloxKey&
   }
 }
 
+// Backward of a reparameterised draw in ONE call: w (after relu) and both parameter derivatives
+// d0 = dw/dp0 (loc | low), d1 = dw/dp1 (scale | high), each times 1[w > 0] under relu —
+// exactly what draw4 returns for deriv = 0, 1, 2, from a single Philox block.
+template <int KIND>
+__device__ __forceinline__ void draw4_grad(uint32_t c0, uint32_t c1, const PhiloxKey& key,
+                                           const float (&a)[4], const float (&b)[4], int flags,
+                                           float (&w)[4], float (&d0)[4], float (&d1)[4]) {
+  static_assert(KIND == kNormal || KIND == kUniform, "only reparameterised draws have derivatives");
+  uint32_t r[4];
+  philox4x32_10(c0, c1, key, r);
+  float t[4];
+  if constexpr (KIND == kNormal) {
+    box_muller(r[0], r[1], t[0], t[1]);
+    box_muller(r[2], r[3], t[2], t[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = __builtin_fmaf(b[j], t[j], a[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { t[j] = u01(r[j]); w[j] = __builtin_fmaf(b[j] - a[j], t[j], a[j]); }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float mask = ((flags & kFlagRelu) && !(w[j] > 0.0f)) ? 0.0f : 1.0f;
+    if (flags & kFlagRelu) w[j] = fmaxf(w[j], 0.0f);
+    d0[j] = ((KIND == kNormal) ? 1.0f : 1.0f - t[j]) * mask;
+    d1[j] = t[j] * mask;
+  }
+}
+
 }  // namespace stag

@@ -76,6 +76,85 @@ def _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len, want_norm_
     return out, ns
 
 
+def _agg_bwd_raw(csrv_t, g, D, spec, g_scale, row_scale, seg_len, want_dp):
+    """One stag_agg_bwd launch on the source-major CSR: dx and, if want_dp, the two per-row
+    parameter-derivative aggregates (same gather, same Philox block)."""
+    dev = _lib.require_device(g, csrv_t.indptr, g_scale, row_scale)
+    dx = torch.empty((csrv_t.n_dst, D), dtype=torch.float32, device=dev)
+    t0 = torch.empty_like(dx) if want_dp else None
+    t1 = torch.empty_like(dx) if want_dp else None
+    plan_t = csrv_t.plan(seg_len)
+    nbytes = (_lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], (3 if want_dp else 1) * D, 0)
+              if plan_t is not None else 0)
+    plan_c, _keep = _plan_struct(csrv_t, seg_len, (D + 255) // 256, nbytes, dev)
+    cs = csrv_t.struct()
+    with torch.cuda.device(dev):
+        rc = _lib.lib().stag_agg_bwd(
+            C.byref(cs), C.byref(plan_c) if plan_c is not None else None, _lib.ptr(g), g.stride(0), D,
+            C.byref(spec), _lib.ptr(g_scale), _lib.ptr(row_scale), _lib.ptr(dx), _lib.ptr(t0),
+            _lib.ptr(t1), D, _lib.stream_of(dev))
+    _lib.check(rc, "stag_agg_bwd")
+    return dx, t0, t1
+
+
+def coldot(x, t0, t1=None):
+    """out_i[k] = sum_n x[n,k] * t_i[n,k]  (stag_coldot; no autograd — a backward-pass helper)."""
+    dev = _lib.require_device(x, t0, t1)
+    x, t0, t1 = _f32c(x), _f32c(t0), _f32c(t1)
+    n, D = x.shape
+    if n == 0:          # empty tensors have no device pointer to hand over
+        z = torch.zeros(D, dtype=torch.float32, device=dev)
+        return z, (z.clone() if t1 is not None else None)
+    nbytes = _lib.lib().stag_coldot_workspace_bytes(D)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    o0 = torch.empty(D, dtype=torch.float32, device=dev)
+    o1 = torch.empty(D, dtype=torch.float32, device=dev) if t1 is not None else None
+    with torch.cuda.device(dev):
+        rc = _lib.lib().stag_coldot(_lib.ptr(x), x.stride(0), _lib.ptr(t0), _lib.ptr(t1), t0.stride(0), n, D,
+                                    _lib.ptr(o0), _lib.ptr(o1), _lib.ptr(ws), nbytes, _lib.stream_of(dev))
+    _lib.check(rc, "stag_coldot")
+    return o0, o1
+
+
+class _NodeLinear(torch.autograd.Function):
+    """y = x @ w for a tall x [N, in] (the dense transform after an aggregation,
+    stag/zoo/gcn.py:97-98).  Forward and dx are plain rocBLAS/hipBLASLt GEMMs; the weight gradient
+    x^T g is a K = N reduction that the library runs as ONE tile column (403 us at N = 169,343,
+    128 x 128, MI355X) — here it is split over K into a batched GEMM + sum (67 us)."""
+
+    SPLIT = 64
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        dx = g @ w.t() if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            n, S = x.shape[0], _NodeLinear.SPLIT
+            n1 = (n // S) * S
+            if n1 >= 64 * S:
+                g = g.contiguous()
+                dw = torch.bmm(x[:n1].view(S, n1 // S, x.shape[1]).transpose(1, 2),
+                               g[:n1].view(S, n1 // S, g.shape[1])).sum(0)
+                if n1 < n:
+                    dw = dw + x[n1:].t() @ g[n1:]
+            else:
+                dw = x.t() @ g
+        return dx, dw
+
+
+def node_linear(x, w):
+    """x [N, in] @ w [in, out] with a split-K weight gradient (see _NodeLinear)."""
+    if x.dim() != 2 or not x.is_contiguous():
+        return x @ w
+    return _NodeLinear.apply(x, w)
+
+
 def _bwd_w_raw(csrv, x, g, D, src_scale, broadcast_x=False, spec=None, reduce_k=False):
     dev = _lib.require_device(x, g)
     cols = 1 if reduce_k else D
@@ -146,7 +225,8 @@ class _Aggregate(torch.autograd.Function):
 class _AggregateVI(torch.autograd.Function):
     """Fused aggregation whose noise parameters carry gradients (`vi=True`, reparameterised
     draw w = p0 + p1 * z | low + (high-low) u; stag/layers.py:123-124).  Nothing [E, D]-sized
-    is saved: the backward redraws z from the counters with spec.deriv = 1 | 2."""
+    is saved: the backward (stag_agg_bwd) redraws z from the counters and returns dx together with
+    the two parameter-derivative aggregates from one pass."""
 
     @staticmethod
     def forward(ctx, x, p0, p1, graph, noise, reduce, src_scale, dst_scale, seg_len):
@@ -169,19 +249,20 @@ class _AggregateVI(torch.autograd.Function):
             inv = 1.0 / graph.csr.degrees.clamp(min=1).to(torch.float32)
             dvec = inv if dvec is None else dvec * inv
         dx = dp0 = dp1 = None
-
-        def transposed(deriv):
-            if deriv == 1 and not noise.relu and noise.kind == _lib.NOISE_NORMAL:
-                spec = _none_spec()              # dw/dloc == 1 everywhere: a noise-free pass
-            else:
-                noise.deriv = deriv
-                spec = noise.spec()
-                noise.deriv = 0
-            return _agg_raw(graph.csr_t, g, D, spec, _lib.REDUCE_SUM, dvec, src_scale, ctx.seg_len)[0]
-
-        if ctx.needs_input_grad[0]:
-            dx = transposed(0)
         per_edge = noise.param_mode >= _lib.PARAM_PER_EDGE1
+        need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        if not per_edge:
+            # scalar / per-channel parameters: ONE transposed pass yields dx and the two
+            # derivative aggregates T_i[u,k] = ss[u] sum_p dw/dp_i[p,k] g'[v_p,k]; then
+            # dp_i[k] = sum_u x[u,k] T_i[u,k]   (sum_e D[e,k] s_u x[u,k] g'[v,k] regrouped by u)
+            dx, t0, t1 = _agg_bwd_raw(graph.csr_t, g, D, noise.spec(), dvec, src_scale, ctx.seg_len, need_p)
+            if not ctx.needs_input_grad[0]:
+                dx = None
+            if need_p:      # dp_i[k] = sum_u x[u,k] T_i[u,k], both in one pass over x
+                c0, c1 = coldot(x, t0, t1)
+                rows = {1: c0, 2: c1}
+        elif ctx.needs_input_grad[0]:
+            dx, _, _ = _agg_bwd_raw(graph.csr_t, g, D, noise.spec(), dvec, src_scale, ctx.seg_len, False)
         gg = None
         for which, need in ((1, ctx.needs_input_grad[1]), (2, ctx.needs_input_grad[2])):
             if not need:
@@ -194,8 +275,7 @@ class _AggregateVI(torch.autograd.Function):
                                reduce_k=noise.param_mode == _lib.PARAM_PER_EDGE1)
                 noise.deriv = 0
             else:
-                # sum_e D[e,k] * s_u x[u,k] * g'[v,k]  =  sum_u x[u,k] * (A_D^T g')[u,k]
-                d = (x * transposed(which)).sum(0)
+                d = rows[which]
             shape = ctx.shapes[which - 1]
             d = d.sum_to_size(shape) if d.dim() >= len(shape) and shape != d.shape else d.reshape(shape)
             if which == 1:

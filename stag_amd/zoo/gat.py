@@ -46,7 +46,7 @@ class GAT(torch.nn.Module):
     def forward(self, graph, feat, get_attention=False, edge_weight=None):
         H, F = self._num_heads, self._out_feats
         h = self.feat_drop(feat)
-        ft = self.fc(h).view(-1, H, F)
+        ft = ops.node_linear(h, self.fc.weight.t()).view(-1, H, F)
         el = (ft * self.attn_l).sum(dim=-1)          # [N, H]  (zoo/gat.py:109)
         er = (ft * self.attn_r).sum(dim=-1)          # [N, H]  (zoo/gat.py:110)
         if edge_weight is not None:

@@ -57,7 +57,7 @@ class GCN(torch.nn.Module):
         rst = ops.aggregate(graph, feat_src.reshape(lead[0], -1), edge_weight, reduce="sum",
                             src_scale=src_scale, dst_scale=dst_scale).reshape(lead)
         if weight is not None:
-            rst = torch.matmul(rst, weight)
+            rst = ops.node_linear(rst, weight)
         if self.bias is not None:
             rst = rst + self.bias
         if self._activation is not None:

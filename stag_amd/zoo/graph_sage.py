@@ -44,7 +44,8 @@ class GraphSAGE(torch.nn.Module):
             check_edge_weight(graph, edge_weight)
         h_self = feat_dst
         if self._aggre_type == "mean":
-            h_neigh = self.fc_neigh(ops.aggregate(graph, feat_src, edge_weight, reduce="mean"))
+            h_neigh = ops.node_linear(ops.aggregate(graph, feat_src, edge_weight, reduce="mean"),
+                                      self.fc_neigh.weight.t())
         elif self._aggre_type == "gcn":
             neigh = ops.aggregate(graph, feat_src, edge_weight, reduce="sum")
             degs = graph.in_degrees().to(feat_dst)
@@ -54,7 +55,7 @@ class GraphSAGE(torch.nn.Module):
                                       "no BASELINE config uses it (scripts pin 'mean')")
         else:
             raise NotImplementedError("'lstm' aggregator is outside the accelerated path")
-        rst = h_neigh if self._aggre_type == "gcn" else self.fc_self(h_self) + h_neigh
+        rst = h_neigh if self._aggre_type == "gcn" else ops.node_linear(h_self, self.fc_self.weight.t()) + h_neigh
         if self.bias is not None:
             rst = rst + self.bias
         if self.activation is not None:

@@ -234,6 +234,84 @@ def test_backward_vs_oracle(dev, oracle):
     assert_close(xd.grad, ref_dx, what="dx explicit")
 
 
+@pytest.mark.parametrize("kind,relu", [("normal", False), ("normal", True), ("uniform", True)])
+@pytest.mark.parametrize("D", [6, 40, 128])
+def test_agg_bwd_one_pass(dev, oracle, kind, relu, D):
+    """stag_agg_bwd: dx and the two parameter-derivative aggregates from ONE pass equal three
+    separate passes (spec.deriv = 0, 1, 2) bit for bit, and the oracle within the bar; hub row
+    (segments + combine) and per-channel parameters included."""
+    from stag_amd import _lib, ops
+    rng = np.random.default_rng(17)
+    n = 150
+    g = random_graph(n, 1500, seed=6, hub=300, device=dev)
+    ogt = oracle_graph(oracle, g, transposed=True)
+    gout = rng.standard_normal((n, D)).astype(np.float32)
+    gs = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    rs = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    p0 = torch.from_numpy(rng.uniform(0.2, 1.0, D).astype(np.float32)).to(dev)
+    p1 = torch.from_numpy(rng.uniform(1.1, 1.8, D).astype(np.float32)).to(dev)
+    gd, gsd, rsd = (torch.from_numpy(a).to(dev) for a in (gout, gs, rs))
+    noise = _noise(g, D, kind, p0, p1, relu=relu, seed=3, offset=11)
+    dx, t0, t1 = ops._agg_bwd_raw(g.csr_t, gd, D, noise.spec(), gsd, rsd, 32, True)
+    only_dx, _, _ = ops._agg_bwd_raw(g.csr_t, gd, D, noise.spec(), gsd, rsd, 32, False)
+    assert torch.equal(dx, only_dx)
+    for deriv, got in ((0, dx), (1, t0), (2, t1)):
+        noise.deriv = deriv
+        sep, _ = ops._agg_raw(g.csr_t, gd, D, noise.spec(), _lib.REDUCE_SUM, gsd, rsd, 32)
+        assert torch.equal(got, sep), f"deriv={deriv}: one pass != separate pass"
+        ref = oracle.agg_fwd(ogt, gout, _ospec(oracle, g, D, kind, p0, p1, relu=relu, seed=3, offset=11, deriv=deriv),
+                             src_scale=gs, dst_scale=rs)
+        assert_close(got, ref, what=f"agg_bwd deriv={deriv}")
+    noise.deriv = 0
+    # argument validation
+    cs = g.csr_t.struct()
+    bern = _noise(g, D, "bernoulli", 0.5)
+    import ctypes as C
+    out = torch.empty(n, D, device=dev)
+    rc = _lib.lib().stag_agg_bwd(C.byref(cs), None, _lib.ptr(gd), D, D, C.byref(bern.spec()), None, None,
+                                 _lib.ptr(out), _lib.ptr(out), _lib.ptr(out), D, None)
+    assert rc == -22      # Bernoulli has no parameter derivative
+
+
+@pytest.mark.parametrize("n,D", [(0, 8), (1, 1), (1000, 6), (20001, 40), (5000, 128), (3000, 300), (700, 1433)])
+def test_coldot(dev, oracle, n, D):
+    from stag_amd import ops
+    rng = np.random.default_rng(n + D)
+    x, t0, t1 = (rng.standard_normal((n, D)).astype(np.float32) for _ in range(3))
+    xd, a, b = (torch.from_numpy(v).to(dev) for v in (x, t0, t1))
+    o0, o1 = ops.coldot(xd, a, b)
+    r0, r1 = oracle.coldot(x, t0, t1)
+    scale = np.sqrt(max(n, 1))            # a column sum of n unit-variance products
+    assert np.abs(o0.cpu().numpy() - r0).max() <= TOL * scale and np.abs(o1.cpu().numpy() - r1).max() <= TOL * scale
+    only0, none = ops.coldot(xd, a)
+    assert none is None and torch.equal(only0, o0)
+    assert torch.equal(ops.coldot(xd, a, b)[1], o1)      # fixed summation order: repeatable
+
+
+def test_node_linear_gradients(dev):
+    """Split-K weight gradient of the dense transform == the plain GEMM's, to fp32 rounding."""
+    from stag_amd import ops
+    torch.manual_seed(0)
+    for n, din, dout in ((169343, 128, 40), (5000, 16, 7), (100, 8, 8)):
+        x = torch.randn(n, din, device=dev, requires_grad=True)
+        w = torch.randn(din, dout, device=dev, requires_grad=True)
+        g = torch.randn(n, dout, device=dev)
+        y = ops.node_linear(x, w)
+        y.backward(g)
+        x2, w2 = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+        y2 = x2 @ w2
+        y2.backward(g)
+        assert torch.equal(y, y2) and torch.allclose(x.grad, x2.grad, rtol=1e-5, atol=1e-5)
+        ref = (x.detach().double().t() @ g.double())
+        tol = 1e-5 * np.sqrt(n) * 4
+        assert (w.grad.double() - ref).abs().max().item() <= tol
+        assert (w.grad.double() - ref).abs().max().item() <= (w2.grad.double() - ref).abs().max().item() * 2 + 1e-6
+    lin = torch.nn.Linear(12, 5, bias=False).to(dev)        # the nn.Linear form used by SAGE / GAT
+    x = torch.randn(9000, 12, device=dev)
+    ops.node_linear(x, lin.weight.t()).sum().backward()
+    assert torch.allclose(lin.weight.grad, x.sum(0).expand(5, 12), rtol=1e-4, atol=1e-3)
+
+
 def test_segment_reduce(dev, oracle):
     from stag_amd import ops
     rng = np.random.default_rng(0)
