@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 5
+#define STAG_ABI_VERSION 6
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -114,6 +114,10 @@ typedef struct stag_noise_spec {
   int32_t chunk_base; /* first global channel / 4 of this shard's channel 0 (channel shards:
                          every GPU holds the whole CSR and D/P of the channels, no exchange) */
   int32_t reserved;
+  const uint64_t* epoch; /* NULL, or a DEVICE counter read at run time: the launch draws with
+                            offset + *epoch.  Lets a captured hipGraph draw fresh noise on every
+                            replay: its kernel nodes keep the offsets they were captured with, and
+                            a node of the same graph advances the counter.                    */
 } stag_noise_spec;
 
 /* Launch plan, built once per graph on the host (stag_plan_count / stag_plan_fill).

@@ -137,7 +137,7 @@ static void edge_weights4(const stag_csr* csr, const stag_noise_spec* s,
   } else {
     int64_t gpos = csr->nidx ? (int64_t)csr->nidx[p] : s->pos_base + p;
     uint32_t r[4];
-    noise_words(s->seed, s->offset, gpos, (uint32_t)(c + s->chunk_base), r);
+    noise_words(s->seed, s->offset + (s->epoch ? *s->epoch : 0) /* host pointer here */, gpos, (uint32_t)(c + s->chunk_base), r);
     float t[4];
     if (s->kind == STAG_NOISE_NORMAL) std_normal4(r, t); else std_uniform4(r, t);
     for (int j = 0; j < 4; ++j) {

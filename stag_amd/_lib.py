@@ -31,7 +31,7 @@ class NoiseSpec(C.Structure):
                 ("p0_scalar", C.c_float), ("p1_scalar", C.c_float),
                 ("relu", C.c_int32), ("in_norm", C.c_int32), ("deriv", C.c_int32),
                 ("group", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64), ("pos_base", C.c_int64),
-                ("chunk_base", C.c_int32), ("reserved", C.c_int32)]
+                ("chunk_base", C.c_int32), ("reserved", C.c_int32), ("epoch", C.c_void_p)]
 
 
 class Plan(C.Structure):
@@ -108,7 +108,7 @@ def lib():
     l.stag_gat_bwd_edge.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp, _vp, _vp, _vp,
                                     C.c_int32, C.c_int32, C.c_float, C.POINTER(NoiseSpec), _vp, _vp,
                                     _vp, _vp]
-    if l.stag_abi_version() != 5:
+    if l.stag_abi_version() != 6:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     _lib = l
     return l

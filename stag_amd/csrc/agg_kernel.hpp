@@ -323,6 +323,7 @@ struct AggTeam {
   static_assert(NOUT == 1 || ((KIND == kNormal || KIND == kUniform) && !PEDGE), "derivatives: reparameterised, per-channel");
   static constexpr bool NEED_EID = (KIND == kExplicit) || PEDGE;
   const AggArgs& a;
+  const PhiloxKey key;     // a.key with the device epoch folded in
   const int k0;
   const uint32_t koff, c1;
   int pend;
@@ -373,7 +374,7 @@ struct AggTeam {
         float w[4];
         [[maybe_unused]] ExtraAcc<NX> dd;          // dd.acc[o] = derivative o of this edge's draw
         if constexpr (NX == 0) edge_weight(I, j, w);
-        else draw4_grad<KIND>(I.nn[j], c1, a.key, pa, pb, a.relu, w, dd.acc[0], dd.acc[1]);
+        else draw4_grad<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w, dd.acc[0], dd.acc[1]);
         if (a.src_scale) {
           asm volatile("" ::: "memory");   // keep this a branch: as selects it costs 6 VALU ops per edge
 #pragma unroll
@@ -476,7 +477,7 @@ struct AggTeam {
           if (a.p1) loadrow4(row_at(a.p1, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, pb);
         }
       }
-      draw4<KIND>(I.nn[j], c1, a.key, pa, pb, a.relu, w);
+      draw4<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w);
     }
   }
 };
@@ -517,7 +518,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
 #endif
 
   AggTeam<KIND, LPE, VEC, PEDGE, BLK, MULT, NOUT> T{
-      a, k0, (uint32_t)k0 * 4u,
+      a, (KIND >= kNormal) ? resolve_epoch(a.key) : a.key, k0, (uint32_t)k0 * 4u,
       (chunk + a.chunk_base) | (a.pos_hi << 20),   // Philox counter word 1: a per-lane constant
       b + len,
       // descriptor of x for the narrow (< 4 GB, ids < 2^24) case; kernel arguments only

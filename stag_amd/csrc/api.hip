@@ -50,6 +50,7 @@ PhiloxKey make_key(const stag_noise_spec* s) {
   k.k1 = (uint32_t)(s->seed >> 32);
   k.o0 = (uint32_t)(s->offset & 0xFFFFFFFFull);
   k.o1 = (uint32_t)(s->offset >> 32);
+  k.epoch = s->epoch;
   return k;
 }
 
@@ -98,10 +99,11 @@ __device__ __forceinline__ void edge_w4(const NoiseArgs& a, int p, int64_t ed, u
   }
   const int64_t gpos = a.nidx ? (int64_t)a.nidx[p] : a.pos_base + p;
   chunk += a.chunk_base;   // global channel group (channel shards)
+  const PhiloxKey key = resolve_epoch(a.key);
   switch (a.kind) {
-    case kNormal: draw4<kNormal>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.nflags, w); break;
-    case kUniform: draw4<kUniform>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.nflags, w); break;
-    case kBernoulli: draw4<kBernoulli>((uint32_t)gpos, ctr1_of(gpos, chunk), a.key, pa, pb, a.nflags, w); break;
+    case kNormal: draw4<kNormal>((uint32_t)gpos, ctr1_of(gpos, chunk), key, pa, pb, a.nflags, w); break;
+    case kUniform: draw4<kUniform>((uint32_t)gpos, ctr1_of(gpos, chunk), key, pa, pb, a.nflags, w); break;
+    case kBernoulli: draw4<kBernoulli>((uint32_t)gpos, ctr1_of(gpos, chunk), key, pa, pb, a.nflags, w); break;
     case kExplicit:
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

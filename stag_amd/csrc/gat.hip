@@ -59,8 +59,8 @@ struct GatArgs {
 };
 
 // the 4 weights of heads [4c, 4c+4) of the edge with noise index n and edge id ed
-__device__ __forceinline__ void head_w4(const GatArgs& a, uint32_t n, int64_t ed, uint32_t chunk,
-                                        float (&w)[4]) {
+__device__ __forceinline__ void head_w4(const GatArgs& a, const PhiloxKey& key, uint32_t n, int64_t ed,
+                                        uint32_t chunk, float (&w)[4]) {
   const int h0 = (int)chunk * 4;
   float pa[4], pb[4];
 #pragma unroll
@@ -78,9 +78,9 @@ __device__ __forceinline__ void head_w4(const GatArgs& a, uint32_t n, int64_t ed
   }
   const uint32_t c1 = chunk | (a.pos_hi << 20);
   switch (a.kind) {
-    case kNormal: draw4<kNormal>(n, c1, a.key, pa, pb, a.relu, w); break;
-    case kUniform: draw4<kUniform>(n, c1, a.key, pa, pb, a.relu, w); break;
-    case kBernoulli: draw4<kBernoulli>(n, c1, a.key, pa, pb, a.relu, w); break;
+    case kNormal: draw4<kNormal>(n, c1, key, pa, pb, a.relu, w); break;
+    case kUniform: draw4<kUniform>(n, c1, key, pa, pb, a.relu, w); break;
+    case kBernoulli: draw4<kBernoulli>(n, c1, key, pa, pb, a.relu, w); break;
     case kExplicit:
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -103,6 +103,7 @@ __device__ __forceinline__ void wave_sync() {
 template <int LPE, bool VEC>
 __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatArgs a) {
   extern __shared__ __align__(16) float lds[];
+  const PhiloxKey key = resolve_epoch(a.key);
   constexpr int TEAMS_PER_BLOCK = 256 / LPE;
   const int H = a.H, F = a.F, HF = a.HF;
   const int team = threadIdx.x / LPE;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatArgs a) {
       const uint32_t n = a.nidx ? (uint32_t)a.nidx[p] : a.pos_lo + (uint32_t)p;
       for (int cc = 0; cc < nchunk; ++cc) {
         float w[4];
-        head_w4(a, n, ed, (uint32_t)cc, w);
+        head_w4(a, key, n, ed, (uint32_t)cc, w);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int h = 4 * cc + j;
@@ -343,6 +344,7 @@ template <int LPE>
 __global__ __launch_bounds__(256) void gat_bwd_edge_kernel(const GatBwdArgs ba) {
   extern __shared__ __align__(16) float lds[];
   const GatArgs& a = ba.f;
+  const PhiloxKey key = resolve_epoch(a.key);
   constexpr int TEAMS_PER_BLOCK = 256 / LPE;
   const int H = a.H, F = a.F, HF = a.HF;
   const int team = threadIdx.x / LPE;
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(256) void gat_bwd_edge_kernel(const GatBwdArgs ba) 
       const uint32_t n = a.nidx ? (uint32_t)a.nidx[p] : a.pos_lo + (uint32_t)p;
       for (int cc = 0; cc < nchunk; ++cc) {
         float w[4];
-        head_w4(a, n, ed, (uint32_t)cc, w);
+        head_w4(a, key, n, ed, (uint32_t)cc, w);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int h = 4 * cc + j;
@@ -463,6 +465,7 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
   if (spec->deriv != 0) return STAG_EINVAL;
   a.key.k0 = (uint32_t)(spec->seed & 0xFFFFFFFFull); a.key.k1 = (uint32_t)(spec->seed >> 32);
   a.key.o0 = (uint32_t)(spec->offset & 0xFFFFFFFFull); a.key.o1 = (uint32_t)(spec->offset >> 32);
+  a.key.epoch = spec->epoch;
   a.pos_lo = (uint32_t)((uint64_t)spec->pos_base & 0xFFFFFFFFull);
   a.pos_hi = (uint32_t)((uint64_t)spec->pos_base >> 32);
   if (spec->kind >= STAG_NOISE_NORMAL && !csr->nidx &&
@@ -548,6 +551,7 @@ extern "C" int stag_gat_bwd_edge(const stag_csr* csr, const stag_plan* plan, con
   a.relu = spec->relu ? kFlagRelu : 0;
   a.key.k0 = (uint32_t)(spec->seed & 0xFFFFFFFFull); a.key.k1 = (uint32_t)(spec->seed >> 32);
   a.key.o0 = (uint32_t)(spec->offset & 0xFFFFFFFFull); a.key.o1 = (uint32_t)(spec->offset >> 32);
+  a.key.epoch = spec->epoch;
   a.pos_lo = (uint32_t)((uint64_t)spec->pos_base & 0xFFFFFFFFull);
   a.pos_hi = (uint32_t)((uint64_t)spec->pos_base >> 32);
   a.attn = const_cast<float*>(attn);

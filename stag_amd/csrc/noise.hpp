@@ -19,7 +19,20 @@ constexpr uint32_t kPhiloxW1 = 0xBB67AE85u;
 struct PhiloxKey {   // wave-uniform: lives in SGPRs
   uint32_t k0, k1;   // lo32(seed), hi32(seed)
   uint32_t o0, o1;   // lo32(offset), hi32(offset)
+  const uint64_t* epoch;   // device counter added to the offset at run time, or null
 };
+
+// The offset a launch really uses: spec.offset + *spec.epoch.  The epoch lives in device
+// memory so that a captured hipGraph draws fresh noise on every replay (the host-side offsets
+// of its kernel nodes are frozen at capture; a node that bumps the epoch is part of the graph).
+__device__ __forceinline__ PhiloxKey resolve_epoch(PhiloxKey k) {
+  if (k.epoch) {
+    const uint64_t o = (((uint64_t)k.o1 << 32) | k.o0) + *k.epoch;   // uniform: scalar load + add
+    k.o0 = (uint32_t)o;
+    k.o1 = (uint32_t)(o >> 32);
+  }
+  return k;
+}
 
 // One Philox4x32-10 block. c0 = lo32(gpos), c1 = chunk | hi(gpos) << 20.
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, const PhiloxKey& key,

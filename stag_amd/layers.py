@@ -110,7 +110,7 @@ class StagLayer(torch.nn.Module):
         if fused_ok and not self.vi:
             return EdgeNoise.from_distribution(
                 graph, sample_dimension, dist, relu=self.relu, in_norm=self.norm,
-                seed=gen.seed, offset=gen.next_offset())
+                seed=gen.seed, offset=gen.next_offset(), epoch=gen.device_epoch)
         reparam = type(dist) in (torch.distributions.Normal, torch.distributions.Uniform)
         if (fused_ok and self.vi and reparam and not self.norm
                 and getattr(self.base_layer, "supports_edge_noise_grad", False)):
@@ -118,16 +118,16 @@ class StagLayer(torch.nn.Module):
             # ops.aggregate returns their gradients by regenerating the noise in the backward
             return EdgeNoise.from_distribution(
                 graph, sample_dimension, dist, relu=self.relu, differentiable=True,
-                seed=gen.seed, offset=gen.next_offset())
+                seed=gen.seed, offset=gen.next_offset(), epoch=gen.device_epoch)
         if fusable(dist) and self.vi and type(dist) in (torch.distributions.Normal,
                                                        torch.distributions.Uniform):
             # reparameterised draw: standard noise from the HIP stream, affine map in
             # torch so autograd reaches loc / log_scale (rsample, stag/layers.py:123-124)
             std = (EdgeNoise(graph, sample_dimension, _lib.NOISE_NORMAL, 0.0, 1.0,
-                             seed=gen.seed, offset=gen.next_offset())
+                             seed=gen.seed, offset=gen.next_offset(), epoch=gen.device_epoch)
                    if isinstance(dist, torch.distributions.Normal) else
                    EdgeNoise(graph, sample_dimension, _lib.NOISE_UNIFORM, 0.0, 1.0,
-                             seed=gen.seed, offset=gen.next_offset()))
+                             seed=gen.seed, offset=gen.next_offset(), epoch=gen.device_epoch))
             z = std.materialize()
             if isinstance(dist, torch.distributions.Normal):
                 return dist.loc + dist.scale * z
@@ -135,7 +135,7 @@ class StagLayer(torch.nn.Module):
         if fusable(dist):   # base layer that cannot take a descriptor: draw, then hand a tensor
             with torch.no_grad():
                 return EdgeNoise.from_distribution(graph, sample_dimension, dist,
-                                                   seed=gen.seed, offset=gen.next_offset()).materialize()
+                                                   seed=gen.seed, offset=gen.next_offset(), epoch=gen.device_epoch).materialize()
         expanded = self.q_a.expand([E, sample_dimension])
         if self.vi:
             return expanded.rsample()

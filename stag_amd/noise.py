@@ -40,7 +40,7 @@ def _param_mode(p, n_edges, dn):
 
 class EdgeNoise:
     def __init__(self, graph, dn, kind, p0, p1=None, relu=False, in_norm=False, seed=0, offset=0,
-                 pos_base=0, differentiable=False, chunk_base=0):
+                 pos_base=0, differentiable=False, chunk_base=0, epoch=None):
         self.graph, self.dn, self.kind = graph, int(dn), int(kind)
         # vi=True: keep the live parameter tensors so ops.aggregate can return their gradients
         # (reparameterised draw; the backward regenerates the noise with spec.deriv = 1 | 2)
@@ -52,6 +52,9 @@ class EdgeNoise:
         self.seed, self.offset, self.pos_base = int(seed), int(offset), int(pos_base)
         # channel shards (partition.ChannelShard): this tensor's channel 0 is global channel 4*chunk_base
         self.chunk_base = int(chunk_base)
+        # device counter added to `offset` when the kernel runs (random.NoiseGenerator.device_epoch):
+        # what makes a captured hipGraph draw fresh noise on every replay
+        self.epoch = epoch
         E = graph.number_of_edges()
         dev = graph.device
         self.param_mode = _lib.PARAM_SCALAR
@@ -60,6 +63,11 @@ class EdgeNoise:
         if kind >= _lib.NOISE_NORMAL:
             ps = [torch.as_tensor(p, dtype=torch.float32) for p in ((p0,) if p1 is None else (p0, p1))]
             mode = max(_param_mode(p, E, dn) for p in ps)
+            if mode == _lib.PARAM_SCALAR and any(p.is_cuda for p in ps):
+                # a scalar that lives on the device (a module's buffer / parameter): reading it
+                # back would stall the stream on every layer call and cannot be captured in a
+                # hipGraph, so it travels as a per-channel row instead
+                mode = _lib.PARAM_PER_CHANNEL
             self.param_mode = mode
             if mode == _lib.PARAM_SCALAR:
                 self.p0_scalar = float(ps[0].detach().reshape(()))
@@ -97,6 +105,7 @@ class EdgeNoise:
         s.relu, s.in_norm, s.deriv = int(self.relu), int(self.in_norm), int(self.deriv)
         s.seed, s.offset, s.pos_base = self.seed, self.offset, self.pos_base
         s.chunk_base = self.chunk_base
+        s.epoch = _lib.ptr(self.epoch)
         return s
 
     def materialize(self):

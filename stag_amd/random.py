@@ -22,7 +22,35 @@ class NoiseGenerator:
         with self._lock:
             self.seed = int(seed) & _MASK64
             self.offset = 0
+            if getattr(self, "_epoch", None) is not None:
+                self._epoch.zero_()
         return self
+
+    # ---- hipGraph support ------------------------------------------------------------
+    # A captured graph freezes the host-side offsets of its kernels.  With a device epoch the
+    # kernels draw at offset + *epoch, and `advance_epoch(k)` — a device-side add that is captured
+    # like any other node — moves every replay to fresh noise:
+    #
+    #     gen.enable_device_epoch(device)
+    #     with torch.cuda.graph(g):
+    #         mark = gen.offset
+    #         loss = model.loss(graph, x, y); loss.backward(); opt.step()
+    #         gen.advance_epoch(gen.offset - mark)
+    #     for _ in range(steps): g.replay()
+    def enable_device_epoch(self, device):
+        """Allocate the device counter; every EdgeNoise drawn from this generator carries it."""
+        self._epoch = torch.zeros(1, dtype=torch.int64, device=device)
+        return self._epoch
+
+    @property
+    def device_epoch(self):
+        return getattr(self, "_epoch", None)
+
+    def advance_epoch(self, k=1):
+        """epoch += k on the device (stream-ordered; capturable)."""
+        if getattr(self, "_epoch", None) is None:
+            raise RuntimeError("enable_device_epoch(device) first")
+        self._epoch.add_(int(k))
 
     def next_offset(self):
         with self._lock:
@@ -31,6 +59,7 @@ class NoiseGenerator:
         return o
 
     def get_state(self):
+        """Host state; add `int(device_epoch)` to the offset yourself when a graph is in use."""
         return {"seed": self.seed, "offset": self.offset}
 
     def set_state(self, state):

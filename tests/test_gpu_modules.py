@@ -475,3 +475,56 @@ def test_full_size_against_oracle_and_repeatability(dev, oracle):
                          oracle.make_spec("normal", 1.0, 0.5, seed=5, offset=0, Dn=H, n_edges=g.number_of_edges()))
     assert_close_rows(g0.reshape(n, -1), ref.reshape(n, -1), deg, what="cfg5 full size vs oracle")
     assert all(torch.equal(ops.gat_aggregate(g, el, er, ft, 0.2, mkh()), g0) for _ in range(30))
+
+
+def test_device_epoch_and_graph_capture(dev):
+    """spec.epoch: the kernels draw at offset + *epoch (a device counter), so a captured hipGraph
+    gets fresh noise per replay.  (1) epoch e at offset o == offset o + e, bit for bit, on every
+    entry point that draws; (2) a captured StagLayer step replays with new noise each time and each
+    replay equals the eager result at the same effective offset; (3) no host sync in the step."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    from stag_amd.random import NoiseGenerator
+    from util import random_graph
+    n, D, H, F = 300, 32, 4, 8
+    g = random_graph(n, 3000, seed=1, hub=200, device=dev)
+    x = torch.randn(n, D, device=dev)
+    epoch = torch.full((1,), 5, dtype=torch.int64, device=dev)
+    mk = lambda off, ep, dn=D: stag_amd.EdgeNoise(g, dn, _lib.NOISE_NORMAL, 1.0, 0.5, seed=9, offset=off, epoch=ep)
+    assert torch.equal(ops.aggregate(g, x, mk(3, epoch)), ops.aggregate(g, x, mk(8, None)))
+    assert torch.equal(mk(3, epoch).materialize(), mk(8, None).materialize())
+    el, er, ft = torch.randn(n, H, device=dev), torch.randn(n, H, device=dev), torch.randn(n, H, F, device=dev)
+    assert torch.equal(ops.gat_aggregate(g, el, er, ft, 0.2, mk(3, epoch, H)),
+                       ops.gat_aggregate(g, el, er, ft, 0.2, mk(8, None, H)))
+    xg = x.clone().requires_grad_(True)
+    ops.aggregate(g, xg, mk(3, epoch)).square().sum().backward()
+    xh = x.clone().requires_grad_(True)
+    ops.aggregate(g, xh, mk(8, None)).square().sum().backward()
+    assert torch.equal(xg.grad, xh.grad)
+
+    # ---- capture one layer step; the generator's device epoch moves the noise between replays
+    gen = NoiseGenerator(seed=77)
+    layer = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(D, 16), q_a=torch.distributions.Normal(1.0, 0.5),
+                                      relu=True, generator=gen).to(dev)
+    ref_layer = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(D, 16), q_a=torch.distributions.Normal(1.0, 0.5),
+                                          relu=True, generator=NoiseGenerator(seed=77)).to(dev)
+    ref_layer.load_state_dict(layer.state_dict())
+    gen.enable_device_epoch(dev)
+    with torch.no_grad():
+        layer(g, x)                        # warm-up outside the capture: plans, counters, caches
+        gen.manual_seed(77)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            mark = gen.offset
+            y = layer(g, x)
+            gen.advance_epoch(gen.offset - mark)
+        outs = []
+        for _ in range(3):
+            graph.replay()
+            outs.append(y.clone())
+        torch.cuda.synchronize()
+        assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
+        for i in range(3):                 # eager twin: one draw per call, offsets 0, 1, 2
+            assert torch.equal(ref_layer(g, x), outs[i])
+        assert int(gen.device_epoch) == 3

@@ -20,14 +20,14 @@ def test_abi_exports_every_declared_symbol():
     assert {"stag_agg_fwd", "stag_noise_materialize", "stag_gat_fwd", "stag_plan_fill"} <= names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/stag_hip.h but not exported"
-    assert lib.stag_abi_version() == 5
+    assert lib.stag_abi_version() == 6
     assert lib.stag_strerror(-22) == b"invalid argument"
 
 
 def test_abi_struct_layouts_match_header():
     from stag_amd import _lib
     assert ctypes.sizeof(_lib.Csr) == 48
-    assert ctypes.sizeof(_lib.NoiseSpec) == 80
+    assert ctypes.sizeof(_lib.NoiseSpec) == 88
     assert ctypes.sizeof(_lib.Plan) == 72
     assert _lib.NoiseSpec.deriv.offset == 40 and _lib.NoiseSpec.seed.offset == 48 and _lib.NoiseSpec.pos_base.offset == 64
 
