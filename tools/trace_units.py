@@ -73,6 +73,15 @@ def main():
         if last.any():
             d = (us(t[:, 3]) - us(t[:, 2]))[last]
             print(f"  combines: n={last.sum()}  duration med {np.median(d):.2f} max {d.max():.2f} us")
+    # edge throughput over time: a unit's edges spread evenly over its loop time
+    nb = int(end.max() // 5) + 1
+    thr = np.zeros(nb)
+    for b in range(nb):
+        lo, hi = 5.0 * b, 5.0 * (b + 1)
+        ov = np.clip(np.minimum(loop_end, hi) - np.maximum(start, lo), 0, None)
+        thr += 0  # (kept for clarity)
+        thr[b] = (ln * ov / np.maximum(loop_end - start, 1e-3)).sum()
+    print("  edges processed per 5 us bin (k):", " ".join(f"{t / 1e3:.0f}" for t in thr))
     # timeline: units finished per 5 us
     hist, edges = np.histogram(end, bins=np.arange(0, end.max() + 5, 5))
     print("  units finishing per 5 us bin:", " ".join(str(h) for h in hist))
