@@ -299,10 +299,20 @@ struct EdgeIdx {        // what the index fetch brings in
   int ee[BLK];          // original edge id (explicit weights / per-edge parameters)
   uint32_t nn[BLK];     // Philox counter word 0 (noise index)
 };
+// per-edge distribution parameters travel with the rows (their loads overlap the gathers):
+// PEDGE 1 = one (p0, p1) pair per edge ([E, 1] parameters), 2 = a row of 4 + 4 ([E, D])
+template <int BLK, int PEDGE>
+struct EdgeParams {};
 template <int BLK>
+struct EdgeParams<BLK, 1> { float q0[BLK], q1[BLK]; };
+template <int BLK>
+struct EdgeParams<BLK, 2> { float pa[BLK][4], pb[BLK][4]; };
+
+template <int BLK, int PEDGE = 0>
 struct EdgeRows {       // what the row fetch brings in
   float xv[BLK][4];
   float xs[BLK];
+  [[no_unique_address]] EdgeParams<BLK, PEDGE> P;
 };
 
 // BLK: edges per arithmetic block (fixes the summation order, so the same for every shape);
@@ -316,12 +326,12 @@ template <>
 struct ExtraAcc<0> {};
 
 // NOUT: 1, or 3 = the weight and its two parameter derivatives side by side (stag_agg_bwd).
-template <int KIND, int LPE, bool VEC, bool PEDGE, int BLK, int MULT = 1, int NOUT = 1>
+template <int KIND, int LPE, bool VEC, int PEDGE, int BLK, int MULT = 1, int NOUT = 1>
 struct AggTeam {
   static constexpr int NB = BLK * MULT;
   static constexpr int NX = NOUT - 1;              // extra outputs
-  static_assert(NOUT == 1 || ((KIND == kNormal || KIND == kUniform) && !PEDGE), "derivatives: reparameterised, per-channel");
-  static constexpr bool NEED_EID = (KIND == kExplicit) || PEDGE;
+  static_assert(NOUT == 1 || ((KIND == kNormal || KIND == kUniform) && PEDGE == 0), "derivatives: reparameterised, per-channel");
+  static constexpr bool NEED_EID = (KIND == kExplicit) || PEDGE != 0;
   const AggArgs& a;
   const PhiloxKey key;     // a.key with the device epoch folded in
   const int k0;
@@ -349,19 +359,26 @@ struct AggTeam {
     }
   }
 
-  __device__ __forceinline__ void fetch_rows(EdgeRows<NB>& R, const EdgeIdx<NB>& I, int p0) const {
+  __device__ __forceinline__ void fetch_rows(EdgeRows<NB, PEDGE>& R, const EdgeIdx<NB>& I, int p0) const {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       if (p0 + j < pend) {
         if (x_buf) bufrow4(rx, I.u[j], a.ldxb, koff, R.xv[j]);
         else loadrow4(row_at(a.x, I.u[j], a.ldxb, koff, (a.wide & 1) != 0), k0, a.D, VEC, R.xv[j]);
         if (a.src_scale) R.xs[j] = a.src_scale[I.u[j]];
+        if constexpr (KIND >= kNormal && PEDGE == 1) {
+          R.P.q0[j] = a.p0[I.ee[j]];
+          R.P.q1[j] = a.p1 ? a.p1[I.ee[j]] : 0.0f;
+        } else if constexpr (KIND >= kNormal && PEDGE == 2) {
+          loadrow4(row_at(a.p0, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, R.P.pa[j]);
+          if (a.p1) loadrow4(row_at(a.p1, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, R.P.pb[j]);
+        }
       }
     }
   }
 
   // the blocks fetched at p0: draw, multiply, fold — one block (BLK edges) at a time
-  __device__ __forceinline__ void compute(EdgeRows<NB>& R, const EdgeIdx<NB>& I, int p0) {
+  __device__ __forceinline__ void compute(EdgeRows<NB, PEDGE>& R, const EdgeIdx<NB>& I, int p0) {
 #pragma unroll
     for (int m = 0; m < MULT; ++m) {
     if (m > 0 && p0 + m * BLK >= pend) break;   // an empty block must not touch the Kahan state
@@ -373,7 +390,7 @@ struct AggTeam {
       if (p0 + j < pend) {
         float w[4];
         [[maybe_unused]] ExtraAcc<NX> dd;          // dd.acc[o] = derivative o of this edge's draw
-        if constexpr (NX == 0) edge_weight(I, j, w);
+        if constexpr (NX == 0) edge_weight(R, I, j, w);
         else draw4_grad<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w, dd.acc[0], dd.acc[1]);
         if (a.src_scale) {
           asm volatile("" ::: "memory");   // keep this a branch: as selects it costs 6 VALU ops per edge
@@ -424,7 +441,7 @@ struct AggTeam {
   // Block sums only (register staging), for the slotted loop: t[m] of this lane's MULT blocks
   // starting at p0 and the weights we[j] of its NB edges (in-norm sums them in edge order);
   // blocks past the unit's end stay zero and are never folded.
-  __device__ __forceinline__ void block_sums(EdgeRows<NB>& R, const EdgeIdx<NB>& I, int p0,
+  __device__ __forceinline__ void block_sums(EdgeRows<NB, PEDGE>& R, const EdgeIdx<NB>& I, int p0,
                                              float (&t)[MULT][4], float (&we)[NB][4]) {
 #pragma unroll
     for (int m = 0; m < MULT; ++m) {
@@ -434,7 +451,7 @@ struct AggTeam {
       for (int j = m * BLK; j < (m + 1) * BLK; ++j) {
         if (p0 + j < pend) {
           float w[4];
-          edge_weight(I, j, w);
+          edge_weight(R, I, j, w);
           if (a.src_scale) {
             asm volatile("" ::: "memory");
 #pragma unroll
@@ -450,7 +467,8 @@ struct AggTeam {
   }
 
   // w[0..3]: the multiplicative weight of edge j of the fetched set on this lane's channels
-  __device__ __forceinline__ void edge_weight(const EdgeIdx<NB>& I, int j, float (&w)[4]) {
+  __device__ __forceinline__ void edge_weight(const EdgeRows<NB, PEDGE>& R, const EdgeIdx<NB>& I, int j,
+                                              float (&w)[4]) {
     if constexpr (KIND == kNone) {
       w[0] = w[1] = w[2] = w[3] = 1.0f;
     } else if constexpr (KIND == kExplicit) {
@@ -466,16 +484,14 @@ struct AggTeam {
         for (int q = 0; q < 4; ++q) w[q] = fmaxf(w[q], 0.0f);
       }
     } else {
-      if constexpr (PEDGE) {
-        if (a.pmode == STAG_PARAM_PER_EDGE1) {
-          const float q0 = a.p0[I.ee[j]];
-          const float q1 = a.p1 ? a.p1[I.ee[j]] : 0.0f;
+      if constexpr (PEDGE == 1) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { pa[q] = q0; pb[q] = q1; }
-        } else {
-          loadrow4(row_at(a.p0, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, pa);
-          if (a.p1) loadrow4(row_at(a.p1, I.ee[j], a.ldwb, koff, (a.wide & 2) != 0), k0, a.D, VEC, pb);
-        }
+        for (int q = 0; q < 4; ++q) { pa[q] = R.P.q0[j]; pb[q] = R.P.q1[j]; }
+        draw4<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w);
+        return;
+      } else if constexpr (PEDGE == 2) {
+        draw4<KIND>(I.nn[j], c1, key, R.P.pa[j], R.P.pb[j], a.relu, w);
+        return;
       }
       draw4<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w);
     }
@@ -484,7 +500,7 @@ struct AggTeam {
 
 // One unit (a whole row or a segment of a long row) on LPE x SLOTS lanes of a wave:
 // c = this lane's chunk (4 channels) of the channel tile, sl = its edge slot.
-template <int KIND, int LPE, bool VEC, bool PEDGE, int SLOTS, int MULT, int NOUT = 1>
+template <int KIND, int LPE, bool VEC, int PEDGE, int SLOTS, int MULT, int NOUT = 1>
 __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const int c, const int sl) {
   static_assert(LPE * SLOTS <= 64 && 64 % (LPE * SLOTS) == 0, "a unit's lanes stay inside one wave");
   static_assert(NOUT == 1 || SLOTS == 1, "the derivative outputs take the one-slot loop");
@@ -542,7 +558,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   // noise (104 vs 98 us): many short-lived waves beat few long-lived ones here.
   const int pend = b + len;
   EdgeIdx<NB> I;
-  EdgeRows<NB> R;
+  EdgeRows<NB, PEDGE> R;
   {
     // the next block's edge records are fetched while this block's rows are in flight: one
     // round trip per block on the unit's critical path instead of two.  Narrow shapes only
@@ -732,7 +748,7 @@ constexpr int heavy_slots_of() {
          : LPE == 16 ? STAG_HSLOTS_LPE16 : LPE == 32 ? STAG_HSLOTS_LPE32 : 1;
 }
 
-template <int KIND, int LPE, bool VEC, bool PEDGE, int NOUT = 1>
+template <int KIND, int LPE, bool VEC, int PEDGE, int NOUT = 1>
 __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_kernel(const AggArgs a) {
   constexpr int HS = NOUT == 1 ? heavy_slots_of<LPE>() : 1;
   const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
@@ -758,7 +774,7 @@ template <int KIND>
 hipError_t agg_launch(const AggArgs& a, bool vec, hipStream_t stream);
 
 template <int KIND, int LPE>
-inline void agg_launch_shape(const AggArgs& a_in, bool vec, bool pedge, int tiles, hipStream_t s) {
+inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles, hipStream_t s) {
   AggArgs a = a_in;
   constexpr int TPB = STAG_BLOCK_THREADS / LPE;
   constexpr int HS = heavy_slots_of<LPE>();
@@ -770,26 +786,31 @@ inline void agg_launch_shape(const AggArgs& a_in, bool vec, bool pedge, int tile
   const dim3 block(STAG_BLOCK_THREADS);
   if constexpr (KIND == kNormal || KIND == kUniform) {
     if (a.outx[0]) {        // weight + both parameter derivatives in one pass (validated on the host: !pedge)
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, false, 3>), grid, block, 0, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, false, 3>), grid, block, 0, s, a);
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 3>), grid, block, 0, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 3>), grid, block, 0, s, a);
       return;
     }
   }
   if constexpr (KIND >= kNormal) {
-    if (pedge) {
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, true>), grid, block, 0, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, true>), grid, block, 0, s, a);
+    if (pedge == 1) {       // [E, 1] parameters: one pair per edge
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 1>), grid, block, 0, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 1>), grid, block, 0, s, a);
+      return;
+    }
+    if (pedge == 2) {       // [E, D] parameters: a row per edge
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 2>), grid, block, 0, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 2>), grid, block, 0, s, a);
       return;
     }
   }
-  if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, false>), grid, block, 0, s, a);
-  else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, false>), grid, block, 0, s, a);
+  if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0>), grid, block, 0, s, a);
+  else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0>), grid, block, 0, s, a);
 }
 
 template <int KIND>
 inline hipError_t agg_launch_impl(const AggArgs& a, bool vec, hipStream_t s) {
   const int nchunk = (a.D + 3) / 4;
-  const bool pedge = (KIND >= kNormal) && (a.pmode >= STAG_PARAM_PER_EDGE1);
+  const int pedge = (KIND < kNormal) ? 0 : a.pmode == STAG_PARAM_PER_EDGE1 ? 1 : a.pmode == STAG_PARAM_PER_EDGE ? 2 : 0;
   // lanes per unit: smallest power of two covering the row, capped at a wave
   int lpe = 1;
   while (lpe < nchunk && lpe < 64) lpe <<= 1;
