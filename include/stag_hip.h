@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 6
+#define STAG_ABI_VERSION 7
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -198,6 +198,19 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x,
                  int64_t ldx, int32_t D, const stag_noise_spec* spec,
                  int32_t reduce, const float* src_scale, const float* dst_scale,
                  float* out, int64_t ldo, float* norm_scale_out, void* stream);
+
+/* n_samples Monte-Carlo draws of the same aggregation from ONE pass over the gathered rows
+ * (up to 4 samples per launch): sample s is stag_agg_fwd with offset + s * offset_stride, bit for
+ * bit, written to out + s * sample_stride (floats).  The n_samples loop of the reference
+ * (stag/models.py:45-55, 67-68) re-runs the whole forward per sample; on the first layer, whose
+ * input is the same for every sample, the gather is shared and only the draws repeat.
+ * kind NORMAL | UNIFORM | BERNOULLI, param_mode SCALAR | PER_CHANNEL, in_norm 0; the plan's
+ * workspace must hold stag_plan_workspace_bytes(n_seg, 4 * D, 0) bytes.                       */
+int stag_agg_fwd_mc(const stag_csr* csr, const stag_plan* plan, const float* x, int64_t ldx,
+                    int32_t D, const stag_noise_spec* spec, int32_t n_samples,
+                    int64_t offset_stride, int32_t reduce, const float* src_scale,
+                    const float* dst_scale, float* out, int64_t ldo, int64_t sample_stride,
+                    void* stream);
 
 /* Backward of stag_agg_fwd with respect to x and to the noise parameters, ONE pass over the
  * source-major CSR (csr_t: rows = source nodes, indices = destination rows, nidx = the forward

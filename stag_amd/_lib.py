@@ -93,6 +93,9 @@ def lib():
                                          C.c_int64, _vp]
     l.stag_agg_bwd_w.argtypes = [C.POINTER(Csr), _vp, C.c_int64, _vp, C.c_int64, C.c_int32, _vp,
                                  C.POINTER(NoiseSpec), C.c_int32, _vp, C.c_int64, _vp]
+    l.stag_agg_fwd_mc.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, C.c_int64, C.c_int32,
+                                  C.POINTER(NoiseSpec), C.c_int32, C.c_int64, C.c_int32, _vp, _vp, _vp,
+                                  C.c_int64, C.c_int64, _vp]
     l.stag_agg_bwd.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, C.c_int64, C.c_int32,
                                C.POINTER(NoiseSpec), _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]
     l.stag_coldot_workspace_bytes.restype = C.c_size_t
@@ -108,7 +111,7 @@ def lib():
     l.stag_gat_bwd_edge.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp, _vp, _vp, _vp,
                                     C.c_int32, C.c_int32, C.c_float, C.POINTER(NoiseSpec), _vp, _vp,
                                     _vp, _vp]
-    if l.stag_abi_version() != 6:
+    if l.stag_abi_version() != 7:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     _lib = l
     return l

@@ -71,7 +71,10 @@ struct AggArgs {
   int32_t mean;
   // output
   float* out;
-  float* outx[2];          // stag_agg_bwd: the two parameter-derivative aggregates, or null
+  float* outx[3];          // extra outputs: stag_agg_bwd's two derivative aggregates, or the
+                           // Monte-Carlo samples 1.. of stag_agg_fwd_mc; outx[0] null: none
+  int32_t mc;              // extra outputs are MC samples: sample s draws at offset + s * mc_stride
+  uint64_t mc_stride;
   int64_t ldo;
   float* norm_scale_out;   // [n_rows, D] or null
   // plan
@@ -325,12 +328,16 @@ struct ExtraAcc {
 template <>
 struct ExtraAcc<0> {};
 
-// NOUT: 1, or 3 = the weight and its two parameter derivatives side by side (stag_agg_bwd).
-template <int KIND, int LPE, bool VEC, int PEDGE, int BLK, int MULT = 1, int NOUT = 1>
+// NOUT outputs from one pass over the gathered rows.  MC = false: 1, or 3 = the weight and its two
+// parameter derivatives (stag_agg_bwd).  MC = true: NOUT Monte-Carlo samples, sample s drawn at
+// offset + s * stride (stag_agg_fwd_mc; the n_samples loop of stag/models.py:45-55 on layer 1).
+template <int KIND, int LPE, bool VEC, int PEDGE, int BLK, int MULT = 1, int NOUT = 1, bool MC = false>
 struct AggTeam {
   static constexpr int NB = BLK * MULT;
   static constexpr int NX = NOUT - 1;              // extra outputs
-  static_assert(NOUT == 1 || ((KIND == kNormal || KIND == kUniform) && PEDGE == 0), "derivatives: reparameterised, per-channel");
+  static_assert(NOUT == 1 || PEDGE == 0, "extra outputs: scalar / per-channel parameters");
+  static_assert(NOUT == 1 || MC || (NOUT == 3 && (KIND == kNormal || KIND == kUniform)), "derivatives: reparameterised draws");
+  static_assert(!MC || KIND >= kNormal, "Monte-Carlo samples need sampled noise");
   static constexpr bool NEED_EID = (KIND == kExplicit) || PEDGE != 0;
   const AggArgs& a;
   const PhiloxKey key;     // a.key with the device epoch folded in
@@ -344,6 +351,7 @@ struct AggTeam {
   float wsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool kahan;
   ExtraAcc<NX> X;
+  PhiloxKey keyx[NX > 0 ? NX : 1];   // MC: the keys of samples 1..NX
 
   // every lane of the team reads the same BLK column ids: broadcast dword loads with
   // immediate offsets, no per-edge vector arithmetic
@@ -390,8 +398,15 @@ struct AggTeam {
       if (p0 + j < pend) {
         float w[4];
         [[maybe_unused]] ExtraAcc<NX> dd;          // dd.acc[o] = derivative o of this edge's draw
-        if constexpr (NX == 0) edge_weight(R, I, j, w);
-        else draw4_grad<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w, dd.acc[0], dd.acc[1]);
+        if constexpr (NX == 0) {
+          edge_weight(R, I, j, w);
+        } else if constexpr (!MC) {
+          draw4_grad<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w, dd.acc[0], dd.acc[1]);
+        } else {
+          draw4<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w);
+#pragma unroll
+          for (int o = 0; o < NX; ++o) draw4<KIND>(I.nn[j], c1, keyx[o], pa, pb, a.relu, dd.acc[o]);
+        }
         if (a.src_scale) {
           asm volatile("" ::: "memory");   // keep this a branch: as selects it costs 6 VALU ops per edge
 #pragma unroll
@@ -500,7 +515,7 @@ struct AggTeam {
 
 // One unit (a whole row or a segment of a long row) on LPE x SLOTS lanes of a wave:
 // c = this lane's chunk (4 channels) of the channel tile, sl = its edge slot.
-template <int KIND, int LPE, bool VEC, int PEDGE, int SLOTS, int MULT, int NOUT = 1>
+template <int KIND, int LPE, bool VEC, int PEDGE, int SLOTS, int MULT, int NOUT = 1, bool MC = false>
 __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const int c, const int sl) {
   static_assert(LPE * SLOTS <= 64 && 64 % (LPE * SLOTS) == 0, "a unit's lanes stay inside one wave");
   static_assert(NOUT == 1 || SLOTS == 1, "the derivative outputs take the one-slot loop");
@@ -533,7 +548,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   if (trace) { trace[0] = wall_clock64(); trace[1] = trace[2] = trace[3] = 0; }
 #endif
 
-  AggTeam<KIND, LPE, VEC, PEDGE, BLK, MULT, NOUT> T{
+  AggTeam<KIND, LPE, VEC, PEDGE, BLK, MULT, NOUT, MC> T{
       a, (KIND >= kNormal) ? resolve_epoch(a.key) : a.key, k0, (uint32_t)k0 * 4u,
       (chunk + a.chunk_base) | (a.pos_hi << 20),   // Philox counter word 1: a per-lane constant
       b + len,
@@ -543,6 +558,10 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
       {a.p0s, a.p0s, a.p0s, a.p0s}, {a.p1s, a.p1s, a.p1s, a.p1s},
       {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f},
       len > kKahanMinLen};
+  if constexpr (MC) {
+#pragma unroll
+    for (int o = 0; o < NOUT - 1; ++o) T.keyx[o] = key_plus(T.key, (uint64_t)(o + 1) * a.mc_stride);
+  }
   if constexpr (KIND >= kNormal) {
     if (a.pmode == STAG_PARAM_PER_CHANNEL) {   // distribution parameters of this lane's 4 channels
       load4(a.p0, k0, a.D, VEC, T.pa);
@@ -748,7 +767,7 @@ constexpr int heavy_slots_of() {
          : LPE == 16 ? STAG_HSLOTS_LPE16 : LPE == 32 ? STAG_HSLOTS_LPE32 : 1;
 }
 
-template <int KIND, int LPE, bool VEC, int PEDGE, int NOUT = 1>
+template <int KIND, int LPE, bool VEC, int PEDGE, int NOUT = 1, bool MC = false>
 __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_kernel(const AggArgs a) {
   constexpr int HS = NOUT == 1 ? heavy_slots_of<LPE>() : 1;
   const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
@@ -765,7 +784,7 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
   }
   const int unit = first + blk * (STAG_BLOCK_THREADS / LPE) + threadIdx.x / LPE;
   if (unit >= a.n_units) return;
-  agg_unit<KIND, LPE, VEC, PEDGE, 1, NOUT == 1 ? mult_of<KIND, LPE>() : 1, NOUT>(a, unit, c, 0);
+  agg_unit<KIND, LPE, VEC, PEDGE, 1, NOUT == 1 ? mult_of<KIND, LPE>() : 1, NOUT, MC>(a, unit, c, 0);
 }
 
 // Launch one (KIND, PEDGE) family; defined per kind in agg_<kind>.hip so the
@@ -784,6 +803,18 @@ inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles
   dim3 grid(a.n_heavy_blocks + (a.n_units - a.n_heavy + TPB - 1) / TPB, tiles);
   if (grid.x == 0) return;
   const dim3 block(STAG_BLOCK_THREADS);
+  if constexpr (KIND >= kNormal) {
+    if (a.mc && a.outx[2]) {   // four Monte-Carlo samples per gathered row (validated on the host: !pedge)
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 4, true>), grid, block, 0, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 4, true>), grid, block, 0, s, a);
+      return;
+    }
+    if (a.mc && a.outx[0]) {   // two
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 2, true>), grid, block, 0, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 2, true>), grid, block, 0, s, a);
+      return;
+    }
+  }
   if constexpr (KIND == kNormal || KIND == kUniform) {
     if (a.outx[0]) {        // weight + both parameter derivatives in one pass (validated on the host: !pedge)
       if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 3>), grid, block, 0, s, a);

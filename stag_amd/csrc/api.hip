@@ -440,12 +440,12 @@ int stag_philox_raw(uint64_t seed, uint64_t offset, int64_t pos0, int64_t n_pos,
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }
 
-// one aggregation launch; out1/out2 non-null: the two parameter-derivative aggregates ride along
+// one aggregation launch; nout > 1: extra outputs ride along — the two parameter-derivative
+// aggregates (nout = 3, mc = 0) or Monte-Carlo samples 1.. (nout = 2 | 4, mc = 1)
 static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x, int64_t ldx,
                       int32_t D, const stag_noise_spec* spec, int32_t reduce, const float* src_scale,
                       const float* dst_scale, float* out, int64_t ldo, float* norm_scale_out,
-                      float* out1, float* out2, void* stream) {
-  const int nout = out1 ? 3 : 1;
+                      int nout, float* const* extra, int mc, uint64_t mc_stride, void* stream) {
   int rc = check_csr(csr);
   if (rc) return rc;
   rc = check_spec(spec);
@@ -485,7 +485,8 @@ static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x
     return STAG_ENOSYS;
   a.src_scale = src_scale; a.dst_scale = dst_scale; a.mean = (reduce == STAG_REDUCE_MEAN);
   a.out = out; a.ldo = ldo; a.norm_scale_out = norm_scale_out;
-  a.outx[0] = out1; a.outx[1] = out2;
+  for (int o = 0; o + 1 < nout; ++o) a.outx[o] = extra[o];
+  a.mc = mc; a.mc_stride = mc_stride;
 
   const bool use_plan = plan && plan->n_units > 0;
   const bool has_segs = use_plan && plan->n_seg > 0;
@@ -500,20 +501,20 @@ static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x
   if (has_segs) {
     if (!plan->long_rows || !plan->long_seg_ptr || !plan->workspace || !plan->seg_counters)
       return STAG_EINVAL;
-    // partial rows: [D sums | D weight sums if in-norm], or [3 x D] with the derivative aggregates
-    const size_t need = nout == 3 ? stag_plan_workspace_bytes(plan->n_seg, 3 * D, 0)
-                                  : stag_plan_workspace_bytes(plan->n_seg, D, spec->in_norm);
+    // partial rows: [D sums | D weight sums if in-norm], or [nout x D] with extra outputs
+    const size_t need = nout > 1 ? stag_plan_workspace_bytes(plan->n_seg, nout * D, 0)
+                                 : stag_plan_workspace_bytes(plan->n_seg, D, spec->in_norm);
     if (plan->workspace_bytes < need) return STAG_ENOMEM;
     a.long_rows = plan->long_rows; a.long_seg_ptr = plan->long_seg_ptr;
     if (need >= (1ull << 32)) return STAG_ENOSYS;   // partials go through a 32-bit buffer descriptor
-    a.ws = plan->workspace; a.ws_stride = D * (nout == 3 ? 3 : (spec->in_norm ? 2 : 1)); a.ws_bytes = (uint32_t)need;
+    a.ws = plan->workspace; a.ws_stride = D * (nout > 1 ? nout : (spec->in_norm ? 2 : 1)); a.ws_bytes = (uint32_t)need;
     a.n_long = plan->n_long; a.seg_counters = plan->seg_counters; a.n_seg = plan->n_seg;
   }
 
   // dwordx4 path needs 16-B aligned rows everywhere a float4 is formed
   bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) && aligned16(out);
   if (norm_scale_out) vec = vec && aligned16(norm_scale_out);
-  if (out1) vec = vec && aligned16(out1) && aligned16(out2);
+  for (int o = 0; o + 1 < nout; ++o) vec = vec && aligned16(extra[o]);
   if (spec->kind == STAG_NOISE_EXPLICIT) vec = vec && aligned16(spec->p0);
   if (spec->kind >= STAG_NOISE_NORMAL && spec->param_mode != STAG_PARAM_SCALAR &&
       spec->param_mode != STAG_PARAM_PER_EDGE1)
@@ -539,7 +540,32 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x, int
                  const float* dst_scale, float* out, int64_t ldo, float* norm_scale_out,
                  void* stream) {
   return agg_common(csr, plan, x, ldx, D, spec, reduce, src_scale, dst_scale, out, ldo, norm_scale_out,
-                    nullptr, nullptr, stream);
+                    1, nullptr, 0, 0, stream);
+}
+
+int stag_agg_fwd_mc(const stag_csr* csr, const stag_plan* plan, const float* x, int64_t ldx,
+                    int32_t D, const stag_noise_spec* spec, int32_t n_samples, int64_t offset_stride,
+                    int32_t reduce, const float* src_scale, const float* dst_scale, float* out,
+                    int64_t ldo, int64_t sample_stride, void* stream) {
+  if (!spec || n_samples < 1 || offset_stride < 0 || !out) return STAG_EINVAL;
+  if (spec->kind < STAG_NOISE_NORMAL || spec->in_norm || spec->deriv) return STAG_EINVAL;
+  if (spec->param_mode != STAG_PARAM_SCALAR && spec->param_mode != STAG_PARAM_PER_CHANNEL) return STAG_EINVAL;
+  if (n_samples > 1 && sample_stride < (int64_t)(csr ? csr->n_dst : 0) * ldo) return STAG_EINVAL;
+  // 4 (then 2, then 1) samples per pass over the gathered rows; every launch starts its own
+  // samples at the right offset, so the result is that of n_samples separate stag_agg_fwd calls
+  stag_noise_spec sp = *spec;
+  for (int32_t s0 = 0; s0 < n_samples;) {
+    const int k = (n_samples - s0 >= 4) ? 4 : (n_samples - s0 >= 2) ? 2 : 1;
+    sp.offset = spec->offset + (uint64_t)s0 * (uint64_t)offset_stride;
+    float* extra[3] = {nullptr, nullptr, nullptr};
+    for (int o = 1; o < k; ++o) extra[o - 1] = out + (int64_t)(s0 + o) * sample_stride;
+    const int rc = agg_common(csr, plan, x, ldx, D, &sp, reduce, src_scale, dst_scale,
+                              out + (int64_t)s0 * sample_stride, ldo, nullptr, k, extra, k > 1 ? 1 : 0,
+                              (uint64_t)offset_stride, stream);
+    if (rc) return rc;
+    s0 += k;
+  }
+  return STAG_OK;
 }
 
 int stag_agg_bwd(const stag_csr* csr_t, const stag_plan* plan_t, const float* g, int64_t ldg,
@@ -555,8 +581,9 @@ int stag_agg_bwd(const stag_csr* csr_t, const stag_plan* plan_t, const float* g,
     if (spec->param_mode != STAG_PARAM_SCALAR && spec->param_mode != STAG_PARAM_PER_CHANNEL) return STAG_EINVAL;
     if (csr_t && csr_t->n_edges > 0 && !csr_t->nidx) return STAG_EINVAL;   // must redraw the FORWARD's noise
   }
+  float* extra[2] = {dp0_rows, dp1_rows};
   return agg_common(csr_t, plan_t, g, ldg, D, spec, STAG_REDUCE_SUM, g_scale, row_scale, dx, ldo, nullptr,
-                    dp0_rows, dp1_rows, stream);
+                    dp0_rows ? 3 : 1, extra, 0, 0, stream);
 }
 
 int stag_noise_materialize(const stag_csr* csr, const stag_noise_spec* spec, int32_t Dn, float* w,

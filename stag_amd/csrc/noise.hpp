@@ -34,6 +34,14 @@ __device__ __forceinline__ PhiloxKey resolve_epoch(PhiloxKey k) {
   return k;
 }
 
+// the key of the stream `d` offsets further on
+__device__ __forceinline__ PhiloxKey key_plus(PhiloxKey k, uint64_t d) {
+  const uint64_t o = (((uint64_t)k.o1 << 32) | k.o0) + d;
+  k.o0 = (uint32_t)o;
+  k.o1 = (uint32_t)(o >> 32);
+  return k;
+}
+
 // One Philox4x32-10 block. c0 = lo32(gpos), c1 = chunk | hi(gpos) << 20.
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, const PhiloxKey& key,
                                               uint32_t (&r)[4]) {

@@ -99,6 +99,37 @@ class StagLayer(torch.nn.Module):
         self._edge_weight_handle = w
         return self.base_layer.forward(graph=graph, feat=feat, edge_weight=w)
 
+    @property
+    def consumes_offset(self):
+        """True if a forward pass takes exactly one offset from the generator (a fusable q_a)."""
+        try:
+            return fusable(self.q_a.base_distribution)
+        except Exception:      # an AmortizedDistribution that was never conditioned
+            return False
+
+    def forward_mc(self, graph, feat, n_samples, offset_stride=1):
+        """n_samples forward passes on the SAME input from one pass over the gathered rows:
+        [n_samples, N, out], sample s drawn at this call's offset + s * offset_stride (what the
+        sequential Monte-Carlo loop of stag/models.py:45-55 would use when every pass consumes
+        offset_stride offsets).  None when the layer cannot batch (the caller then loops)."""
+        if torch.is_grad_enabled() or self.norm or not getattr(self.base_layer, "supports_edge_noise_mc", False):
+            return None
+        graph = graph.local_var()
+        self.q_a.condition(graph, feat)
+        dist = self.q_a.base_distribution
+        if not fusable(dist):
+            return None
+        dn = self._sample_dimension(feat)
+        gen = self._generator()
+        w = EdgeNoise.from_distribution(graph, dn, dist, relu=self.relu, seed=gen.seed, offset=gen.offset,
+                                        epoch=gen.device_epoch)
+        if w.param_mode > _lib.PARAM_PER_CHANNEL:
+            return None
+        gen.next_offset()
+        w.n_samples, w.offset_stride = int(n_samples), int(offset_stride)
+        self._edge_weight_handle = None      # no single [E, Dn] sample stands for this call
+        return self.base_layer.forward(graph=graph, feat=feat, edge_weight=w)
+
     def rsample_noise(self, graph, sample_dimension):
         """Edge weights of shape [E, sample_dimension] (stag/layers.py:115-129): an
         EdgeNoise descriptor when the draw can be fused into the aggregation (relu and

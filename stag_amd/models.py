@@ -39,7 +39,39 @@ class StagModel(torch.nn.Module):
         return feat
 
     def _mc_mean(self, graph, feat, n_samples):
+        batched = self._mc_first_layer_batched(graph, feat, n_samples)
+        if batched is not None:
+            return batched
         return torch.stack([self._forward(graph, feat) for _ in range(n_samples)], 0).mean(0)
+
+    def _mc_first_layer_batched(self, graph, feat, n_samples):
+        """The Monte-Carlo loop with the FIRST layer's samples drawn from one pass over the
+        gathered rows (its input is the same for every sample; StagLayer.forward_mc), the other
+        layers per sample.  Every sample sees exactly the noise the sequential loop would give it
+        (sample s, layer l draws at offset base + s * L + l), so the result is unchanged."""
+        first = self.layers[0] if len(self.layers) else None
+        if n_samples < 2 or torch.is_grad_enabled() or not hasattr(first, "forward_mc"):
+            return None
+        stoch = [l for l in self.layers if hasattr(l, "forward_mc")]
+        gens = {id(l._generator()) for l in stoch}
+        if len(gens) != 1 or not all(l.consumes_offset for l in stoch):
+            return None
+        gen, L = first._generator(), len(stoch)
+        base = gen.offset
+        graph = graph.local_var()
+        h1 = first.forward_mc(graph, feat, n_samples, offset_stride=L)
+        if h1 is None:
+            gen.offset = base
+            return None
+        outs = []
+        for s in range(n_samples):
+            gen.offset = base + s * L + 1
+            h = h1[s]
+            for layer in self.layers[1:]:
+                h = layer(graph, h)
+            outs.append(h)
+        gen.offset = base + n_samples * L
+        return torch.stack(outs, 0).mean(0)
 
     def forward(self, graph, feat, n_samples=1, return_parameters=False):
         """Monte-Carlo average over `n_samples` noisy passes; noise stays on at eval time

@@ -55,6 +55,9 @@ class EdgeNoise:
         # device counter added to `offset` when the kernel runs (random.NoiseGenerator.device_epoch):
         # what makes a captured hipGraph draw fresh noise on every replay
         self.epoch = epoch
+        # Monte-Carlo batching (StagLayer.forward_mc): n_samples draws at offset + s * offset_stride,
+        # ops.aggregate then returns [n_samples, N, D] from shared gathers
+        self.n_samples, self.offset_stride = 1, 1
         E = graph.number_of_edges()
         dev = graph.device
         self.param_mode = _lib.PARAM_SCALAR

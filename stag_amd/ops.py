@@ -305,6 +305,14 @@ def aggregate(graph, x, weight=None, reduce="sum", src_scale=None, dst_scale=Non
             w = w.expand(w.shape[0], D)
     if noise is not None and noise.dn != D:
         raise ValueError(f"noise width {noise.dn} != feature width {D}")
+    if noise is not None and noise.n_samples > 1:
+        if _broadcast_x:
+            raise ValueError("Monte-Carlo batching does not apply to a broadcast row")
+        import copy
+        one = copy.copy(noise)
+        one.n_samples = 1
+        return aggregate_mc(graph, x, one, noise.n_samples, noise.offset_stride, reduce=reduce,
+                            src_scale=src_scale, dst_scale=dst_scale, seg_len=seg_len)
     if noise is not None and noise.grad_params is not None and torch.is_grad_enabled():
         p0, p1 = (torch.as_tensor(p, dtype=torch.float32, device=x.device) for p in noise.grad_params)
         if p0.requires_grad or p1.requires_grad:
@@ -315,6 +323,44 @@ def aggregate(graph, x, weight=None, reduce="sum", src_scale=None, dst_scale=Non
                                       _f32c(dst_scale), seg_len)
     return _Aggregate.apply(x, w, graph, noise, _REDUCE[reduce], _f32c(src_scale),
                             _f32c(dst_scale), seg_len, _broadcast_x)
+
+
+def aggregate_mc(graph, x, noise, n_samples, offset_stride=1, reduce="sum", src_scale=None,
+                 dst_scale=None, seg_len=DEFAULT_SEG_LEN):
+    """[n_samples, N, D]: sample s == aggregate(graph, x, noise at offset + s * offset_stride), bit for
+    bit, from one pass over the gathered rows per 4 samples (stag_agg_fwd_mc).  Inference path of the
+    reference's Monte-Carlo loop (stag/models.py:45-55); no autograd — with gradients enabled, or
+    for noise the fused sampler does not cover, it is the stack of n_samples ordinary calls."""
+    def one(s):
+        import copy
+        nz = copy.copy(noise)
+        nz.offset = noise.offset + s * offset_stride
+        return aggregate(graph, x, nz, reduce=reduce, src_scale=src_scale, dst_scale=dst_scale, seg_len=seg_len)
+    fusable_mc = (isinstance(noise, EdgeNoise) and noise.kind >= _lib.NOISE_NORMAL and not noise.in_norm
+                  and noise.param_mode <= _lib.PARAM_PER_CHANNEL)
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or (noise is not None and noise.grad_params is not None
+                                                                  and any(torch.is_tensor(p) and p.requires_grad
+                                                                          for p in noise.grad_params)))
+    if not fusable_mc or needs_grad or n_samples == 1:
+        return torch.stack([one(s) for s in range(n_samples)], 0)
+    if noise.dn != x.shape[1]:
+        raise ValueError(f"noise width {noise.dn} != feature width {x.shape[1]}")
+    x = _f32c(x)
+    src_scale, dst_scale = _f32c(src_scale), _f32c(dst_scale)
+    csrv, D = graph.csr, x.shape[1]
+    dev = _lib.require_device(x, csrv.indptr, src_scale, dst_scale)
+    out = torch.empty((n_samples, csrv.n_dst, D), dtype=torch.float32, device=dev)
+    plan_t = csrv.plan(seg_len)
+    nbytes = _lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], 4 * D, 0) if plan_t is not None else 0
+    plan_c, _keep = _plan_struct(csrv, seg_len, (D + 255) // 256, nbytes, dev)
+    cs, spec = csrv.struct(), noise.spec()
+    with torch.cuda.device(dev):
+        rc = _lib.lib().stag_agg_fwd_mc(
+            C.byref(cs), C.byref(plan_c) if plan_c is not None else None, _lib.ptr(x), x.stride(0), D,
+            C.byref(spec), n_samples, offset_stride, _REDUCE[reduce], _lib.ptr(src_scale), _lib.ptr(dst_scale),
+            _lib.ptr(out), D, csrv.n_dst * D, _lib.stream_of(dev))
+    _lib.check(rc, "stag_agg_fwd_mc")
+    return out
 
 
 def materialize_noise(graph, noise):

@@ -18,6 +18,7 @@ from ._common import DGLError, check_edge_weight, degree_scale, expand_as_pair
 class GCN(torch.nn.Module):
     supports_edge_noise = True
     supports_edge_noise_grad = True   # vi=True stays fused (ops._AggregateVI)
+    supports_edge_noise_mc = True     # an EdgeNoise with n_samples > 1 yields [S, N, out]
 
     def __init__(self, in_feats, out_feats, norm="both", weight=True, bias=True, activation=None,
                  allow_zero_in_degree=False):
@@ -55,7 +56,8 @@ class GCN(torch.nn.Module):
             weight = self.weight
         lead = feat_src.shape
         rst = ops.aggregate(graph, feat_src.reshape(lead[0], -1), edge_weight, reduce="sum",
-                            src_scale=src_scale, dst_scale=dst_scale).reshape(lead)
+                            src_scale=src_scale, dst_scale=dst_scale)
+        rst = rst.reshape(lead if rst.dim() == 2 else (rst.shape[0],) + tuple(lead))   # [S, ...]: MC samples
         if weight is not None:
             rst = ops.node_linear(rst, weight)
         if self.bias is not None:

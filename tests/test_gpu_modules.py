@@ -528,3 +528,41 @@ def test_device_epoch_and_graph_capture(dev):
         for i in range(3):                 # eager twin: one draw per call, offsets 0, 1, 2
             assert torch.equal(ref_layer(g, x), outs[i])
         assert int(gen.device_epoch) == 3
+
+
+def test_model_monte_carlo_first_layer_batched(dev):
+    """StagModel(..., n_samples=S) at inference draws the first layer's S samples from one pass over
+    the gathered rows; every sample sees the noise the sequential loop would give it, so the mean
+    is unchanged bit for bit, and the generator ends where the loop would leave it."""
+    import stag_amd
+    from stag_amd.random import NoiseGenerator
+    from util import random_graph
+    n, D = 400, 24
+    g = random_graph(n, 4000, seed=3, hub=300, device=dev)
+    x = torch.randn(n, D, device=dev)
+    N = torch.distributions.Normal
+    for first_kw in (dict(q_a=N(1.0, 0.5)), dict(q_a=torch.distributions.Bernoulli(0.7)), dict(q_a=N(1.0, 0.5), relu=True, vi=True)):
+        gen = NoiseGenerator(seed=5)
+        layers = [stag_amd.layers.StagLayer(stag_amd.zoo.GCN(D, 16, activation=torch.relu), generator=gen, **first_kw),
+                  stag_amd.layers.StagLayer(stag_amd.zoo.GraphSAGE(16, 16, activation=torch.relu), generator=gen,
+                                            q_a=N(1.0, 0.3)),
+                  stag_amd.layers.StagLayer(stag_amd.zoo.GCN(16, 5), generator=gen, q_a=N(1.0, 0.3))]
+        for l in layers:
+            l.to(dev)
+        model = stag_amd.models.StagModel(layers)
+        calls = []
+        orig = layers[0].forward_mc
+        layers[0].forward_mc = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        with torch.no_grad():
+            gen.manual_seed(5)
+            got = model(g, x, n_samples=5, return_parameters=True)
+            end = gen.offset
+            gen.manual_seed(5)
+            ref = torch.stack([model._forward(g, x) for _ in range(5)], 0).mean(0)
+            assert gen.offset == end == 15
+        assert calls, "the batched first layer was not used"
+        assert torch.equal(got, ref)
+    # with gradients enabled the loop is the reference's
+    gen.manual_seed(5)
+    model(g, x.requires_grad_(True), n_samples=2, return_parameters=True).sum().backward()
+    assert x.grad is not None

@@ -312,6 +312,35 @@ def test_node_linear_gradients(dev):
     assert torch.allclose(lin.weight.grad, x.sum(0).expand(5, 12), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("kind", ["normal", "uniform", "bernoulli"])
+@pytest.mark.parametrize("D", [6, 128])
+def test_monte_carlo_samples_one_pass(dev, oracle, kind, D):
+    """stag_agg_fwd_mc: S samples from one pass over the gathered rows == S separate launches at
+    offsets o + s * stride, bit for bit (hub row, per-channel parameters, relu, degree scalings)."""
+    import copy
+    from stag_amd import ops
+    rng = np.random.default_rng(23)
+    n = 200
+    g = random_graph(n, 2000, seed=8, hub=400, device=dev)
+    x = torch.randn(n, D, device=dev)
+    ss, ds = torch.rand(n, device=dev) + 0.5, torch.rand(n, device=dev) + 0.5
+    p0 = torch.from_numpy(rng.uniform(0.3, 0.9, D).astype(np.float32)).to(dev)
+    p1 = None if kind == "bernoulli" else torch.from_numpy(rng.uniform(1.0, 1.6, D).astype(np.float32)).to(dev)
+    noise = _noise(g, D, kind, p0, p1, relu=(kind == "normal"), seed=4, offset=100)
+    for S, stride in ((1, 1), (2, 1), (3, 5), (4, 3), (7, 2)):
+        got = ops.aggregate_mc(g, x, noise, S, offset_stride=stride, reduce="mean", src_scale=ss, dst_scale=ds, seg_len=32)
+        assert got.shape == (S, n, D)
+        for s in range(S):
+            nz = copy.copy(noise)
+            nz.offset = 100 + s * stride
+            assert torch.equal(got[s], ops.aggregate(g, x, nz, reduce="mean", src_scale=ss, dst_scale=ds, seg_len=32)), (S, s)
+    og = oracle_graph(oracle, g)
+    ref = oracle.agg_fwd(og, x.cpu().numpy(), _ospec(oracle, g, D, kind, p0, p1, relu=(kind == "normal"), seed=4, offset=103),
+                         reduce=oracle.REDUCE_MEAN, src_scale=ss.cpu().numpy(), dst_scale=ds.cpu().numpy())
+    assert_close(ops.aggregate_mc(g, x, noise, 4, offset_stride=1, reduce="mean", src_scale=ss, dst_scale=ds)[3], ref,
+                 what="mc sample 3 vs oracle")
+
+
 def test_segment_reduce(dev, oracle):
     from stag_amd import ops
     rng = np.random.default_rng(0)
