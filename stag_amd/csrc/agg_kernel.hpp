@@ -327,6 +327,12 @@ struct ExtraAcc {
 };
 template <>
 struct ExtraAcc<0> {};
+template <int N>
+struct ExtraKeys {        // MC: the Philox keys of samples 1..N (SGPRs)
+  PhiloxKey k[N];
+};
+template <>
+struct ExtraKeys<0> {};
 
 // NOUT outputs from one pass over the gathered rows.  MC = false: 1, or 3 = the weight and its two
 // parameter derivatives (stag_agg_bwd).  MC = true: NOUT Monte-Carlo samples, sample s drawn at
@@ -350,8 +356,8 @@ struct AggTeam {
   float acc[4] = {0.f, 0.f, 0.f, 0.f}, comp[4] = {0.f, 0.f, 0.f, 0.f};
   float wsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool kahan;
-  ExtraAcc<NX> X;
-  PhiloxKey keyx[NX > 0 ? NX : 1];   // MC: the keys of samples 1..NX
+  [[no_unique_address]] ExtraAcc<NX> X;
+  [[no_unique_address]] ExtraKeys<MC ? NX : 0> KX;
 
   // every lane of the team reads the same BLK column ids: broadcast dword loads with
   // immediate offsets, no per-edge vector arithmetic
@@ -405,7 +411,7 @@ struct AggTeam {
         } else {
           draw4<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w);
 #pragma unroll
-          for (int o = 0; o < NX; ++o) draw4<KIND>(I.nn[j], c1, keyx[o], pa, pb, a.relu, dd.acc[o]);
+          for (int o = 0; o < NX; ++o) draw4<KIND>(I.nn[j], c1, KX.k[o], pa, pb, a.relu, dd.acc[o]);
         }
         if (a.src_scale) {
           asm volatile("" ::: "memory");   // keep this a branch: as selects it costs 6 VALU ops per edge
@@ -560,7 +566,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
       len > kKahanMinLen};
   if constexpr (MC) {
 #pragma unroll
-    for (int o = 0; o < NOUT - 1; ++o) T.keyx[o] = key_plus(T.key, (uint64_t)(o + 1) * a.mc_stride);
+    for (int o = 0; o < NOUT - 1; ++o) T.KX.k[o] = key_plus(T.key, (uint64_t)(o + 1) * a.mc_stride);
   }
   if constexpr (KIND >= kNormal) {
     if (a.pmode == STAG_PARAM_PER_CHANNEL) {   // distribution parameters of this lane's 4 channels

@@ -321,3 +321,27 @@ def test_abi_argument_validation_without_gpu():
     assert lib.stag_segment_reduce(f, 4, 4, None, 2, 0, f, 4, None) == EINVAL
     assert lib.stag_noise_materialize(C.byref(csr), C.byref(spec), 0, f, 4, None) == EINVAL
     assert lib.stag_philox_raw(0, 0, 0, 4, 0, f, None) == EINVAL
+
+
+def test_hot_kernel_register_budget():
+    """The aggregation kernels are occupancy-sensitive (one VGPR over a step costs a wave per SIMD
+    and ~15 % of the launch): the compiler's resource report, saved by the Makefile next to the
+    objects, must keep the wide shapes at >= 7 waves per SIMD (8 without noise)."""
+    import re
+    import subprocess
+    csrc = os.path.join(ROOT, "stag_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "-j", "8"], check=True, stdout=subprocess.DEVNULL)
+
+    def usage(kind_file):
+        text = open(os.path.join(csrc, "_obj", f"{kind_file}.remarks")).read()
+        out = {}
+        for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)", text, re.S):
+            name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+            out[name] = (int(m.group(2)), int(m.group(3)))
+        return out
+    normal, none = usage("agg_normal"), usage("agg_none")
+    for lpe in (32, 64):         # D = 128 (the headline) and D >= 256
+        v, occ = normal[f"void stag::agg_kernel<2, {lpe}, true, 0, 1, false>(stag::AggArgs)"]
+        assert occ >= 7 and v <= 72, f"Normal, LPE {lpe}: {v} VGPRs, {occ} waves/SIMD"
+        v, occ = none[f"void stag::agg_kernel<0, {lpe}, true, 0, 1, false>(stag::AggArgs)"]
+        assert occ >= 7 and v <= 72, f"no noise, LPE {lpe}: {v} VGPRs, {occ} waves/SIMD"
