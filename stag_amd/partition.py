@@ -203,6 +203,13 @@ class GraphShard:
         if self.exchange == "halo":
             if x_local.shape[0] != self.n_rows:
                 raise ValueError(f"rank {self.rank} owns {self.n_rows} rows, got {x_local.shape[0]}")
+            if not (torch.is_grad_enabled() and x_local.requires_grad):
+                # inference: the collective writes straight behind the local rows (no concatenation copy)
+                buf = torch.empty((self.n_buf,) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
+                buf[:self.n_rows].copy_(x_local)
+                dist.all_to_all_single(buf[self.n_rows:], x_local.index_select(0, self.send_idx),
+                                       self.out_splits, self.in_splits, group=self.group)
+                return buf
             recv = _HaloAllToAll.apply(x_local, self.send_idx, self.in_splits, self.out_splits, self.group)
             return torch.cat([x_local, recv], 0)
         x_pad = self.pad_rows(x_local)

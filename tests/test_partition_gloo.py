@@ -43,6 +43,8 @@ def _worker(rank, world, port, tmp):
         xl = torch.from_numpy(x[hs.row_lo:hs.row_hi]).requires_grad_(True)
         xf = hs.halo_gather(xl)
         assert xf.shape[0] == hs.n_buf == hs.n_rows + sum(hs.out_splits) < n + 1
+        with torch.no_grad():               # inference form: the collective writes behind the local rows
+            assert torch.equal(hs.halo_gather(xl.detach()), xf.detach())
         og = O.CsrGraph(hs.local_indptr.numpy(), hs.local_indices.numpy(), n_src=hs.n_buf)
         spec = O.make_spec("normal", 1.0, 0.5, seed=77, offset=5, pos_base=hs.pos_base, Dn=x.shape[1], n_edges=og.n_edges)
         np.save(os.path.join(tmp, f"halo{rank}.npy"), O.agg_fwd(og, xf.detach().numpy(), spec))
