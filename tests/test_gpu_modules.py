@@ -566,3 +566,35 @@ def test_model_monte_carlo_first_layer_batched(dev):
     gen.manual_seed(5)
     model(g, x.requires_grad_(True), n_samples=2, return_parameters=True).sum().backward()
     assert x.grad is not None
+
+
+def test_bench_contract_and_smoke(dev):
+    """The driver's entry points, run the way the driver runs them: `python bench.py` prints ONE JSON
+    line with the contract's keys (plus `roofline` and `cpu_baseline`), and smoke() passes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "30", "--warmup", "5",
+                        "--cpu-budget-s", "3"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 30 and line["warmup"] == 5 and line["unit"] == "edges/s"
+    assert line["dtype"] == "f32" and line["data"] == "synthetic" and line["vs_baseline"] is None
+    assert "workload" in line["config"] and "model" not in line["config"]
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 1.0
+    # value = edges per step / wall time per step; device time agrees with wall time within 10 %
+    assert abs(line["value"] - 1166243 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
+    assert abs(rf["device_ms_per_step"] - line["ms_per_step"]) / line["ms_per_step"] < 0.10
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "edges/s" and cb["cores"] >= 1 and cb["value"] > 0
+    import __graft_entry__
+    __graft_entry__.smoke()
