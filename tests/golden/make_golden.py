@@ -364,6 +364,23 @@ def main():
         out, attn = gat(g, x, get_attention=True, edge_weight=wh)
         fx[f"{tag}_out"], fx[f"{tag}_attn"] = out.detach().numpy(), attn.detach().numpy()
 
+    # ---- (c') GatedGCN (stag/zoo/gated_gcn.py:6-61): with edge weights it aggregates h itself,
+    #      without them B(h); batch norm in training mode, residual on
+    torch.manual_seed(17)
+    gated = zoo.GatedGCN(16, 16, dropout=0.0, batch_norm=True, residual=True)
+    for k, v in gated.state_dict().items():
+        fx[f"gated_sd_{k}"] = v.numpy().copy()
+    gated.train()
+    fx["gated_out"] = quiet(gated, g, x, edge_weight=w).detach().numpy()
+    gated2 = zoo.GatedGCN(16, 16, dropout=0.0, batch_norm=True, residual=True)
+    gated2.load_state_dict({k[len("gated_sd_"):]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("gated_sd_")})
+    gated2.train()
+    fx["gated_out_noweight"] = quiet(gated2, g, x).detach().numpy()
+    gated3 = zoo.GatedGCN(16, 8, batch_norm=False, residual=True)      # residual silently off: 16 != 8
+    for k, v in gated3.state_dict().items():
+        fx[f"gated3_sd_{k}"] = v.numpy().copy()
+    fx["gated3_out_noweight"] = quiet(gated3, g, x).detach().numpy()
+
     # ---- (d) StagModel.loss_terms on a 2-layer GCN stack ------------------------
     torch.manual_seed(9)
     l1 = StagLayer(zoo.GCN(16, 8, activation=torch.relu), q_a=torch.distributions.Normal(1.0, 0.4), vi=True)

@@ -86,6 +86,23 @@ def test_gcn_sage_gat_modules_golden(dev, golden):
         assert_close(attn, golden[tag + "_attn"], what=tag + " attention")
 
 
+def test_gated_gcn_module_golden(dev, golden):
+    """zoo.GatedGCN against the reference's own forward (stag/zoo/gated_gcn.py:25-55)."""
+    import stag_amd
+    g = _graph(golden, "hub40", dev)
+    x = torch.from_numpy(golden["zoo_x"]).to(dev)
+    w = torch.from_numpy(golden["zoo_w"]).to(dev)
+    for weighted, key in ((True, "gated_out"), (False, "gated_out_noweight")):
+        layer = stag_amd.zoo.GatedGCN(16, 16, dropout=0.0, batch_norm=True, residual=True).to(dev)
+        layer.load_state_dict(_sd(golden, "gated_sd_", dev))
+        layer.train()
+        assert_close(layer(g, x, edge_weight=w) if weighted else layer(g, x), golden[key], what=key)
+    layer = stag_amd.zoo.GatedGCN(16, 8, batch_norm=False, residual=True).to(dev)
+    layer.load_state_dict(_sd(golden, "gated3_sd_", dev))
+    assert layer.residual is False
+    assert_close(layer(g, x), golden["gated3_out_noweight"], what="gated 16->8")
+
+
 def test_stag_model_loss_and_grads_golden(dev, golden, monkeypatch):
     """2-layer vi=True GCN stack: NLL, KL and gradients equal the reference's when the layers
     are fed the reference's sampled weights (stag/models.py:63-85)."""

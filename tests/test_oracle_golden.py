@@ -122,6 +122,30 @@ def test_sage_golden(oracle, golden):
     assert_close(np.maximum(rst, 0), golden["sage_out"], what="sage")
 
 
+def test_gated_gcn_golden(oracle, golden):
+    """GatedGCN (stag/zoo/gated_gcn.py:25-55): with edge weights the layer aggregates h itself
+    (`u_mul_e('h', w)`), without them B(h); then A(h) + sum, batch norm with batch statistics,
+    relu, residual."""
+    g, *_ = _g(oracle, golden, "hub40")
+    x, w = golden["zoo_x"].astype(np.float64), golden["zoo_w"]
+
+    def finish(h, sd, bn=True, residual=True):
+        if bn:
+            mu, var = h.mean(0), h.var(0)            # training mode: biased batch statistics
+            h = (h - mu) / np.sqrt(var + 1e-5) * golden[sd + "bn_node_h.weight"] + golden[sd + "bn_node_h.bias"]
+        h = np.maximum(h, 0)
+        return x + h if residual else h
+    A = lambda sd: x @ golden[sd + "A.weight"].T.astype(np.float64) + golden[sd + "A.bias"]
+    B = lambda sd: x @ golden[sd + "B.weight"].T.astype(np.float64) + golden[sd + "B.bias"]
+    agg = oracle.agg_fwd(g, x.astype(np.float32), oracle.make_spec("explicit", w))
+    assert_close(finish(A("gated_sd_") + agg, "gated_sd_"), golden["gated_out"], what="gated, edge weights")
+    agg = oracle.agg_fwd(g, B("gated_sd_").astype(np.float32), oracle.make_spec("none"))
+    assert_close(finish(A("gated_sd_") + agg, "gated_sd_"), golden["gated_out_noweight"], what="gated, no weights")
+    agg = oracle.agg_fwd(g, B("gated3_sd_").astype(np.float32), oracle.make_spec("none"))
+    assert_close(finish(A("gated3_sd_") + agg, "gated3_sd_", bn=False, residual=False), golden["gated3_out_noweight"],
+                 what="gated 16->8: no batch norm, residual silently off")
+
+
 @pytest.mark.parametrize("tag", ["gat", "gat_last"])
 def test_gat_golden(oracle, golden, tag):
     """GAT with per-head weights scaling the logits before the softmax (stag/zoo/gat.py:93-141)."""
