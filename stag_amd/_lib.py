@@ -142,5 +142,29 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_of(device):
+    """hipStream_t (as an int) of torch's current stream on `device`; the raw getter skips the
+    Stream object (4 us -> 0.3 us of the ~25 us a call costs on the host)."""
+    if _raw_stream is not None and device.index is not None:
+        return _raw_stream(device.index)
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class on_device:
+    """`with torch.cuda.device(dev)` only when `dev` is not already current (the common case)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        self.ctx = None if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False

@@ -88,7 +88,7 @@ def build_csr(src, dst, n_src, n_dst):
         eid = torch.empty(E, dtype=torch.int32, device=dev)
         nbytes = lib.stag_csr_build_workspace_bytes(n_dst, E)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = lib.stag_csr_build(_lib.ptr(src32), _lib.ptr(dst32), n_src, n_dst, E, _lib.ptr(indptr),
                                     _lib.ptr(indices), _lib.ptr(eid), None, _lib.ptr(ws), nbytes,
                                     _lib.stream_of(dev))

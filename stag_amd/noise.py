@@ -63,7 +63,10 @@ class EdgeNoise:
         self.param_mode = _lib.PARAM_SCALAR
         self.p0 = self.p1 = None
         self.p0_scalar = self.p1_scalar = 0.0
-        if kind >= _lib.NOISE_NORMAL:
+        if kind >= _lib.NOISE_NORMAL and all(isinstance(p, (int, float)) for p in ((p0,) if p1 is None else (p0, p1))):
+            self.p0_scalar = float(p0)                  # plain numbers: no tensor round trip
+            self.p1_scalar = float(p1) if p1 is not None else 0.0
+        elif kind >= _lib.NOISE_NORMAL:
             ps = [torch.as_tensor(p, dtype=torch.float32) for p in ((p0,) if p1 is None else (p0, p1))]
             mode = max(_param_mode(p, E, dn) for p in ps)
             if mode == _lib.PARAM_SCALAR and any(p.is_cuda for p in ps):

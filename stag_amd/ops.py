@@ -67,7 +67,7 @@ def _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len, want_norm_
               if plan_t is not None else 0)
     plan_c, _keep = _plan_struct(csrv, seg_len, (D + 255) // 256, nbytes, dev)
     cs = csrv.struct()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.lib().stag_agg_fwd(
             C.byref(cs), C.byref(plan_c) if plan_c is not None else None, _lib.ptr(x),
             0 if broadcast_x else x.stride(0), D, C.byref(spec), reduce, _lib.ptr(src_scale),
@@ -88,7 +88,7 @@ def _agg_bwd_raw(csrv_t, g, D, spec, g_scale, row_scale, seg_len, want_dp):
               if plan_t is not None else 0)
     plan_c, _keep = _plan_struct(csrv_t, seg_len, (D + 255) // 256, nbytes, dev)
     cs = csrv_t.struct()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.lib().stag_agg_bwd(
             C.byref(cs), C.byref(plan_c) if plan_c is not None else None, _lib.ptr(g), g.stride(0), D,
             C.byref(spec), _lib.ptr(g_scale), _lib.ptr(row_scale), _lib.ptr(dx), _lib.ptr(t0),
@@ -109,7 +109,7 @@ def coldot(x, t0, t1=None):
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     o0 = torch.empty(D, dtype=torch.float32, device=dev)
     o1 = torch.empty(D, dtype=torch.float32, device=dev) if t1 is not None else None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.lib().stag_coldot(_lib.ptr(x), x.stride(0), _lib.ptr(t0), _lib.ptr(t1), t0.stride(0), n, D,
                                     _lib.ptr(o0), _lib.ptr(o1), _lib.ptr(ws), nbytes, _lib.stream_of(dev))
     _lib.check(rc, "stag_coldot")
@@ -160,7 +160,7 @@ def _bwd_w_raw(csrv, x, g, D, src_scale, broadcast_x=False, spec=None, reduce_k=
     cols = 1 if reduce_k else D
     dw = torch.empty((csrv.n_edges, cols), dtype=torch.float32, device=dev)
     cs = csrv.struct()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.lib().stag_agg_bwd_w(C.byref(cs), _lib.ptr(x), 0 if broadcast_x else x.stride(0),
                                        _lib.ptr(g), g.stride(0), D, _lib.ptr(src_scale),
                                        C.byref(spec) if spec is not None else None, int(reduce_k),
@@ -354,7 +354,7 @@ def aggregate_mc(graph, x, noise, n_samples, offset_stride=1, reduce="sum", src_
     nbytes = _lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], 4 * D, 0) if plan_t is not None else 0
     plan_c, _keep = _plan_struct(csrv, seg_len, (D + 255) // 256, nbytes, dev)
     cs, spec = csrv.struct(), noise.spec()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.lib().stag_agg_fwd_mc(
             C.byref(cs), C.byref(plan_c) if plan_c is not None else None, _lib.ptr(x), x.stride(0), D,
             C.byref(spec), n_samples, offset_stride, _REDUCE[reduce], _lib.ptr(src_scale), _lib.ptr(dst_scale),
@@ -369,7 +369,7 @@ def materialize_noise(graph, noise):
     dev = _lib.require_device(csrv.indptr)
     w = torch.empty((csrv.n_edges, noise.dn), dtype=torch.float32, device=dev)
     spec, cs = noise.spec(), csrv.struct()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.lib().stag_noise_materialize(C.byref(cs), C.byref(spec), noise.dn, _lib.ptr(w),
                                                noise.dn, _lib.stream_of(dev))
     _lib.check(rc, "stag_noise_materialize")
@@ -379,7 +379,7 @@ def materialize_noise(graph, noise):
 def philox_raw(seed, offset, pos0, n_pos, n_chunk, device):
     out = torch.empty((n_pos, n_chunk, 4), dtype=torch.int32, device=device)
     dev = _lib.require_device(out)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.lib().stag_philox_raw(seed, offset, pos0, n_pos, n_chunk, _lib.ptr(out),
                                         _lib.stream_of(dev))
     _lib.check(rc, "stag_philox_raw")
@@ -393,7 +393,7 @@ class _SegmentReduce(torch.autograd.Function):
         dev = _lib.require_device(x, offsets)
         B, D = offsets.shape[0] - 1, x.shape[1]
         out = torch.empty((B, D), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().stag_segment_reduce(_lib.ptr(x), x.stride(0), D, _lib.ptr(offsets), B,
                                                 reduce, _lib.ptr(out), D, _lib.stream_of(dev))
         _lib.check(rc, "stag_segment_reduce")
@@ -449,7 +449,7 @@ class _GatAggregate(torch.autograd.Function):
         nbytes = _lib.lib().stag_gat_workspace_bytes(plan_t["n_seg"], H, F) if plan_t is not None else 0
         plan_c, _keep = _plan_struct(csrv, seg_len, 1, nbytes, dev)
         cs = csrv.struct()
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().stag_gat_fwd(C.byref(cs), C.byref(plan_c) if plan_c is not None else None,
                                          _lib.ptr(el), _lib.ptr(er), _lib.ptr(ft), H, F,
                                          float(neg_slope), C.byref(spec), _lib.ptr(nscale),
@@ -484,7 +484,7 @@ class _GatAggregate(torch.autograd.Function):
         dw = torch.empty((csrv.n_edges, H), dtype=torch.float32, device=dev) if want_dw else None
         plan_c, _keep = _plan_struct(csrv, ctx.seg_len, 1, 0, dev)
         cs = csrv.struct()
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().stag_gat_bwd_edge(
                 C.byref(cs), C.byref(plan_c) if plan_c is not None else None, _lib.ptr(el),
                 _lib.ptr(er), _lib.ptr(ft), _lib.ptr(attn), _lib.ptr(G), _lib.ptr(gdo), H, F,
