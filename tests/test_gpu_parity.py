@@ -235,7 +235,7 @@ def test_backward_vs_oracle(dev, oracle):
 
 
 @pytest.mark.parametrize("kind,relu", [("normal", False), ("normal", True), ("uniform", True)])
-@pytest.mark.parametrize("D", [6, 40, 128])
+@pytest.mark.parametrize("D", [6, 40, 128, 300])
 def test_agg_bwd_one_pass(dev, oracle, kind, relu, D):
     """stag_agg_bwd: dx and the two parameter-derivative aggregates from ONE pass equal three
     separate passes (spec.deriv = 0, 1, 2) bit for bit, and the oracle within the bar; hub row
@@ -313,7 +313,7 @@ def test_node_linear_gradients(dev):
 
 
 @pytest.mark.parametrize("kind", ["normal", "uniform", "bernoulli"])
-@pytest.mark.parametrize("D", [6, 128])
+@pytest.mark.parametrize("D", [6, 128, 300])
 def test_monte_carlo_samples_one_pass(dev, oracle, kind, D):
     """stag_agg_fwd_mc: S samples from one pass over the gathered rows == S separate launches at
     offsets o + s * stride, bit for bit (hub row, per-channel parameters, relu, degree scalings)."""
