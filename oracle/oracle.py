@@ -283,3 +283,24 @@ def coldot(x, t0, t1=None):
     x64 = np.asarray(x, dtype=np.float64)
     o0 = (x64 * np.asarray(t0, dtype=np.float64)).sum(0)
     return o0, (None if t1 is None else (x64 * np.asarray(t1, dtype=np.float64)).sum(0))
+
+
+def agg_bwd(g_t, gout, spec, g_scale=None, row_scale=None, want_dp=True):
+    """CPU twin of stag_agg_bwd on the source-major CSR `g_t` (its nidx = forward positions):
+    (dx, dp0_rows, dp1_rows) = the aggregation with spec.deriv = 0, 1, 2."""
+    outs = []
+    for deriv in ((0, 1, 2) if want_dp else (0,)):
+        s = NoiseSpec.from_buffer_copy(spec)
+        s.deriv = deriv
+        outs.append(agg_fwd(g_t, gout, s, src_scale=g_scale, dst_scale=row_scale))
+    return tuple(outs) if want_dp else (outs[0], None, None)
+
+
+def agg_fwd_mc(g, x, spec, n_samples, offset_stride=1, **kw):
+    """CPU twin of stag_agg_fwd_mc: [n_samples, N, D], sample s drawn at offset + s * offset_stride."""
+    outs = []
+    for s_i in range(n_samples):
+        s = NoiseSpec.from_buffer_copy(spec)
+        s.offset = spec.offset + s_i * offset_stride
+        outs.append(agg_fwd(g, x, s, **kw))
+    return np.stack(outs, 0)

@@ -335,10 +335,12 @@ def test_monte_carlo_samples_one_pass(dev, oracle, kind, D):
             nz.offset = 100 + s * stride
             assert torch.equal(got[s], ops.aggregate(g, x, nz, reduce="mean", src_scale=ss, dst_scale=ds, seg_len=32)), (S, s)
     og = oracle_graph(oracle, g)
-    ref = oracle.agg_fwd(og, x.cpu().numpy(), _ospec(oracle, g, D, kind, p0, p1, relu=(kind == "normal"), seed=4, offset=103),
-                         reduce=oracle.REDUCE_MEAN, src_scale=ss.cpu().numpy(), dst_scale=ds.cpu().numpy())
-    assert_close(ops.aggregate_mc(g, x, noise, 4, offset_stride=1, reduce="mean", src_scale=ss, dst_scale=ds)[3], ref,
-                 what="mc sample 3 vs oracle")
+    ref = oracle.agg_fwd_mc(og, x.cpu().numpy(), _ospec(oracle, g, D, kind, p0, p1, relu=(kind == "normal"), seed=4, offset=100),
+                            4, offset_stride=3, reduce=oracle.REDUCE_MEAN, src_scale=ss.cpu().numpy(),
+                            dst_scale=ds.cpu().numpy())
+    got = ops.aggregate_mc(g, x, noise, 4, offset_stride=3, reduce="mean", src_scale=ss, dst_scale=ds)
+    for s in range(4):
+        assert_close(got[s], ref[s], what=f"mc sample {s} vs oracle twin")
 
 
 def test_segment_reduce(dev, oracle):
