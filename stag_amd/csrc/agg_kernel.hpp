@@ -560,7 +560,10 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
       b + len,
       // descriptor of x for the narrow (< 4 GB, ids < 2^24) case; kernel arguments only
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000),
-      VEC && (a.wide & 1) == 0,
+      // rows go through the descriptor as ONE dwordx4 whenever the narrow form applies — also when
+      // D is not a multiple of 4: the load is dword-aligned, the tail lanes pick up neighbouring
+      // floats (or 0 past the end) that never reach a store
+      (a.wide & 1) == 0 && a.x_bytes != 0,
       {a.p0s, a.p0s, a.p0s, a.p0s}, {a.p1s, a.p1s, a.p1s, a.p1s},
       {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f},
       len > kKahanMinLen};
