@@ -55,6 +55,11 @@ def main():
     t = timeit(lambda i=0: ops.aggregate(g3, x3, mk3(i), reduce="mean"))
     b = 4 * (n3 + 1) + 4 * E3 + 8 * n3 * 256
     print(f"cfg3 SAGE mean D=256        : {t:8.1f} us  {E3 / t / 1e3:6.2f} Gedges/s  alg {b / t / 1e3:7.1f} GB/s ({b / t / 1e3 / 80:.1f} %)")
+    x50 = torch.randn(n3, 50, device=dev)          # PPI's input width: the first layer aggregates at D=50
+    mk50 = lambda i: stag_amd.EdgeNoise(g3, 50, _lib.NOISE_NORMAL, 1.0, 0.5, seed=1, offset=i)
+    t = timeit(lambda i=0: ops.aggregate(g3, x50, mk50(i), reduce="mean"))
+    b = 4 * (n3 + 1) + 4 * E3 + 8 * n3 * 50
+    print(f"cfg3 SAGE mean D=50 (layer 1): {t:8.1f} us  {E3 / t / 1e3:6.2f} Gedges/s  alg {b / t / 1e3:7.1f} GB/s ({b / t / 1e3 / 80:.1f} %)")
     # cfg4 molecules D=128 + readout
     s4, d4, sizes = synthetic.molecules_like(4096)
     n4, E4 = int(sizes.sum()), len(s4)
