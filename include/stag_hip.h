@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 7
+#define STAG_ABI_VERSION 8
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -231,19 +231,26 @@ int stag_agg_bwd(const stag_csr* csr_t, const stag_plan* plan_t, const float* g,
                  int64_t ldo, void* stream);
 
 /* w[eid, k] for every edge of the shard: what the reference keeps in
- * `self._edge_weight_sample` (stag/layers.py:107). relu and in_norm applied.   */
-int stag_noise_materialize(const stag_csr* csr, const stag_noise_spec* spec,
-                           int32_t Dn, float* w, int64_t ldw, void* stream);
+ * `self._edge_weight_sample` (stag/layers.py:107). relu and in_norm applied.
+ * plan (may be NULL): the units bound what one team walks, so a hub row does not serialise.
+ * norm_scale: [n_dst, Dn] device scratch, required when spec.in_norm (the row factors are
+ * computed first, by the aggregation kernel on a broadcast row; with a plan that has segments
+ * its workspace must hold stag_plan_workspace_bytes(n_seg, Dn, 1) bytes); NULL otherwise.    */
+int stag_noise_materialize(const stag_csr* csr, const stag_plan* plan, const stag_noise_spec* spec,
+                           int32_t Dn, float* w, int64_t ldw, float* norm_scale, void* stream);
 
 /* Gradient w.r.t. per-edge weights or per-edge distribution parameters:
  *   dw[eid, k] = D[p, k] * sscale[u] * x[u, k] * g[v, k]      (g already carries dst scaling)
  * D = 1 for an explicit weight (spec NULL or kind NONE/EXPLICIT); D = dw/dp0 | dw/dp1 of the
  * regenerated draw when spec.deriv = 1 | 2 (AmortizedDistribution with vi=True).
- * reduce_k != 0: dw is [E, 1] = sum over k (per-edge parameters of shape [E, 1]).       */
-int stag_agg_bwd_w(const stag_csr* csr, const float* x, int64_t ldx,
+ * dw1 != NULL (kind NORMAL | UNIFORM): BOTH derivatives from one pass and one Philox block —
+ * dw takes dw/dp0, dw1 takes dw/dp1, spec.deriv is ignored.
+ * reduce_k != 0: dw (dw1) is [E, 1] = sum over k (per-edge parameters of shape [E, 1]).
+ * plan (may be NULL): as for stag_noise_materialize.                                         */
+int stag_agg_bwd_w(const stag_csr* csr, const stag_plan* plan, const float* x, int64_t ldx,
                    const float* g, int64_t ldg, int32_t D,
                    const float* src_scale, const stag_noise_spec* spec, int32_t reduce_k,
-                   float* dw, int64_t ldw, void* stream);
+                   float* dw, float* dw1, int64_t ldw, void* stream);
 
 /* per-graph readout of a batched graph: out[b,:] = sum|mean of x[offsets[b]:offsets[b+1],:]
  * (dgl.sum_nodes / dgl.mean_nodes, stag/layers.py:165,177)                      */

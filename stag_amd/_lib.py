@@ -89,10 +89,10 @@ def lib():
     l.stag_philox_raw.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]
     l.stag_agg_fwd.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, C.c_int64, C.c_int32,
                                C.POINTER(NoiseSpec), C.c_int32, _vp, _vp, _vp, C.c_int64, _vp, _vp]
-    l.stag_noise_materialize.argtypes = [C.POINTER(Csr), C.POINTER(NoiseSpec), C.c_int32, _vp,
-                                         C.c_int64, _vp]
-    l.stag_agg_bwd_w.argtypes = [C.POINTER(Csr), _vp, C.c_int64, _vp, C.c_int64, C.c_int32, _vp,
-                                 C.POINTER(NoiseSpec), C.c_int32, _vp, C.c_int64, _vp]
+    l.stag_noise_materialize.argtypes = [C.POINTER(Csr), C.POINTER(Plan), C.POINTER(NoiseSpec), C.c_int32,
+                                         _vp, C.c_int64, _vp, _vp]
+    l.stag_agg_bwd_w.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, C.c_int64, _vp, C.c_int64, C.c_int32,
+                                 _vp, C.POINTER(NoiseSpec), C.c_int32, _vp, _vp, C.c_int64, _vp]
     l.stag_agg_fwd_mc.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, C.c_int64, C.c_int32,
                                   C.POINTER(NoiseSpec), C.c_int32, C.c_int64, C.c_int32, _vp, _vp, _vp,
                                   C.c_int64, C.c_int64, _vp]
@@ -111,7 +111,7 @@ def lib():
     l.stag_gat_bwd_edge.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp, _vp, _vp, _vp,
                                     C.c_int32, C.c_int32, C.c_float, C.POINTER(NoiseSpec), _vp, _vp,
                                     _vp, _vp]
-    if l.stag_abi_version() != 7:
+    if l.stag_abi_version() != 8:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     _lib = l
     return l

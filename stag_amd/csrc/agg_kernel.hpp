@@ -204,6 +204,7 @@ __device__ __forceinline__ void agg_epilogue(const AggArgs& a, int v, int deg, i
     }
     if (a.norm_scale_out) store4(a.norm_scale_out + (int64_t)v * a.D, k0, a.D, vec, s);
   }
+  if (!a.out) return;      // only the in-norm factor was asked for
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] *= dv;
   store4(a.out + (int64_t)v * a.ldo, k0, a.D, vec, acc);

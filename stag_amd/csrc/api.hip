@@ -81,7 +81,48 @@ struct NoiseArgs {
   uint32_t chunk_base;
   float* w;
   int64_t ldw;
+  // launch plan (nullable): units bound the edges one team walks, so a hub row is many teams
+  const stag_unit* units;
+  const int32_t* long_rows;
+  int32_t n_units;
+  const float* norm_scale;   // [n_rows, Dn] in-norm factor (materialise), or null
 };
+
+// the unit a team owns: destination row, first position, number of edges
+__device__ __forceinline__ bool unit_of(const NoiseArgs& a, int unit, int& row, int& b, int& len) {
+  if (unit >= a.n_units) return false;
+  if (a.units) {
+    const int4 q = *reinterpret_cast<const int4*>(a.units + unit);
+    row = q.w >= 0 ? a.long_rows[q.x] : q.x; b = q.y; len = q.z;
+  } else {
+    row = unit; b = a.indptr[unit]; len = a.indptr[unit + 1] - b;
+  }
+  return true;
+}
+
+__device__ __forceinline__ void edge_params4(const NoiseArgs& a, int64_t ed, int k0, float (&pa)[4], float (&pb)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = k0 + j;
+    const bool in = k < a.Dn;
+    float q0 = a.p0s, q1 = a.p1s;
+    if (a.pmode == 1) { q0 = in ? a.p0[k] : 0.f; q1 = (in && a.p1) ? a.p1[k] : 0.f; }
+    else if (a.pmode == 2) { q0 = a.p0[ed]; q1 = a.p1 ? a.p1[ed] : 0.f; }
+    else if (a.pmode == 3) { q0 = in ? a.p0[ed * a.Dn + k] : 0.f; q1 = (in && a.p1) ? a.p1[ed * a.Dn + k] : 0.f; }
+    pa[j] = q0; pb[j] = q1;
+  }
+}
+
+// w (after relu) and both parameter derivatives of the edge at position p (Normal | Uniform)
+__device__ __forceinline__ void edge_w4_grad(const NoiseArgs& a, const PhiloxKey& key, int p, int64_t ed,
+                                             uint32_t chunk, float (&w)[4], float (&d0)[4], float (&d1)[4]) {
+  float pa[4], pb[4];
+  edge_params4(a, ed, (int)chunk * 4, pa, pb);
+  const int64_t gpos = a.nidx ? (int64_t)a.nidx[p] : a.pos_base + p;
+  chunk += a.chunk_base;
+  if (a.kind == kNormal) draw4_grad<kNormal>((uint32_t)gpos, ctr1_of(gpos, chunk), key, pa, pb, a.nflags, w, d0, d1);
+  else draw4_grad<kUniform>((uint32_t)gpos, ctr1_of(gpos, chunk), key, pa, pb, a.nflags, w, d0, d1);
+}
 
 __device__ __forceinline__ void edge_w4(const NoiseArgs& a, int p, int64_t ed, uint32_t chunk,
                                         float (&w)[4]) {
@@ -115,52 +156,48 @@ __device__ __forceinline__ void edge_w4(const NoiseArgs& a, int p, int64_t ed, u
   }
 }
 
-// one wave per destination row; lanes = LPE chunk lanes x (64/LPE) edge slots.
-// Writes what StagLayer keeps in `_edge_weight_sample` (stag/layers.py:107).
-template <int LPE>
+// A team of LPE lanes per unit of the plan (a row, or a <= seg_len piece of a long row — a hub is
+// many teams, not one wave walking 13k edges), 4 channels per lane, two edges in flight.
+// Writes what StagLayer keeps in `_edge_weight_sample` (stag/layers.py:107); the in-norm factor
+// of the row comes in as `norm_scale` (computed by stag_agg_fwd on a broadcast row of ones).
+template <int LPE, bool VEC>
 __global__ __launch_bounds__(256) void noise_materialize_kernel(const NoiseArgs a) {
-  constexpr int EPT = 64 / LPE;
-  const int lane = threadIdx.x & 63;
-  const int c = lane % LPE, ep = lane / LPE;
-  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int c = threadIdx.x % LPE;
+  const int unit = blockIdx.x * (256 / LPE) + threadIdx.x / LPE;
   const uint32_t chunk = blockIdx.y * LPE + c;
   const int k0 = (int)chunk * 4;
-  const bool rowok = v < a.n_rows;
-  const bool active = rowok && k0 < a.Dn;
-  const int b = rowok ? a.indptr[v] : 0, e = rowok ? a.indptr[v + 1] : 0;
+  int row, b, len;
+  if (!unit_of(a, unit, row, b, len) || k0 >= a.Dn) return;
   float s[4] = {1.f, 1.f, 1.f, 1.f};
-  if (a.in_norm) {
-    float wsum[4] = {0.f, 0.f, 0.f, 0.f};
-    if (active)
-      for (int p = b + ep; p < e; p += EPT) {
-        float w[4];
-        edge_w4(a, p, a.eid ? a.eid[p] : p, chunk, w);
+  if (a.norm_scale) load4(a.norm_scale + (int64_t)row * a.Dn, k0, a.Dn, VEC, s);
+  for (int p = b; p < b + len; p += 2) {
+    float w[2][4];
+    int64_t ed[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wsum[j] += w[j];
+    for (int j = 0; j < 2; ++j) {
+      if (p + j < b + len) {
+        ed[j] = a.eid ? a.eid[p + j] : p + j;
+        edge_w4(a, p + j, ed[j], chunk, w[j]);
       }
+    }
 #pragma unroll
-    for (int m = LPE; m < 64; m <<= 1)
+    for (int j = 0; j < 2; ++j) {
+      if (p + j < b + len) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wsum[j] += __shfl_xor(wsum[j], m);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] = (wsum[j] != 0.f) ? (float)(e - b) / wsum[j] : 1.f;
-  }
-  if (!active) return;
-  for (int p = b + ep; p < e; p += EPT) {
-    const int64_t ed = a.eid ? a.eid[p] : p;
-    float w[4];
-    edge_w4(a, p, ed, chunk, w);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (k0 + j < a.Dn) a.w[ed * a.ldw + k0 + j] = w[j] * s[j];
+        for (int q = 0; q < 4; ++q) w[j][q] *= s[q];
+        store4(a.w + ed[j] * a.ldw, k0, a.Dn, VEC, w[j]);
+      }
+    }
   }
 }
 
 // dw[eid, k] = D[p,k] * sscale[u] * x[u,k] * g[v,k]   (stag_agg_bwd_w)
-// One wave per destination row; lanes = LPE chunk lanes x (64/LPE) edge slots, the channel
-// tiles are walked inside the team so that the optional reduction over k is one fixed-order sum.
+// A team of LPE lanes per unit of the plan, 4 channels per lane, two edges in flight; the row
+// of g is the unit's own row.  D = 1 (explicit weights), one regenerated derivative
+// (spec.deriv), or BOTH derivatives from one Philox block (w1 non-null).  With reduce_k the
+// channel tiles are walked inside the team so that the sum over k is one fixed-order sum.
 struct BwdWArgs {
-  NoiseArgs n;          // n.kind < kNormal or n.nflags >> 1 == 0  =>  D = 1
+  NoiseArgs n;          // n.kind < kNormal or (n.nflags >> 1 == 0 and !w1)  =>  D = 1
   const int32_t* indices;
   const float* x;
   int64_t ldx;
@@ -168,50 +205,86 @@ struct BwdWArgs {
   int64_t ldg;
   const float* src_scale;
   int32_t reduce_k;
+  float* w1;            // second output (d / d p1) when both derivatives are asked for
 };
 
-template <int LPE>
+template <int LPE, bool VEC>
 __global__ __launch_bounds__(256) void agg_bwd_w_kernel(const BwdWArgs b) {
-  constexpr int EPT = 64 / LPE;
   const NoiseArgs& a = b.n;
-  const int lane = threadIdx.x & 63;
-  const int c = lane % LPE, ep = lane / LPE;
-  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (v >= a.n_rows) return;
+  const int c = threadIdx.x % LPE;
+  const int unit = blockIdx.x * (256 / LPE) + threadIdx.x / LPE;
+  int v, rb, len;
+  if (!unit_of(a, unit, v, rb, len)) return;
   const int D = a.Dn;
-  const int nchunk = (D + 3) / 4;
-  const bool use_d = a.kind >= kNormal && (a.nflags >> kDerivShift) != 0;
-  const int rb = a.indptr[v], re = a.indptr[v + 1];
-  for (int p0 = rb; p0 < re; p0 += EPT) {
-    const int p = p0 + ep;
-    const bool live = p < re;
-    const int u = live ? b.indices[p] : 0;
-    const int64_t ed = live ? (a.eid ? a.eid[p] : p) : 0;
-    const float ss = (live && b.src_scale) ? b.src_scale[u] : 1.0f;
-    float tot = 0.f;
-    for (int tile = 0; tile * LPE < nchunk; ++tile) {
+  const int ntile = ((D + 3) / 4 + LPE - 1) / LPE;
+  const bool both = b.w1 != nullptr;
+  const bool use_d = a.kind >= kNormal && (both || (a.nflags >> kDerivShift) != 0);
+  const PhiloxKey key = resolve_epoch(a.key);
+  float gv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ntile == 1 && c * 4 < D) load4(b.g + (int64_t)v * b.ldg, c * 4, D, VEC, gv);
+  for (int p0 = rb; p0 < rb + len; p0 += 2) {
+    int u[2];
+    int64_t ed[2];
+    float ss[2], tot0[2] = {0.f, 0.f}, tot1[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool live = p0 + j < rb + len;
+      u[j] = live ? b.indices[p0 + j] : 0;
+      ed[j] = live ? (a.eid ? a.eid[p0 + j] : p0 + j) : 0;
+      ss[j] = (live && b.src_scale) ? b.src_scale[u[j]] : 1.0f;
+    }
+    for (int tile = 0; tile < ntile; ++tile) {
       const uint32_t chunk = tile * LPE + c;
       const int k0 = (int)chunk * 4;
-      float val[4] = {0.f, 0.f, 0.f, 0.f};
-      if (live && k0 < D) {
-        float dwt[4] = {1.f, 1.f, 1.f, 1.f};
-        if (use_d) edge_w4(a, p, ed, chunk, dwt);
+      if (k0 >= D) continue;
+      if (ntile > 1) load4(b.g + (int64_t)v * b.ldg, k0, D, VEC, gv);
+      float xv[2][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (k0 + j < D)
-            val[j] = dwt[j] * (ss * b.x[(int64_t)u * b.ldx + k0 + j]) * b.g[(int64_t)v * b.ldg + k0 + j];
-        if (!b.reduce_k) {
+      for (int j = 0; j < 2; ++j)
+        if (p0 + j < rb + len) load4(b.x + (int64_t)u[j] * b.ldx, k0, D, VEC, xv[j]);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (k0 + j < D) a.w[ed * a.ldw + k0 + j] = val[j];
+      for (int j = 0; j < 2; ++j) {
+        if (p0 + j < rb + len) {
+          float val[4], o0[4], o1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) val[q] = (k0 + q < D) ? (ss[j] * xv[j][q]) * gv[q] : 0.f;
+          if (both) {
+            float w[4], d0[4], d1[4];
+            edge_w4_grad(a, key, p0 + j, ed[j], chunk, w, d0, d1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { o0[q] = d0[q] * val[q]; o1[q] = d1[q] * val[q]; }
+          } else if (use_d) {
+            float dwt[4];
+            edge_w4(a, p0 + j, ed[j], chunk, dwt);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o0[q] = dwt[q] * val[q];
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o0[q] = val[q];
+          }
+          if (!b.reduce_k) {
+            store4(a.w + ed[j] * a.ldw, k0, D, VEC, o0);
+            if (both) store4(b.w1 + ed[j] * a.ldw, k0, D, VEC, o1);
+          } else {
+            tot0[j] += (o0[0] + o0[1]) + (o0[2] + o0[3]);
+            tot1[j] += (o1[0] + o1[1]) + (o1[2] + o1[3]);
+          }
         }
       }
-      tot += (val[0] + val[1]) + (val[2] + val[3]);
     }
     if (b.reduce_k) {
 #pragma unroll
-      for (int m = 1; m < LPE; m <<= 1) tot += __shfl_xor(tot, m);
-      if (live && c == 0) a.w[ed * a.ldw] = tot;
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int m = 1; m < LPE; m <<= 1) {
+          tot0[j] += __shfl_xor(tot0[j], m);
+          if (both) tot1[j] += __shfl_xor(tot1[j], m);
+        }
+        if (p0 + j < rb + len && c == 0) {
+          a.w[ed[j] * a.ldw] = tot0[j];
+          if (both) b.w1[ed[j] * a.ldw] = tot1[j];
+        }
+      }
     }
   }
 }
@@ -450,7 +523,8 @@ static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x
   if (rc) return rc;
   rc = check_spec(spec);
   if (rc) return rc;
-  if (!out || D <= 0 || (ldx != 0 && ldx < D) || ldo < D) return STAG_EINVAL;   // ldx == 0: one broadcast row
+  // ldx == 0: one broadcast row; out may be NULL when only the in-norm factor is wanted
+  if ((!out && !norm_scale_out) || D <= 0 || (ldx != 0 && ldx < D) || ldo < D) return STAG_EINVAL;
   if (csr->n_edges > 0 && !x) return STAG_EINVAL;
   if (reduce != STAG_REDUCE_SUM && reduce != STAG_REDUCE_MEAN) return STAG_EINVAL;
   if (csr->n_dst == 0) return STAG_OK;
@@ -512,7 +586,7 @@ static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x
   }
 
   // dwordx4 path needs 16-B aligned rows everywhere a float4 is formed
-  bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) && aligned16(out);
+  bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) && (!out || aligned16(out));
   if (norm_scale_out) vec = vec && aligned16(norm_scale_out);
   for (int o = 0; o + 1 < nout; ++o) vec = vec && aligned16(extra[o]);
   if (spec->kind == STAG_NOISE_EXPLICIT) vec = vec && aligned16(spec->p0);
@@ -586,14 +660,57 @@ int stag_agg_bwd(const stag_csr* csr_t, const stag_plan* plan_t, const float* g,
                     dp0_rows ? 3 : 1, extra, 0, 0, stream);
 }
 
-int stag_noise_materialize(const stag_csr* csr, const stag_noise_spec* spec, int32_t Dn, float* w,
-                           int64_t ldw, void* stream) {
+// plan fields the unit-walking auxiliary kernels need
+static int set_units(NoiseArgs& a, const stag_csr* csr, const stag_plan* plan) {
+  a.n_units = csr->n_dst;
+  if (plan && plan->n_units > 0) {
+    if (!plan->units || !aligned16(plan->units)) return STAG_EINVAL;
+    if (plan->n_seg > 0 && !plan->long_rows) return STAG_EINVAL;
+    a.units = plan->units; a.long_rows = plan->long_rows; a.n_units = plan->n_units;
+  }
+  return STAG_OK;
+}
+
+#define STAG_LPE_DISPATCH(KERNEL, lpe, vec, grid, s, args)                                      \
+  do {                                                                                          \
+    switch (lpe) {                                                                              \
+      case 64: if (vec) hipLaunchKernelGGL((KERNEL<64, true>), grid, dim3(256), 0, s, args);    \
+               else     hipLaunchKernelGGL((KERNEL<64, false>), grid, dim3(256), 0, s, args); break; \
+      case 32: if (vec) hipLaunchKernelGGL((KERNEL<32, true>), grid, dim3(256), 0, s, args);    \
+               else     hipLaunchKernelGGL((KERNEL<32, false>), grid, dim3(256), 0, s, args); break; \
+      case 16: if (vec) hipLaunchKernelGGL((KERNEL<16, true>), grid, dim3(256), 0, s, args);    \
+               else     hipLaunchKernelGGL((KERNEL<16, false>), grid, dim3(256), 0, s, args); break; \
+      case 8:  if (vec) hipLaunchKernelGGL((KERNEL<8, true>), grid, dim3(256), 0, s, args);     \
+               else     hipLaunchKernelGGL((KERNEL<8, false>), grid, dim3(256), 0, s, args); break;  \
+      case 4:  if (vec) hipLaunchKernelGGL((KERNEL<4, true>), grid, dim3(256), 0, s, args);     \
+               else     hipLaunchKernelGGL((KERNEL<4, false>), grid, dim3(256), 0, s, args); break;  \
+      case 2:  if (vec) hipLaunchKernelGGL((KERNEL<2, true>), grid, dim3(256), 0, s, args);     \
+               else     hipLaunchKernelGGL((KERNEL<2, false>), grid, dim3(256), 0, s, args); break;  \
+      default: if (vec) hipLaunchKernelGGL((KERNEL<1, true>), grid, dim3(256), 0, s, args);     \
+               else     hipLaunchKernelGGL((KERNEL<1, false>), grid, dim3(256), 0, s, args); break;  \
+    }                                                                                           \
+  } while (0)
+
+int stag_noise_materialize(const stag_csr* csr, const stag_plan* plan, const stag_noise_spec* spec,
+                           int32_t Dn, float* w, int64_t ldw, float* norm_scale, void* stream) {
   int rc = check_csr(csr);
   if (rc) return rc;
   rc = check_spec(spec);
   if (rc) return rc;
   if (!w || Dn <= 0 || ldw < Dn) return STAG_EINVAL;
+  if (spec->in_norm && !norm_scale) return STAG_EINVAL;   // [n_dst, Dn] scratch for the row factors
   if (csr->n_dst == 0 || csr->n_edges == 0) return STAG_OK;
+  if (spec->in_norm) {
+    // the in-norm factor indeg / sum_in w of every (row, channel): the aggregation kernel on one
+    // broadcast row of ones, which draws the same weights (stag/layers.py:12-28)
+    stag_noise_spec sp = *spec;
+    sp.deriv = 0;
+    // (x = one broadcast row, whose values do not enter the factor: the first Dn floats of w;
+    //  out = NULL: only norm_scale_out is written)
+    rc = agg_common(csr, plan, w, 0, Dn, &sp, STAG_REDUCE_SUM, nullptr, nullptr, nullptr, Dn, norm_scale,
+                    1, nullptr, 0, 0, stream);
+    if (rc) return rc;
+  }
   NoiseArgs a{};
   a.indptr = csr->indptr; a.eid = csr->eid; a.nidx = csr->nidx; a.n_rows = csr->n_dst;
   a.Dn = Dn; a.kind = spec->kind; a.p0 = spec->p0; a.p1 = spec->p1;
@@ -601,59 +718,53 @@ int stag_noise_materialize(const stag_csr* csr, const stag_noise_spec* spec, int
   a.pmode = spec->kind >= STAG_NOISE_NORMAL ? spec->param_mode : 0;
   a.nflags = (spec->relu ? kFlagRelu : 0) | (spec->deriv << kDerivShift); a.in_norm = spec->in_norm;
   a.key = make_key(spec); a.pos_base = spec->pos_base; a.chunk_base = (uint32_t)spec->chunk_base;
-  a.w = w; a.ldw = ldw;
+  a.w = w; a.ldw = ldw; a.norm_scale = spec->in_norm ? norm_scale : nullptr;
+  rc = set_units(a, csr, plan);
+  if (rc) return rc;
   const int nchunk = (Dn + 3) / 4;
   int lpe = 1;
   while (lpe < nchunk && lpe < 64) lpe <<= 1;
-  dim3 grid((csr->n_dst + 3) / 4, (nchunk + lpe - 1) / lpe);
+  const bool vec = (Dn % 4 == 0) && (ldw % 4 == 0) && aligned16(w) && (!a.norm_scale || aligned16(norm_scale));
+  const dim3 grid((a.n_units + 256 / lpe - 1) / (256 / lpe), (nchunk + lpe - 1) / lpe);
   hipStream_t s = (hipStream_t)stream;
-  switch (lpe) {
-    case 64: hipLaunchKernelGGL(noise_materialize_kernel<64>, grid, dim3(256), 0, s, a); break;
-    case 32: hipLaunchKernelGGL(noise_materialize_kernel<32>, grid, dim3(256), 0, s, a); break;
-    case 16: hipLaunchKernelGGL(noise_materialize_kernel<16>, grid, dim3(256), 0, s, a); break;
-    case 8: hipLaunchKernelGGL(noise_materialize_kernel<8>, grid, dim3(256), 0, s, a); break;
-    case 4: hipLaunchKernelGGL(noise_materialize_kernel<4>, grid, dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(noise_materialize_kernel<2>, grid, dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL(noise_materialize_kernel<1>, grid, dim3(256), 0, s, a); break;
-  }
+  STAG_LPE_DISPATCH(noise_materialize_kernel, lpe, vec, grid, s, a);
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }
 
-int stag_agg_bwd_w(const stag_csr* csr, const float* x, int64_t ldx, const float* g, int64_t ldg,
-                   int32_t D, const float* src_scale, const stag_noise_spec* spec, int32_t reduce_k,
-                   float* dw, int64_t ldw, void* stream) {
+int stag_agg_bwd_w(const stag_csr* csr, const stag_plan* plan, const float* x, int64_t ldx,
+                   const float* g, int64_t ldg, int32_t D, const float* src_scale,
+                   const stag_noise_spec* spec, int32_t reduce_k, float* dw, float* dw1, int64_t ldw,
+                   void* stream) {
   int rc = check_csr(csr);
   if (rc) return rc;
   if (spec) { rc = check_spec(spec); if (rc) return rc; }
   if (!x || !g || !dw || D <= 0 || (ldx != 0 && ldx < D) || ldg < D) return STAG_EINVAL;
   if (ldw < (reduce_k ? 1 : D)) return STAG_EINVAL;
+  if (dw1 && !(spec && (spec->kind == STAG_NOISE_NORMAL || spec->kind == STAG_NOISE_UNIFORM))) return STAG_EINVAL;
   if (csr->n_dst == 0 || csr->n_edges == 0) return STAG_OK;
   BwdWArgs b{};
   NoiseArgs& a = b.n;
   a.indptr = csr->indptr; a.eid = csr->eid; a.nidx = csr->nidx; a.n_rows = csr->n_dst; a.Dn = D;
-  if (spec && spec->kind >= STAG_NOISE_NORMAL && spec->deriv != 0) {
+  if (spec && spec->kind >= STAG_NOISE_NORMAL && (spec->deriv != 0 || dw1)) {
     a.kind = spec->kind; a.p0 = spec->p0; a.p1 = spec->p1;
     a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar; a.pmode = spec->param_mode;
-    a.nflags = (spec->relu ? kFlagRelu : 0) | (spec->deriv << kDerivShift);
+    a.nflags = (spec->relu ? kFlagRelu : 0) | ((dw1 ? 0 : spec->deriv) << kDerivShift);
     a.key = make_key(spec); a.pos_base = spec->pos_base; a.chunk_base = (uint32_t)spec->chunk_base;
   }
   a.w = dw; a.ldw = ldw;
+  rc = set_units(a, csr, plan);
+  if (rc) return rc;
   b.indices = csr->indices; b.x = x; b.ldx = ldx; b.g = g; b.ldg = ldg; b.src_scale = src_scale;
-  b.reduce_k = reduce_k ? 1 : 0;
+  b.reduce_k = reduce_k ? 1 : 0; b.w1 = dw1;
   const int nchunk = (D + 3) / 4;
   int lpe = 1;
   while (lpe < nchunk && lpe < 64) lpe <<= 1;
-  const dim3 grid((csr->n_dst + 3) / 4);
+  bool vec = (D % 4 == 0) && (ldx % 4 == 0) && (ldg % 4 == 0) && aligned16(x) && aligned16(g);
+  if (!reduce_k) vec = vec && (ldw % 4 == 0) && aligned16(dw) && (!dw1 || aligned16(dw1));
+  if (a.kind >= kNormal && a.pmode == STAG_PARAM_PER_CHANNEL) vec = vec && aligned16(a.p0) && (!a.p1 || aligned16(a.p1));
+  const dim3 grid((a.n_units + 256 / lpe - 1) / (256 / lpe));
   hipStream_t s = (hipStream_t)stream;
-  switch (lpe) {
-    case 64: hipLaunchKernelGGL(agg_bwd_w_kernel<64>, grid, dim3(256), 0, s, b); break;
-    case 32: hipLaunchKernelGGL(agg_bwd_w_kernel<32>, grid, dim3(256), 0, s, b); break;
-    case 16: hipLaunchKernelGGL(agg_bwd_w_kernel<16>, grid, dim3(256), 0, s, b); break;
-    case 8: hipLaunchKernelGGL(agg_bwd_w_kernel<8>, grid, dim3(256), 0, s, b); break;
-    case 4: hipLaunchKernelGGL(agg_bwd_w_kernel<4>, grid, dim3(256), 0, s, b); break;
-    case 2: hipLaunchKernelGGL(agg_bwd_w_kernel<2>, grid, dim3(256), 0, s, b); break;
-    default: hipLaunchKernelGGL(agg_bwd_w_kernel<1>, grid, dim3(256), 0, s, b); break;
-  }
+  STAG_LPE_DISPATCH(agg_bwd_w_kernel, lpe, vec, grid, s, b);
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }
 

@@ -155,18 +155,24 @@ def node_linear(x, w):
     return _NodeLinear.apply(x, w)
 
 
-def _bwd_w_raw(csrv, x, g, D, src_scale, broadcast_x=False, spec=None, reduce_k=False):
+def _bwd_w_raw(csrv, x, g, D, src_scale, broadcast_x=False, spec=None, reduce_k=False, both=False,
+               seg_len=DEFAULT_SEG_LEN):
+    """stag_agg_bwd_w over the plan's units.  both=True: (d/dp0, d/dp1) of a Normal | Uniform spec
+    from one pass; else the single tensor selected by spec.deriv (or the plain dw)."""
     dev = _lib.require_device(x, g)
     cols = 1 if reduce_k else D
     dw = torch.empty((csrv.n_edges, cols), dtype=torch.float32, device=dev)
+    dw1 = torch.empty_like(dw) if both else None
+    plan_c, _keep = _plan_struct(csrv, seg_len, 1, 0, dev)
     cs = csrv.struct()
     with _lib.on_device(dev):
-        rc = _lib.lib().stag_agg_bwd_w(C.byref(cs), _lib.ptr(x), 0 if broadcast_x else x.stride(0),
+        rc = _lib.lib().stag_agg_bwd_w(C.byref(cs), C.byref(plan_c) if plan_c is not None else None,
+                                       _lib.ptr(x), 0 if broadcast_x else x.stride(0),
                                        _lib.ptr(g), g.stride(0), D, _lib.ptr(src_scale),
                                        C.byref(spec) if spec is not None else None, int(reduce_k),
-                                       _lib.ptr(dw), cols, _lib.stream_of(dev))
+                                       _lib.ptr(dw), _lib.ptr(dw1), cols, _lib.stream_of(dev))
     _lib.check(rc, "stag_agg_bwd_w")
-    return dw
+    return (dw, dw1) if both else dw
 
 
 class _Aggregate(torch.autograd.Function):
@@ -218,7 +224,8 @@ class _Aggregate(torch.autograd.Function):
             dx, _ = _agg_raw(graph.csr_t, g, D, spec, _lib.REDUCE_SUM, dvec, src_scale, ctx.seg_len)
         if w is not None and ctx.needs_input_grad[1]:
             gg = g if dvec is None else g * dvec.unsqueeze(1)
-            dw = _bwd_w_raw(graph.csr, x, gg.contiguous(), D, src_scale, broadcast_x=ctx.broadcast_x)
+            dw = _bwd_w_raw(graph.csr, x, gg.contiguous(), D, src_scale, broadcast_x=ctx.broadcast_x,
+                            seg_len=ctx.seg_len)
         return dx, dw, None, None, None, None, None, None, None
 
 
@@ -263,19 +270,17 @@ class _AggregateVI(torch.autograd.Function):
                 rows = {1: c0, 2: c1}
         elif ctx.needs_input_grad[0]:
             dx, _, _ = _agg_bwd_raw(graph.csr_t, g, D, noise.spec(), dvec, src_scale, ctx.seg_len, False)
-        gg = None
+        if per_edge and need_p:
+            # per-edge (amortised) parameters: both derivatives from ONE pass over the edges
+            gg = (g if dvec is None else g * dvec.unsqueeze(1)).contiguous()
+            e0, e1 = _bwd_w_raw(graph.csr, x, gg, D, src_scale, spec=noise.spec(),
+                                reduce_k=noise.param_mode == _lib.PARAM_PER_EDGE1, both=True,
+                                seg_len=ctx.seg_len)
+            rows = {1: e0, 2: e1}
         for which, need in ((1, ctx.needs_input_grad[1]), (2, ctx.needs_input_grad[2])):
             if not need:
                 continue
-            if per_edge:
-                if gg is None:
-                    gg = (g if dvec is None else g * dvec.unsqueeze(1)).contiguous()
-                noise.deriv = which
-                d = _bwd_w_raw(graph.csr, x, gg, D, src_scale, spec=noise.spec(),
-                               reduce_k=noise.param_mode == _lib.PARAM_PER_EDGE1)
-                noise.deriv = 0
-            else:
-                d = rows[which]
+            d = rows[which]
             shape = ctx.shapes[which - 1]
             d = d.sum_to_size(shape) if d.dim() >= len(shape) and shape != d.shape else d.reshape(shape)
             if which == 1:
@@ -363,15 +368,22 @@ def aggregate_mc(graph, x, noise, n_samples, offset_stride=1, reduce="sum", src_
     return out
 
 
-def materialize_noise(graph, noise):
+def materialize_noise(graph, noise, seg_len=DEFAULT_SEG_LEN):
     """The [E, Dn] tensor the reference would have sampled (rows by edge id)."""
     csrv = graph.csr
     dev = _lib.require_device(csrv.indptr)
-    w = torch.empty((csrv.n_edges, noise.dn), dtype=torch.float32, device=dev)
+    dn = noise.dn
+    w = torch.empty((csrv.n_edges, dn), dtype=torch.float32, device=dev)
+    ns = torch.empty((csrv.n_dst, dn), dtype=torch.float32, device=dev) if noise.in_norm else None
+    plan_t = csrv.plan(seg_len)
+    nbytes = (_lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], dn, 1)
+              if (plan_t is not None and noise.in_norm) else 0)
+    plan_c, _keep = _plan_struct(csrv, seg_len, (dn + 255) // 256, nbytes, dev)
     spec, cs = noise.spec(), csrv.struct()
     with _lib.on_device(dev):
-        rc = _lib.lib().stag_noise_materialize(C.byref(cs), C.byref(spec), noise.dn, _lib.ptr(w),
-                                               noise.dn, _lib.stream_of(dev))
+        rc = _lib.lib().stag_noise_materialize(C.byref(cs), C.byref(plan_c) if plan_c is not None else None,
+                                               C.byref(spec), dn, _lib.ptr(w), dn, _lib.ptr(ns),
+                                               _lib.stream_of(dev))
     _lib.check(rc, "stag_noise_materialize")
     return w
 

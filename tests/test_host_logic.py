@@ -20,7 +20,7 @@ def test_abi_exports_every_declared_symbol():
     assert {"stag_agg_fwd", "stag_noise_materialize", "stag_gat_fwd", "stag_plan_fill"} <= names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/stag_hip.h but not exported"
-    assert lib.stag_abi_version() == 7
+    assert lib.stag_abi_version() == 8
     assert lib.stag_strerror(-22) == b"invalid argument"
 
 
@@ -319,7 +319,7 @@ def test_abi_argument_validation_without_gpu():
     assert lib.stag_plan_workspace_bytes(0, 128, 0) == 0 and lib.stag_plan_workspace_bytes(3, 128, 1) == 3 * 128 * 2 * 4
     assert lib.stag_csr_build(None, None, 2, 2, 5, indptr.ctypes.data, None, None, None, None, 0, None) == EINVAL
     assert lib.stag_segment_reduce(f, 4, 4, None, 2, 0, f, 4, None) == EINVAL
-    assert lib.stag_noise_materialize(C.byref(csr), C.byref(spec), 0, f, 4, None) == EINVAL
+    assert lib.stag_noise_materialize(C.byref(csr), None, C.byref(spec), 0, f, 4, None, None) == EINVAL
     assert lib.stag_philox_raw(0, 0, 0, 4, 0, f, None) == EINVAL
 
 
