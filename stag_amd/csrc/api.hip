@@ -124,6 +124,29 @@ __device__ __forceinline__ void edge_w4_grad(const NoiseArgs& a, const PhiloxKey
   else draw4_grad<kUniform>((uint32_t)gpos, ctr1_of(gpos, chunk), key, pa, pb, a.nflags, w, d0, d1);
 }
 
+// as above with the edge's parameters already loaded (per-edge [E, 1] pairs travel with the rows)
+__device__ __forceinline__ void edge_w4_grad_p(const NoiseArgs& a, const PhiloxKey& key, int p, uint32_t chunk,
+                                               const float (&pa)[4], const float (&pb)[4], float (&w)[4],
+                                               float (&d0)[4], float (&d1)[4]) {
+  const int64_t gpos = a.nidx ? (int64_t)a.nidx[p] : a.pos_base + p;
+  chunk += a.chunk_base;
+  if (a.kind == kNormal) draw4_grad<kNormal>((uint32_t)gpos, ctr1_of(gpos, chunk), key, pa, pb, a.nflags, w, d0, d1);
+  else draw4_grad<kUniform>((uint32_t)gpos, ctr1_of(gpos, chunk), key, pa, pb, a.nflags, w, d0, d1);
+}
+
+// sum over the LPE lanes of a team, result in every lane: DPP inside a row of 16 lanes (quad
+// swaps, half-row and row mirrors: 4 full-rate ops), ds_bpermute only across rows
+template <int LPE>
+__device__ __forceinline__ float team_sum(float v) {
+  if constexpr (LPE >= 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm 1,0,3,2
+  if constexpr (LPE >= 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm 2,3,0,1
+  if constexpr (LPE >= 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  if constexpr (LPE >= 16) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)); // row_mirror
+  if constexpr (LPE >= 32) v += __shfl_xor(v, 16);
+  if constexpr (LPE >= 64) v += __shfl_xor(v, 32);
+  return v;
+}
+
 __device__ __forceinline__ void edge_w4(const NoiseArgs& a, int p, int64_t ed, uint32_t chunk,
                                         float (&w)[4]) {
   const int k0 = (int)chunk * 4;
@@ -208,8 +231,10 @@ struct BwdWArgs {
   float* w1;            // second output (d / d p1) when both derivatives are asked for
 };
 
-template <int LPE, bool VEC>
-__global__ __launch_bounds__(256) void agg_bwd_w_kernel(const BwdWArgs b) {
+// MODE 0: D = 1 (no draw); 1: one derivative selected by the flags (any kind / parameter mode);
+// 2: both derivatives.  Separate instantiations: together they cost 140 VGPRs (3 waves per SIMD).
+template <int LPE, bool VEC, int MODE>
+__device__ __forceinline__ void agg_bwd_w_body(const BwdWArgs& b) {
   const NoiseArgs& a = b.n;
   const int c = threadIdx.x % LPE;
   const int unit = blockIdx.x * (256 / LPE) + threadIdx.x / LPE;
@@ -217,21 +242,25 @@ __global__ __launch_bounds__(256) void agg_bwd_w_kernel(const BwdWArgs b) {
   if (!unit_of(a, unit, v, rb, len)) return;
   const int D = a.Dn;
   const int ntile = ((D + 3) / 4 + LPE - 1) / LPE;
-  const bool both = b.w1 != nullptr;
-  const bool use_d = a.kind >= kNormal && (both || (a.nflags >> kDerivShift) != 0);
-  const PhiloxKey key = resolve_epoch(a.key);
+  constexpr bool both = MODE == 2;
+  constexpr bool use_d = MODE >= 1;
+  const PhiloxKey key = MODE == 2 ? resolve_epoch(a.key) : a.key;
   float gv[4] = {0.f, 0.f, 0.f, 0.f};
   if (ntile == 1 && c * 4 < D) load4(b.g + (int64_t)v * b.ldg, c * 4, D, VEC, gv);
   for (int p0 = rb; p0 < rb + len; p0 += 2) {
     int u[2];
     int64_t ed[2];
-    float ss[2], tot0[2] = {0.f, 0.f}, tot1[2] = {0.f, 0.f};
+    float ss[2], tot0[2] = {0.f, 0.f}, tot1[2] = {0.f, 0.f}, q0[2] = {0.f, 0.f}, q1[2] = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const bool live = p0 + j < rb + len;
       u[j] = live ? b.indices[p0 + j] : 0;
       ed[j] = live ? (a.eid ? a.eid[p0 + j] : p0 + j) : 0;
       ss[j] = (live && b.src_scale) ? b.src_scale[u[j]] : 1.0f;
+      if (both && a.pmode == 2 && live) {     // [E, 1] parameters: in flight with the rows
+        q0[j] = a.p0[ed[j]];
+        q1[j] = a.p1 ? a.p1[ed[j]] : 0.f;
+      }
     }
     for (int tile = 0; tile < ntile; ++tile) {
       const uint32_t chunk = tile * LPE + c;
@@ -248,12 +277,17 @@ __global__ __launch_bounds__(256) void agg_bwd_w_kernel(const BwdWArgs b) {
           float val[4], o0[4], o1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int q = 0; q < 4; ++q) val[q] = (k0 + q < D) ? (ss[j] * xv[j][q]) * gv[q] : 0.f;
-          if (both) {
+          if constexpr (both) {
             float w[4], d0[4], d1[4];
-            edge_w4_grad(a, key, p0 + j, ed[j], chunk, w, d0, d1);
+            if (a.pmode == 2) {
+              const float pa[4] = {q0[j], q0[j], q0[j], q0[j]}, pb[4] = {q1[j], q1[j], q1[j], q1[j]};
+              edge_w4_grad_p(a, key, p0 + j, chunk, pa, pb, w, d0, d1);
+            } else {
+              edge_w4_grad(a, key, p0 + j, ed[j], chunk, w, d0, d1);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) { o0[q] = d0[q] * val[q]; o1[q] = d1[q] * val[q]; }
-          } else if (use_d) {
+          } else if constexpr (use_d) {
             float dwt[4];
             edge_w4(a, p0 + j, ed[j], chunk, dwt);
 #pragma unroll
@@ -275,11 +309,8 @@ __global__ __launch_bounds__(256) void agg_bwd_w_kernel(const BwdWArgs b) {
     if (b.reduce_k) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int m = 1; m < LPE; m <<= 1) {
-          tot0[j] += __shfl_xor(tot0[j], m);
-          if (both) tot1[j] += __shfl_xor(tot1[j], m);
-        }
+        tot0[j] = team_sum<LPE>(tot0[j]);
+        if (both) tot1[j] = team_sum<LPE>(tot1[j]);
         if (p0 + j < rb + len && c == 0) {
           a.w[ed[j] * a.ldw] = tot0[j];
           if (both) b.w1[ed[j] * a.ldw] = tot1[j];
@@ -288,6 +319,13 @@ __global__ __launch_bounds__(256) void agg_bwd_w_kernel(const BwdWArgs b) {
     }
   }
 }
+
+template <int LPE, bool VEC>
+__global__ __launch_bounds__(256) void agg_bwd_w_kernel0(const BwdWArgs b) { agg_bwd_w_body<LPE, VEC, 0>(b); }
+template <int LPE, bool VEC>
+__global__ __launch_bounds__(256) void agg_bwd_w_kernel1(const BwdWArgs b) { agg_bwd_w_body<LPE, VEC, 1>(b); }
+template <int LPE, bool VEC>
+__global__ __launch_bounds__(256) void agg_bwd_w_kernel2(const BwdWArgs b) { agg_bwd_w_body<LPE, VEC, 2>(b); }
 
 // out[b, :] = sum | mean of x[offsets[b]:offsets[b+1], :]   (dgl.sum_nodes / mean_nodes)
 // A team of LPE lanes per graph of the batch, 4 channels (one dwordx4) per lane, 4 rows in
@@ -764,7 +802,9 @@ int stag_agg_bwd_w(const stag_csr* csr, const stag_plan* plan, const float* x, i
   if (a.kind >= kNormal && a.pmode == STAG_PARAM_PER_CHANNEL) vec = vec && aligned16(a.p0) && (!a.p1 || aligned16(a.p1));
   const dim3 grid((a.n_units + 256 / lpe - 1) / (256 / lpe));
   hipStream_t s = (hipStream_t)stream;
-  STAG_LPE_DISPATCH(agg_bwd_w_kernel, lpe, vec, grid, s, b);
+  if (dw1) STAG_LPE_DISPATCH(agg_bwd_w_kernel2, lpe, vec, grid, s, b);
+  else if (a.kind >= kNormal) STAG_LPE_DISPATCH(agg_bwd_w_kernel1, lpe, vec, grid, s, b);
+  else STAG_LPE_DISPATCH(agg_bwd_w_kernel0, lpe, vec, grid, s, b);
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }
 
