@@ -160,6 +160,24 @@ class AmortizedDistribution(Distribution):
             torch.nn.init.constant_(self.parameters_mlp[key].bias, float(target))
 
     def condition(self, graph, feat):
+        """h_e = act(W [h_src || h_dst] + b) (stag/distributions.py:178-183, 225-227), computed as
+        act((feat W_src^T)[src] + (feat W_dst^T)[dst] + b): the Linear runs over the N node rows
+        and the E-row work is two gathers — no [E, 2 in] concatenation, no E-row GEMM — and the
+        gathers' backward is the aggregation kernel, not a scatter-add."""
+        lin = self.embedding_mlp[0]
+        if feat.is_cuda and feat.dim() == 2 and isinstance(lin, torch.nn.Linear):
+            from . import ops
+            k = feat.shape[1]
+            h = (ops.gather_rows(graph, ops.node_linear(feat, lin.weight[:, :k].t()), "src")
+                 + ops.gather_rows(graph, ops.node_linear(feat, lin.weight[:, k:].t()), "dst"))
+            if lin.bias is not None:
+                h = h + lin.bias
+            for mod in list(self.embedding_mlp)[1:]:
+                h = mod(h)
+            self.new_parameters = {
+                name: ops.node_linear(h, head.weight.t()) + head.bias
+                for name, head in ((n, self.parameters_mlp[n]) for n in self.new_parameter_names)}
+            return self
         src, dst = graph.edges()
         h = self.embedding_mlp(torch.cat([feat[src], feat[dst]], dim=-1))
         self.new_parameters = {k: self.parameters_mlp[k](h) for k in self.new_parameter_names}

@@ -32,8 +32,8 @@ def _in_norm(graph, edge_weight_sample):
     current = graph.ndata["h_a"]
     desired = graph.in_degrees().unsqueeze(-1).to(current.dtype)
     scaling = torch.where(current != 0.0, desired / current, torch.ones_like(current))
-    _, dst = graph.edges()
-    return edge_weight_sample * scaling[dst]
+    from . import ops
+    return edge_weight_sample * ops.gather_rows(graph, scaling, "dst")
 
 
 class StagLayer(torch.nn.Module):

@@ -41,7 +41,9 @@ def _param_mode(p, n_edges, dn):
 class EdgeNoise:
     def __init__(self, graph, dn, kind, p0, p1=None, relu=False, in_norm=False, seed=0, offset=0,
                  pos_base=0, differentiable=False, chunk_base=0, epoch=None):
-        self.graph, self.dn, self.kind = graph, int(dn), int(kind)
+        # the owner of the cached structure, not a local_var() copy (whose frames hold step tensors)
+        self.graph = graph._cache_owner() if hasattr(graph, "_cache_owner") else graph
+        self.dn, self.kind = int(dn), int(kind)
         # vi=True: keep the live parameter tensors so ops.aggregate can return their gradients
         # (reparameterised draw; the backward regenerates the noise with spec.deriv = 1 | 2)
         self.grad_params = None

@@ -17,6 +17,13 @@ from .noise import EdgeNoise
 _REDUCE = {"sum": _lib.REDUCE_SUM, "mean": _lib.REDUCE_MEAN}
 
 
+def _owner(graph):
+    """The graph object that owns the cached structure.  Autograd contexts keep THIS, never a
+    `local_var()` copy: a copy's frames hold the step's tensors, whose grad_fn holds the context
+    — a cycle through the autograd graph that kept an [E, D] tensor alive per training step."""
+    return graph._cache_owner() if hasattr(graph, "_cache_owner") else graph
+
+
 def _f32c(t):
     if t is None:
         return None
@@ -155,6 +162,38 @@ def node_linear(x, w):
     return _NodeLinear.apply(x, w)
 
 
+class _GatherRows(torch.autograd.Function):
+    """x[src] or x[dst] as an [E, D] tensor by edge id.  Forward is an index_select; the backward —
+    a scatter-add of E rows into N — is the aggregation kernel with the incoming gradient as
+    explicit edge weights over one broadcast row of ones (torch's index backward takes 3.9 ms
+    for [1.17M, 128] on MI355X, this 0.2 ms)."""
+
+    @staticmethod
+    def forward(ctx, x, graph, which):
+        src, dst = graph.edges()
+        ctx.graph, ctx.which = _owner(graph), which
+        return x.index_select(0, (src if which == "src" else dst).long())
+
+    @staticmethod
+    def backward(ctx, g):
+        graph = ctx.graph
+        g = _f32c(g)
+        csrv = graph.csr_t if ctx.which == "src" else graph.csr
+        D = g.shape[1]
+        ones = torch.ones(D, dtype=torch.float32, device=g.device)
+        out, _ = _agg_raw(csrv, ones, D, _explicit_spec(g), _lib.REDUCE_SUM, None, None, DEFAULT_SEG_LEN,
+                          broadcast_x=True)
+        return out, None, None
+
+
+def gather_rows(graph, x, which):
+    """x[u] (which="src") or x[v] (which="dst") for every edge u -> v, rows by edge id."""
+    if x.dim() != 2 or not x.is_cuda:
+        src, dst = graph.edges()
+        return x[(src if which == "src" else dst).long()]
+    return _GatherRows.apply(x, graph, which)
+
+
 def _bwd_w_raw(csrv, x, g, D, src_scale, broadcast_x=False, spec=None, reduce_k=False, both=False,
                seg_len=DEFAULT_SEG_LEN):
     """stag_agg_bwd_w over the plan's units.  both=True: (d/dp0, d/dp1) of a Normal | Uniform spec
@@ -192,7 +231,7 @@ class _Aggregate(torch.autograd.Function):
         want_ns = bool(spec.in_norm) and any(ctx.needs_input_grad[:2])
         out, ns = _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len,
                            want_norm_scale=want_ns, broadcast_x=broadcast_x)
-        ctx.graph, ctx.noise, ctx.reduce, ctx.seg_len = graph, noise, reduce, seg_len
+        ctx.graph, ctx.noise, ctx.reduce, ctx.seg_len = _owner(graph), noise, reduce, seg_len
         ctx.broadcast_x = broadcast_x
         ctx.D = D
         need_x = w is not None and ctx.needs_input_grad[1]   # x is only read by dw
@@ -241,7 +280,7 @@ class _AggregateVI(torch.autograd.Function):
         D = x.shape[1]
         spec = noise.spec()
         out, _ = _agg_raw(graph.csr, x, D, spec, reduce, src_scale, dst_scale, seg_len)
-        ctx.graph, ctx.noise, ctx.reduce, ctx.seg_len, ctx.D = graph, noise, reduce, seg_len, D
+        ctx.graph, ctx.noise, ctx.reduce, ctx.seg_len, ctx.D = _owner(graph), noise, reduce, seg_len, D
         ctx.shapes = (p0.shape, p1.shape)
         ctx.save_for_backward(x, src_scale, dst_scale)
         return out
@@ -468,7 +507,7 @@ class _GatAggregate(torch.autograd.Function):
                                          _lib.ptr(out), _lib.ptr(attn), _lib.stream_of(dev))
         _lib.check(rc, "stag_gat_fwd")
         if need_grad:
-            ctx.graph, ctx.noise, ctx.neg_slope, ctx.seg_len = graph, noise, float(neg_slope), seg_len
+            ctx.graph, ctx.noise, ctx.neg_slope, ctx.seg_len = _owner(graph), noise, float(neg_slope), seg_len
             ctx.save_for_backward(el, er, ft, w, attn, out, nscale)
         if want_attn:
             ctx.mark_non_differentiable(attn)

@@ -27,7 +27,13 @@ class GIN(torch.nn.Module):
         if edge_weight is not None:
             check_edge_weight(graph, edge_weight)
         neigh = ops.aggregate(graph, feat, edge_weight, reduce=self._aggregator_type)
-        rst = self.apply_func((1 + self.eps) * feat + neigh)
+        h = (1 + self.eps) * feat + neigh
+        if isinstance(self.apply_func, torch.nn.Linear):      # split-K weight gradient (ops.node_linear)
+            rst = ops.node_linear(h, self.apply_func.weight.t())
+            if self.apply_func.bias is not None:
+                rst = rst + self.apply_func.bias
+        else:
+            rst = self.apply_func(h)
         if self.activation is not None:
             rst = self.activation(rst)
         return rst

@@ -615,3 +615,33 @@ def test_bench_contract_and_smoke(dev):
     assert cb["kind"] == "port" and cb["unit"] == "edges/s" and cb["cores"] >= 1 and cb["value"] > 0
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+def test_no_memory_growth_across_training_steps(dev):
+    """Every layer mode, forward + backward repeated: device memory in use must not grow from step
+    to step.  (Autograd contexts once kept a `local_var()` graph whose frames held the step's
+    [E, D] tensors — a cycle through the autograd graph, 650 MB per step at cfg2 size.)"""
+    import gc
+    import stag_amd
+    from util import random_graph
+    n, D = 3000, 32
+    g = random_graph(n, 40000, seed=1, hub=500, device=dev)
+    x = torch.randn(n, D, device=dev, requires_grad=True)
+    gout = torch.randn(n, D, device=dev)
+    N = torch.distributions.Normal
+    modes = [dict(q_a=N(1.0, 0.5)), dict(q_a=N(1.0, 0.5), vi=True, relu=True), dict(q_a=N(1.0, 0.5), vi=True, norm=True),
+             dict(q_a=torch.distributions.Bernoulli(0.5), norm=True),
+             dict(q_a=stag_amd.distributions.AmortizedDistribution(D, 1, init_like=N(1.0, 0.3)), vi=True),
+             dict(q_a=stag_amd.distributions.AmortizedDistribution(D, D, init_like=N(1.0, 0.3)), vi=True)]
+    for kw in modes:
+        layer = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(D, D), **kw).to(dev)
+        mem = []
+        for i in range(5):
+            for p in layer.parameters():
+                p.grad = None
+            layer(g, x).backward(gout)
+            torch.cuda.synchronize()
+            mem.append(torch.cuda.memory_allocated())
+        assert mem[4] <= mem[2], (kw, mem)
+        del layer
+        gc.collect()
