@@ -54,6 +54,7 @@ struct GatArgs {
   int32_t n_long;
   int32_t* seg_counters;
   float* ws;             // [n_seg][HF + 2*H]: acc, then m[H], l[H]
+  int32_t n_seg;         // units [0, n_seg) are the segments of long rows
   int32_t ws_stride;
   uint32_t ws_bytes;
 };
@@ -303,10 +304,17 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatArgs a) {
       store4(a.out + (int64_t)row * HF, k0, HF, VEC, A);
     }
     if (!a.attn) return;
+    // The row's edges are normalised by gat_attn_seg_kernel, one team per segment (a single team
+    // walking a 13k-edge hub took 1.1 ms): leave the merged statistics in the row's first slot.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every lane has read the slot's old m, l
     wave_sync();
 #pragma unroll
     for (int q = 0; q < NS; ++q)
-      if (kin && k0 + q < HF && (k0 + q) % F == 0) { stat[hq[q]] = M[q]; stat[H + hq[q]] = L[q]; }
+      if (kin && k0 + q < HF && (k0 + q) % F == 0) {
+        a.ws[(int64_t)s0 * a.ws_stride + HF + hq[q]] = M[q];
+        a.ws[(int64_t)s0 * a.ws_stride + HF + H + hq[q]] = L[q];
+      }
+    return;
   }
   // ---- attention values a[eid, h] = exp(logit - m) / l over the WHOLE row
   //      (get_attention=True, stag/zoo/gat.py:146-147).  The raw logits were stored
@@ -319,6 +327,23 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatArgs a) {
       const float lg = a.attn[ed * H + h];
       a.attn[ed * H + h] = __expf(lg - stat[h]) / stat[H + h];
     }
+  }
+}
+
+// attention values of the LONG rows: a[eid, h] = exp(logit - M[h]) / L[h], one wave per segment
+// (<= seg_len edges), statistics from the row's first workspace slot (written by the row's last
+// arriver in gat_fwd_kernel; this kernel runs behind it on the stream).
+__global__ __launch_bounds__(256) void gat_attn_seg_kernel(const GatArgs a) {
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= a.n_seg) return;
+  const int lane = threadIdx.x & 63;
+  const int4 q = *reinterpret_cast<const int4*>(a.units + s);     // segments are units [0, n_seg)
+  const int s0 = a.long_seg_ptr[q.x];
+  const float* st = a.ws + (int64_t)s0 * a.ws_stride + a.HF;
+  for (int p = q.y + lane; p < q.y + q.z; p += 64) {
+    const int64_t ed = a.eid ? a.eid[p] : p;
+    for (int h = 0; h < a.H; ++h)
+      a.attn[ed * a.H + h] = __expf(a.attn[ed * a.H + h] - st[h]) / st[a.H + h];
   }
 }
 
@@ -493,7 +518,7 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
       if (need >= (1ull << 32)) return STAG_ENOSYS;
       a.long_rows = plan->long_rows; a.long_seg_ptr = plan->long_seg_ptr; a.n_long = plan->n_long;
       a.seg_counters = plan->seg_counters; a.ws = plan->workspace;
-      a.ws_stride = HF + 2 * H; a.ws_bytes = (uint32_t)need;
+      a.ws_stride = HF + 2 * H; a.ws_bytes = (uint32_t)need; a.n_seg = plan->n_seg;
     }
   }
   bool vec = (F % 4 == 0) && aligned16(ft) && aligned16(out);
@@ -519,6 +544,8 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
     default: STAG_GAT_LAUNCH(4); break;
   }
 #undef STAG_GAT_LAUNCH
+  if (a.attn && a.ws && a.n_seg > 0)    // the long rows' attention values, one wave per segment
+    hipLaunchKernelGGL(gat_attn_seg_kernel, dim3((a.n_seg + 3) / 4), dim3(256), 0, s, a);
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }
 
