@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 8
+#define STAG_ABI_VERSION 9
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -271,7 +271,10 @@ int stag_coldot(const float* x, int64_t ldx, const float* t0, const float* t1, i
  *   e[p,h]  = w[p,h] * leaky_relu(el[u_p,h] + er[v,h])     stag/zoo/gat.py:114-119
  *   a[p,h]  = softmax over the in-edges of v                stag/zoo/gat.py:122
  *   out[v,h,:] = sum_p a[p,h] * ft[u_p,h,:]                 stag/zoo/gat.py:125-126
- * ft is [N, H*F] row-major (H*F <= 256, H <= 64); attn_out (may be NULL) receives a[eid, h].
+ * ft is [N, H*F] row-major (H*F <= 256, H <= 64).  stats_out (may be NULL) receives the softmax
+ * statistics of every destination row, [M, 2H] = max logit m[H] then sum l[H] of exp(e - m):
+ * everything that depends on a[p,h] later (stag_gat_attn, stag_gat_bwd_edge) is computed from
+ * them, so no [E, H] tensor leaves this kernel.
  * `plan` as for stag_agg_fwd, with a workspace of stag_gat_workspace_bytes() (long rows
  * are merged from per-segment softmax states).  When spec.in_norm is set, `norm_scale`
  * [M, H] must hold indeg / sum_in(w) per destination and head (stag/layers.py:8-36):
@@ -280,19 +283,27 @@ size_t stag_gat_workspace_bytes(int32_t n_seg, int32_t H, int32_t F);
 int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const float* el, const float* er,
                  const float* ft, int32_t H, int32_t F, float neg_slope,
                  const stag_noise_spec* spec, const float* norm_scale, float* out,
-                 float* attn_out, void* stream);
+                 float* stats_out, void* stream);
+
+/* The attention values a[eid, h] = exp(e[p,h] - m[v,h]) / l[v,h] (get_attention=True,
+ * stag/zoo/gat.py:146-147) from the statistics of stag_gat_fwd; same spec (the noisy logits are
+ * redrawn from their counters).                                                               */
+int stag_gat_attn(const stag_csr* csr, const stag_plan* plan, const float* el, const float* er,
+                  int32_t H, float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
+                  const float* stats, float* attn_out, void* stream);
 
 /* Per-edge part of the GAT backward (the rest is stag_agg_fwd on the transposed CSR):
  *   da = <g[v,h,:], ft[u,h,:]>,  ds = a * (da - gdo[v,h]),  gdo[v,h] = <g[v,h,:], out[v,h,:]>
  *   de[eid,h] = ds * w * lrelu'(el[u,h] + er[v,h])      sum over in-edges -> d er, over out-edges -> d el
  *   dw[eid,h] = ds * lrelu(...) * norm_scale            (NULL: not wanted)
+ * a is recomputed from `stats`; attn_out (may be NULL) receives a[eid, h] as a by-product:
  * d ft[u,h,:] = sum_{out-edges} a[e,h] * g[v,h,:]  is stag_agg_fwd on the transposed CSR with
  * EXPLICIT weights a[E,H] and spec.group = F.  Requires F % 4 == 0, F/4 a power of two.  */
 int stag_gat_bwd_edge(const stag_csr* csr, const stag_plan* plan, const float* el,
-                      const float* er, const float* ft, const float* attn, const float* g,
+                      const float* er, const float* ft, const float* stats, const float* g,
                       const float* gdo, int32_t H, int32_t F, float neg_slope,
-                      const stag_noise_spec* spec, const float* norm_scale, float* de, float* dw,
-                      void* stream);
+                      const stag_noise_spec* spec, const float* norm_scale, float* de,
+                      float* dw, float* attn_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -108,10 +108,12 @@ def lib():
     l.stag_gat_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     l.stag_gat_fwd.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp, C.c_int32, C.c_int32,
                                C.c_float, C.POINTER(NoiseSpec), _vp, _vp, _vp, _vp]
+    l.stag_gat_attn.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, C.c_int32, C.c_float,
+                                C.POINTER(NoiseSpec), _vp, _vp, _vp, _vp]
     l.stag_gat_bwd_edge.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp, _vp, _vp, _vp,
                                     C.c_int32, C.c_int32, C.c_float, C.POINTER(NoiseSpec), _vp, _vp,
-                                    _vp, _vp]
-    if l.stag_abi_version() != 8:
+                                    _vp, _vp, _vp]
+    if l.stag_abi_version() != 9:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     _lib = l
     return l

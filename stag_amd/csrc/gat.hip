@@ -43,8 +43,8 @@ struct GatArgs {
   PhiloxKey key;
   uint32_t pos_lo, pos_hi;
   float* out;
-  float* attn;           // [E, H] by edge id, or null
-  uint32_t attn_bytes;
+  float* attn;           // [E, H] by edge id, or null (gat_attn_kernel / backward by-product)
+  float* stats;          // [n_rows, 2H] softmax statistics per row: m[H] then l[H], or null
   uint32_t ft_bytes;     // extent of ft when it fits a buffer descriptor, else 0
   // plan
   const stag_unit* units;
@@ -137,8 +137,6 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatArgs a) {
   const int nchunk = (H + 3) / 4;
   const __amdgpu_buffer_rsrc_t rft =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ft), 0, (int)a.ft_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rattn =
-      __builtin_amdgcn_make_buffer_rsrc(a.attn, 0, (int)a.attn_bytes, 0x00020000);
   const bool ft_buf = VEC && a.ft_bytes != 0;
 
   constexpr int NS = VEC ? 1 : 4;          // softmax states per lane
@@ -169,10 +167,6 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatArgs a) {
             const float ns = a.nscale ? a.nscale[(int64_t)row * H + h] : 1.0f;
             const float lg = (w[j] * ns) * lr;
             logit[c * H + h] = lg;
-            // raw logit, write-through: whoever finalises the row normalises it (below)
-            if (a.attn)
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lg), rattn,
-                                                    (int)(((uint32_t)ed * (uint32_t)H + (uint32_t)h) * 4u), 0, 16);
           }
         }
       }
@@ -229,7 +223,6 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatArgs a) {
     }
   }
 
-  float* stat = logit;   // [2][H] softmax statistics for the attention pass (LDS reuse)
   if (slot < 0) {
     // ---- whole row: normalise and store ------------------------------------------------------
     if (kin) {
@@ -241,13 +234,16 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatArgs a) {
       }
       store4(a.out + (int64_t)row * HF, k0, HF, VEC, o);
     }
-    if (!a.attn) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this team's own logit stores have landed
-    wave_sync();
-    // the lane holding a head's first channel publishes that head's statistics
+    // the lane holding a head's first channel publishes that head's statistics: the attention
+    // values and the backward pass are computed from them (no [E, H] tensor leaves this kernel)
+    if (a.stats) {
 #pragma unroll
-    for (int q = 0; q < NS; ++q)
-      if (k0 + q < HF && (k0 + q) % F == 0) { stat[hq[q]] = m[q]; stat[H + hq[q]] = l[q]; }
+      for (int q = 0; q < NS; ++q)
+        if (k0 + q < HF && (k0 + q) % F == 0) {
+          a.stats[(int64_t)row * 2 * H + hq[q]] = m[q];
+          a.stats[(int64_t)row * 2 * H + H + hq[q]] = l[q];
+        }
+    }
   } else {
     // ---- segment: publish (acc, m, l) write-through, take a ticket ---------------------------
     const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)a.ws_bytes, 0x00020000);
@@ -303,47 +299,53 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatArgs a) {
       }
       store4(a.out + (int64_t)row * HF, k0, HF, VEC, A);
     }
-    if (!a.attn) return;
-    // The row's edges are normalised by gat_attn_seg_kernel, one team per segment (a single team
-    // walking a 13k-edge hub took 1.1 ms): leave the merged statistics in the row's first slot.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every lane has read the slot's old m, l
-    wave_sync();
+    if (a.stats && kin) {
 #pragma unroll
-    for (int q = 0; q < NS; ++q)
-      if (kin && k0 + q < HF && (k0 + q) % F == 0) {
-        a.ws[(int64_t)s0 * a.ws_stride + HF + hq[q]] = M[q];
-        a.ws[(int64_t)s0 * a.ws_stride + HF + H + hq[q]] = L[q];
-      }
-    return;
-  }
-  // ---- attention values a[eid, h] = exp(logit - m) / l over the WHOLE row
-  //      (get_attention=True, stag/zoo/gat.py:146-147).  The raw logits were stored
-  //      write-through and drained before any ticket, and this team is behind its acquire.
-  wave_sync();
-  const int rb = a.indptr[row], re = a.indptr[row + 1];
-  for (int p = rb + c; p < re; p += LPE) {
-    const int64_t ed = a.eid ? a.eid[p] : p;
-    for (int h = 0; h < H; ++h) {
-      const float lg = a.attn[ed * H + h];
-      a.attn[ed * H + h] = __expf(lg - stat[h]) / stat[H + h];
+      for (int q = 0; q < NS; ++q)
+        if (k0 + q < HF && (k0 + q) % F == 0) {
+          a.stats[(int64_t)row * 2 * H + hq[q]] = M[q];
+          a.stats[(int64_t)row * 2 * H + H + hq[q]] = L[q];
+        }
     }
   }
 }
 
-// attention values of the LONG rows: a[eid, h] = exp(logit - M[h]) / L[h], one wave per segment
-// (<= seg_len edges), statistics from the row's first workspace slot (written by the row's last
-// arriver in gat_fwd_kernel; this kernel runs behind it on the stream).
-__global__ __launch_bounds__(256) void gat_attn_seg_kernel(const GatArgs a) {
-  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (s >= a.n_seg) return;
-  const int lane = threadIdx.x & 63;
-  const int4 q = *reinterpret_cast<const int4*>(a.units + s);     // segments are units [0, n_seg)
-  const int s0 = a.long_seg_ptr[q.x];
-  const float* st = a.ws + (int64_t)s0 * a.ws_stride + a.HF;
-  for (int p = q.y + lane; p < q.y + q.z; p += 64) {
+// Attention values a[eid, h] = exp(logit - m[v,h]) / l[v,h] (get_attention=True,
+// stag/zoo/gat.py:146-147) from the row statistics of gat_fwd_kernel: 8 lanes per unit of the
+// plan, a lane per edge; the noisy logit is redrawn from its counters.
+__global__ __launch_bounds__(256) void gat_attn_kernel(const GatArgs a) {
+  const PhiloxKey key = resolve_epoch(a.key);
+  const int c = threadIdx.x & 7;
+  const int unit = blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (unit >= a.n_units) return;
+  int v, b, len, slot = -1;
+  if (a.units) {
+    const int4 q = *reinterpret_cast<const int4*>(a.units + unit);
+    v = q.x; b = q.y; len = q.z; slot = q.w;
+  } else {
+    v = unit; b = a.indptr[v]; len = a.indptr[v + 1] - b;
+  }
+  const int row = (slot >= 0) ? a.long_rows[v] : v;
+  const int H = a.H, nchunk = (H + 3) / 4;
+  const float* st = a.stats + (int64_t)row * 2 * H;
+  for (int p = b + c; p < b + len; p += 8) {
+    const int u = a.indices[p];
     const int64_t ed = a.eid ? a.eid[p] : p;
-    for (int h = 0; h < a.H; ++h)
-      a.attn[ed * a.H + h] = __expf(a.attn[ed * a.H + h] - st[h]) / st[a.H + h];
+    const uint32_t n = a.nidx ? (uint32_t)a.nidx[p] : a.pos_lo + (uint32_t)p;
+    for (int cc = 0; cc < nchunk; ++cc) {
+      float w[4];
+      head_w4(a, key, n, ed, (uint32_t)cc, w);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int h = 4 * cc + j;
+        if (h < H) {
+          const float e = a.el[(int64_t)u * H + h] + a.er[(int64_t)row * H + h];
+          const float lr = e > 0.f ? e : a.neg_slope * e;
+          const float ns = a.nscale ? a.nscale[(int64_t)row * H + h] : 1.0f;
+          a.attn[ed * H + h] = __expf((w[j] * ns) * lr - st[h]) / st[H + h];
+        }
+      }
+    }
   }
 }
 
@@ -423,28 +425,47 @@ __global__ __launch_bounds__(256) void gat_bwd_edge_kernel(const GatBwdArgs ba) 
           if (h < H) {
             const float e = a.el[(int64_t)u * H + h] + a.er[(int64_t)row * H + h];
             const float ns = a.nscale ? a.nscale[(int64_t)row * H + h] : 1.0f;
-            sa[c * H + h] = a.attn[ed * H + h];
+            const float lr = e > 0.f ? e : a.neg_slope * e;
+            // the attention value, from the row statistics of the forward pass
+            const float at = __expf((w[j] * ns) * lr - a.stats[(int64_t)row * 2 * H + h]) /
+                             a.stats[(int64_t)row * 2 * H + H + h];
+            sa[c * H + h] = at;
+            if (a.attn) a.attn[ed * H + h] = at;      // by-product: the weights of the d ft aggregation
             sc1[c * H + h] = (w[j] * ns) * (e > 0.f ? 1.0f : a.neg_slope);
-            sc2[c * H + h] = (e > 0.f ? e : a.neg_slope * e) * ns;
+            sc2[c * H + h] = lr * ns;
           }
         }
       }
     }
     wave_sync();
-    for (int i = 0; i < nb; ++i) {
-      const int ui = __builtin_amdgcn_ds_bpermute((team_lane0 + i) << 2, u);
-      const int ei = __builtin_amdgcn_ds_bpermute((team_lane0 + i) << 2, edl);
-      float dot = 0.f;
-      if (kin) {
-        float fv[4];
-        load4(a.ft + (int64_t)ui * HF, k0, HF, true, fv);
-        dot = (gv[0] * fv[0] + gv[1] * fv[1]) + (gv[2] * fv[2] + gv[3] * fv[3]);
+    for (int i = 0; i < nb; i += 4) {      // four rows in flight
+      int ui[4], ei[4];
+      float fv[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ui[j] = __builtin_amdgcn_ds_bpermute((team_lane0 + i + j) << 2, u);
+        ei[j] = __builtin_amdgcn_ds_bpermute((team_lane0 + i + j) << 2, edl);
       }
-      for (int m = 1; m < lanes_per_head; m <<= 1) dot += __shfl_xor(dot, m);
-      if (kin && (k0 % F) == 0) {
-        const float ds = sa[i * H + hl] * (dot - gdo);
-        ba.de[(int64_t)ei * H + hl] = ds * sc1[i * H + hl];
-        if (ba.dw) ba.dw[(int64_t)ei * H + hl] = ds * sc2[i * H + hl];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i + j < nb && kin) load4(a.ft + (int64_t)ui[j] * HF, k0, HF, true, fv[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float dot = 0.f;
+        if (i + j < nb && kin)
+          dot = (gv[0] * fv[j][0] + gv[1] * fv[j][1]) + (gv[2] * fv[j][2] + gv[3] * fv[j][3]);
+        // sum over the F/4 lanes of the head: DPP inside a row of 16 lanes, bpermute only beyond
+        if (lanes_per_head >= 2) dot += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dot), 0xB1, 0xF, 0xF, true));
+        if (lanes_per_head >= 4) dot += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dot), 0x4E, 0xF, 0xF, true));
+        if (lanes_per_head >= 8) dot += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dot), 0x141, 0xF, 0xF, true));
+        if (lanes_per_head >= 16) dot += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dot), 0x140, 0xF, 0xF, true));
+        if (lanes_per_head >= 32) dot += __shfl_xor(dot, 16);
+        if (lanes_per_head >= 64) dot += __shfl_xor(dot, 32);
+        if (i + j < nb && kin && (k0 % F) == 0) {
+          const float ds = sa[(i + j) * H + hl] * (dot - gdo);
+          ba.de[(int64_t)ei[j] * H + hl] = ds * sc1[(i + j) * H + hl];
+          if (ba.dw) ba.dw[(int64_t)ei[j] * H + hl] = ds * sc2[(i + j) * H + hl];
+        }
       }
     }
   }
@@ -462,7 +483,7 @@ extern "C" size_t stag_gat_workspace_bytes(int32_t n_seg, int32_t H, int32_t F) 
 extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const float* el,
                             const float* er, const float* ft, int32_t H, int32_t F, float neg_slope,
                             const stag_noise_spec* spec, const float* norm_scale, float* out,
-                            float* attn_out, void* stream) {
+                            float* stats_out, void* stream) {
   if (!csr || !csr->indptr || csr->n_dst < 0 || csr->n_edges < 0) return STAG_EINVAL;
   if (!spec || spec->kind < STAG_NOISE_NONE || spec->kind > STAG_NOISE_BERNOULLI) return STAG_EINVAL;
   if (!out || H <= 0 || F <= 0) return STAG_EINVAL;
@@ -496,12 +517,7 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
   if (spec->kind >= STAG_NOISE_NORMAL && !csr->nidx &&
       (uint64_t)a.pos_lo + (uint64_t)csr->n_edges > (1ull << 32))
     return STAG_ENOSYS;
-  a.out = out; a.attn = attn_out;
-  if (attn_out) {
-    const uint64_t ab = (uint64_t)csr->n_edges * (uint64_t)H * 4u;
-    if (ab >= (1ull << 32)) return STAG_ENOSYS;
-    a.attn_bytes = (uint32_t)ab;
-  }
+  a.out = out; a.stats = stats_out;
   const uint64_t ftb = (uint64_t)csr->n_src * (uint64_t)HF * 4u;
   a.ft_bytes = (ftb < (1ull << 32) && csr->n_src < (1 << 24)) ? (uint32_t)ftb : 0u;
 
@@ -544,16 +560,60 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
     default: STAG_GAT_LAUNCH(4); break;
   }
 #undef STAG_GAT_LAUNCH
-  if (a.attn && a.ws && a.n_seg > 0)    // the long rows' attention values, one wave per segment
-    hipLaunchKernelGGL(gat_attn_seg_kernel, dim3((a.n_seg + 3) / 4), dim3(256), 0, s, a);
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}
+
+// the argument block the attention / backward kernels share with the forward
+static int fill_edge_args(GatArgs& a, const stag_csr* csr, const stag_plan* plan, const float* el,
+                          const float* er, int32_t H, float neg_slope, const stag_noise_spec* spec,
+                          const float* norm_scale, const float* stats) {
+  a.indptr = csr->indptr; a.indices = csr->indices; a.eid = csr->eid; a.nidx = csr->nidx;
+  a.n_rows = csr->n_dst; a.el = el; a.er = er;
+  a.nscale = spec->in_norm ? norm_scale : nullptr;
+  a.H = H; a.neg_slope = neg_slope;
+  a.kind = spec->kind; a.p0 = spec->p0; a.p1 = spec->p1; a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar;
+  a.pmode = spec->kind >= STAG_NOISE_NORMAL ? spec->param_mode : 0;
+  a.relu = spec->relu ? kFlagRelu : 0;
+  a.key.k0 = (uint32_t)(spec->seed & 0xFFFFFFFFull); a.key.k1 = (uint32_t)(spec->seed >> 32);
+  a.key.o0 = (uint32_t)(spec->offset & 0xFFFFFFFFull); a.key.o1 = (uint32_t)(spec->offset >> 32);
+  a.key.epoch = spec->epoch;
+  a.pos_lo = (uint32_t)((uint64_t)spec->pos_base & 0xFFFFFFFFull);
+  a.pos_hi = (uint32_t)((uint64_t)spec->pos_base >> 32);
+  a.stats = const_cast<float*>(stats);
+  a.n_units = csr->n_dst;
+  if (plan && plan->n_units > 0) {
+    if (!plan->units || !aligned16(plan->units)) return STAG_EINVAL;
+    if (plan->n_seg > 0 && !plan->long_rows) return STAG_EINVAL;
+    a.units = plan->units; a.n_units = plan->n_units; a.long_rows = plan->long_rows;
+  }
+  return STAG_OK;
+}
+
+extern "C" int stag_gat_attn(const stag_csr* csr, const stag_plan* plan, const float* el,
+                             const float* er, int32_t H, float neg_slope, const stag_noise_spec* spec,
+                             const float* norm_scale, const float* stats, float* attn_out,
+                             void* stream) {
+  if (!csr || !csr->indptr || csr->n_dst < 0 || csr->n_edges < 0) return STAG_EINVAL;
+  if (!spec || spec->kind < STAG_NOISE_NONE || spec->kind > STAG_NOISE_BERNOULLI || spec->deriv) return STAG_EINVAL;
+  if (!attn_out || !stats || H <= 0 || H > 64) return STAG_EINVAL;
+  if (spec->chunk_base != 0) return STAG_ENOSYS;
+  if (spec->in_norm && !norm_scale) return STAG_EINVAL;
+  if (csr->n_dst == 0 || csr->n_edges == 0) return STAG_OK;
+  if (!csr->indices || !el || !er) return STAG_EINVAL;
+  if (spec->kind == STAG_NOISE_EXPLICIT && !spec->p0) return STAG_EINVAL;
+  GatArgs a{};
+  const int rc = fill_edge_args(a, csr, plan, el, er, H, neg_slope, spec, norm_scale, stats);
+  if (rc) return rc;
+  a.attn = attn_out;
+  hipLaunchKernelGGL(gat_attn_kernel, dim3((a.n_units + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }
 
 extern "C" int stag_gat_bwd_edge(const stag_csr* csr, const stag_plan* plan, const float* el,
-                                 const float* er, const float* ft, const float* attn, const float* g,
+                                 const float* er, const float* ft, const float* stats, const float* g,
                                  const float* gdo, int32_t H, int32_t F, float neg_slope,
                                  const stag_noise_spec* spec, const float* norm_scale, float* de,
-                                 float* dw, void* stream) {
+                                 float* dw, float* attn_out, void* stream) {
   if (!csr || !csr->indptr || csr->n_dst < 0 || csr->n_edges < 0) return STAG_EINVAL;
   if (!spec || spec->kind < STAG_NOISE_NONE || spec->kind > STAG_NOISE_BERNOULLI || spec->deriv) return STAG_EINVAL;
   if (!de || H <= 0 || F <= 0) return STAG_EINVAL;
@@ -563,31 +623,15 @@ extern "C" int stag_gat_bwd_edge(const stag_csr* csr, const stag_plan* plan, con
   if (spec->chunk_base != 0) return STAG_ENOSYS;
   if (spec->in_norm && !norm_scale) return STAG_EINVAL;
   if (csr->n_dst == 0 || csr->n_edges == 0) return STAG_OK;
-  if (!csr->indices || !el || !er || !ft || !attn || !g || !gdo) return STAG_EINVAL;
+  if (!csr->indices || !el || !er || !ft || !stats || !g || !gdo) return STAG_EINVAL;
   if (!aligned16(ft) || !aligned16(g)) return STAG_EINVAL;
   if (spec->kind == STAG_NOISE_EXPLICIT && !spec->p0) return STAG_EINVAL;
   const int HF = (int)HF64;
   GatBwdArgs ba{};
   GatArgs& a = ba.f;
-  a.indptr = csr->indptr; a.indices = csr->indices; a.eid = csr->eid; a.nidx = csr->nidx;
-  a.n_rows = csr->n_dst; a.el = el; a.er = er; a.ft = ft;
-  a.nscale = spec->in_norm ? norm_scale : nullptr;
-  a.H = H; a.F = F; a.HF = HF; a.neg_slope = neg_slope;
-  a.kind = spec->kind; a.p0 = spec->p0; a.p1 = spec->p1; a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar;
-  a.pmode = spec->kind >= STAG_NOISE_NORMAL ? spec->param_mode : 0;
-  a.relu = spec->relu ? kFlagRelu : 0;
-  a.key.k0 = (uint32_t)(spec->seed & 0xFFFFFFFFull); a.key.k1 = (uint32_t)(spec->seed >> 32);
-  a.key.o0 = (uint32_t)(spec->offset & 0xFFFFFFFFull); a.key.o1 = (uint32_t)(spec->offset >> 32);
-  a.key.epoch = spec->epoch;
-  a.pos_lo = (uint32_t)((uint64_t)spec->pos_base & 0xFFFFFFFFull);
-  a.pos_hi = (uint32_t)((uint64_t)spec->pos_base >> 32);
-  a.attn = const_cast<float*>(attn);
-  a.n_units = csr->n_dst;
-  if (plan && plan->n_units > 0) {
-    if (!plan->units || !aligned16(plan->units)) return STAG_EINVAL;
-    if (plan->n_seg > 0 && !plan->long_rows) return STAG_EINVAL;
-    a.units = plan->units; a.n_units = plan->n_units; a.long_rows = plan->long_rows;
-  }
+  const int rc = fill_edge_args(a, csr, plan, el, er, H, neg_slope, spec, norm_scale, stats);
+  if (rc) return rc;
+  a.ft = ft; a.F = F; a.HF = HF; a.attn = attn_out;
   ba.g = g; ba.gdo = gdo; ba.de = de; ba.dw = dw;
   const int nchunk = (HF + 3) / 4;
   int lpe = 4;

@@ -146,6 +146,7 @@ class AmortizedDistribution(Distribution):
         self.distribution_type = base_distribution_class
         self.out_features = out_features
         self.new_parameters = None
+        self._base = None
         if init_like is not None:
             self._init_like(init_like)
 
@@ -177,10 +178,12 @@ class AmortizedDistribution(Distribution):
             self.new_parameters = {
                 name: ops.node_linear(h, head.weight.t()) + head.bias
                 for name, head in ((n, self.parameters_mlp[n]) for n in self.new_parameter_names)}
+            self._base = None
             return self
         src, dst = graph.edges()
         h = self.embedding_mlp(torch.cat([feat[src], feat[dst]], dim=-1))
         self.new_parameters = {k: self.parameters_mlp[k](h) for k in self.new_parameter_names}
+        self._base = None
         return self
 
     def arguments(self):
@@ -191,4 +194,10 @@ class AmortizedDistribution(Distribution):
 
     @property
     def base_distribution(self):
-        return self.base_distribution_class(**self.arguments())
+        """Built once per condition() (the layer reads it several times per forward: each build
+        is an exp over [E, out_features], and torch's argument validation — two reductions over the
+        parameters and a host synchronisation — is skipped: the scale is an exp, positive by
+        construction)."""
+        if self._base is None:
+            self._base = self.base_distribution_class(**self.arguments(), validate_args=False)
+        return self._base

@@ -494,21 +494,31 @@ class _GatAggregate(torch.autograd.Function):
         nscale = _gat_norm_scale(csrv, noise, H, seg_len, dev) if spec.in_norm else None
         need_grad = any(ctx.needs_input_grad[:4])
         out = torch.empty((csrv.n_dst, H, F), dtype=torch.float32, device=dev)
-        attn = (torch.empty((csrv.n_edges, H), dtype=torch.float32, device=dev)
-                if (want_attn or need_grad) else None)      # the backward needs a[E, H]
+        # softmax statistics per row [N, 2H]: the backward and the attention values are computed
+        # from them (storing a[E, H] from the forward kernel cost it 250 us at cfg5)
+        stats = (torch.empty((csrv.n_dst, 2 * H), dtype=torch.float32, device=dev)
+                 if (want_attn or need_grad) else None)
         plan_t = csrv.plan(seg_len)
         nbytes = _lib.lib().stag_gat_workspace_bytes(plan_t["n_seg"], H, F) if plan_t is not None else 0
         plan_c, _keep = _plan_struct(csrv, seg_len, 1, nbytes, dev)
         cs = csrv.struct()
+        attn = None
         with _lib.on_device(dev):
             rc = _lib.lib().stag_gat_fwd(C.byref(cs), C.byref(plan_c) if plan_c is not None else None,
                                          _lib.ptr(el), _lib.ptr(er), _lib.ptr(ft), H, F,
                                          float(neg_slope), C.byref(spec), _lib.ptr(nscale),
-                                         _lib.ptr(out), _lib.ptr(attn), _lib.stream_of(dev))
-        _lib.check(rc, "stag_gat_fwd")
+                                         _lib.ptr(out), _lib.ptr(stats), _lib.stream_of(dev))
+            _lib.check(rc, "stag_gat_fwd")
+            if want_attn:
+                attn = torch.empty((csrv.n_edges, H), dtype=torch.float32, device=dev)
+                rc = _lib.lib().stag_gat_attn(C.byref(cs), C.byref(plan_c) if plan_c is not None else None,
+                                              _lib.ptr(el), _lib.ptr(er), H, float(neg_slope), C.byref(spec),
+                                              _lib.ptr(nscale), _lib.ptr(stats), _lib.ptr(attn),
+                                              _lib.stream_of(dev))
+                _lib.check(rc, "stag_gat_attn")
         if need_grad:
             ctx.graph, ctx.noise, ctx.neg_slope, ctx.seg_len = _owner(graph), noise, float(neg_slope), seg_len
-            ctx.save_for_backward(el, er, ft, w, attn, out, nscale)
+            ctx.save_for_backward(el, er, ft, w, stats, out, nscale)
         if want_attn:
             ctx.mark_non_differentiable(attn)
             return out, attn
@@ -516,7 +526,7 @@ class _GatAggregate(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out, *unused):
-        el, er, ft, w, attn, out, nscale = ctx.saved_tensors
+        el, er, ft, w, stats, out, nscale = ctx.saved_tensors
         graph, noise = ctx.graph, ctx.noise
         H, F = ft.shape[1], ft.shape[2]
         HF = H * F
@@ -533,14 +543,17 @@ class _GatAggregate(torch.autograd.Function):
         want_dw = w is not None and ctx.needs_input_grad[3]
         de = torch.empty((csrv.n_edges, H), dtype=torch.float32, device=dev)
         dw = torch.empty((csrv.n_edges, H), dtype=torch.float32, device=dev) if want_dw else None
+        # a[E, H], a by-product of the edge pass: the weights of the d ft aggregation
+        attn = (torch.empty((csrv.n_edges, H), dtype=torch.float32, device=dev)
+                if ctx.needs_input_grad[2] else None)
         plan_c, _keep = _plan_struct(csrv, ctx.seg_len, 1, 0, dev)
         cs = csrv.struct()
         with _lib.on_device(dev):
             rc = _lib.lib().stag_gat_bwd_edge(
                 C.byref(cs), C.byref(plan_c) if plan_c is not None else None, _lib.ptr(el),
-                _lib.ptr(er), _lib.ptr(ft), _lib.ptr(attn), _lib.ptr(G), _lib.ptr(gdo), H, F,
+                _lib.ptr(er), _lib.ptr(ft), _lib.ptr(stats), _lib.ptr(G), _lib.ptr(gdo), H, F,
                 ctx.neg_slope, C.byref(spec), _lib.ptr(nscale), _lib.ptr(de), _lib.ptr(dw),
-                _lib.stream_of(dev))
+                _lib.ptr(attn), _lib.stream_of(dev))
         if rc == -38:
             raise NotImplementedError("GAT backward needs out_feats % 4 == 0 and out_feats / 4 a power of two")
         _lib.check(rc, "stag_gat_bwd_edge")
