@@ -149,7 +149,9 @@ def main():
         # path with several ranks sharing one card (RCCL refuses two ranks on one device)
         backend = os.environ.get("STAG_BENCH_BACKEND", "nccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            import datetime
+            # a collective that never completes should end the run in minutes, not in half an hour
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=5))
         else:
             dist.init_process_group(backend)
 
