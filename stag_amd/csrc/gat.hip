@@ -333,17 +333,25 @@ __global__ __launch_bounds__(256) void gat_attn_kernel(const GatArgs a) {
     const int64_t ed = a.eid ? a.eid[p] : p;
     const uint32_t n = a.nidx ? (uint32_t)a.nidx[p] : a.pos_lo + (uint32_t)p;
     for (int cc = 0; cc < nchunk; ++cc) {
-      float w[4];
+      float w[4], at[4];
       head_w4(a, key, n, ed, (uint32_t)cc, w);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int h = 4 * cc + j;
+        at[j] = 0.f;
         if (h < H) {
           const float e = a.el[(int64_t)u * H + h] + a.er[(int64_t)row * H + h];
           const float lr = e > 0.f ? e : a.neg_slope * e;
           const float ns = a.nscale ? a.nscale[(int64_t)row * H + h] : 1.0f;
-          a.attn[ed * H + h] = __expf((w[j] * ns) * lr - st[h]) / st[H + h];
+          at[j] = __expf((w[j] * ns) * lr - st[h]) / st[H + h];
         }
+      }
+      if ((H & 3) == 0) {       // one 16-byte store per head chunk
+        *reinterpret_cast<float4*>(a.attn + ed * H + 4 * cc) = make_float4(at[0], at[1], at[2], at[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (4 * cc + j < H) a.attn[ed * H + 4 * cc + j] = at[j];
       }
     }
   }
