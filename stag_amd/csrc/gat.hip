@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void gat_bwd_edge_kernel(const GatBwdArgs ba) 
       edl = (int)ed;
       const uint32_t n = a.nidx ? (uint32_t)a.nidx[p] : a.pos_lo + (uint32_t)p;
       for (int cc = 0; cc < nchunk; ++cc) {
-        float w[4];
+        float w[4], at4[4] = {0.f, 0.f, 0.f, 0.f};
         head_w4(a, key, n, ed, (uint32_t)cc, w);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -438,9 +438,18 @@ __global__ __launch_bounds__(256) void gat_bwd_edge_kernel(const GatBwdArgs ba) 
             const float at = __expf((w[j] * ns) * lr - a.stats[(int64_t)row * 2 * H + h]) /
                              a.stats[(int64_t)row * 2 * H + H + h];
             sa[c * H + h] = at;
-            if (a.attn) a.attn[ed * H + h] = at;      // by-product: the weights of the d ft aggregation
+            at4[j] = at;
             sc1[c * H + h] = (w[j] * ns) * (e > 0.f ? 1.0f : a.neg_slope);
             sc2[c * H + h] = lr * ns;
+          }
+        }
+        if (a.attn) {      // by-product: the weights of the d ft aggregation, 16 bytes per head chunk
+          if ((H & 3) == 0) {
+            *reinterpret_cast<float4*>(a.attn + ed * H + 4 * cc) = make_float4(at4[0], at4[1], at4[2], at4[3]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (4 * cc + j < H) a.attn[ed * H + 4 * cc + j] = at4[j];
           }
         }
       }
