@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 9
+#define STAG_ABI_VERSION 10
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -294,6 +294,7 @@ int stag_gat_attn(const stag_csr* csr, const stag_plan* plan, const float* el, c
 
 /* Per-edge part of the GAT backward (the rest is stag_agg_fwd on the transposed CSR):
  *   da = <g[v,h,:], ft[u,h,:]>,  ds = a * (da - gdo[v,h]),  gdo[v,h] = <g[v,h,:], out[v,h,:]>
+ *   (`out` is the forward's output [M, H*F]; gdo is formed in the kernel)
  *   de[eid,h] = ds * w * lrelu'(el[u,h] + er[v,h])      sum over in-edges -> d er, over out-edges -> d el
  *   dw[eid,h] = ds * lrelu(...) * norm_scale            (NULL: not wanted)
  * a is recomputed from `stats`; attn_out (may be NULL) receives a[eid, h] as a by-product:
@@ -301,7 +302,7 @@ int stag_gat_attn(const stag_csr* csr, const stag_plan* plan, const float* el, c
  * EXPLICIT weights a[E,H] and spec.group = F.  Requires F % 4 == 0, F/4 a power of two.  */
 int stag_gat_bwd_edge(const stag_csr* csr, const stag_plan* plan, const float* el,
                       const float* er, const float* ft, const float* stats, const float* g,
-                      const float* gdo, int32_t H, int32_t F, float neg_slope,
+                      const float* out, int32_t H, int32_t F, float neg_slope,
                       const stag_noise_spec* spec, const float* norm_scale, float* de,
                       float* dw, float* attn_out, void* stream);
 

@@ -113,7 +113,7 @@ def lib():
     l.stag_gat_bwd_edge.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp, _vp, _vp, _vp,
                                     C.c_int32, C.c_int32, C.c_float, C.POINTER(NoiseSpec), _vp, _vp,
                                     _vp, _vp, _vp]
-    if l.stag_abi_version() != 9:
+    if l.stag_abi_version() != 10:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     _lib = l
     return l

@@ -370,7 +370,8 @@ __global__ __launch_bounds__(256) void gat_attn_kernel(const GatArgs a) {
 struct GatBwdArgs {
   GatArgs f;
   const float* g;      // [n_rows, H*F]
-  const float* gdo;    // [n_rows, H]
+  const float* gdo;    // [n_rows, H] = <g[v,h,:], out[v,h,:]>, or null: computed here from `out`
+  const float* out;    // [n_rows, H*F] forward output (used when gdo is null)
   float* de;           // [E, H] by edge id
   float* dw;           // [E, H] by edge id, or null
 };
@@ -407,11 +408,25 @@ __global__ __launch_bounds__(256) void gat_bwd_edge_kernel(const GatBwdArgs ba) 
   const int nchunk = (H + 3) / 4;
   const int lanes_per_head = F / 4;
 
+  // sum over the F/4 lanes of a head: DPP inside a row of 16 lanes, bpermute only beyond
+  auto head_sum = [&](float x) {
+    if (lanes_per_head >= 2) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
+    if (lanes_per_head >= 4) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));
+    if (lanes_per_head >= 8) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));
+    if (lanes_per_head >= 16) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true));
+    if (lanes_per_head >= 32) x += __shfl_xor(x, 16);
+    if (lanes_per_head >= 64) x += __shfl_xor(x, 32);
+    return x;
+  };
   float gv[4] = {0.f, 0.f, 0.f, 0.f};
   float gdo = 0.f;
-  if (kin) {
-    load4(ba.g + (int64_t)row * HF, k0, HF, true, gv);
-    gdo = ba.gdo[(int64_t)row * H + hl];
+  if (kin) load4(ba.g + (int64_t)row * HF, k0, HF, true, gv);
+  if (ba.gdo) {
+    if (kin) gdo = ba.gdo[(int64_t)row * H + hl];
+  } else {                      // <g[v,h,:], out[v,h,:]> of the unit's own row
+    float ov[4] = {0.f, 0.f, 0.f, 0.f};
+    if (kin) load4(ba.out + (int64_t)row * HF, k0, HF, true, ov);
+    gdo = head_sum((gv[0] * ov[0] + gv[1] * ov[1]) + (gv[2] * ov[2] + gv[3] * ov[3]));
   }
 
   for (int i0 = 0; i0 < len; i0 += LPE) {
@@ -471,13 +486,7 @@ __global__ __launch_bounds__(256) void gat_bwd_edge_kernel(const GatBwdArgs ba) 
         float dot = 0.f;
         if (i + j < nb && kin)
           dot = (gv[0] * fv[j][0] + gv[1] * fv[j][1]) + (gv[2] * fv[j][2] + gv[3] * fv[j][3]);
-        // sum over the F/4 lanes of the head: DPP inside a row of 16 lanes, bpermute only beyond
-        if (lanes_per_head >= 2) dot += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dot), 0xB1, 0xF, 0xF, true));
-        if (lanes_per_head >= 4) dot += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dot), 0x4E, 0xF, 0xF, true));
-        if (lanes_per_head >= 8) dot += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dot), 0x141, 0xF, 0xF, true));
-        if (lanes_per_head >= 16) dot += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dot), 0x140, 0xF, 0xF, true));
-        if (lanes_per_head >= 32) dot += __shfl_xor(dot, 16);
-        if (lanes_per_head >= 64) dot += __shfl_xor(dot, 32);
+        dot = head_sum(dot);
         if (i + j < nb && kin && (k0 % F) == 0) {
           const float ds = sa[(i + j) * H + hl] * (dot - gdo);
           ba.de[(int64_t)ei[j] * H + hl] = ds * sc1[(i + j) * H + hl];
@@ -628,7 +637,7 @@ extern "C" int stag_gat_attn(const stag_csr* csr, const stag_plan* plan, const f
 
 extern "C" int stag_gat_bwd_edge(const stag_csr* csr, const stag_plan* plan, const float* el,
                                  const float* er, const float* ft, const float* stats, const float* g,
-                                 const float* gdo, int32_t H, int32_t F, float neg_slope,
+                                 const float* out, int32_t H, int32_t F, float neg_slope,
                                  const stag_noise_spec* spec, const float* norm_scale, float* de,
                                  float* dw, float* attn_out, void* stream) {
   if (!csr || !csr->indptr || csr->n_dst < 0 || csr->n_edges < 0) return STAG_EINVAL;
@@ -640,8 +649,8 @@ extern "C" int stag_gat_bwd_edge(const stag_csr* csr, const stag_plan* plan, con
   if (spec->chunk_base != 0) return STAG_ENOSYS;
   if (spec->in_norm && !norm_scale) return STAG_EINVAL;
   if (csr->n_dst == 0 || csr->n_edges == 0) return STAG_OK;
-  if (!csr->indices || !el || !er || !ft || !stats || !g || !gdo) return STAG_EINVAL;
-  if (!aligned16(ft) || !aligned16(g)) return STAG_EINVAL;
+  if (!csr->indices || !el || !er || !ft || !stats || !g || !out) return STAG_EINVAL;
+  if (!aligned16(ft) || !aligned16(g) || !aligned16(out)) return STAG_EINVAL;
   if (spec->kind == STAG_NOISE_EXPLICIT && !spec->p0) return STAG_EINVAL;
   const int HF = (int)HF64;
   GatBwdArgs ba{};
@@ -649,7 +658,7 @@ extern "C" int stag_gat_bwd_edge(const stag_csr* csr, const stag_plan* plan, con
   const int rc = fill_edge_args(a, csr, plan, el, er, H, neg_slope, spec, norm_scale, stats);
   if (rc) return rc;
   a.ft = ft; a.F = F; a.HF = HF; a.attn = attn_out;
-  ba.g = g; ba.gdo = gdo; ba.de = de; ba.dw = dw;
+  ba.g = g; ba.gdo = nullptr; ba.out = out; ba.de = de; ba.dw = dw;
   const int nchunk = (HF + 3) / 4;
   int lpe = 4;
   while (lpe < nchunk) lpe <<= 1;

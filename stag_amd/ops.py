@@ -533,7 +533,6 @@ class _GatAggregate(torch.autograd.Function):
         csrv, csrt = graph.csr, graph.csr_t
         dev = ft.device
         G = _f32c(grad_out)
-        gdo = (G * out).sum(-1).contiguous()                       # <G, out> per (v, h)
         if noise is not None:
             spec = noise.spec()
         elif w is not None:
@@ -551,7 +550,7 @@ class _GatAggregate(torch.autograd.Function):
         with _lib.on_device(dev):
             rc = _lib.lib().stag_gat_bwd_edge(
                 C.byref(cs), C.byref(plan_c) if plan_c is not None else None, _lib.ptr(el),
-                _lib.ptr(er), _lib.ptr(ft), _lib.ptr(stats), _lib.ptr(G), _lib.ptr(gdo), H, F,
+                _lib.ptr(er), _lib.ptr(ft), _lib.ptr(stats), _lib.ptr(G), _lib.ptr(out), H, F,
                 ctx.neg_slope, C.byref(spec), _lib.ptr(nscale), _lib.ptr(de), _lib.ptr(dw),
                 _lib.ptr(attn), _lib.stream_of(dev))
         if rc == -38:
