@@ -580,4 +580,30 @@ def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False
     w = weight if torch.is_tensor(weight) else None
     if w is not None and w.shape[0] != graph.number_of_edges():
         raise AssertionError("edge_weight.shape[0] != number_of_edges")
+    H, F = ft.shape[1], ft.shape[2]
+    if H > 64 or H * F > 256 or (F % 4 != 0 or ((F // 4) & (F // 4 - 1)) != 0) and torch.is_grad_enabled():
+        return _gat_composed(graph, el, er, ft, neg_slope, noise, w, want_attn, seg_len)
     return _GatAggregate.apply(el, er, ft, w, graph, noise, neg_slope, want_attn, seg_len)
+
+
+def _gat_composed(graph, el, er, ft, neg_slope, noise, w, want_attn, seg_len):
+    """The same layer outside the fused kernel's shape limits (one wave spans the H*F row: H <= 64,
+    H*F <= 256; its backward wants F/4 a power of two): logits and the edge softmax as torch ops over
+    [E, H] (segment max by scatter-reduce), the sums and the weighted aggregation on the aggregation
+    kernel, which tiles any width.  Device-only like everything else; several passes instead of one."""
+    N, H, F = ft.shape
+    _, dst = graph.edges()
+    dst = dst.long()
+    e = torch.nn.functional.leaky_relu(gather_rows(graph, el, "src") + gather_rows(graph, er, "dst"), neg_slope)
+    if noise is not None:
+        w = noise.materialize()              # [E, H], relu / in-norm applied (stag/zoo/gat.py:117-119)
+    if w is not None:
+        e = e * (w if w.dim() == 2 else w.reshape(w.shape[0], -1))
+    m = torch.full((N, H), float("-inf"), dtype=e.dtype, device=e.device)
+    m = m.scatter_reduce(0, dst.unsqueeze(1).expand(-1, H), e.detach(), reduce="amax", include_self=True)
+    p = torch.exp(e - m[dst])
+    l = aggregate(graph, torch.ones(1, H, device=e.device), p, seg_len=seg_len, _broadcast_x=True)   # sum_in p
+    a = p / gather_rows(graph, l, "dst")
+    out = aggregate(graph, ft.reshape(N, H * F), a.repeat_interleave(F, dim=1), seg_len=seg_len)
+    out = out.reshape(N, H, F)
+    return (out, a.detach()) if want_attn else out

@@ -645,3 +645,41 @@ def test_no_memory_growth_across_training_steps(dev):
         assert mem[4] <= mem[2], (kw, mem)
         del layer
         gc.collect()
+
+
+@pytest.mark.parametrize("H,F", [(4, 128), (2, 6), (3, 12)])
+def test_gat_outside_the_fused_kernel_limits(dev, oracle, H, F):
+    """H*F > 256 (one wave no longer spans the row) and, under autograd, F/4 not a power of two:
+    the layer is composed from the aggregation kernel and [E, H] torch ops; forward against the
+    oracle, gradients against a float64 torch restatement."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    from util import random_graph
+    n = 60
+    g = random_graph(n, 500, seed=5, hub=80, device=dev)
+    src, dst = (t.long() for t in g.edges())
+    torch.manual_seed(H * 100 + F)
+    el, er, ft = (torch.randn(n, H, device=dev, requires_grad=True), torch.randn(n, H, device=dev, requires_grad=True),
+                  torch.randn(n, H, F, device=dev, requires_grad=True))
+    noise = stag_amd.EdgeNoise(g, H, _lib.NOISE_NORMAL, 1.0, 0.5, seed=3, offset=2)
+    out, attn = ops.gat_aggregate(g, el, er, ft, 0.2, noise, want_attn=True)
+    og = oracle_graph(oracle, g)
+    sp = oracle.make_spec("normal", 1.0, 0.5, seed=3, offset=2, Dn=H, n_edges=g.number_of_edges())
+    ref, ref_attn = oracle.gat_fwd(og, el.detach().cpu().numpy(), er.detach().cpu().numpy(), ft.detach().cpu().numpy(),
+                                   0.2, sp, want_attn=True)
+    assert_close(out, ref, what="composed GAT out")
+    assert_close(attn, ref_attn, what="composed GAT attention")
+    G = torch.randn_like(out)
+    out.backward(G)
+    # float64 restatement with the same (materialised) weights
+    w = noise.materialize().double()
+    el2, er2, ft2 = (t.detach().double().requires_grad_(True) for t in (el, er, ft))
+    e = torch.nn.functional.leaky_relu(el2[src] + er2[dst], 0.2) * w
+    m = torch.full((n, H), -1e300, dtype=torch.float64, device=dev).scatter_reduce(0, dst.unsqueeze(1).expand(-1, H), e.detach(), "amax")
+    p = torch.exp(e - m[dst])
+    l = torch.zeros(n, H, dtype=torch.float64, device=dev).index_add(0, dst, p)
+    a = p / l[dst]
+    o2 = torch.zeros(n, H, F, dtype=torch.float64, device=dev).index_add(0, dst, a.unsqueeze(-1) * ft2[src])
+    o2.backward(G.double())
+    for got, want, name in ((el.grad, el2.grad, "d el"), (er.grad, er2.grad, "d er"), (ft.grad, ft2.grad, "d ft")):
+        assert_close(got, want.float().cpu().numpy(), what=name)
