@@ -263,9 +263,17 @@ class Graph:
         from .noise import EdgeNoise
         if not isinstance(message_func, fn.Message) or not isinstance(reduce_func, fn.Reduce):
             raise TypeError("update_all takes stag_amd.function builtins")
-        if reduce_func.kind == "max":
-            raise NotImplementedError("max reducer (SAGE 'pool') is outside the accelerated path")
         kind = message_func.kind
+        if reduce_func.kind == "max":          # composed, not fused (ops.aggregate_max)
+            if kind not in ("copy_u", "u_mul_e"):
+                raise NotImplementedError(f"update_all max with message {kind}")
+            x = self.srcdata[message_func.fields[0]]
+            w = self.edata[message_func.fields[1]] if kind == "u_mul_e" else None
+            if torch.is_tensor(w):
+                w = w.reshape(w.shape[0], -1)
+            out = ops.aggregate_max(self, x.reshape(x.shape[0], -1), w)
+            self.dstdata[reduce_func.out] = out.reshape((self._n,) + tuple(x.shape[1:]))
+            return
         if kind == "copy_u":
             x, w = self.srcdata[message_func.fields[0]], None
         elif kind == "u_mul_e":

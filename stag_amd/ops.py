@@ -369,6 +369,25 @@ def aggregate(graph, x, weight=None, reduce="sum", src_scale=None, dst_scale=Non
                             _f32c(dst_scale), seg_len, _broadcast_x)
 
 
+def aggregate_max(graph, x, weight=None):
+    """out[v,:] = max_{e=(u->v)} w[e,:] * x[u,:], 0 for rows without in-edges (DGL's `fn.max`;
+    GraphSAGE 'pool', stag/zoo/graph_sage.py:90-93).  Not a fused path: the messages are formed
+    ([E, D]: a kernel-backed gather, the noise materialised) and reduced with scatter-amax."""
+    if x.dim() != 2:
+        raise ValueError("aggregate_max expects x of shape [N, D]")
+    m = gather_rows(graph, x, "src")
+    if isinstance(weight, EdgeNoise):
+        weight = weight.materialize()
+    if weight is not None:
+        if weight.shape[0] != graph.number_of_edges():
+            raise AssertionError("edge_weight.shape[0] != number_of_edges")
+        m = m * (weight if weight.dim() == 2 else weight.unsqueeze(1))
+    _, dst = graph.edges()
+    n = graph.number_of_dst_nodes() if hasattr(graph, "number_of_dst_nodes") else graph.number_of_nodes()
+    out = torch.zeros((n, x.shape[1]), dtype=m.dtype, device=m.device)
+    return out.scatter_reduce(0, dst.long().unsqueeze(1).expand(-1, x.shape[1]), m, reduce="amax", include_self=False)
+
+
 def aggregate_mc(graph, x, noise, n_samples, offset_stride=1, reduce="sum", src_scale=None,
                  dst_scale=None, seg_len=DEFAULT_SEG_LEN):
     """[n_samples, N, D]: sample s == aggregate(graph, x, noise at offset + s * offset_stride), bit for

@@ -50,9 +50,8 @@ class GraphSAGE(torch.nn.Module):
             neigh = ops.aggregate(graph, feat_src, edge_weight, reduce="sum")
             degs = graph.in_degrees().to(feat_dst)
             h_neigh = self.fc_neigh((neigh + feat_dst) / (degs.unsqueeze(-1) + 1))
-        elif self._aggre_type == "pool":
-            raise NotImplementedError("'pool' (max reducer) is outside the accelerated path; "
-                                      "no BASELINE config uses it (scripts pin 'mean')")
+        elif self._aggre_type == "pool":     # max reducer: composed, not fused (ops.aggregate_max)
+            h_neigh = self.fc_neigh(ops.aggregate_max(graph, torch.relu(self.fc_pool(feat_src)), edge_weight))
         else:
             raise NotImplementedError("'lstm' aggregator is outside the accelerated path")
         rst = h_neigh if self._aggre_type == "gcn" else ops.node_linear(h_self, self.fc_self.weight.t()) + h_neigh
