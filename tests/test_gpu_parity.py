@@ -353,6 +353,19 @@ def test_segment_reduce(dev, oracle):
         got = ops.segment_reduce(torch.from_numpy(x).to(dev), torch.from_numpy(offs).to(dev), red)
         ref = oracle.segment_reduce(x, offs, oracle.REDUCE_MEAN if red == "mean" else oracle.REDUCE_SUM)
         assert_close(got, ref, what=f"segment {red}")
+    # long segments (average > 256 rows) take the chunked two-stage form; a long, an empty, a
+    # short and a chunk-aligned segment side by side, with the gradient
+    sizes = np.array([4000, 0, 10, 512, 478])
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    x = rng.standard_normal((int(sizes.sum()), 24)).astype(np.float32)
+    for red in ("sum", "mean"):
+        xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+        got = ops.segment_reduce(xd, torch.from_numpy(offs).to(dev), red)
+        ref = oracle.segment_reduce(x, offs, oracle.REDUCE_MEAN if red == "mean" else oracle.REDUCE_SUM)
+        assert np.abs(got.detach().cpu().numpy() - ref).max() <= TOL * (1 + np.abs(ref).max()) * 4, red
+        got.sum().backward()
+        want = np.repeat(1.0 / np.maximum(sizes, 1) if red == "mean" else np.ones(len(sizes)), sizes)
+        assert np.allclose(xd.grad.cpu().numpy(), want[:, None], rtol=1e-6)
 
 
 @pytest.mark.parametrize("H,F", [(3, 4), (8, 32), (4, 5), (1, 64), (4, 64), (2, 6)])
