@@ -175,9 +175,15 @@ class AmortizedDistribution(Distribution):
                 h = h + lin.bias
             for mod in list(self.embedding_mlp)[1:]:
                 h = mod(h)
-            self.new_parameters = {
-                name: ops.node_linear(h, head.weight.t()) + head.bias
-                for name, head in ((n, self.parameters_mlp[n]) for n in self.new_parameter_names)}
+            heads = [self.parameters_mlp[n] for n in self.new_parameter_names]
+            if sum(hd.out_features for hd in heads) <= 64:
+                # narrow heads ([E, 1] parameters): ONE product over the E rows of h, then split
+                y = ops.node_linear(h, torch.cat([hd.weight for hd in heads], 0).t())
+                y = y + torch.cat([hd.bias for hd in heads], 0)
+                outs = torch.split(y, [hd.out_features for hd in heads], dim=1)
+            else:   # wide heads stay separate: their outputs are consumed as contiguous [E, D] rows
+                outs = [ops.node_linear(h, hd.weight.t()) + hd.bias for hd in heads]
+            self.new_parameters = dict(zip(self.new_parameter_names, outs))
             self._base = None
             return self
         src, dst = graph.edges()
