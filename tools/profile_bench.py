@@ -70,13 +70,14 @@ def main():
     ap.add_argument("--feat", type=int, default=128)
     ap.add_argument("--graph", default="arxiv")
     ap.add_argument("--seg-len", type=int, default=64)
+    ap.add_argument("--tag", default="n1", help="file-name tag: bench_<tag>.json, bench_<tag>_kernel_stats.csv, ...")
     ap.add_argument("--summarize-only", action="store_true",
                     help="rebuild the summaries from the CSVs already under gpurun_out/prof/ (no GPU needed)")
     args = ap.parse_args()
     if args.summarize_only:
         global run_prof
         run_prof = lambda tag, prof_args, bench_args, scratch: (os.path.join(scratch, tag), None)
-    scratch = os.path.join(ROOT, "gpurun_out", "prof")
+    scratch = os.path.join(ROOT, "gpurun_out", "prof" if args.tag == "n1" else f"prof_{args.tag}")
     # only gpurun_out/ travels back from the GPU box: copy the result into profiles/<round>/ afterwards
     dst = os.path.join(ROOT, "gpurun_out", "profiles", args.round)
     os.makedirs(dst, exist_ok=True)
@@ -87,12 +88,12 @@ def main():
     out, line = run_prof("stats", ["--kernel-trace", "--stats"], ["--steps", "200", "--warmup", "20", *common], scratch)
     stats = find(out, "kernel_stats.csv")
     rows = list(csv.DictReader(open(stats)))
-    with open(os.path.join(dst, "bench_n1_kernel_stats.csv"), "w") as f:
+    with open(os.path.join(dst, f"bench_{args.tag}_kernel_stats.csv"), "w") as f:
         f.write(open(stats).read())
     agg = [r for r in rows if kernel_sub in r["Name"]]
     print("kernel stats:", [(r["Name"][:60], r["Calls"], r["AverageNs"]) for r in agg])
     if line:
-        with open(os.path.join(dst, "bench_n1.json"), "w") as f:
+        with open(os.path.join(dst, f"bench_{args.tag}.json"), "w") as f:
             json.dump(line, f, indent=1)
             f.write("\n")
 
@@ -127,7 +128,7 @@ def main():
             "avg_waves_per_simd": sq["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * xcd_cycles),
             "wait_frac_of_wave_life": sq["SQ_WAIT_ANY"] / max(sq["SQ_WAVE_CYCLES"], 1.0),
         }
-    with open(os.path.join(dst, "bench_n1_pmc_summary.json"), "w") as f:
+    with open(os.path.join(dst, f"bench_{args.tag}_pmc_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
         f.write("\n")
     print(json.dumps(summary["traffic"], indent=1))
