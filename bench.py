@@ -112,21 +112,20 @@ def cpu_baseline(src, dst, n, x, kind, budget_s):
 
 def measured_traffic(args, world):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same workload
-    (profiles/<round>/bench_n1_pmc_summary.json: FETCH_SIZE x2 per the gfx950 correction, plus
+    (profiles/<round>/bench_*_pmc_summary.json: FETCH_SIZE x2 per the gfx950 correction, plus
     WRITE_SIZE); None when no profile of this exact workload is committed."""
     if world != 1:
         return None
     key = f"{args.graph}/{args.noise}/D{args.feat}/seg{args.seg_len}"
     best = None
-    for d in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-        f = os.path.join(ROOT, "profiles", d, "bench_n1_pmc_summary.json")
-        if os.path.exists(f):
-            try:
-                t = json.load(open(f)).get("traffic", {})
-                if t.get("workload") == key:
-                    best = float(t["traffic_bytes_per_launch"])
-            except (ValueError, KeyError):
-                pass
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "bench_*_pmc_summary.json"))):
+        try:
+            t = json.load(open(f)).get("traffic", {})
+            if t.get("workload") == key:
+                best = float(t["traffic_bytes_per_launch"])     # the latest round that measured it
+        except (ValueError, KeyError):
+            pass
     return best
 
 
