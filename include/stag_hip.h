@@ -29,7 +29,7 @@
  * Noise stream (normative; the CPU oracle in oracle/ restates it)
  *   One Philox4x32-10 call yields the noise of 4 consecutive channels of one
  *   edge:
- *       gpos = noise_index(position)           (see stag_csr.nidx, pos_base)
+ *       gpos = spec.pos_base + (csr.nidx ? csr.nidx[position] : position)
  *       ctr  = { lo32(gpos), chunk | (hi32(gpos) << 20), lo32(offset), hi32(offset) }
  *       key  = { lo32(seed), hi32(seed) }
  *       (r0,r1,r2,r3) = philox4x32_10(ctr, key)      channel k = 4*chunk + j uses r_j
@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 10
+#define STAG_ABI_VERSION 11
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -88,9 +88,12 @@ typedef struct stag_csr {
   const int32_t* indptr;  /* [M+1]                                                   */
   const int32_t* indices; /* [E] source row of each CSR position                     */
   const int32_t* eid;     /* [E] original edge id of each position; NULL = identity  */
-  const int32_t* nidx;    /* [E] noise index of each position (used by the backward
-                             pass, which walks the transposed graph but must redraw
-                             the forward pass's noise); NULL = pos_base + position  */
+  const int32_t* nidx;    /* [E] LOCAL noise index of each position, in [0, E): the backward
+                             pass walks the transposed graph but must redraw the forward
+                             pass's noise, so nidx = forward position of the same edge.
+                             NULL = the position itself.  The global index of the draw is
+                             spec.pos_base + nidx[position]; one call must not straddle a
+                             2^32 boundary of the global index space (STAG_ENOSYS)         */
 } stag_csr;
 
 typedef struct stag_noise_spec {

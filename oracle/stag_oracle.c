@@ -135,7 +135,7 @@ static void edge_weights4(const stag_csr* csr, const stag_noise_spec* s,
     for (int j = 0; j < 4; ++j)
       w[j] = (k0 + j < Dn) ? s->p0[eid * (int64_t)(Dn / grp) + (k0 + j) / grp] : 0.0f;
   } else {
-    int64_t gpos = csr->nidx ? (int64_t)csr->nidx[p] : s->pos_base + p;
+    int64_t gpos = s->pos_base + (csr->nidx ? (int64_t)csr->nidx[p] : (int64_t)p);
     uint32_t r[4];
     noise_words(s->seed, s->offset + (s->epoch ? *s->epoch : 0) /* host pointer here */, gpos, (uint32_t)(c + s->chunk_base), r);
     float t[4];

@@ -17,6 +17,7 @@ _SO = os.path.join(_HERE, "libstag_hip.so")
 NOISE_NONE, NOISE_EXPLICIT, NOISE_NORMAL, NOISE_UNIFORM, NOISE_BERNOULLI = range(5)
 PARAM_SCALAR, PARAM_PER_CHANNEL, PARAM_PER_EDGE1, PARAM_PER_EDGE = range(4)
 REDUCE_SUM, REDUCE_MEAN = 0, 1
+HEAVY_LEN = 16   # STAG_HEAVY_LEN (include/stag_hip.h)
 
 _vp = C.c_void_p
 
@@ -113,7 +114,7 @@ def lib():
     l.stag_gat_bwd_edge.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp, _vp, _vp, _vp,
                                     C.c_int32, C.c_int32, C.c_float, C.POINTER(NoiseSpec), _vp, _vp,
                                     _vp, _vp, _vp]
-    if l.stag_abi_version() != 10:
+    if l.stag_abi_version() != 11:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     _lib = l
     return l

@@ -369,7 +369,7 @@ struct AggTeam {
       if (p < pend) {
         I.u[j] = a.indices[p];
         if constexpr (NEED_EID) I.ee[j] = a.eid ? a.eid[p] : p;
-        if constexpr (KIND >= kNormal) I.nn[j] = a.nidx ? (uint32_t)a.nidx[p] : a.pos_lo + (uint32_t)p;
+        if constexpr (KIND >= kNormal) I.nn[j] = a.pos_lo + (a.nidx ? (uint32_t)a.nidx[p] : (uint32_t)p);
       }
     }
   }

@@ -118,7 +118,7 @@ __device__ __forceinline__ void edge_w4_grad(const NoiseArgs& a, const PhiloxKey
                                              uint32_t chunk, float (&w)[4], float (&d0)[4], float (&d1)[4]) {
   float pa[4], pb[4];
   edge_params4(a, ed, (int)chunk * 4, pa, pb);
-  const int64_t gpos = a.nidx ? (int64_t)a.nidx[p] : a.pos_base + p;
+  const int64_t gpos = a.pos_base + (a.nidx ? (int64_t)a.nidx[p] : (int64_t)p);
   chunk += a.chunk_base;
   if (a.kind == kNormal) draw4_grad<kNormal>((uint32_t)gpos, ctr1_of(gpos, chunk), key, pa, pb, a.nflags, w, d0, d1);
   else draw4_grad<kUniform>((uint32_t)gpos, ctr1_of(gpos, chunk), key, pa, pb, a.nflags, w, d0, d1);
@@ -128,7 +128,7 @@ __device__ __forceinline__ void edge_w4_grad(const NoiseArgs& a, const PhiloxKey
 __device__ __forceinline__ void edge_w4_grad_p(const NoiseArgs& a, const PhiloxKey& key, int p, uint32_t chunk,
                                                const float (&pa)[4], const float (&pb)[4], float (&w)[4],
                                                float (&d0)[4], float (&d1)[4]) {
-  const int64_t gpos = a.nidx ? (int64_t)a.nidx[p] : a.pos_base + p;
+  const int64_t gpos = a.pos_base + (a.nidx ? (int64_t)a.nidx[p] : (int64_t)p);
   chunk += a.chunk_base;
   if (a.kind == kNormal) draw4_grad<kNormal>((uint32_t)gpos, ctr1_of(gpos, chunk), key, pa, pb, a.nflags, w, d0, d1);
   else draw4_grad<kUniform>((uint32_t)gpos, ctr1_of(gpos, chunk), key, pa, pb, a.nflags, w, d0, d1);
@@ -161,7 +161,7 @@ __device__ __forceinline__ void edge_w4(const NoiseArgs& a, int p, int64_t ed, u
     else if (a.pmode == 3) { q0 = in ? a.p0[ed * a.Dn + k] : 0.f; q1 = (in && a.p1) ? a.p1[ed * a.Dn + k] : 0.f; }
     pa[j] = q0; pb[j] = q1;
   }
-  const int64_t gpos = a.nidx ? (int64_t)a.nidx[p] : a.pos_base + p;
+  const int64_t gpos = a.pos_base + (a.nidx ? (int64_t)a.nidx[p] : (int64_t)p);
   chunk += a.chunk_base;   // global channel group (channel shards)
   const PhiloxKey key = resolve_epoch(a.key);
   switch (a.kind) {
@@ -590,10 +590,10 @@ static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x
   a.pos_lo = (uint32_t)((uint64_t)spec->pos_base & 0xFFFFFFFFull);
   a.pos_hi = (uint32_t)((uint64_t)spec->pos_base >> 32);
   a.chunk_base = (uint32_t)spec->chunk_base;
-  // one launch must not straddle a 2^32 boundary of the global position space (the kernel
-  // keeps hi32 in a scalar): shards are < 2^31 edges, so split the call at the boundary
-  if (spec->kind >= STAG_NOISE_NORMAL && !csr->nidx &&
-      (uint64_t)a.pos_lo + (uint64_t)csr->n_edges > (1ull << 32))
+  // one launch must not straddle a 2^32 boundary of the global position space (the kernel keeps
+  // hi32 in a scalar and adds pos_lo to the local index in 32 bits, with or without nidx): shards
+  // are < 2^31 edges, so split the call at the boundary
+  if (spec->kind >= STAG_NOISE_NORMAL && (uint64_t)a.pos_lo + (uint64_t)csr->n_edges > (1ull << 32))
     return STAG_ENOSYS;
   a.src_scale = src_scale; a.dst_scale = dst_scale; a.mean = (reduce == STAG_REDUCE_MEAN);
   a.out = out; a.ldo = ldo; a.norm_scale_out = norm_scale_out;

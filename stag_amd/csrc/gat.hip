@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatArgs a) {
       const int p = b + i0 + c;
       u = a.indices[p];
       const int64_t ed = a.eid ? a.eid[p] : p;
-      const uint32_t n = a.nidx ? (uint32_t)a.nidx[p] : a.pos_lo + (uint32_t)p;
+      const uint32_t n = a.pos_lo + (a.nidx ? (uint32_t)a.nidx[p] : (uint32_t)p);
       for (int cc = 0; cc < nchunk; ++cc) {
         float w[4];
         head_w4(a, key, n, ed, (uint32_t)cc, w);
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void gat_attn_kernel(const GatArgs a) {
   for (int p = b + c; p < b + len; p += 8) {
     const int u = a.indices[p];
     const int64_t ed = a.eid ? a.eid[p] : p;
-    const uint32_t n = a.nidx ? (uint32_t)a.nidx[p] : a.pos_lo + (uint32_t)p;
+    const uint32_t n = a.pos_lo + (a.nidx ? (uint32_t)a.nidx[p] : (uint32_t)p);
     for (int cc = 0; cc < nchunk; ++cc) {
       float w[4], at[4];
       head_w4(a, key, n, ed, (uint32_t)cc, w);
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void gat_bwd_edge_kernel(const GatBwdArgs ba) 
       u = a.indices[p];
       const int64_t ed = a.eid ? a.eid[p] : p;
       edl = (int)ed;
-      const uint32_t n = a.nidx ? (uint32_t)a.nidx[p] : a.pos_lo + (uint32_t)p;
+      const uint32_t n = a.pos_lo + (a.nidx ? (uint32_t)a.nidx[p] : (uint32_t)p);
       for (int cc = 0; cc < nchunk; ++cc) {
         float w[4], at4[4] = {0.f, 0.f, 0.f, 0.f};
         head_w4(a, key, n, ed, (uint32_t)cc, w);
@@ -540,8 +540,7 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
   a.key.epoch = spec->epoch;
   a.pos_lo = (uint32_t)((uint64_t)spec->pos_base & 0xFFFFFFFFull);
   a.pos_hi = (uint32_t)((uint64_t)spec->pos_base >> 32);
-  if (spec->kind >= STAG_NOISE_NORMAL && !csr->nidx &&
-      (uint64_t)a.pos_lo + (uint64_t)csr->n_edges > (1ull << 32))
+  if (spec->kind >= STAG_NOISE_NORMAL && (uint64_t)a.pos_lo + (uint64_t)csr->n_edges > (1ull << 32))
     return STAG_ENOSYS;
   a.out = out; a.stats = stats_out;
   const uint64_t ftb = (uint64_t)csr->n_src * (uint64_t)HF * 4u;

@@ -73,6 +73,25 @@ class CsrView:
                 counters={})
         return self._plans[seg_len]
 
+    def subplan(self, seg_len, keep):
+        """The plan of `seg_len` restricted to the units keep[i] is True for (a host bool array over
+        the plan's units; the segments of a long row must be kept or dropped together).  Order is the
+        plan's, so segments still come first and the heavy units stay a prefix."""
+        full = self.plan(seg_len)
+        units = full["units"].cpu().numpy()[:full["n_units"]]
+        keep = np.asarray(keep, bool)
+        sel = units[keep]
+        n_seg = int((sel[:, 3] >= 0).sum()) if len(sel) else 0
+        if n_seg not in (0, full["n_seg"]):
+            raise ValueError("a sub-plan takes all segments of the long rows or none")
+        dev = self.indptr.device
+        buf = np.zeros((max(len(sel), 1), 4), np.int32)
+        buf[:len(sel)] = sel
+        return dict(seg_len=seg_len, n_units=int(len(sel)), n_long=full["n_long"] if n_seg else 0, n_seg=n_seg,
+                    n_heavy=n_seg + int((sel[n_seg:, 2] > _lib.HEAVY_LEN).sum()) if len(sel) else 0,
+                    units=torch.from_numpy(buf).to(dev), long_rows=full["long_rows"],
+                    long_seg_ptr=full["long_seg_ptr"], counters={})
+
 
 def build_csr(src, dst, n_src, n_dst):
     """Stable destination-major CSR from COO (position order inside a row = ascending

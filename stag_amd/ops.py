@@ -46,16 +46,22 @@ def _explicit_spec(w, relu=False, in_norm=False):
     return s
 
 
-def _plan_struct(csrv, seg_len, tiles, nbytes, dev):
-    """ctypes stag_plan for csrv (None when planning is off), plus the tensors it points into."""
-    plan_t = csrv.plan(seg_len)
+def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None):
+    """ctypes stag_plan for csrv (None when planning is off), plus the tensors it points into.
+    plan_t: a sub-plan of csrv (CsrView.subplan) instead of its whole plan."""
+    if plan_t is None:
+        plan_t = csrv.plan(seg_len)
     if plan_t is None:
         return None, None
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev) if nbytes else None
-    counters = plan_t["counters"].get(tiles)
-    if counters is None:   # zero once; every completed launch leaves them zero again
+    # arrival counters of the long rows: one set per (channel tiles, stream) — two launches that may
+    # be in flight together (different streams) must not share them; zeroed once, every completed
+    # launch leaves them zero again
+    key = (tiles, _lib.stream_of(dev))
+    counters = plan_t["counters"].get(key)
+    if counters is None:
         counters = torch.zeros(max(plan_t["n_long"], 1) * tiles, dtype=torch.int32, device=dev)
-        plan_t["counters"][tiles] = counters
+        plan_t["counters"][key] = counters
     plan_c = _lib.Plan(plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"],
                        _lib.ptr(plan_t["units"]), _lib.ptr(plan_t["long_rows"]),
                        _lib.ptr(plan_t["long_seg_ptr"]), _lib.ptr(counters), _lib.ptr(ws), nbytes,
@@ -64,15 +70,18 @@ def _plan_struct(csrv, seg_len, tiles, nbytes, dev):
 
 
 def _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len, want_norm_scale=False,
-             broadcast_x=False):
-    """One stag_agg_fwd launch on csrv (a CsrView). x: [n_src, D] fp32 contiguous."""
+             broadcast_x=False, out=None, plan_t=None):
+    """One stag_agg_fwd launch on csrv (a CsrView). x: [n_src, D] fp32 contiguous.
+    out / plan_t: write the rows of a sub-plan's units into an existing [n_dst, D] tensor."""
     dev = _lib.require_device(x, csrv.indptr, src_scale, dst_scale)
-    out = torch.empty((csrv.n_dst, D), dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty((csrv.n_dst, D), dtype=torch.float32, device=dev)
     ns = torch.empty((csrv.n_dst, D), dtype=torch.float32, device=dev) if want_norm_scale else None
-    plan_t = csrv.plan(seg_len)
+    if plan_t is None:
+        plan_t = csrv.plan(seg_len)
     nbytes = (_lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], D, int(spec.in_norm))
               if plan_t is not None else 0)
-    plan_c, _keep = _plan_struct(csrv, seg_len, (D + 255) // 256, nbytes, dev)
+    plan_c, _keep = _plan_struct(csrv, seg_len, (D + 255) // 256, nbytes, dev, plan_t)
     cs = csrv.struct()
     with _lib.on_device(dev):
         rc = _lib.lib().stag_agg_fwd(
@@ -329,14 +338,38 @@ class _AggregateVI(torch.autograd.Function):
         return dx, dp0, dp1, None, None, None, None, None, None
 
 
+def aggregate_into(csrv, x, out, weight, reduce, src_scale, dst_scale, plan_t):
+    """The rows of ONE sub-plan of csrv (CsrView.subplan) written into `out` [n_dst, D]; no autograd.
+    How a node-range shard launches its local-source rows while the halo exchange is in flight and
+    the other rows behind it (partition.GraphShard.aggregate); every row is reduced exactly as
+    a whole-plan launch would reduce it."""
+    x = _f32c(x)
+    if weight is None:
+        spec = _none_spec()
+    elif isinstance(weight, EdgeNoise):
+        if weight.dn != x.shape[1]:
+            raise ValueError(f"noise width {weight.dn} != feature width {x.shape[1]}")
+        spec = weight.spec()
+    else:
+        raise TypeError("aggregate_into takes None or an EdgeNoise")
+    _agg_raw(csrv, x, x.shape[1], spec, _REDUCE[reduce], _f32c(src_scale), _f32c(dst_scale),
+             plan_t["seg_len"], out=out, plan_t=plan_t)
+    return out
+
+
 def aggregate(graph, x, weight=None, reduce="sum", src_scale=None, dst_scale=None,
-              seg_len=DEFAULT_SEG_LEN, _broadcast_x=False):
+              seg_len=DEFAULT_SEG_LEN, _broadcast_x=False, _gathered=False):
     """out[v,:] = dscale[v] * sum|mean_{e=(u->v)} w[e,:] * sscale[u] * x[u,:]
 
     weight: None (plain copy_u), a tensor [E, D] indexed by edge id (explicit
-    `edge_weight`, stag/zoo/gcn.py:60-63), or an EdgeNoise (fused sampling)."""
+    `edge_weight`, stag/zoo/gcn.py:60-63), or an EdgeNoise (fused sampling).
+    On a node-range shard (partition.GraphShard) x holds this rank's rows and the call includes
+    the halo exchange."""
     if x.dim() != 2:
         raise ValueError("aggregate expects x of shape [N, D]")
+    if getattr(graph, "is_shard", False) and not _gathered and not _broadcast_x:
+        return graph.aggregate(x, weight, reduce=reduce, src_scale_local=src_scale,
+                               dst_scale_local=dst_scale, seg_len=seg_len)
     noise = weight if isinstance(weight, EdgeNoise) else None
     w = weight if torch.is_tensor(weight) else None
     D = x.shape[1]
@@ -356,7 +389,7 @@ def aggregate(graph, x, weight=None, reduce="sum", src_scale=None, dst_scale=Non
         one = copy.copy(noise)
         one.n_samples = 1
         return aggregate_mc(graph, x, one, noise.n_samples, noise.offset_stride, reduce=reduce,
-                            src_scale=src_scale, dst_scale=dst_scale, seg_len=seg_len)
+                            src_scale=src_scale, dst_scale=dst_scale, seg_len=seg_len, _gathered=_gathered)
     if noise is not None and noise.grad_params is not None and torch.is_grad_enabled():
         p0, p1 = (torch.as_tensor(p, dtype=torch.float32, device=x.device) for p in noise.grad_params)
         if p0.requires_grad or p1.requires_grad:
@@ -389,7 +422,7 @@ def aggregate_max(graph, x, weight=None):
 
 
 def aggregate_mc(graph, x, noise, n_samples, offset_stride=1, reduce="sum", src_scale=None,
-                 dst_scale=None, seg_len=DEFAULT_SEG_LEN):
+                 dst_scale=None, seg_len=DEFAULT_SEG_LEN, _gathered=False):
     """[n_samples, N, D]: sample s == aggregate(graph, x, noise at offset + s * offset_stride), bit for
     bit, from one pass over the gathered rows per 4 samples (stag_agg_fwd_mc).  Inference path of the
     reference's Monte-Carlo loop (stag/models.py:45-55); no autograd — with gradients enabled, or
@@ -398,7 +431,10 @@ def aggregate_mc(graph, x, noise, n_samples, offset_stride=1, reduce="sum", src_
         import copy
         nz = copy.copy(noise)
         nz.offset = noise.offset + s * offset_stride
-        return aggregate(graph, x, nz, reduce=reduce, src_scale=src_scale, dst_scale=dst_scale, seg_len=seg_len)
+        return aggregate(graph, x, nz, reduce=reduce, src_scale=src_scale, dst_scale=dst_scale, seg_len=seg_len,
+                         _gathered=_gathered)
+    if getattr(graph, "is_shard", False) and not _gathered:
+        return torch.stack([one(s) for s in range(n_samples)], 0)
     fusable_mc = (isinstance(noise, EdgeNoise) and noise.kind >= _lib.NOISE_NORMAL and not noise.in_norm
                   and noise.param_mode <= _lib.PARAM_PER_CHANNEL)
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or (noise is not None and noise.grad_params is not None
@@ -622,15 +658,20 @@ class _GatAggregate(torch.autograd.Function):
 
 
 def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False,
-                  seg_len=DEFAULT_SEG_LEN):
+                  seg_len=DEFAULT_SEG_LEN, _gathered=False):
     """Fused noisy-logit edge softmax + aggregation (stag/zoo/gat.py:114-126).
-    el: [N,H], er: [N,H], ft: [N,H,F]; weight: None | [E,H] tensor | EdgeNoise(dn=H)."""
+    el: [N,H], er: [N,H], ft: [N,H,F]; weight: None | [E,H] tensor | EdgeNoise(dn=H).
+    On a node-range shard the inputs are this rank's rows and the call includes the exchange."""
+    if getattr(graph, "is_shard", False) and not _gathered:
+        return graph.gat_aggregate(el, er, ft, neg_slope, weight, seg_len=seg_len, want_attn=want_attn)
     noise = weight if isinstance(weight, EdgeNoise) else None
     w = weight if torch.is_tensor(weight) else None
     if w is not None and w.shape[0] != graph.number_of_edges():
         raise AssertionError("edge_weight.shape[0] != number_of_edges")
     H, F = ft.shape[1], ft.shape[2]
     if H > 64 or H * F > 256 or (F % 4 != 0 or ((F // 4) & (F // 4 - 1)) != 0) and torch.is_grad_enabled():
+        if getattr(graph, "is_shard", False):
+            raise NotImplementedError("the composed GAT path (H > 64 or H*F > 256) is not partitioned")
         return _gat_composed(graph, el, er, ft, neg_slope, noise, w, want_attn, seg_len)
     return _GatAggregate.apply(el, er, ft, w, graph, noise, neg_slope, want_attn, seg_len)
 

@@ -10,11 +10,29 @@ new functionality — the reference is single-process).
     them, so 42 % less traffic than gathering everything; xGMI is point-to-point, and
     an all-to-all drives all 7 links at once).  exchange="allgather": equal-size padded
     shards, one all_gather_into_tensor (what a denser halo degenerates to);
-    the local CSR's column ids are pre-mapped to rows of the exchanged buffer, so the
-    aggregation kernel is the single-GPU kernel, unchanged;
+    the local CSR's column ids are pre-mapped to rows of the exchanged buffer
+    [my rows | rows from rank 0 | from rank 1 | ...], so the aggregation kernel is the
+    single-GPU kernel, unchanged;
+    the rows whose sources are ALL local form their own unit list (`plan_split`): their
+    launch overlaps the collective, the remaining rows are launched behind it;
     Philox counters are keyed by the GLOBAL CSR position (`pos_base` = first global
-    position of the shard), so 1/2/4/8-GPU outputs are bit-identical;
+    position of the shard), and every row is reduced by exactly one rank in the
+    single-GPU order, so 1/2/4/8-GPU outputs are bit-identical;
     backward = the transposed exchange (reduce-scatter of dx).
+
+Two constructors with identical results:
+    GraphShard(src, dst, n, rank, world)         every rank holds the whole COO list
+                                                 (O(E log E) per rank, no communication);
+    GraphShard.from_edge_slices(src_part, ...)   every rank starts from ANY E/P slice of the
+                                                 edge list — the form for graphs that do not
+                                                 fit one GPU: two all-reduced degree vectors,
+                                                 one all-to-all that routes every edge to the
+                                                 owner of its destination, a local stable sort,
+                                                 one all-to-all of the needed-row ids.
+
+A shard duck-types the graph surface the layers touch (`local_var`, `in_degrees`,
+`out_degrees`, `number_of_edges`, ...): `StagLayer(zoo.GCN | GraphSAGE | GIN | GAT)` runs on
+it with `feat` = this rank's rows; ops.aggregate / ops.gat_aggregate route through the shard.
 
 Channel sharding (`ChannelShard`) is the alternative for graphs that FIT one GPU (arxiv: 5 MB
 of CSR): every rank keeps the whole CSR and D/P of the feature channels.  The channels of the
@@ -22,14 +40,14 @@ aggregation are independent, so the step needs NO exchange at all, and the only 
 GCN layer is the all-to-all that turns the channel-sharded result into row shards for the
 dense transform (`to_row_shards`, N*D/P floats per rank; the halo exchange moves up to
 N*D*(P-1)/P).  What does not shrink with P is the per-edge part (index loads, address
-arithmetic), so this mode stops scaling at about D/P = 32 (DESIGN.md section 8).  Philox
+arithmetic), so this mode stops scaling at about D/P = 32 (DESIGN.md section 6).  Philox
 counters are keyed by the GLOBAL channel (`chunk_base`), so outputs are again bit-identical.
 """
 import numpy as np
 import torch
 import torch.distributed as dist
 
-from .graph import CsrView, build_csr
+from .graph import DEFAULT_SEG_LEN, CsrView, build_csr
 
 
 def edge_balanced_bounds(indptr, world):
@@ -87,79 +105,184 @@ class _HaloGather(torch.autograd.Function):
         return out, None
 
 
+def _owner_of(ids, bounds_t, world):
+    """Rank owning each node id (ids: int64 tensor; bounds_t: [world+1] int64 tensor on its device)."""
+    return torch.bucketize(ids, bounds_t[1:-1], right=True).clamp_(max=world - 1)
+
+
+def _split_sorted(ids, bounds_t, world):
+    """A sorted id tensor cut at the rank bounds -> list of `world` tensors."""
+    cuts = torch.searchsorted(ids, bounds_t[1:-1]).tolist() if world > 1 else []
+    return list(torch.tensor_split(ids, cuts)) if world > 1 else [ids]
+
+
 class GraphShard:
-    """The rows of one rank, shaped like a stag_amd.Graph for ops.aggregate / EdgeNoise."""
+    """The rows of one rank, shaped like a stag_amd.Graph for the layers, ops.aggregate and EdgeNoise."""
 
     is_block = False
+    is_shard = True
 
     def __init__(self, src, dst, n_nodes, rank, world, device=None, group=None, exchange="halo"):
+        """Every rank holds the whole COO list (arxiv: 19 MB).  O(E log E) per rank — one stable sort
+        and one pass over the edges that leave this rank's node range — and no communication."""
+        src = torch.as_tensor(np.asarray(src) if not torch.is_tensor(src) else src).to(torch.int64)
+        dst = torch.as_tensor(np.asarray(dst) if not torch.is_tensor(dst) else dst).to(torch.int64)
+        self._init_common(n_nodes, rank, world, device, group, exchange)
+        N, world, rank = self.n_global, self.world, self.rank
+        E = int(src.shape[0])
+        # global stable dst-major order (same as graph.build_csr => same global positions)
+        order = torch.sort(dst, stable=True).indices
+        counts = torch.bincount(dst, minlength=N)
+        indptr = torch.zeros(N + 1, dtype=torch.int64, device=src.device)
+        indptr[1:] = torch.cumsum(counts, 0)
+        out_deg = torch.bincount(src, minlength=N)
+        self._set_bounds(indptr)
+        lo, hi = self.row_lo, self.row_hi
+        p_lo, p_hi = int(indptr[lo]), int(indptr[hi])
+        mine = order[p_lo:p_hi]
+        g_src = src[mine]
+        # what the peers need from me: edges that start in my node range and end elsewhere
+        bt = self._bounds_t.to(src.device)
+        m = (src >= lo) & (src < hi)
+        s_m, d_owner = src[m], _owner_of(dst[m], bt, world)
+        away = d_owner != rank
+        keys = torch.unique(d_owner[away] * N + s_m[away])                # sorted by (peer, id)
+        send_owner = torch.div(keys, N, rounding_mode="floor") if N else keys
+        in_splits = torch.bincount(send_owner, minlength=world).tolist()
+        self._finish(indptr[lo:hi + 1] - p_lo, g_src, mine, p_lo, E, counts[lo:hi], out_deg,
+                     send_ids=keys - send_owner * N, in_splits=in_splits)
+
+    @classmethod
+    def from_edge_slices(cls, src_part, dst_part, eid_base, n_nodes, rank, world, device=None, group=None,
+                         exchange="halo"):
+        """Distributed construction: this rank contributes the edges with global ids
+        [eid_base, eid_base + len(src_part)) — any slice of the COO list — and ends up with the
+        shard `GraphShard(src, dst, ...)` would have built from the whole list.  Per-rank work and
+        memory are O(E / world + N): two all-reduced degree vectors (N ints), one all-to-all that
+        routes each edge to the owner of its destination, a local stable sort, and one all-to-all of
+        the ids of the rows each rank needs from each peer."""
+        self = cls.__new__(cls)
+        self._init_common(n_nodes, rank, world, device, group, exchange)
+        N = self.n_global
+        src_part = torch.as_tensor(src_part).to(torch.int64)
+        dst_part = torch.as_tensor(dst_part).to(torch.int64)
+        cdev = src_part.device
+        deg = torch.stack([torch.bincount(dst_part, minlength=N), torch.bincount(src_part, minlength=N)])
+        if world > 1:
+            dist.all_reduce(deg, group=group)
+        counts, out_deg = deg[0], deg[1]
+        indptr = torch.zeros(N + 1, dtype=torch.int64, device=cdev)
+        indptr[1:] = torch.cumsum(counts, 0)
+        E = int(indptr[-1])
+        self._set_bounds(indptr)
+        lo, hi = self.row_lo, self.row_hi
+        bt = self._bounds_t.to(cdev)
+        eid = torch.arange(eid_base, eid_base + src_part.shape[0], dtype=torch.int64, device=cdev)
+        # route every edge to the rank that owns its destination row
+        d_owner = _owner_of(dst_part, bt, world)
+        by_owner = torch.sort(d_owner, stable=True).indices
+        payload = torch.stack([src_part[by_owner], dst_part[by_owner], eid[by_owner]], 1).contiguous()   # [n, 3]
+        n_to = torch.bincount(d_owner, minlength=world)
+        if world > 1:
+            n_from = torch.empty_like(n_to)
+            dist.all_to_all_single(n_from, n_to, group=group)
+            recv = torch.empty((int(n_from.sum()), 3), dtype=torch.int64, device=cdev)
+            dist.all_to_all_single(recv, payload, n_from.tolist(), n_to.tolist(), group=group)
+        else:
+            recv = payload
+        # stable destination-major order of my rows: ascending (dst, original edge id)
+        order = torch.sort(recv[:, 2], stable=True).indices
+        order = order[torch.sort(recv[order, 1], stable=True).indices]
+        g_src, eid_g = recv[order, 0].contiguous(), recv[order, 2].contiguous()
+        p_lo = int(indptr[lo])
+        self._finish(indptr[lo:hi + 1] - p_lo, g_src, eid_g, p_lo, E, counts[lo:hi], out_deg,
+                     send_ids=None, in_splits=None)
+        return self
+
+    # ---- construction helpers ----------------------------------------------------------------
+    def _init_common(self, n_nodes, rank, world, device, group, exchange):
         if exchange not in ("halo", "allgather"):
             raise ValueError("exchange must be 'halo' or 'allgather'")
         self.exchange = exchange if world > 1 else "allgather"
-        src = np.asarray(src, dtype=np.int64)
-        dst = np.asarray(dst, dtype=np.int64)
         self.rank, self.world, self.group = int(rank), int(world), group
         self.n_global = int(n_nodes)
-        E = len(src)
-        # global stable dst-major order (same as graph.build_csr => same global positions)
-        order = np.argsort(dst, kind="stable")
-        counts = np.bincount(dst, minlength=n_nodes)
-        indptr = np.zeros(n_nodes + 1, dtype=np.int64)
-        indptr[1:] = np.cumsum(counts)
-        self.bounds = edge_balanced_bounds(indptr, world)
-        self.max_rows = int(np.max(np.diff(self.bounds))) if world else 0
-        lo, hi = int(self.bounds[rank]), int(self.bounds[rank + 1])
-        self.row_lo, self.row_hi = lo, hi
-        p_lo, p_hi = int(indptr[lo]), int(indptr[hi])
-        self.pos_base = p_lo
-        self.n_edges_global = E
-        g_src = src[order[p_lo:p_hi]]
-        owner = np.searchsorted(self.bounds, g_src, side="right") - 1
-        owner = np.minimum(owner, world - 1)
-        dev = torch.device(device) if device is not None else torch.device("cpu")
-        self._device = dev
-        if self.exchange == "allgather":
-            buf_row = owner * self.max_rows + (g_src - self.bounds[owner])
-            self.n_buf = world * self.max_rows
-        else:
-            # buffer = [my rows | rows needed from rank 0 | from rank 1 | ...], each peer's part
-            # sorted by global id.  Every rank derives every pair's list from the same global
-            # CSR, so no negotiation round is needed.
-            sorted_src = src[order]
-            src_owner = np.minimum(np.searchsorted(self.bounds, sorted_src, side="right") - 1, world - 1)
-            edge_rank = np.minimum(np.searchsorted(indptr[self.bounds], np.arange(E), side="right") - 1,
-                                   world - 1)            # rank owning each CSR position
-            def needed(r, q):    # global ids rank r needs from rank q
-                m = (edge_rank == r) & (src_owner == q)
-                return np.unique(sorted_src[m])
-            recv_lists = [needed(rank, q) if q != rank else np.zeros(0, np.int64) for q in range(world)]
-            send_lists = [needed(r, rank) if r != rank else np.zeros(0, np.int64) for r in range(world)]
-            self.recv_ids = np.concatenate(recv_lists) if world > 1 else np.zeros(0, np.int64)   # global ids, buffer order
-            self.out_splits = [len(l) for l in recv_lists]      # rows I receive from each peer
-            self.in_splits = [len(l) for l in send_lists]       # rows I send to each peer
-            self.send_idx = torch.from_numpy(
-                (np.concatenate(send_lists) - lo).astype(np.int64) if sum(self.in_splits) else np.zeros(0, np.int64)).to(dev)
-            offs = np.concatenate([[0], np.cumsum(self.out_splits)])[:-1] + (hi - lo)
-            buf_row = np.empty(len(g_src), dtype=np.int64)
-            mine = owner == rank
-            buf_row[mine] = g_src[mine] - lo
-            for q in range(world):
-                if q == rank or not self.out_splits[q]:
-                    continue
-                m = owner == q
-                buf_row[m] = offs[q] + np.searchsorted(recv_lists[q], g_src[m])
-            self.n_buf = (hi - lo) + int(sum(self.out_splits))
-        self.local_indptr = torch.from_numpy((indptr[lo:hi + 1] - p_lo).astype(np.int32)).to(dev)
-        self.local_indices = torch.from_numpy(buf_row.astype(np.int32)).to(dev)
-        self.local_eid_global = torch.from_numpy(order[p_lo:p_hi].astype(np.int64)).to(dev)
-        self.n_rows = hi - lo
-        self._csr = CsrView(self.n_rows, self.n_buf, self.local_indptr, self.local_indices, None)
+        self._device = torch.device(device) if device is not None else torch.device("cpu")
+        self.ndata, self.edata = {}, {}
         self._csr_t = None
-        self._in_deg = torch.from_numpy(counts[lo:hi].astype(np.int64)).to(dev)
+        self._plan_split = {}
+        self._origin = self
 
-    # ---- Graph-like surface used by ops / EdgeNoise ---------------------------------
+    def _set_bounds(self, indptr):
+        self.bounds = edge_balanced_bounds(indptr.cpu().numpy(), self.world)
+        self._bounds_t = torch.from_numpy(self.bounds)
+        self.max_rows = int(np.max(np.diff(self.bounds))) if self.world else 0
+        self.row_lo, self.row_hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
+
+    def _finish(self, indptr_rel, g_src, eid_g, p_lo, n_edges_global, in_deg_local, out_deg_global,
+                send_ids, in_splits):
+        """Column ids -> rows of the exchanged buffer; the send / receive lists; device tensors."""
+        rank, world, dev = self.rank, self.world, self._device
+        lo, hi = self.row_lo, self.row_hi
+        self.pos_base, self.n_edges_global = int(p_lo), int(n_edges_global)
+        self.n_rows = hi - lo
+        bt = self._bounds_t.to(g_src.device)
+        owner = _owner_of(g_src, bt, world)
+        if self.exchange == "allgather":
+            buf_row = owner * self.max_rows + (g_src - bt[owner])
+            self.n_buf = world * self.max_rows
+            gid = torch.full((self.n_buf,), -1, dtype=torch.int64, device=g_src.device)
+            for q in range(world):
+                a, b = int(self.bounds[q]), int(self.bounds[q + 1])
+                gid[q * self.max_rows:q * self.max_rows + (b - a)] = torch.arange(a, b, device=g_src.device)
+            self.recv_ids = np.zeros(0, np.int64)
+            self.out_splits = self.in_splits = [0] * world
+            self.send_idx = torch.zeros(0, dtype=torch.int64, device=dev)
+        else:
+            # buffer = [my rows | rows needed from rank 0 | from rank 1 | ...], each peer's part sorted by
+            # global id: the receive lists follow from this rank's own edges alone
+            need = torch.unique(g_src[owner != rank])                           # sorted
+            recv_lists = _split_sorted(need, bt, world)
+            self.out_splits = [int(l.shape[0]) for l in recv_lists]              # rows I receive from each peer
+            if send_ids is None:        # distributed construction: tell every peer which rows it must send
+                n_need = torch.tensor(self.out_splits, dtype=torch.int64, device=need.device)
+                n_send = torch.empty_like(n_need)
+                dist.all_to_all_single(n_send, n_need, group=self.group)
+                in_splits = n_send.tolist()
+                send_ids = torch.empty(int(n_send.sum()), dtype=torch.int64, device=need.device)
+                dist.all_to_all_single(send_ids, need, in_splits, self.out_splits, group=self.group)
+            self.in_splits = [int(v) for v in in_splits]                        # rows I send to each peer
+            self.recv_ids = need.cpu().numpy()                                   # global ids, buffer order
+            self.send_idx = (send_ids - lo).to(dev)
+            buf_row = torch.where(owner == rank, g_src - lo,
+                                  (hi - lo) + torch.searchsorted(need, g_src))
+            self.n_buf = (hi - lo) + int(need.shape[0])
+            gid = torch.cat([torch.arange(lo, hi, device=g_src.device), need])
+        if self.n_buf >= 2 ** 31 or g_src.shape[0] >= 2 ** 31:
+            raise ValueError("a shard holds at most 2^31-1 edges / buffer rows: use more ranks")
+        self.local_indptr = indptr_rel.to(torch.int32).to(dev)
+        self.local_indices = buf_row.to(torch.int32).to(dev)
+        self.local_eid_global = eid_g.to(dev)
+        self._csr = CsrView(self.n_rows, self.n_buf, self.local_indptr, self.local_indices, None)
+        self._in_deg = in_deg_local.to(torch.int64).to(dev)
+        # global out-degree of the node behind every buffer row (GCN's source scaling indexes columns)
+        self._out_deg_buf = torch.where(gid >= 0, out_deg_global[gid.clamp(min=0)],
+                                        torch.zeros_like(gid)).to(dev)
+        # rows whose sources are all local can be aggregated while the exchange is in flight
+        E_loc = int(g_src.shape[0])
+        if E_loc:
+            rows = torch.repeat_interleave(torch.arange(self.n_rows, device=g_src.device),
+                                           (indptr_rel[1:] - indptr_rel[:-1]))
+            remote = torch.zeros(self.n_rows, dtype=torch.int64, device=g_src.device)
+            remote.index_add_(0, rows, (buf_row >= self.n_rows).to(torch.int64))
+            self._row_is_local = (remote == 0).cpu().numpy()
+        else:
+            self._row_is_local = np.ones(self.n_rows, bool)
+
+    # ---- Graph-like surface used by the layers / ops / EdgeNoise -----------------------------
     device = property(lambda self: self._device)
     csr = property(lambda self: self._csr)
+    srcdata = property(lambda self: self.ndata)
+    dstdata = property(lambda self: self.ndata)
 
     def number_of_edges(self):
         return self._csr.n_edges
@@ -167,25 +290,61 @@ class GraphShard:
     def number_of_nodes(self):
         return self.n_rows
 
+    number_of_dst_nodes = num_dst_nodes = num_nodes = number_of_nodes
+    num_edges = number_of_edges
+
+    def number_of_src_nodes(self):
+        return self.n_buf
+
     def in_degrees(self):
+        """In-degree of this rank's rows (all their in-edges live on this rank)."""
         return self._in_deg
 
+    def out_degrees(self):
+        """GLOBAL out-degree of the node behind every row of the exchanged buffer [n_buf]: source-side
+        scalings (GCN norm='both', stag/zoo/gcn.py:67-75) are indexed by column id."""
+        return self._out_deg_buf
+
+    def local_var(self):
+        g = GraphShard.__new__(GraphShard)
+        g.__dict__.update(self.__dict__)
+        g.ndata, g.edata = dict(self.ndata), dict(self.edata)
+        return g
+
     def _cache_owner(self):
-        return self
+        return self._origin
+
+    def edges(self):
+        raise NotImplementedError("a shard keeps its edges in CSR form over the exchanged buffer; per-edge "
+                                  "endpoint gathers (AmortizedDistribution) are not partitioned")
 
     @property
     def csr_t(self):
-        """Source-major twin over the gathered buffer rows (backward)."""
-        if self._csr_t is None:
+        """Source-major twin over the gathered buffer rows (backward).  nidx = LOCAL forward position;
+        the library adds spec.pos_base (include/stag_hip.h: stag_csr.nidx)."""
+        o = self._origin
+        if o._csr_t is None:
             E = self._csr.n_edges
             rows = torch.repeat_interleave(
                 torch.arange(self.n_rows, dtype=torch.int32, device=self._device),
                 (self.local_indptr[1:] - self.local_indptr[:-1]).long())
             indptr, indices, eid = build_csr(rows, self.local_indices, self.n_rows, self.n_buf)
-            # local position p is the forward position; its global noise index adds pos_base
-            nidx = (eid.long() + self.pos_base).to(torch.int32) if E else eid
-            self._csr_t = CsrView(self.n_buf, self.n_rows, indptr, indices, None, nidx)
-        return self._csr_t
+            o._csr_t = CsrView(self.n_buf, self.n_rows, indptr, indices, None, eid if E else None)
+        return o._csr_t
+
+    def plan_split(self, seg_len=DEFAULT_SEG_LEN):
+        """(local plan, remote plan): the launch plan of `csr` cut into the rows every source of which
+        is a local row — their launch needs no exchanged data — and the rest.  Unit order inside each
+        part is the plan's (longest first), each row is still reduced whole, in the same order, by the
+        same kernel: results do not change."""
+        o = self._origin
+        if seg_len not in o._plan_split:
+            full = self._csr.plan(seg_len)
+            units = full["units"].cpu().numpy()[:full["n_units"]]
+            whole = units[:, 3] < 0
+            loc = whole & self._row_is_local[np.where(whole, units[:, 0], 0)]
+            o._plan_split[seg_len] = (self._csr.subplan(seg_len, loc), self._csr.subplan(seg_len, ~loc))
+        return o._plan_split[seg_len]
 
     # ---- the exchange step ---------------------------------------------------------
     def pad_rows(self, x_local):
@@ -197,19 +356,45 @@ class GraphShard:
                           dtype=x_local.dtype, device=x_local.device)
         return torch.cat([x_local, pad], 0)
 
+    def exchange_bytes(self, D, itemsize=4):
+        """Bytes this rank receives / sends per exchange of D-wide rows."""
+        if self.world == 1:
+            return 0, 0
+        if self.exchange == "halo":
+            return sum(self.out_splits) * D * itemsize, sum(self.in_splits) * D * itemsize
+        return (self.world - 1) * self.max_rows * D * itemsize, (self.world - 1) * self.max_rows * D * itemsize
+
+    def halo_start(self, x_local):
+        """Begin the exchange: -> (buffer [n_buf, D] whose local rows are filled, work | None).  The
+        remote rows are valid after `work.wait()`, which orders the CURRENT stream behind the
+        collective (RCCL runs it on its own stream): kernels launched in between overlap it."""
+        if x_local.shape[0] != self.n_rows:
+            raise ValueError(f"rank {self.rank} owns {self.n_rows} rows, got {x_local.shape[0]}")
+        tail = tuple(x_local.shape[1:])
+        if self.exchange == "halo":
+            buf = torch.empty((self.n_buf,) + tail, dtype=x_local.dtype, device=x_local.device)
+            buf[:self.n_rows].copy_(x_local)
+            send = x_local.index_select(0, self.send_idx)
+            work = dist.all_to_all_single(buf[self.n_rows:], send, self.out_splits, self.in_splits,
+                                          group=self.group, async_op=True)
+            return buf, work
+        x_pad = self.pad_rows(x_local).contiguous()
+        if self.world == 1:
+            return x_pad, None
+        buf = torch.empty((self.world * self.max_rows,) + tail, dtype=x_local.dtype, device=x_local.device)
+        return buf, dist.all_gather_into_tensor(buf, x_pad, group=self.group, async_op=True)
+
     def halo_gather(self, x_local):
         """[n_rows, D] on every rank -> [n_buf, D] source features this rank's CSR indexes
-        (one collective: RCCL over xGMI on GPUs, gloo in the CPU tests)."""
+        (one collective: RCCL over xGMI on GPUs, gloo in the CPU tests).  Differentiable."""
+        if not (torch.is_grad_enabled() and x_local.requires_grad):
+            buf, work = self.halo_start(x_local)
+            if work is not None:
+                work.wait()
+            return buf
         if self.exchange == "halo":
             if x_local.shape[0] != self.n_rows:
                 raise ValueError(f"rank {self.rank} owns {self.n_rows} rows, got {x_local.shape[0]}")
-            if not (torch.is_grad_enabled() and x_local.requires_grad):
-                # inference: the collective writes straight behind the local rows (no concatenation copy)
-                buf = torch.empty((self.n_buf,) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
-                buf[:self.n_rows].copy_(x_local)
-                dist.all_to_all_single(buf[self.n_rows:], x_local.index_select(0, self.send_idx),
-                                       self.out_splits, self.in_splits, group=self.group)
-                return buf
             recv = _HaloAllToAll.apply(x_local, self.send_idx, self.in_splits, self.out_splits, self.group)
             return torch.cat([x_local, recv], 0)
         x_pad = self.pad_rows(x_local)
@@ -221,41 +406,67 @@ class GraphShard:
         """This rank's rows of a replicated [N, D] tensor (test / setup helper)."""
         return x_global[self.row_lo:self.row_hi]
 
+    def _buffer_scale(self, s):
+        """A source-side scale as a vector over buffer rows: [n_buf] is taken as is; [n_rows] (a value
+        per local node) is exchanged once and cached."""
+        if s is None or s.shape[0] == self.n_buf:     # (n_buf == n_rows: nothing is received, same thing)
+            return s
+        cache = self._origin.__dict__.setdefault("_scale_cache", {})
+        key = (s.data_ptr(), s._version)
+        if key not in cache:
+            cache.clear()
+            with torch.no_grad():
+                cache[key] = (s, self.halo_gather(s.detach().reshape(-1, 1)).reshape(-1).contiguous())
+        return cache[key][1]
+
     def aggregate(self, x_local, weight=None, reduce="sum", src_scale_local=None,
-                  dst_scale_local=None, seg_len=None):
-        """One partitioned layer-forward: halo all-gather + the single-GPU fused kernel on
-        this rank's rows.  `weight`: None or an EdgeNoise built on this shard (its
-        pos_base is forced to the shard's global offset)."""
+                  dst_scale_local=None, seg_len=None, overlap=True):
+        """One partitioned layer-forward: halo exchange + the single-GPU fused kernel on this rank's
+        rows.  `weight`: None or an EdgeNoise built on this shard (its pos_base is forced to the
+        shard's global offset).  src_scale_local: [n_rows] (exchanged) or [n_buf] (`out_degrees()`-
+        derived, used as is).  Without gradients the rows whose sources are all local are launched
+        while the collective is in flight (`overlap`)."""
         from . import ops
-        from .graph import DEFAULT_SEG_LEN
         from .noise import EdgeNoise
-        x_full = self.halo_gather(x_local)
+        seg_len = DEFAULT_SEG_LEN if seg_len is None else seg_len
         if isinstance(weight, EdgeNoise):
             weight.pos_base = self.pos_base
-        src_scale = None
-        if src_scale_local is not None:
-            src_scale = self.halo_gather(src_scale_local.reshape(-1, 1)).reshape(-1)
-        return ops.aggregate(self, x_full, weight, reduce=reduce, src_scale=src_scale,
-                             dst_scale=dst_scale_local,
-                             seg_len=DEFAULT_SEG_LEN if seg_len is None else seg_len)
+        src_scale = self._buffer_scale(src_scale_local)
+        needs_grad = torch.is_grad_enabled() and (
+            x_local.requires_grad or (torch.is_tensor(weight) and weight.requires_grad) or
+            (isinstance(weight, EdgeNoise) and weight.grad_params is not None))
+        fusable = weight is None or (isinstance(weight, EdgeNoise) and weight.n_samples == 1)
+        if needs_grad or not overlap or not fusable or self.world == 1 or not x_local.is_cuda or seg_len <= 0:
+            x_full = self.halo_gather(x_local)
+            return ops.aggregate(self, x_full, weight, reduce=reduce, src_scale=src_scale,
+                                 dst_scale=dst_scale_local, seg_len=seg_len, _gathered=True)
+        buf, work = self.halo_start(x_local)
+        p_loc, p_rem = self.plan_split(seg_len)
+        out = torch.empty((self.n_rows, x_local.shape[1]), dtype=torch.float32, device=x_local.device)
+        if p_loc["n_units"]:
+            ops.aggregate_into(self._csr, buf, out, weight, reduce, src_scale, dst_scale_local, p_loc)
+        if work is not None:
+            work.wait()
+        if p_rem["n_units"]:
+            ops.aggregate_into(self._csr, buf, out, weight, reduce, src_scale, dst_scale_local, p_rem)
+        return out
 
-    def gat_aggregate(self, el_local, er_local, ft_local, neg_slope=0.2, weight=None, seg_len=None):
+    def gat_aggregate(self, el_local, er_local, ft_local, neg_slope=0.2, weight=None, seg_len=None,
+                      want_attn=False):
         """Partitioned GAT layer-forward (BASELINE cfg5): ONE exchange carries [ft | el] of the
         referenced source rows (H*F + H columns), then the single-GPU fused kernel runs on this
         rank's rows.  `weight`: None or an EdgeNoise(dn=H) built on this shard."""
         from . import ops
-        from .graph import DEFAULT_SEG_LEN
         from .noise import EdgeNoise
         n, H, F = ft_local.shape
         packed = torch.cat([ft_local.reshape(n, H * F), el_local], 1)
         full = self.halo_gather(packed)
         ft_full = full[:, :H * F].reshape(-1, H, F)
         el_full = full[:, H * F:]
-        er_rows = er_local
         if isinstance(weight, EdgeNoise):
             weight.pos_base = self.pos_base
-        return ops.gat_aggregate(self, el_full, er_rows, ft_full, neg_slope, weight,
-                                 seg_len=DEFAULT_SEG_LEN if seg_len is None else seg_len)
+        return ops.gat_aggregate(self, el_full, er_local, ft_full, neg_slope, weight, want_attn=want_attn,
+                                 seg_len=DEFAULT_SEG_LEN if seg_len is None else seg_len, _gathered=True)
 
 
 # ------------------------------------------------------------------------------------- #
@@ -285,7 +496,6 @@ class ChannelShard:
 
     def aggregate(self, x_cols, weight=None, reduce="sum", src_scale=None, dst_scale=None, seg_len=None):
         from . import ops
-        from .graph import DEFAULT_SEG_LEN
         from .noise import EdgeNoise
         if x_cols.shape[1] != self.dn:
             raise ValueError(f"rank {self.rank} owns {self.dn} channels, got {x_cols.shape[1]}")

@@ -54,3 +54,27 @@ def molecules_like(n_graphs=4096, mean_nodes=26, seed=2):
         srcs.append(s); dsts.append(d)
         off += n
     return np.concatenate(srcs), np.concatenate(dsts), sizes.astype(np.int64)
+
+
+PPI_NODES, PPI_EDGES, PPI_GRAPHS = 56_944, 818_716, 24
+
+
+def ppi_like(n_graphs=PPI_GRAPHS, n_nodes=PPI_NODES, n_edges=PPI_EDGES, seed=3):
+    """Batch of `n_graphs` PPI-sized graphs as ONE block-diagonal graph (`dgl.batch`,
+    scripts/ppi_mle/run.py:12-14): sizes spread 0.25x-1.5x around the mean (PPI: 591-3480 nodes),
+    edges in proportion to size, skewed in-degree and uniform sources INSIDE each graph, no edge
+    between graphs.  Totals are exact.  Returns (src, dst, batch_num_nodes)."""
+    rng = np.random.default_rng(seed)
+    w = rng.uniform(0.25, 1.5, n_graphs)
+    sizes = np.maximum(2, np.floor(w / w.sum() * n_nodes)).astype(np.int64)
+    sizes[-1] += n_nodes - sizes.sum()
+    ecnt = np.floor(sizes / sizes.sum() * n_edges).astype(np.int64)
+    ecnt[-1] += n_edges - ecnt.sum()
+    srcs, dsts, off = [], [], 0
+    for b in range(n_graphs):
+        s, d = arxiv_like(n_nodes=int(sizes[b]), n_edges=int(ecnt[b]), max_in_degree=max(8, int(sizes[b]) // 6),
+                          n_hubs=8, sigma=0.9, seed=seed * 1000 + b)
+        srcs.append(s + off)
+        dsts.append(d + off)
+        off += int(sizes[b])
+    return np.concatenate(srcs), np.concatenate(dsts), sizes

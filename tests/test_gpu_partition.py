@@ -1,0 +1,150 @@
+"""Node-range shards on the GPU: sub-plan launches, the overlapped step, and whole LAYERS
+(StagLayer over zoo.GCN / GraphSAGE / GIN / GAT) running on a shard — two ranks sharing the one card of
+the GPU box, gloo standing in for RCCL (two RCCL ranks cannot share a device) — against the same layer
+on the whole graph in one process.  Reference call shape kept: stag/layers.py:109-113."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from util import TOL, assert_close
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _graph(seed=5, n=700, e=9000, hub=1200):
+    rng = np.random.default_rng(seed)
+    dst = np.concatenate([rng.integers(0, n - 1, e), np.full(hub, 11)])     # a 1200-edge hub, node n-1 isolated
+    src = rng.integers(0, n, len(dst))
+    return src, dst, n
+
+
+def test_subplans_reproduce_the_whole_plan(dev):
+    """Two launches over complementary sub-plans write exactly what one launch over the whole plan writes."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    src, dst, n = _graph()
+    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
+    for D in (128, 16, 50):
+        x = torch.randn(n, D, device=dev)
+        for kind, kw in ((_lib.NOISE_NORMAL, {}), (_lib.NOISE_BERNOULLI, {"in_norm": True})):
+            mk = lambda: stag_amd.EdgeNoise(g, D, kind, 1.0 if kind == _lib.NOISE_NORMAL else 0.6,
+                                            0.5 if kind == _lib.NOISE_NORMAL else None, seed=3, offset=9, **kw)
+            whole = ops.aggregate(g, x, mk())
+            full = g.csr.plan(64)
+            units = full["units"].cpu().numpy()[:full["n_units"]]
+            rng = np.random.default_rng(D)
+            keep = (units[:, 3] < 0) & (rng.random(len(units)) < 0.4)        # some whole rows; all segments stay together
+            a, b = g.csr.subplan(64, keep), g.csr.subplan(64, ~keep)
+            assert a["n_units"] + b["n_units"] == full["n_units"] and a["n_seg"] == 0 and b["n_seg"] == full["n_seg"]
+            out = torch.full((n, D), float("nan"), device=dev)
+            ops.aggregate_into(g.csr, x, out, mk(), "sum", None, None, a)
+            assert torch.isnan(out).any()                                     # the other rows are still untouched
+            ops.aggregate_into(g.csr, x, out, mk(), "sum", None, None, b)
+            assert torch.equal(out, whole)
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import stag_amd
+        from stag_amd import _lib, ops
+        from stag_amd.partition import GraphShard
+        dev = torch.device("cuda:0")
+        src, dst, n = _graph()
+        D = 64
+        gen = torch.Generator().manual_seed(1)
+        x = torch.randn(n, D, generator=gen)
+        gout = torch.randn(n, 32, generator=gen)
+        sh = GraphShard(src, dst, n, rank, world, device=dev)
+        lo, hi = sh.row_lo, sh.row_hi
+        res = {}
+        # ---- the overlapped inference step == the plain one, bit for bit ---------------------------------
+        xl = x[lo:hi].to(dev)
+        mk = lambda: stag_amd.EdgeNoise(sh, D, _lib.NOISE_NORMAL, 1.0, 0.5, seed=4, offset=2)
+        with torch.no_grad():
+            a = sh.aggregate(xl, mk(), overlap=True)
+            b = sh.aggregate(xl, mk(), overlap=False)
+        assert torch.equal(a, b)
+        p_loc, p_rem = sh.plan_split(64)
+        assert p_loc["n_units"] > 0 and p_rem["n_units"] > 0
+        res["agg"] = a.cpu()
+        # ---- whole layers on the shard: forward + backward ---------------------------------------------
+        for name in ("gcn", "sage", "gin", "gat", "gcn_vi"):
+            torch.manual_seed(7)
+            if name in ("gcn", "gcn_vi"):
+                base = stag_amd.zoo.GCN(D, 32)
+            elif name == "sage":
+                base = stag_amd.zoo.GraphSAGE(D, 32, aggregator_type="mean")
+            elif name == "gin":
+                base = stag_amd.zoo.GIN(D, 32)
+            else:
+                base = stag_amd.zoo.GAT(D, 8, num_heads=4)
+            layer = stag_amd.layers.StagLayer(base, q_a=torch.distributions.Normal(1.0, 0.5), relu=(name == "gcn_vi"),
+                                              vi=(name == "gcn_vi")).to(dev)
+            stag_amd.manual_seed(99)
+            xg = x[lo:hi].to(dev).requires_grad_(True)
+            out = layer(sh, xg)
+            assert out.shape[0] == hi - lo
+            (out.reshape(hi - lo, -1) * gout[lo:hi].to(dev)).sum().backward()
+            grads = {}
+            for k, p in layer.named_parameters():      # replicated parameters: sum the ranks' partial gradients
+                gsum = p.grad.detach().clone()
+                dist.all_reduce(gsum)
+                grads[k] = gsum.cpu()
+            res[name] = {"out": out.detach().cpu(), "dx": xg.grad.cpu(), "grads": grads}
+        torch.save(res, os.path.join(tmp, f"rank{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_layers_on_two_shards_match_the_whole_graph(dev, tmp_path):
+    import torch.multiprocessing as mp
+    import stag_amd
+    from stag_amd import _lib, ops
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    src, dst, n = _graph()
+    D = 64
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(n, D, generator=gen)
+    gout = torch.randn(n, 32, generator=gen)
+    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
+    whole = ops.aggregate(g, x.to(dev), stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, 1.0, 0.5, seed=4, offset=2))
+    assert torch.equal(torch.cat([p["agg"] for p in parts], 0), whole.cpu()), "partitioned aggregation: bit-identical"
+    for name in ("gcn", "sage", "gin", "gat", "gcn_vi"):
+        torch.manual_seed(7)
+        if name in ("gcn", "gcn_vi"):
+            base = stag_amd.zoo.GCN(D, 32)
+        elif name == "sage":
+            base = stag_amd.zoo.GraphSAGE(D, 32, aggregator_type="mean")
+        elif name == "gin":
+            base = stag_amd.zoo.GIN(D, 32)
+        else:
+            base = stag_amd.zoo.GAT(D, 8, num_heads=4)
+        layer = stag_amd.layers.StagLayer(base, q_a=torch.distributions.Normal(1.0, 0.5), relu=(name == "gcn_vi"),
+                                          vi=(name == "gcn_vi")).to(dev)
+        stag_amd.manual_seed(99)
+        xg = x.to(dev).requires_grad_(True)
+        out = layer(g, xg)
+        (out.reshape(n, -1) * gout.to(dev)).sum().backward()
+        got_out = torch.cat([p[name]["out"] for p in parts], 0)
+        got_dx = torch.cat([p[name]["dx"] for p in parts], 0)
+        assert_close(got_out, out.detach().cpu().numpy(), TOL, f"{name}: layer output on shards")
+        assert_close(got_dx, xg.grad.cpu().numpy(), 2 * TOL, f"{name}: d/dx on shards")   # sums over ranks' partials
+        for k, p in layer.named_parameters():
+            ref = p.grad.cpu().numpy()
+            scale = max(1.0, float(np.abs(ref).max()))
+            assert_close(parts[0][name]["grads"][k] / scale, ref / scale, 5e-5, f"{name}: d/d{k} summed over ranks")

@@ -20,7 +20,7 @@ def test_abi_exports_every_declared_symbol():
     assert {"stag_agg_fwd", "stag_noise_materialize", "stag_gat_fwd", "stag_plan_fill"} <= names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/stag_hip.h but not exported"
-    assert lib.stag_abi_version() == 10
+    assert lib.stag_abi_version() == 11
     assert lib.stag_strerror(-22) == b"invalid argument"
 
 
@@ -107,6 +107,29 @@ def test_plan_covers_every_edge_once(seg_len):
     ld = deg[long_rows[:p["n_long"]]]
     assert (np.diff(ld) <= 0).all(), "hub rows first"
     assert set(units[units[:, 3] >= 0][:, 3]) == set(range(p["n_seg"]))
+
+
+def test_subplan_partitions_the_units():
+    """CsrView.subplan: complementary masks over the plan's units give two plans that cover every unit once,
+    keep the plan's order, keep the segments together and the heavy units a prefix."""
+    import stag_amd
+    rng = np.random.default_rng(2)
+    n = 300
+    dst = np.concatenate([rng.integers(0, n, 2500), np.full(400, 9), np.full(70, 21)])
+    src = rng.integers(0, n, len(dst))
+    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n)
+    full = g.csr.plan(64)
+    units = full["units"].numpy()[:full["n_units"]]
+    keep = (units[:, 3] < 0) & (units[:, 0] % 3 == 0)
+    a, b = g.csr.subplan(64, keep), g.csr.subplan(64, ~keep)
+    ua, ub = a["units"].numpy()[:a["n_units"]], b["units"].numpy()[:b["n_units"]]
+    assert np.array_equal(ua, units[keep]) and np.array_equal(ub, units[~keep])
+    assert a["n_seg"] == 0 and a["n_long"] == 0 and b["n_seg"] == full["n_seg"] and b["n_long"] == full["n_long"]
+    for p_, u in ((a, ua), (b, ub)):
+        heavy = (u[:, 3] >= 0) | (u[:, 2] > 16)
+        assert heavy[:p_["n_heavy"]].all() and not heavy[p_["n_heavy"]:].any()
+    with pytest.raises(ValueError):
+        g.csr.subplan(64, units[:, 1] % 2 == 0)          # splits the segments of a long row
 
 
 def test_edge_noise_param_modes():

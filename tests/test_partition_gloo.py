@@ -61,6 +61,28 @@ def _worker(rank, world, port, tmp):
                 cnt[ids - hs.row_lo] += r + 1
         assert np.allclose(xl.grad.numpy(), np.broadcast_to(cnt[:, None], xl.shape))
 
+        # ---- distributed construction: every rank starts from E/world edges ---------------------------
+        cuts = [len(src) * r // world for r in range(world + 1)]
+        ds = GraphShard.from_edge_slices(src[cuts[rank]:cuts[rank + 1]], dst[cuts[rank]:cuts[rank + 1]],
+                                         cuts[rank], n, rank, world, exchange="halo")
+        assert np.array_equal(ds.bounds, hs.bounds) and ds.pos_base == hs.pos_base and ds.n_buf == hs.n_buf
+        for name in ("local_indptr", "local_indices", "local_eid_global", "send_idx", "_in_deg", "_out_deg_buf"):
+            assert torch.equal(getattr(ds, name), getattr(hs, name)), name
+        assert ds.in_splits == hs.in_splits and ds.out_splits == hs.out_splits
+        assert np.array_equal(ds.recv_ids, hs.recv_ids) and np.array_equal(ds._row_is_local, hs._row_is_local)
+        assert ds.n_edges_global == len(src)
+        # degrees: in-degree of my rows, GLOBAL out-degree of the node behind every buffer row
+        gid = np.concatenate([np.arange(hs.row_lo, hs.row_hi), hs.recv_ids])
+        assert np.array_equal(hs.out_degrees().numpy(), np.bincount(src, minlength=n)[gid])
+        assert np.array_equal(hs.in_degrees().numpy(), np.bincount(dst, minlength=n)[hs.row_lo:hs.row_hi])
+        # rows whose sources are all local: exactly those with no column id in the received part
+        ip, ix = hs.local_indptr.numpy(), hs.local_indices.numpy()
+        want_local = np.array([(ix[ip[v]:ip[v + 1]] < hs.n_rows).all() for v in range(hs.n_rows)])
+        assert np.array_equal(hs._row_is_local, want_local)
+        # a source-side scale given per LOCAL node is exchanged once into buffer order
+        sc = torch.arange(hs.row_lo, hs.row_hi, dtype=torch.float32)
+        assert np.array_equal(hs._buffer_scale(sc).numpy(), gid.astype(np.float32))
+
         # ---- exchange="allgather" ----------------------------------------------------------------------
         sh = GraphShard(src, dst, n, rank, world, exchange="allgather")
         # every rank owns a contiguous row range; the ranges tile [0, n)
@@ -82,10 +104,11 @@ def _worker(rank, world, port, tmp):
         gsum.backward()
         want = float(sum(r + 1 for r in range(world)))
         assert torch.allclose(x_local.grad, torch.full_like(x_local, want))
-        # source-major twin of the shard: nidx carries the GLOBAL position of each edge
+        # source-major twin of the shard: nidx = LOCAL forward position (the library adds pos_base)
         t = sh.csr_t
         assert t.n_dst == sh.n_buf and t.n_src == sh.n_rows
-        assert int(t.nidx.min()) >= sh.pos_base and int(t.nidx.max()) < sh.pos_base + E_loc
+        assert int(t.nidx.min()) >= 0 and int(t.nidx.max()) < E_loc
+        assert np.array_equal(np.sort(t.nidx.numpy()), np.arange(E_loc))
         # ---- channel shards: whole CSR everywhere, D/P channels each, no exchange in the step ---------
         from stag_amd.partition import ChannelShard
 
@@ -110,7 +133,7 @@ def _worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 3])
 def test_partition_two_ranks_matches_single(world, tmp_path, oracle):
     import socket
     with socket.socket() as s:

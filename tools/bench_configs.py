@@ -1,14 +1,23 @@
 #!/usr/bin/env python
 """Timings of the other BASELINE configs' hot ops on one GPU (not the bench line).
-  cfg3  PPI-like GraphSAGE: mean aggregation, D=256
-  cfg4  molhiv-like GIN: 4096 small graphs batched, D=128, + mean readout
-  cfg5  arxiv GAT: H=8, F=32, noise [E,8]
+  cfg3     PPI-like GraphSAGE (24 graphs batched): mean aggregation, D=256
+  cfg3_l1  the same batch at D=50 (PPI's input width: the first layer)
+  cfg4     molhiv-like GIN: 4096 small graphs batched, sum, D=128, + mean readout
+  cfg4_l1  the same batch at D=9 (molhiv's atom features: the first layer)
+  cfg5     arxiv GAT: H=8, F=32, noise [E,8], forward
+  cfg5_train   the same, forward + backward (gat_bwd_edge_kernel and the d ft / d el / d er passes)
+
+    python tools/bench_configs.py [--only cfg5,cfg5_train] [--steps 50] [--json out.json]
+
+One JSON object per config on stdout (and collected in --json): device time per step (HIP events),
+algorithmic bytes and the resulting fraction of the 8 TB/s HBM roofline.
+tools/profile_configs.py runs this script under rocprofv3 for profiles/<round>/.
 """
+import argparse
+import json
 import os
 import sys
-import time
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,64 +25,118 @@ sys.path.insert(0, ROOT)
 import stag_amd  # noqa: E402
 from stag_amd import _lib, ops, synthetic  # noqa: E402
 
+ALL = ["cfg5", "cfg5_train", "cfg3", "cfg3_l1", "cfg4", "cfg4_l1"]
 
-def timeit(fn, steps=50, warmup=5):
-    for _ in range(warmup):
-        fn()
+
+def timeit(fn, steps, warmup):
+    for i in range(warmup):
+        fn(i)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(steps):
-        fn(i)
+        fn(warmup + i)
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / steps * 1e3
+    return e0.elapsed_time(e1) / steps * 1e3   # us
+
+
+def report(name, what, t_us, E, b_alg, extra=None):
+    line = {"config": name, "what": what, "us_per_step": round(t_us, 2), "edges": E,
+            "edges_per_s": E / t_us * 1e6, "algorithmic_bytes": b_alg,
+            "achieved_GBs": b_alg / t_us / 1e3, "frac_of_8TBs": b_alg / t_us / 1e3 / 8000.0}
+    if extra:
+        line.update(extra)
+    print(json.dumps(line), flush=True)
+    return line
 
 
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=",".join(ALL))
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--noise", default="normal", choices=["normal", "none"])
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    only = [s for s in args.only.split(",") if s]
     dev = torch.device("cuda:0")
-    src, dst = synthetic.arxiv_like(seed=1)
-    n, E = synthetic.ARXIV_NODES, len(src)
-    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
-    g.csr.plan(64)
-    # cfg5 GAT
-    H, F = 8, 32
-    el, er = torch.randn(n, H, device=dev), torch.randn(n, H, device=dev)
-    ft = torch.randn(n, H, F, device=dev)
-    mk = lambda i: stag_amd.EdgeNoise(g, H, _lib.NOISE_NORMAL, 1.0, 0.5, seed=1, offset=i)
-    t = timeit(lambda i=0: ops.gat_aggregate(g, el, er, ft, 0.2, mk(i)))
-    b_alg = 4 * (n + 1) + 4 * E + 8 * n * H + 2 * 4 * n * H * F
-    print(f"cfg5 GAT H=8 F=32 noise[E,8]: {t:8.1f} us  {E / t / 1e3:6.2f} Gedges/s  alg {b_alg / t / 1e3:7.1f} GB/s ({b_alg / t / 1e3 / 80:.1f} % of 8 TB/s)")
-    t = timeit(lambda i=0: ops.gat_aggregate(g, el, er, ft, 0.2, None))
-    print(f"cfg5 GAT no noise           : {t:8.1f} us")
-    # cfg3 SAGE mean D=256 on a PPI-sized graph
-    n3, E3 = 56944, 818716
-    s3, d3 = synthetic.arxiv_like(n_nodes=n3, n_edges=E3, max_in_degree=700, n_hubs=50, sigma=0.9, seed=3)
-    g3 = stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), n3, device=dev)
-    x3 = torch.randn(n3, 256, device=dev)
-    mk3 = lambda i: stag_amd.EdgeNoise(g3, 256, _lib.NOISE_NORMAL, 1.0, 0.5, seed=1, offset=i)
-    t = timeit(lambda i=0: ops.aggregate(g3, x3, mk3(i), reduce="mean"))
-    b = 4 * (n3 + 1) + 4 * E3 + 8 * n3 * 256
-    print(f"cfg3 SAGE mean D=256        : {t:8.1f} us  {E3 / t / 1e3:6.2f} Gedges/s  alg {b / t / 1e3:7.1f} GB/s ({b / t / 1e3 / 80:.1f} %)")
-    x50 = torch.randn(n3, 50, device=dev)          # PPI's input width: the first layer aggregates at D=50
-    mk50 = lambda i: stag_amd.EdgeNoise(g3, 50, _lib.NOISE_NORMAL, 1.0, 0.5, seed=1, offset=i)
-    t = timeit(lambda i=0: ops.aggregate(g3, x50, mk50(i), reduce="mean"))
-    b = 4 * (n3 + 1) + 4 * E3 + 8 * n3 * 50
-    print(f"cfg3 SAGE mean D=50 (layer 1): {t:8.1f} us  {E3 / t / 1e3:6.2f} Gedges/s  alg {b / t / 1e3:7.1f} GB/s ({b / t / 1e3 / 80:.1f} %)")
-    # cfg4 molecules D=128 + readout
-    s4, d4, sizes = synthetic.molecules_like(4096)
-    n4, E4 = int(sizes.sum()), len(s4)
-    g4 = stag_amd.Graph(torch.from_numpy(s4), torch.from_numpy(d4), n4,
-                        batch_num_nodes=torch.from_numpy(sizes).to(dev), device=dev)
-    x4 = torch.randn(n4, 128, device=dev)
-    mk4 = lambda i: stag_amd.EdgeNoise(g4, 128, _lib.NOISE_NORMAL, 1.0, 0.5, seed=1, offset=i)
-    t = timeit(lambda i=0: ops.aggregate(g4, x4, mk4(i)))
-    b = 4 * (n4 + 1) + 4 * E4 + 8 * n4 * 128
-    print(f"cfg4 GIN sum D=128 (N={n4}, E={E4}): {t:8.1f} us  {E4 / t / 1e3:6.2f} Gedges/s  alg {b / t / 1e3:7.1f} GB/s ({b / t / 1e3 / 80:.1f} %)")
-    offs = torch.zeros(len(sizes) + 1, dtype=torch.int32, device=dev)
-    offs[1:] = torch.cumsum(torch.from_numpy(sizes).to(dev), 0).to(torch.int32)
-    t = timeit(lambda i=0: ops.segment_reduce(x4, offs, "mean"))
-    print(f"cfg4 mean readout [4096,128]: {t:8.1f} us")
+    out = []
+
+    def mk(g, dn):
+        if args.noise == "none":
+            return lambda i: None
+        return lambda i: stag_amd.EdgeNoise(g, dn, _lib.NOISE_NORMAL, 1.0, 0.5, seed=1, offset=i)
+
+    if any(c.startswith("cfg5") for c in only):
+        src, dst = synthetic.arxiv_like(seed=1)
+        n, E = synthetic.ARXIV_NODES, len(src)
+        g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
+        g.csr.plan(64)
+        H, F = 8, 32
+        el, er = torch.randn(n, H, device=dev), torch.randn(n, H, device=dev)
+        ft = torch.randn(n, H, F, device=dev)
+        b_alg = 4 * (n + 1) + 4 * E + 8 * n * H + 2 * 4 * n * H * F      # 363.0 MB
+        noise = mk(g, H)
+        if "cfg5" in only:
+            with torch.no_grad():
+                t = timeit(lambda i: ops.gat_aggregate(g, el, er, ft, 0.2, noise(i)), args.steps, args.warmup)
+            out.append(report("cfg5", f"GAT forward H=8 F=32 noise[E,8]={args.noise}", t, E, b_alg))
+        if "cfg5_train" in only:
+            g.csr_t.plan(64)
+            elg, erg, ftg = (t_.clone().requires_grad_(True) for t_ in (el, er, ft))
+            gout = torch.randn(n, H, F, device=dev)
+
+            def step(i):
+                elg.grad = erg.grad = ftg.grad = None
+                ops.gat_aggregate(g, elg, erg, ftg, 0.2, noise(i)).backward(gout)
+            t = timeit(step, args.steps, args.warmup)
+            # forward bytes + backward: read g, ft, out once, write d ft once, d el / d er, de[E,H] written + read
+            out.append(report("cfg5_train", f"GAT forward+backward (ops.gat_aggregate) noise={args.noise}",
+                              t, E, b_alg, {"note": "frac is forward-only algorithmic bytes over fwd+bwd time"}))
+        del g
+
+    if any(c.startswith("cfg3") for c in only):
+        s3, d3, sizes3 = synthetic.ppi_like()
+        n3, E3 = int(sizes3.sum()), len(s3)
+        g3 = stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), n3,
+                            batch_num_nodes=torch.from_numpy(sizes3).to(dev), device=dev)
+        g3.csr.plan(64)
+        for name, D in (("cfg3", 256), ("cfg3_l1", 50)):
+            if name not in only:
+                continue
+            x3 = torch.randn(n3, D, device=dev)
+            noise = mk(g3, D)
+            with torch.no_grad():
+                t = timeit(lambda i: ops.aggregate(g3, x3, noise(i), reduce="mean"), args.steps, args.warmup)
+            b = 4 * (n3 + 1) + 4 * E3 + 8 * n3 * D
+            out.append(report(name, f"SAGE mean D={D}, 24 PPI-like graphs batched (N={n3}, E={E3}) noise={args.noise}",
+                              t, E3, b))
+        del g3
+
+    if any(c.startswith("cfg4") for c in only):
+        s4, d4, sizes = synthetic.molecules_like(4096)
+        n4, E4 = int(sizes.sum()), len(s4)
+        g4 = stag_amd.Graph(torch.from_numpy(s4), torch.from_numpy(d4), n4,
+                            batch_num_nodes=torch.from_numpy(sizes).to(dev), device=dev)
+        g4.csr.plan(64)
+        offs = torch.zeros(len(sizes) + 1, dtype=torch.int32, device=dev)
+        offs[1:] = torch.cumsum(torch.from_numpy(sizes).to(dev), 0).to(torch.int32)
+        for name, D in (("cfg4", 128), ("cfg4_l1", 9)):
+            if name not in only:
+                continue
+            x4 = torch.randn(n4, D, device=dev)
+            noise = mk(g4, D)
+            with torch.no_grad():
+                t = timeit(lambda i: ops.aggregate(g4, x4, noise(i)), args.steps, args.warmup)
+                tr = timeit(lambda i: ops.segment_reduce(x4, offs, "mean"), args.steps, args.warmup)
+            b = 4 * (n4 + 1) + 4 * E4 + 8 * n4 * D
+            out.append(report(name, f"GIN sum D={D}, 4096 molecules batched (N={n4}, E={E4}) noise={args.noise}",
+                              t, E4, b, {"mean_readout_us": round(tr, 2)}))
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump(out, f, indent=1)
+            f.write("\n")
 
 
 if __name__ == "__main__":
