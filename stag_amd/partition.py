@@ -329,7 +329,8 @@ class GraphShard:
                 torch.arange(self.n_rows, dtype=torch.int32, device=self._device),
                 (self.local_indptr[1:] - self.local_indptr[:-1]).long())
             indptr, indices, eid = build_csr(rows, self.local_indices, self.n_rows, self.n_buf)
-            o._csr_t = CsrView(self.n_buf, self.n_rows, indptr, indices, None, eid if E else None)
+            # edge data (explicit weights, GAT's de / a) is indexed by local edge id = forward position
+            o._csr_t = CsrView(self.n_buf, self.n_rows, indptr, indices, eid if E else None, eid if E else None)
         return o._csr_t
 
     def plan_split(self, seg_len=DEFAULT_SEG_LEN):

@@ -223,13 +223,13 @@ def test_shard_equals_whole_graph(dev):
                 buf[q * sh.max_rows:q * sh.max_rows + hi - lo] = x[lo:hi]
             noise = mk(sh)
             noise.pos_base = sh.pos_base
-            parts.append(ops.aggregate(sh, buf, noise))
+            parts.append(ops.aggregate(sh, buf, noise, _gathered=True))
             hs = GraphShard(src, dst, n, r, world, device=dev, exchange="halo")
             buf = torch.cat([x[hs.row_lo:hs.row_hi], x[torch.from_numpy(hs.recv_ids).to(dev)]], 0)   # all-to-all result
             assert buf.shape[0] == hs.n_buf
             noise = mk(hs)
             noise.pos_base = hs.pos_base
-            parts_halo.append(ops.aggregate(hs, buf, noise))
+            parts_halo.append(ops.aggregate(hs, buf, noise, _gathered=True))
         assert torch.equal(torch.cat(parts, 0), whole)
         assert torch.equal(torch.cat(parts_halo, 0), whole)
     # channel shards: whole CSR on every rank, D/P channels each, no exchange; per-channel params follow

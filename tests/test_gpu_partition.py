@@ -96,6 +96,8 @@ def _worker(rank, world, port, tmp):
             (out.reshape(hi - lo, -1) * gout[lo:hi].to(dev)).sum().backward()
             grads = {}
             for k, p in layer.named_parameters():      # replicated parameters: sum the ranks' partial gradients
+                if p.grad is None:                     # p_a's parameters only see the KL term
+                    continue
                 gsum = p.grad.detach().clone()
                 dist.all_reduce(gsum)
                 grads[k] = gsum.cpu()
@@ -145,6 +147,9 @@ def test_layers_on_two_shards_match_the_whole_graph(dev, tmp_path):
         assert_close(got_out, out.detach().cpu().numpy(), TOL, f"{name}: layer output on shards")
         assert_close(got_dx, xg.grad.cpu().numpy(), 2 * TOL, f"{name}: d/dx on shards")   # sums over ranks' partials
         for k, p in layer.named_parameters():
+            if p.grad is None:
+                assert k not in parts[0][name]["grads"]
+                continue
             ref = p.grad.cpu().numpy()
             scale = max(1.0, float(np.abs(ref).max()))
             assert_close(parts[0][name]["grads"][k] / scale, ref / scale, 5e-5, f"{name}: d/d{k} summed over ranks")
