@@ -184,6 +184,15 @@ int stag_csr_build(const int32_t* src, const int32_t* dst, int32_t n_src, int32_
 int stag_philox_raw(uint64_t seed, uint64_t offset, int64_t pos0, int64_t n_pos,
                     int32_t n_chunk, uint32_t* out, void* stream);
 
+/* ---- test hook: the three hardware functions a NORMAL draw is made of, over ALL 2^23 inputs ----
+ *   rad[m] = sqrt(-2 ln(2 - f12(m)))   cosv[m] = cos(2 pi (f12(m) - 1))   sinv[m] = sin(...)
+ * as the kernels evaluate them (v_log_f32 / v_sqrt_f32 / v_cos_f32 / v_sin_f32; a draw is
+ * z_a = rad[r_a & 0x7FFFFF] * cosv[r_b & 0x7FFFFF], z_b = rad[..] * sinv[..], one fp32 multiply).
+ * Each table is [2^23] floats (32 MB).  The CPU oracle loads them to redraw the device's normals bit
+ * for bit; the tests also compare every entry with libm, so the approximations are pinned
+ * exhaustively rather than by sampling.                                                       */
+int stag_normal_tables(float* rad, float* cosv, float* sinv, void* stream);
+
 /* ---- the hot path ---------------------------------------------------------
  * out[v, k] = dscale[v] * s[v, k] * sum_{p in row v} w[p, k] * sscale[u_p] * x[u_p, k]
  *   u_p     = csr.indices[p]

@@ -83,6 +83,25 @@ def set_threads(n):
     gomp.omp_set_num_threads(int(n))
 
 
+_normal_tables = None
+
+
+def set_normal_tables(tables):
+    """tables: None (default: normals are the fp64 expression rounded once), or a [3, 2^23] float32 array
+    (rad, cos, sin) produced by the DEVICE (stag_normal_tables): the oracle then redraws the device's
+    normals bit for bit, z = rad[m_a] * cos|sin[m_b].  The array is kept alive here."""
+    global _normal_tables
+    if tables is None:
+        _normal_tables = None
+        _check(lib().stag_set_normal_tables_cpu(None, None, None), "set_normal_tables")
+        return
+    t = np.ascontiguousarray(tables, dtype=np.float32)
+    if t.shape != (3, 1 << 23):
+        raise ValueError("normal tables must be [3, 2^23]")
+    _normal_tables = t
+    _check(lib().stag_set_normal_tables_cpu(_p(t[0], _f32p), _p(t[1], _f32p), _p(t[2], _f32p)), "set_normal_tables")
+
+
 def _f32(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
 

@@ -100,7 +100,30 @@ static inline void std_uniform4(const uint32_t r[4], float u[4]) {
   for (int j = 0; j < 4; ++j) u[j] = f12(r[j]) - 1.0f;
 }
 
+/* Optional: the device's own evaluation of the three functions a normal draw is made of, for all
+ * 2^23 mantissas (include/stag_hip.h: stag_normal_tables).  With the tables loaded the oracle redraws
+ * the device's normals BIT FOR BIT (z = rad[m_a] * cos[m_b], one fp32 multiply, as in the kernel), so
+ * what is left between the two is arithmetic on identical weights.  Without them (the default; what
+ * the CPU tests and the golden fixtures use) the draw is the fp64 expression rounded once. */
+static const float* g_tab_rad = NULL;
+static const float* g_tab_cos = NULL;
+static const float* g_tab_sin = NULL;
+
+int stag_set_normal_tables_cpu(const float* rad, const float* cosv, const float* sinv) {
+  if ((rad == NULL) != (cosv == NULL) || (rad == NULL) != (sinv == NULL)) return STAG_EINVAL;
+  g_tab_rad = rad; g_tab_cos = cosv; g_tab_sin = sinv;
+  return STAG_OK;
+}
+
 static inline void std_normal4(const uint32_t r[4], float z[4]) {
+  if (g_tab_rad) {
+    for (int h = 0; h < 2; ++h) {
+      const float rad = g_tab_rad[r[2 * h] & 0x007FFFFFu];
+      z[2 * h] = rad * g_tab_cos[r[2 * h + 1] & 0x007FFFFFu];
+      z[2 * h + 1] = rad * g_tab_sin[r[2 * h + 1] & 0x007FFFFFu];
+    }
+    return;
+  }
   for (int h = 0; h < 2; ++h) {
     double u1 = 2.0 - (double)f12(r[2 * h]);           /* (0, 1] */
     double u2 = (double)f12(r[2 * h + 1]) - 1.0;       /* [0, 1) */

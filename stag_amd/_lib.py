@@ -88,6 +88,7 @@ def lib():
     l.stag_csr_build.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp, _vp, _vp, _vp,
                                  C.c_size_t, _vp]
     l.stag_philox_raw.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]
+    l.stag_normal_tables.argtypes = [_vp, _vp, _vp, _vp]
     l.stag_agg_fwd.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, C.c_int64, C.c_int32,
                                C.POINTER(NoiseSpec), C.c_int32, _vp, _vp, _vp, C.c_int64, _vp, _vp]
     l.stag_noise_materialize.argtypes = [C.POINTER(Csr), C.POINTER(Plan), C.POINTER(NoiseSpec), C.c_int32,

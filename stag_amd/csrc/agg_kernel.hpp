@@ -129,8 +129,8 @@ __device__ __forceinline__ void store4_sc1(__amdgpu_buffer_rsrc_t rsrc, uint32_t
 // sum[q] = sum over segments s0..s1-1 of ws[s][k0+q], in segment order, Kahan-compensated
 template <int NF, bool VEC>
 __device__ __forceinline__ void kahan_sum_partials(const float* ws, int ws_stride, int s0, int s1,
-                                                   int k0, int D, float (&sum)[4]) {
-  float comp[4] = {0.f, 0.f, 0.f, 0.f};
+                                                   int k0, int D, float (&sum)[4], float (&comp)[4]) {
+  comp[0] = comp[1] = comp[2] = comp[3] = 0.f;
   sum[0] = sum[1] = sum[2] = sum[3] = 0.f;
 #pragma unroll 1
   for (int s = s0; s < s1; s += NF) {
@@ -160,6 +160,9 @@ __device__ __forceinline__ void agg_epilogue_extra(const AggArgs& a, float* out,
 // group order.  SLOTS edge slots of the unit take one group each per round and exchange the group
 // sums (ds_bpermute; slot0 = byte address of slot 0's lane with my channels): same arithmetic
 // for every SLOTS.
+// What a group sum loses to rounding (its Kahan residual) is not dropped: it joins the second level's
+// compensation, so the second level does not undo the first: the result is the sum of the partials
+// to about one rounding of the result.  (Written to stay inside the hot loop's register budget.)
 constexpr int kCombineGroup = 16;
 template <int NF, bool VEC, int LPE, int SLOTS>
 __device__ __forceinline__ void two_level_sum(const float* ws, int ws_stride, int s0, int s1, int k0,
@@ -169,8 +172,11 @@ __device__ __forceinline__ void two_level_sum(const float* ws, int ws_stride, in
 #pragma unroll 1
   for (int g0 = s0; g0 < s1; g0 += kCombineGroup * SLOTS) {
     const int gs = g0 + sl * kCombineGroup;
-    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
-    if (gs < s1) kahan_sum_partials<NF, VEC>(ws, ws_stride, gs, min(gs + kCombineGroup, s1), k0, D, gsum);
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f}, gres[4] = {0.f, 0.f, 0.f, 0.f};   // group sum, what it still owes
+    if (gs < s1) {
+      const int ge = min(gs + kCombineGroup, s1);
+      kahan_sum_partials<NF, VEC>(ws, ws_stride, gs, ge, k0, D, gsum, gres);
+    }
 #pragma unroll
     for (int j = 0; j < SLOTS; ++j) {
       if (g0 + j * kCombineGroup < s1) {            // uniform over the unit's lanes
@@ -179,6 +185,10 @@ __device__ __forceinline__ void two_level_sum(const float* ws, int ws_stride, in
           const float gj = SLOTS > 1 ? __int_as_float(__builtin_amdgcn_ds_bpermute(
                                            slot0 + j * (LPE << 2), __float_as_int(gsum[q])))
                                      : gsum[q];
+          const float rj = SLOTS > 1 ? __int_as_float(__builtin_amdgcn_ds_bpermute(
+                                           slot0 + j * (LPE << 2), __float_as_int(gres[q])))
+                                     : gres[q];
+          comp[q] += rj;                            // true group sum = gj - rj
           const float y = gj - comp[q];
           const float n = sum[q] + y;
           comp[q] = (n - sum[q]) - y;
@@ -187,6 +197,8 @@ __device__ __forceinline__ void two_level_sum(const float* ws, int ws_stride, in
       }
     }
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sum[q] -= comp[q];
 }
 
 // epilogue shared by whole-row units and the last-arriver combine
@@ -445,6 +457,7 @@ struct AggTeam {
   // fold one block into the unit's sum; compensated (Kahan) once a unit is long enough for
   // the running sum to dwarf a block, so a 13k-edge hub row keeps ~1e-6 relative accuracy
   __device__ __forceinline__ void fold(const float (&t)[4]) { fold_into(acc, comp, t); }
+
   __device__ __forceinline__ void fold_into(float (&s)[4], float (&cmp)[4], const float (&t)[4]) const {
     if (kahan) {
 #pragma unroll

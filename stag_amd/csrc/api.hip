@@ -64,6 +64,15 @@ __global__ void philox_raw_kernel(PhiloxKey key, int64_t pos0, int64_t n_pos, in
   *reinterpret_cast<uint4*>(out + i * 4) = make_uint4(r[0], r[1], r[2], r[3]);
 }
 
+// the hardware functions of a normal draw, tabulated over all 2^23 mantissas (stag_normal_tables)
+__global__ void normal_tables_kernel(float* rad, float* cosv, float* sinv) {
+  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= (1u << 23)) return;
+  rad[m] = bm_radius(m);
+  cosv[m] = bm_cos(m);
+  sinv[m] = bm_sin(m);
+}
+
 // w of the 4 channels [k0, k0+4) of the edge at position p, before in-norm
 struct NoiseArgs {
   const int32_t* indptr;
@@ -548,6 +557,12 @@ int stag_philox_raw(uint64_t seed, uint64_t offset, int64_t pos0, int64_t n_pos,
   s.seed = seed; s.offset = offset;
   hipLaunchKernelGGL(philox_raw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, make_key(&s), pos0, n_pos, n_chunk, out);
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}
+
+int stag_normal_tables(float* rad, float* cosv, float* sinv, void* stream) {
+  if (!rad || !cosv || !sinv) return STAG_EINVAL;
+  hipLaunchKernelGGL(normal_tables_kernel, dim3((1u << 23) / 256), dim3(256), 0, (hipStream_t)stream, rad, cosv, sinv);
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }
 

@@ -87,13 +87,21 @@ __device__ __forceinline__ float u01(uint32_t r) { return f12(r) - 1.0f; }
 // Box-Muller on the hardware transcendentals: v_log_f32 is log2 and v_sin/v_cos take
 // revolutions (and are periodic in them), so neither ln, nor 2*pi, nor the "- 1" of the
 // angle costs an instruction: u1 = 2 - f12(ra) in (0,1], angle = f12(rb) revolutions.
-__device__ __forceinline__ void box_muller(uint32_t ra, uint32_t rb, float& za, float& zb) {
+// The three functions of 23 random bits a normal draw is made of.  stag_normal_tables (api.hip)
+// tabulates exactly these for all 2^23 inputs: the CPU oracle can then redraw the device's normals
+// bit for bit, and the tables themselves are checked exhaustively against libm.
+__device__ __forceinline__ float bm_radius(uint32_t ra) {
   const float u1 = 2.0f - f12(ra);
-  const float th = f12(rb);
   // -2 ln(u1) = (-2 ln 2) * log2(u1)
-  const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
-  za = rad * __builtin_amdgcn_cosf(th);
-  zb = rad * __builtin_amdgcn_sinf(th);
+  return __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+}
+__device__ __forceinline__ float bm_cos(uint32_t rb) { return __builtin_amdgcn_cosf(f12(rb)); }
+__device__ __forceinline__ float bm_sin(uint32_t rb) { return __builtin_amdgcn_sinf(f12(rb)); }
+
+__device__ __forceinline__ void box_muller(uint32_t ra, uint32_t rb, float& za, float& zb) {
+  const float rad = bm_radius(ra);
+  za = rad * bm_cos(rb);
+  zb = rad * bm_sin(rb);
 }
 
 enum : int { kNone = 0, kExplicit = 1, kNormal = 2, kUniform = 3, kBernoulli = 4 };

@@ -492,6 +492,17 @@ def philox_raw(seed, offset, pos0, n_pos, n_chunk, device):
     return out
 
 
+def normal_tables(device):
+    """(rad, cos, sin): the hardware functions of a Normal draw over all 2^23 mantissas, [3, 2^23] fp32
+    (stag_normal_tables; test hook — the CPU oracle redraws the device's normals from them)."""
+    t = torch.empty((3, 1 << 23), dtype=torch.float32, device=device)
+    dev = _lib.require_device(t)
+    with _lib.on_device(dev):
+        rc = _lib.lib().stag_normal_tables(_lib.ptr(t[0]), _lib.ptr(t[1]), _lib.ptr(t[2]), _lib.stream_of(dev))
+    _lib.check(rc, "stag_normal_tables")
+    return t
+
+
 def _segment_reduce_raw(x, offsets, reduce, dev):
     B, D = offsets.shape[0] - 1, x.shape[1]
     out = torch.empty((B, D), dtype=torch.float32, device=dev)

@@ -1,0 +1,218 @@
+"""BASELINE configs[2] and configs[3] at workload size against the CPU oracle (run on the GPU box: -m gpu).
+
+  cfg3  PPI GraphSAGE, 24 graphs per batch (scripts/ppi_mle/run.py:71-77, dgl.batch at :12-14): one
+        block-diagonal graph, N = 56,944, E = 818,716; mean aggregation at D = 50 (PPI's input width:
+        layer 1) and D = 256 (hidden: layers 2, 3); stag/zoo/graph_sage.py:70-75,107.
+  cfg4  ogbg-molhiv GIN, 4096 molecules per batch (scripts/molhiv_mle/run.py:112-123): N ~ 106 k,
+        E ~ 218 k, degree 1-4; sum aggregation at D = 9 (atom features) and D = 128, then the per-graph
+        mean readout (stag/layers.py:168-178); stag/zoo/gin.py:4-11 = DGL GINConv:
+        rst = Linear((1 + eps) * x_dst + sum_in w (.) x_src).
+Also: AmortizedDistribution.condition on device tensors (its split-GEMM + kernel-gather branch) against the
+fixtures the reference's own condition() produced (stag/distributions.py:221-233).
+
+Bars: every aggregated feature |a - b| <= 1e-5 (1 + |b|), flat, against the oracle drawing the device's
+normals (util.hw_normals) and, on rows of up to 256 in-edges, against the oracle's own libm normals;
+layer outputs behind a dense transform 2e-5 (an fp32 GEMM over K <= 256 on either side).
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import TOL, assert_close, hw_normals, oracle_graph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ppi(dev):
+    import stag_amd
+    from stag_amd import synthetic
+    src, dst, sizes = synthetic.ppi_like()
+    n = int(sizes.sum())
+    assert (n, len(src), len(sizes)) == (synthetic.PPI_NODES, synthetic.PPI_EDGES, 24)
+    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n,
+                       batch_num_nodes=torch.from_numpy(sizes).to(dev), device=dev)
+    return g, n, sizes
+
+
+@pytest.fixture(scope="module")
+def molecules(dev):
+    import stag_amd
+    from stag_amd import synthetic
+    src, dst, sizes = synthetic.molecules_like(4096)
+    n = int(sizes.sum())
+    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n,
+                       batch_num_nodes=torch.from_numpy(sizes).to(dev), device=dev)
+    return g, n, sizes
+
+
+def _normal(g, D, seed, offset, **kw):
+    import stag_amd
+    from stag_amd import _lib
+    return stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, 1.0, 0.5, seed=seed, offset=offset, **kw)
+
+
+@pytest.mark.parametrize("D", [50, 256])
+def test_cfg3_ppi_sage_mean_aggregation(dev, oracle, ppi, D):
+    from stag_amd import ops
+    g, n, sizes = ppi
+    og = oracle_graph(oracle, g)
+    x = torch.randn(n, D, generator=torch.Generator().manual_seed(D))
+    xd = x.to(dev)
+    spec = oracle.make_spec("normal", 1.0, 0.5, seed=31, offset=2, Dn=D, n_edges=g.number_of_edges())
+    got = ops.aggregate(g, xd, _normal(g, D, 31, 2), reduce="mean")
+    with hw_normals(oracle, dev):
+        ref = oracle.agg_fwd(og, x.numpy(), spec, reduce=oracle.REDUCE_MEAN)
+    assert_close(got, ref, what=f"cfg3 SAGE mean D={D}, every row")
+    ref_libm = oracle.agg_fwd(og, x.numpy(), spec, reduce=oracle.REDUCE_MEAN)
+    assert_close(got, ref_libm, what=f"cfg3 SAGE mean D={D} vs libm normals")      # mean: sums / deg, well inside
+    # block-diagonal batch: a graph's rows depend on that graph's rows only
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    x2 = xd.clone()
+    x2[offs[3]:offs[4]] = 0.0                              # wipe graph 3
+    got2 = ops.aggregate(g, x2, _normal(g, D, 31, 2), reduce="mean")
+    keep = torch.ones(n, dtype=torch.bool, device=dev)
+    keep[offs[3]:offs[4]] = False
+    assert torch.equal(got2[keep], got[keep]) and float(got2[~keep].abs().max()) == 0.0
+    # Bernoulli + in-norm, the other distribution of the scripts (scripts/ppi_mle/run.py --distribution)
+    import stag_amd
+    from stag_amd import _lib
+    b = stag_amd.EdgeNoise(g, D, _lib.NOISE_BERNOULLI, 0.7, None, seed=5, offset=1, in_norm=True)
+    refb = oracle.agg_fwd(og, x.numpy(), oracle.make_spec("bernoulli", 0.7, in_norm=True, seed=5, offset=1, Dn=D,
+                                                           n_edges=g.number_of_edges()), reduce=oracle.REDUCE_MEAN)
+    assert_close(ops.aggregate(g, xd, b, reduce="mean"), refb, what=f"cfg3 Bernoulli + in-norm D={D}")
+
+
+def test_cfg3_sage_layer_stack_against_oracle_formula(dev, oracle, ppi):
+    """StagLayer(GraphSAGE) 50 -> 256 -> 256 on the batch: every layer's output against
+    fc_self(h) + fc_neigh(mean_in(w (.) h)) + bias computed from the oracle's aggregation in fp64
+    (stag/zoo/graph_sage.py:70-75, 107-111)."""
+    import stag_amd
+    g, n, _ = ppi
+    og = oracle_graph(oracle, g)
+    torch.manual_seed(3)
+    dims = [50, 256, 256]
+    layers = [stag_amd.layers.StagLayer(stag_amd.zoo.GraphSAGE(a, b, aggregator_type="mean"),
+                                        q_a=torch.distributions.Normal(1.0, 0.5)).to(dev)
+              for a, b in zip(dims[:-1], dims[1:])]
+    h = torch.randn(n, 50, generator=torch.Generator().manual_seed(8)).to(dev)
+    stag_amd.manual_seed(4242)
+    with torch.no_grad(), hw_normals(oracle, dev):
+        for layer in layers:
+            out = layer(g, h)
+            nz = layer._edge_weight_handle
+            D = h.shape[1]
+            spec = oracle.make_spec("normal", 1.0, 0.5, seed=nz.seed, offset=nz.offset, Dn=D, n_edges=g.number_of_edges())
+            agg = oracle.agg_fwd(og, h.cpu().numpy(), spec, reduce=oracle.REDUCE_MEAN).astype(np.float64)
+            b = layer.base_layer
+            ref = (h.cpu().numpy().astype(np.float64) @ b.fc_self.weight.detach().cpu().numpy().astype(np.float64).T
+                   + agg @ b.fc_neigh.weight.detach().cpu().numpy().astype(np.float64).T
+                   + b.bias.detach().cpu().numpy().astype(np.float64))
+            assert_close(out, ref, tol=2 * TOL, what=f"cfg3 SAGE layer {D}->{out.shape[1]}")
+            h = torch.relu(out)
+
+
+@pytest.mark.parametrize("D", [9, 128])
+def test_cfg4_molhiv_gin_sum_and_readout(dev, oracle, molecules, D):
+    import stag_amd
+    from stag_amd import ops
+    g, n, sizes = molecules
+    assert len(sizes) == 4096 and int(g.in_degrees().max()) <= 64       # tiny rows: no segments at all
+    og = oracle_graph(oracle, g)
+    x = torch.randn(n, D, generator=torch.Generator().manual_seed(D))
+    xd = x.to(dev)
+    spec = oracle.make_spec("normal", 1.0, 0.5, seed=77, offset=9, Dn=D, n_edges=g.number_of_edges())
+    got = ops.aggregate(g, xd, _normal(g, D, 77, 9))
+    assert_close(got, oracle.agg_fwd(og, x.numpy(), spec), what=f"cfg4 GIN sum D={D} vs libm normals")
+    with hw_normals(oracle, dev):
+        assert_close(got, oracle.agg_fwd(og, x.numpy(), spec), what=f"cfg4 GIN sum D={D}")
+    # the per-graph mean readout of the batch (stag/layers.py:168-178 = dgl.mean_nodes)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    read = stag_amd.layers.MeanNodes()(g, got)
+    assert read.shape == (4096, D)
+    assert_close(read, oracle.segment_reduce(got.cpu().numpy(), offs, oracle.REDUCE_MEAN), what=f"cfg4 MeanNodes D={D}")
+    tot = stag_amd.layers.SumNodes()(g, got)
+    assert_close(tot, oracle.segment_reduce(got.cpu().numpy(), offs, oracle.REDUCE_SUM), what=f"cfg4 SumNodes D={D}")
+
+
+@pytest.mark.parametrize("agg,eps,learn", [("sum", 0.0, False), ("sum", 0.3, True), ("mean", 0.1, False)])
+def test_gin_module_against_oracle_formula(dev, oracle, molecules, agg, eps, learn):
+    """zoo.GIN (stag/zoo/gin.py:4-11; DGL GINConv with apply_func = Linear):
+    rst = W ((1 + eps) x + sum|mean_in w (.) x_src) + b, w explicit or drawn; forward and d/dx."""
+    import stag_amd
+    g, n, _ = molecules
+    og = oracle_graph(oracle, g)
+    D, out_f = 9, 32
+    torch.manual_seed(11)
+    gin = stag_amd.zoo.GIN(D, out_f, aggregator_type=agg, init_eps=eps, learn_eps=learn).to(dev)
+    assert ("eps" in dict(gin.named_parameters())) == learn
+    x = torch.randn(n, D, generator=torch.Generator().manual_seed(2))
+    W = gin.apply_func.weight.detach().cpu().numpy().astype(np.float64)
+    bias = gin.apply_func.bias.detach().cpu().numpy().astype(np.float64)
+    red = oracle.REDUCE_MEAN if agg == "mean" else oracle.REDUCE_SUM
+    # explicit edge weight (the boundary's call shape: base_layer.forward(graph, feat, edge_weight=w))
+    w = torch.rand(g.number_of_edges(), D, generator=torch.Generator().manual_seed(3)) + 0.5
+    neigh = oracle.agg_fwd(og, x.numpy(), oracle.make_spec("explicit", w.numpy()), reduce=red).astype(np.float64)
+    ref = ((1.0 + eps) * x.numpy().astype(np.float64) + neigh) @ W.T + bias
+    xd = x.to(dev).requires_grad_(True)
+    out = gin(g, xd, edge_weight=w.to(dev))
+    assert_close(out, ref, tol=2 * TOL, what=f"GIN {agg} explicit weight")
+    # d/dx of sum(out * G): (1 + eps) G W + A^T (G W) with the same weights, from the oracle's transposed pass
+    G = torch.randn(n, out_f, generator=torch.Generator().manual_seed(4))
+    out.backward(G.to(dev))
+    GW = G.numpy().astype(np.float64) @ W
+    ogt = oracle_graph(oracle, g, transposed=True)
+    gscale = (1.0 / np.maximum(g.in_degrees().cpu().numpy(), 1)).astype(np.float32) if agg == "mean" else None
+    back = oracle.agg_fwd(ogt, GW.astype(np.float32), oracle.make_spec("explicit", w.numpy()), src_scale=gscale)
+    assert_close(xd.grad, (1.0 + eps) * GW + back, tol=5 * TOL, what=f"GIN {agg} d/dx")
+    # drawn weights through StagLayer
+    layer = stag_amd.layers.StagLayer(gin, q_a=torch.distributions.Normal(1.0, 0.5)).to(dev)
+    stag_amd.manual_seed(6)
+    with torch.no_grad(), hw_normals(oracle, dev):
+        out = layer(g, x.to(dev))
+        nz = layer._edge_weight_handle
+        spec = oracle.make_spec("normal", 1.0, 0.5, seed=nz.seed, offset=nz.offset, Dn=D, n_edges=g.number_of_edges())
+        neigh = oracle.agg_fwd(og, x.numpy(), spec, reduce=red).astype(np.float64)
+    assert_close(out, ((1.0 + eps) * x.numpy().astype(np.float64) + neigh) @ W.T + bias, tol=2 * TOL,
+                 what=f"StagLayer(GIN {agg})")
+
+
+@pytest.mark.parametrize("tag,of", [("re", 1), ("rec", 16)])
+def test_amortized_condition_on_device_golden(dev, golden, tag, of):
+    """AmortizedDistribution.condition's device branch (one GEMM over the N node rows per half of the
+    embedding weight, two kernel-backed gathers, the parameter heads; stag_amd/distributions.py) against the
+    per-edge loc / log_scale the reference's own condition() produced (stag/distributions.py:221-233), and
+    the layer output with the reference's sampled weights injected."""
+    import stag_amd
+    from stag_amd.distributions import AmortizedDistribution
+    q = AmortizedDistribution(16, of).to(dev)
+    sd = {k[len(f"amort_{tag}_sd_"):]: torch.from_numpy(golden[k]) for k in golden.files
+          if k.startswith(f"amort_{tag}_sd_")}
+    q.load_state_dict(sd)
+    g = stag_amd.Graph(torch.from_numpy(golden["hub40_src"]), torch.from_numpy(golden["hub40_dst"]), 40, device=dev)
+    x = torch.from_numpy(golden[f"amort_{tag}_x"]).to(dev).requires_grad_(True)
+    q.condition(g, x)
+    assert q.new_parameters["loc"].is_cuda and q.new_parameters["loc"].shape == (g.number_of_edges(), of)
+    assert_close(q.new_parameters["loc"], golden[f"amort_{tag}_loc"], what=f"{tag} loc")
+    assert_close(q.new_parameters["log_scale"], golden[f"amort_{tag}_log_scale"], what=f"{tag} log_scale")
+    # gradients reach the MLP and the features through the kernel-backed gathers: compare with the plain
+    # torch form of the same expression (the reference's dataflow: cat -> Linear, stag/distributions.py:225-231)
+    (q.new_parameters["loc"].sum() + (q.new_parameters["log_scale"] ** 2).sum()).backward()
+    got = {k: p.grad.clone() for k, p in q.named_parameters()}
+    gx = x.grad.clone()
+    q.zero_grad()
+    x2 = x.detach().clone().requires_grad_(True)
+    src, dst = g.edges()
+    h = q.embedding_mlp(torch.cat([x2[src], x2[dst]], dim=-1))
+    loc, ls = q.parameters_mlp["loc"](h), q.parameters_mlp["log_scale"](h)
+    (loc.sum() + (ls ** 2).sum()).backward()
+    assert_close(gx, x2.grad.cpu().numpy(), tol=5 * TOL, what=f"{tag} d/dx")
+    for k, p in q.named_parameters():
+        ref = p.grad.cpu().numpy()
+        s = max(1.0, float(np.abs(ref).max()))
+        assert_close(got[k] / s, ref / s, tol=5 * TOL, what=f"{tag} d/d{k}")
+    # the reference's layer output with ITS sampled weights injected through the explicit-weight kernel
+    from stag_amd import ops
+    w = torch.from_numpy(golden[f"amort_{tag}_w"]).to(dev)
+    out = ops.aggregate(g, x.detach(), w.expand(g.number_of_edges(), 16).contiguous())
+    assert_close(out, golden[f"amort_{tag}_out"], what=f"{tag} layer output (SumBase)")

@@ -43,6 +43,50 @@ def test_philox_words_bit_exact(dev, oracle):
         assert np.array_equal(got, ref)
 
 
+def test_normal_tables_exhaustive(dev):
+    """The hardware functions a Normal draw is made of (v_log/v_sqrt, v_cos, v_sin) over ALL 2^23 inputs
+    against fp64: the approximation the noise stream is defined with (include/stag_hip.h) is pinned
+    entry by entry, not by sampling."""
+    from stag_amd import ops
+    t = ops.normal_tables(dev).cpu().numpy().astype(np.float64)
+    m = np.arange(1 << 23, dtype=np.uint32)
+    f12 = ((m & 0x7FFFFF) | 0x3F800000).view(np.float32).astype(np.float64)
+    rad = np.sqrt(-2.0 * np.log(2.0 - f12))
+    ang = 2.0 * np.pi * (f12 - 1.0)
+    rel = np.abs(t[0] - rad)[1:] / rad[1:]                # m = 0: u1 = 1, radius exactly 0
+    assert t[0][0] == 0.0
+    e_c, e_s = np.abs(t[1] - np.cos(ang)), np.abs(t[2] - np.sin(ang))
+    print(f"radius: max rel {rel.max():.3e} rms {np.sqrt((rel ** 2).mean()):.3e}; "
+          f"cos: max abs {e_c.max():.3e} rms {np.sqrt((e_c ** 2).mean()):.3e}; "
+          f"sin: max abs {e_s.max():.3e} rms {np.sqrt((e_s ** 2).mean()):.3e}")
+    assert rel.max() <= 4e-7 and e_c.max() <= 4e-7 and e_s.max() <= 4e-7
+    assert np.all(np.abs(t[1]) <= 1.0) and np.all(np.abs(t[2]) <= 1.0) and np.all(t[0] >= 0.0)
+
+
+def test_normal_draws_bit_exact_from_tables(dev, oracle):
+    """With the device's tables loaded, the oracle's normals ARE the kernel's normals: [E, Dn] fields
+    (scalar / per-channel / per-edge parameters, relu) compare equal, not close."""
+    from util import hw_normals
+    g = random_graph(200, 3000, seed=9, hub=400, device=dev)
+    E, dn = g.number_of_edges(), 12
+    rng = np.random.default_rng(4)
+    cases = [(1.0, 0.5, False), (0.2, 1.0, True),
+             (torch.tensor(rng.uniform(0.5, 1.5, dn).astype(np.float32), device=dev),
+              torch.tensor(rng.uniform(0.1, 1.0, dn).astype(np.float32), device=dev), False),
+             (torch.tensor(rng.uniform(0.5, 1.5, (E, dn)).astype(np.float32), device=dev),
+              torch.tensor(rng.uniform(0.1, 1.0, (E, dn)).astype(np.float32), device=dev), True)]
+    og = oracle_graph(oracle, g)
+    with hw_normals(oracle, dev):
+        for p0, p1, relu in cases:
+            got = _noise(g, dn, "normal", p0, p1, relu=relu, seed=77, offset=6).materialize().cpu().numpy()
+            ref = oracle.noise_materialize(og, _ospec(oracle, g, dn, "normal", p0, p1, relu=relu, seed=77, offset=6), dn)
+            assert np.array_equal(got, ref)
+    # and without them the two differ by the hardware's approximation error only
+    ref = oracle.noise_materialize(og, _ospec(oracle, g, dn, "normal", 1.0, 0.5, seed=77, offset=6), dn)
+    got = _noise(g, dn, "normal", 1.0, 0.5, seed=77, offset=6).materialize().cpu().numpy()
+    assert 0 < np.abs(got - ref).max() <= 1e-6
+
+
 def test_csr_bit_exact(dev, oracle):
     g = random_graph(300, 4000, seed=3, hub=500, device=dev)
     src, dst = (t.cpu().numpy() for t in g.edges())
