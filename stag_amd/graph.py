@@ -348,18 +348,40 @@ def rand_graph(num_nodes, num_edges, device=None, generator=None):
     return Graph(src, dst, num_nodes, device=device)
 
 
+def _carry_frames(g, new, edata):
+    """Node frames and the batch structure survive an edge transform, as in DGL (the reference's scripts
+    read g.ndata['feat'] / ['label'] / ['train_mask'] after remove_self_loop + add_self_loop,
+    scripts/citation_mle/gcn/run.py:52-53)."""
+    new.ndata = dict(g.ndata)
+    new._batch_num_nodes = g._batch_num_nodes
+    new.edata = edata
+    return new
+
+
 def remove_self_loop(g):
+    """`dgl.remove_self_loop`: edge frames keep the rows of the surviving edges."""
     keep = g._src != g._dst
-    return Graph(g._src[keep], g._dst[keep], g._n)
+    edata = {k: (v[keep] if torch.is_tensor(v) and v.shape[:1] == keep.shape else v) for k, v in g.edata.items()}
+    return _carry_frames(g, Graph(g._src[keep], g._dst[keep], g._n), edata)
 
 
 def add_self_loop(g):
+    """`dgl.add_self_loop`: one loop per node appended after the existing edges; their rows of every edge
+    frame are zero, as in DGL."""
     loop = torch.arange(g._n, dtype=torch.int32, device=g.device)
-    return Graph(torch.cat([g._src, loop]), torch.cat([g._dst, loop]), g._n)
+    edata = {k: torch.cat([v, v.new_zeros((g._n,) + tuple(v.shape[1:]))], 0) for k, v in g.edata.items()
+             if torch.is_tensor(v)}
+    return _carry_frames(g, Graph(torch.cat([g._src, loop]), torch.cat([g._dst, loop]), g._n), edata)
 
 
-def add_reverse_edges(g):
-    return Graph(torch.cat([g._src, g._dst]), torch.cat([g._dst, g._src]), g._n)
+def add_reverse_edges(g, copy_ndata=True, copy_edata=False):
+    """`dgl.add_reverse_edges` (defaults as DGL's: node frames kept, edge frames dropped unless copy_edata,
+    in which case a reverse edge carries its original's row)."""
+    edata = ({k: torch.cat([v, v], 0) for k, v in g.edata.items() if torch.is_tensor(v)} if copy_edata else {})
+    new = _carry_frames(g, Graph(torch.cat([g._src, g._dst]), torch.cat([g._dst, g._src]), g._n), edata)
+    if not copy_ndata:
+        new.ndata = {}
+    return new
 
 
 def batch(graphs):

@@ -669,7 +669,7 @@ class _GatAggregate(torch.autograd.Function):
 
 
 def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False,
-                  seg_len=DEFAULT_SEG_LEN, _gathered=False):
+                  seg_len=DEFAULT_SEG_LEN, _gathered=False, attn_fn=None):
     """Fused noisy-logit edge softmax + aggregation (stag/zoo/gat.py:114-126).
     el: [N,H], er: [N,H], ft: [N,H,F]; weight: None | [E,H] tensor | EdgeNoise(dn=H).
     On a node-range shard the inputs are this rank's rows and the call includes the exchange."""
@@ -680,14 +680,15 @@ def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False
     if w is not None and w.shape[0] != graph.number_of_edges():
         raise AssertionError("edge_weight.shape[0] != number_of_edges")
     H, F = ft.shape[1], ft.shape[2]
-    if H > 64 or H * F > 256 or (F % 4 != 0 or ((F // 4) & (F // 4 - 1)) != 0) and torch.is_grad_enabled():
+    if (attn_fn is not None or H > 64 or H * F > 256
+            or (F % 4 != 0 or ((F // 4) & (F // 4 - 1)) != 0) and torch.is_grad_enabled()):
         if getattr(graph, "is_shard", False):
-            raise NotImplementedError("the composed GAT path (H > 64 or H*F > 256) is not partitioned")
-        return _gat_composed(graph, el, er, ft, neg_slope, noise, w, want_attn, seg_len)
+            raise NotImplementedError("the composed GAT path (attention dropout, H > 64 or H*F > 256) is not partitioned")
+        return _gat_composed(graph, el, er, ft, neg_slope, noise, w, want_attn, seg_len, attn_fn)
     return _GatAggregate.apply(el, er, ft, w, graph, noise, neg_slope, want_attn, seg_len)
 
 
-def _gat_composed(graph, el, er, ft, neg_slope, noise, w, want_attn, seg_len):
+def _gat_composed(graph, el, er, ft, neg_slope, noise, w, want_attn, seg_len, attn_fn=None):
     """The same layer outside the fused kernel's shape limits (one wave spans the H*F row: H <= 64,
     H*F <= 256; its backward wants F/4 a power of two): logits and the edge softmax as torch ops over
     [E, H] (segment max by scatter-reduce), the sums and the weighted aggregation on the aggregation
@@ -705,6 +706,8 @@ def _gat_composed(graph, el, er, ft, neg_slope, noise, w, want_attn, seg_len):
     p = torch.exp(e - m[dst])
     l = aggregate(graph, torch.ones(1, H, device=e.device), p, seg_len=seg_len, _broadcast_x=True)   # sum_in p
     a = p / gather_rows(graph, l, "dst")
+    if attn_fn is not None:                  # e.g. attention dropout (stag/zoo/gat.py:122)
+        a = attn_fn(a)
     out = aggregate(graph, ft.reshape(N, H * F), a.repeat_interleave(F, dim=1), seg_len=seg_len)
     out = out.reshape(N, H, F)
     return (out, a.detach()) if want_attn else out

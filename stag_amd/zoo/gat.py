@@ -20,8 +20,7 @@ class GAT(torch.nn.Module):
         self.attn_l = torch.nn.Parameter(torch.empty(1, num_heads, out_feats))
         self.attn_r = torch.nn.Parameter(torch.empty(1, num_heads, out_feats))
         self.feat_drop = torch.nn.Dropout(feat_drop)
-        if attn_drop != 0.0:
-            raise NotImplementedError("attention dropout is not fused; use attn_drop=0")
+        self.attn_drop = torch.nn.Dropout(attn_drop)     # stag/zoo/gat.py:122: dropout on the edge softmax
         self.bias = torch.nn.Parameter(torch.empty(num_heads * out_feats)) if bias else None
         if residual:
             self.res_fc = (torch.nn.Linear(in_feats, num_heads * out_feats, bias=False)
@@ -57,8 +56,12 @@ class GAT(torch.nn.Module):
         el, er = elr[:, :H], elr[:, H:]
         if edge_weight is not None:
             assert edge_weight.shape[0] == graph.number_of_edges()
+        # attention dropout (the reference's scripts train with attn_drop=0.6) needs a[E, H] between the
+        # softmax and the weighted sum: that step goes through the composed form; eval mode and
+        # attn_drop = 0 stay on the fused kernel
+        drop = self.attn_drop if (self.training and self.attn_drop.p > 0.0) else None
         res = ops.gat_aggregate(graph, el, er, ft, self._negative_slope, edge_weight,
-                                want_attn=get_attention)
+                                want_attn=get_attention, attn_fn=drop)
         rst, attn = res if get_attention else (res, None)
         if self.res_fc is not None:
             rst = rst + self.res_fc(h).view(h.shape[0], -1, F)

@@ -12,7 +12,7 @@ fixtures the reference's own condition() produced (stag/distributions.py:221-233
 
 Bars: every aggregated feature |a - b| <= 1e-5 (1 + |b|), flat, against the oracle drawing the device's
 normals (util.hw_normals) and, on rows of up to 256 in-edges, against the oracle's own libm normals;
-layer outputs behind a dense transform 2e-5 (an fp32 GEMM over K <= 256 on either side).
+layer outputs behind a dense transform and gradients: the same bar (measured: <= 2.4e-6).
 """
 import numpy as np
 import pytest
@@ -108,7 +108,7 @@ def test_cfg3_sage_layer_stack_against_oracle_formula(dev, oracle, ppi):
             ref = (h.cpu().numpy().astype(np.float64) @ b.fc_self.weight.detach().cpu().numpy().astype(np.float64).T
                    + agg @ b.fc_neigh.weight.detach().cpu().numpy().astype(np.float64).T
                    + b.bias.detach().cpu().numpy().astype(np.float64))
-            assert_close(out, ref, tol=2 * TOL, what=f"cfg3 SAGE layer {D}->{out.shape[1]}")
+            assert_close(out, ref, what=f"cfg3 SAGE layer {D}->{out.shape[1]}")
             h = torch.relu(out)
 
 
@@ -156,7 +156,7 @@ def test_gin_module_against_oracle_formula(dev, oracle, molecules, agg, eps, lea
     ref = ((1.0 + eps) * x.numpy().astype(np.float64) + neigh) @ W.T + bias
     xd = x.to(dev).requires_grad_(True)
     out = gin(g, xd, edge_weight=w.to(dev))
-    assert_close(out, ref, tol=2 * TOL, what=f"GIN {agg} explicit weight")
+    assert_close(out, ref, what=f"GIN {agg} explicit weight")
     # d/dx of sum(out * G): (1 + eps) G W + A^T (G W) with the same weights, from the oracle's transposed pass
     G = torch.randn(n, out_f, generator=torch.Generator().manual_seed(4))
     out.backward(G.to(dev))
@@ -164,7 +164,7 @@ def test_gin_module_against_oracle_formula(dev, oracle, molecules, agg, eps, lea
     ogt = oracle_graph(oracle, g, transposed=True)
     gscale = (1.0 / np.maximum(g.in_degrees().cpu().numpy(), 1)).astype(np.float32) if agg == "mean" else None
     back = oracle.agg_fwd(ogt, GW.astype(np.float32), oracle.make_spec("explicit", w.numpy()), src_scale=gscale)
-    assert_close(xd.grad, (1.0 + eps) * GW + back, tol=5 * TOL, what=f"GIN {agg} d/dx")
+    assert_close(xd.grad, (1.0 + eps) * GW + back, what=f"GIN {agg} d/dx")
     # drawn weights through StagLayer
     layer = stag_amd.layers.StagLayer(gin, q_a=torch.distributions.Normal(1.0, 0.5)).to(dev)
     stag_amd.manual_seed(6)
@@ -173,7 +173,7 @@ def test_gin_module_against_oracle_formula(dev, oracle, molecules, agg, eps, lea
         nz = layer._edge_weight_handle
         spec = oracle.make_spec("normal", 1.0, 0.5, seed=nz.seed, offset=nz.offset, Dn=D, n_edges=g.number_of_edges())
         neigh = oracle.agg_fwd(og, x.numpy(), spec, reduce=red).astype(np.float64)
-    assert_close(out, ((1.0 + eps) * x.numpy().astype(np.float64) + neigh) @ W.T + bias, tol=2 * TOL,
+    assert_close(out, ((1.0 + eps) * x.numpy().astype(np.float64) + neigh) @ W.T + bias,
                  what=f"StagLayer(GIN {agg})")
 
 
@@ -206,11 +206,11 @@ def test_amortized_condition_on_device_golden(dev, golden, tag, of):
     h = q.embedding_mlp(torch.cat([x2[src], x2[dst]], dim=-1))
     loc, ls = q.parameters_mlp["loc"](h), q.parameters_mlp["log_scale"](h)
     (loc.sum() + (ls ** 2).sum()).backward()
-    assert_close(gx, x2.grad.cpu().numpy(), tol=5 * TOL, what=f"{tag} d/dx")
+    assert_close(gx, x2.grad.cpu().numpy(), what=f"{tag} d/dx")
     for k, p in q.named_parameters():
         ref = p.grad.cpu().numpy()
         s = max(1.0, float(np.abs(ref).max()))
-        assert_close(got[k] / s, ref / s, tol=5 * TOL, what=f"{tag} d/d{k}")
+        assert_close(got[k] / s, ref / s, what=f"{tag} d/d{k}")
     # the reference's layer output with ITS sampled weights injected through the explicit-weight kernel
     from stag_amd import ops
     w = torch.from_numpy(golden[f"amort_{tag}_w"]).to(dev)

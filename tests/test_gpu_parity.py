@@ -59,7 +59,7 @@ def test_normal_tables_exhaustive(dev):
     print(f"radius: max rel {rel.max():.3e} rms {np.sqrt((rel ** 2).mean()):.3e}; "
           f"cos: max abs {e_c.max():.3e} rms {np.sqrt((e_c ** 2).mean()):.3e}; "
           f"sin: max abs {e_s.max():.3e} rms {np.sqrt((e_s ** 2).mean()):.3e}")
-    assert rel.max() <= 4e-7 and e_c.max() <= 4e-7 and e_s.max() <= 4e-7
+    assert rel.max() <= 2e-7 and e_c.max() <= 2e-7 and e_s.max() <= 2e-7     # measured: 1.37e-7, 1.25e-7, 1.25e-7
     assert np.all(np.abs(t[1]) <= 1.0) and np.all(np.abs(t[2]) <= 1.0) and np.all(t[0] >= 0.0)
 
 
@@ -458,7 +458,7 @@ def test_gat_hub_rows_and_seg_len(dev, oracle):
     for sl in (64, 16, 1000, 0):
         out, attn = ops.gat_aggregate(g, *args, 0.2, w, want_attn=True, seg_len=sl)
         # one 9000-term fp32 sum (no plan) drifts past 1e-5; the default plan (64) must not
-        tol = TOL if 0 < sl <= 64 else 3 * TOL
+        tol = TOL if 0 < sl <= 64 else 2 * TOL
         assert_close(out, ref, tol=tol, what=f"gat hub seg_len={sl}")
         assert_close(attn, ref_attn, tol=tol, what=f"gat hub attn seg_len={sl}")
         out2 = ops.gat_aggregate(g, *args, 0.2, w, seg_len=sl)
@@ -532,5 +532,5 @@ def test_fuzz_agg_against_oracle(dev, oracle):
         got = ops.aggregate(g, t(x), w, reduce=reduce, src_scale=t(ss), dst_scale=t(ds), seg_len=seg_len)
         ref = oracle.agg_fwd(og, x, spec, reduce=oracle.REDUCE_MEAN if reduce == "mean" else oracle.REDUCE_SUM,
                              src_scale=ss, dst_scale=ds)
-        assert_close(got, ref, tol=2 * TOL if seg_len in (0, 1000) else TOL,
+        assert_close(got, ref,
                      what=f"fuzz {it}: n={n} E={E} D={D} {kind} seg={seg_len} {reduce} relu={relu}")

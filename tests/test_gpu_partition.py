@@ -145,11 +145,11 @@ def test_layers_on_two_shards_match_the_whole_graph(dev, tmp_path):
         got_out = torch.cat([p[name]["out"] for p in parts], 0)
         got_dx = torch.cat([p[name]["dx"] for p in parts], 0)
         assert_close(got_out, out.detach().cpu().numpy(), TOL, f"{name}: layer output on shards")
-        assert_close(got_dx, xg.grad.cpu().numpy(), 2 * TOL, f"{name}: d/dx on shards")   # sums over ranks' partials
+        assert_close(got_dx, xg.grad.cpu().numpy(), TOL, f"{name}: d/dx on shards")
         for k, p in layer.named_parameters():
             if p.grad is None:
                 assert k not in parts[0][name]["grads"]
                 continue
             ref = p.grad.cpu().numpy()
             scale = max(1.0, float(np.abs(ref).max()))
-            assert_close(parts[0][name]["grads"][k] / scale, ref / scale, 5e-5, f"{name}: d/d{k} summed over ranks")
+            assert_close(parts[0][name]["grads"][k] / scale, ref / scale, TOL, f"{name}: d/d{k} summed over ranks")

@@ -132,6 +132,35 @@ def test_subplan_partitions_the_units():
         g.csr.subplan(64, units[:, 1] % 2 == 0)          # splits the segments of a long row
 
 
+def test_graph_transforms_keep_frames():
+    """remove_self_loop / add_self_loop / add_reverse_edges keep node frames and the batch structure as DGL
+    does; the reference's scripts read g.ndata after them (scripts/citation_mle/gcn/run.py:52-53,
+    scripts/arxiv_mle/gcn/run.py:53-55)."""
+    import stag_amd
+    src = torch.tensor([0, 1, 1, 2, 3, 3])
+    dst = torch.tensor([1, 1, 2, 0, 3, 0])
+    g = stag_amd.Graph(src, dst, 4, batch_num_nodes=torch.tensor([3, 1]))
+    g.ndata["feat"] = torch.arange(8.0).reshape(4, 2)
+    g.ndata["train_mask"] = torch.tensor([True, False, True, False])
+    g.edata["w"] = torch.arange(6.0).unsqueeze(1)
+    r = stag_amd.remove_self_loop(g)
+    assert r.number_of_edges() == 4 and torch.equal(r.ndata["feat"], g.ndata["feat"])
+    assert torch.equal(r.edata["w"].squeeze(1), torch.tensor([0.0, 2.0, 3.0, 5.0]))     # rows of the surviving edges
+    assert torch.equal(r.batch_num_nodes(), g.batch_num_nodes())
+    a = stag_amd.add_self_loop(r)
+    assert a.number_of_edges() == 8 and torch.equal(a.ndata["train_mask"], g.ndata["train_mask"])
+    assert torch.equal(a.edata["w"].squeeze(1), torch.tensor([0.0, 2.0, 3.0, 5.0, 0.0, 0.0, 0.0, 0.0]))
+    assert torch.equal(a.edges()[0][-4:], torch.arange(4)) and torch.equal(a.edges()[1][-4:], torch.arange(4))
+    b = stag_amd.add_reverse_edges(a)
+    assert b.number_of_edges() == 16 and "feat" in b.ndata and b.edata == {}         # DGL default: copy_edata=False
+    b2 = stag_amd.add_reverse_edges(a, copy_edata=True)
+    assert torch.equal(b2.edata["w"][8:], a.edata["w"])
+    assert "feat" not in g.edata and g.number_of_edges() == 6                          # the input is untouched
+    # the reference script's sequence (scripts/arxiv_mle/gcn/run.py:53-55)
+    h = stag_amd.add_reverse_edges(stag_amd.add_self_loop(stag_amd.remove_self_loop(g)))
+    assert torch.equal(h.ndata["feat"], g.ndata["feat"]) and h.number_of_nodes() == 4
+
+
 def test_edge_noise_param_modes():
     import stag_amd
     from stag_amd import _lib

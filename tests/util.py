@@ -1,4 +1,6 @@
 """Shared helpers for the parity tests."""
+import os
+
 import numpy as np
 import torch
 
@@ -14,6 +16,8 @@ def assert_close(got, ref, tol=TOL, what=""):
     if torch.is_tensor(got):
         got = got.detach().cpu().numpy()
     err = scaled_err(got, ref)
+    if os.environ.get("STAG_PRINT_ERR"):      # how close each comparison runs to its bar (tolerance audits)
+        print(f"ERR {what}: {err:.3e} (tol {tol:.1e})")
     assert err <= tol, f"{what}: scaled error {err:.3e} > {tol:.1e}"
 
 
