@@ -494,7 +494,7 @@ def philox_raw(seed, offset, pos0, n_pos, n_chunk, device):
 
 def normal_tables(device):
     """(rad, cos, sin): the hardware functions of a Normal draw over all 2^23 mantissas, [3, 2^23] fp32
-    (stag_normal_tables; test hook — the CPU oracle redraws the device's normals from them)."""
+    (stag_normal_tables; test hook — a CPU checker can redraw the device's normals from them)."""
     t = torch.empty((3, 1 << 23), dtype=torch.float32, device=device)
     dev = _lib.require_device(t)
     with _lib.on_device(dev):
