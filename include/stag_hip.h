@@ -154,7 +154,12 @@ typedef struct stag_plan {
   int32_t n_heavy;             /* units[0, n_heavy): all segments, then the whole rows longer
                                   than STAG_HEAVY_LEN edges (stag_plan_count reports it); the
                                   kernel spreads each of them over more lanes.  0 is valid.  */
-  int32_t reserved;
+  int32_t n_blocks;            /* 0: no block plan                                          */
+  const int32_t* block_ptr;    /* [n_blocks+1] unit offsets (stag_plan_blocks): consecutive units
+                                  batched per workgroup, at most STAG_BLOCK_EDGES edges and
+                                  STAG_BLOCK_UNITS units each.  The GAT kernels draw the weights and
+                                  form the logits of a whole batch edge-parallel, then gather.
+                                  NULL: those kernels take one unit per team instead.        */
 } stag_plan;
 
 int stag_abi_version(void);
@@ -169,6 +174,13 @@ int stag_plan_fill(const int32_t* indptr_host, int32_t n_dst, int32_t seg_len,
                    stag_unit* units_host, int32_t* long_rows_host,
                    int32_t* long_seg_ptr_host);
 size_t stag_plan_workspace_bytes(int32_t n_seg, int32_t D, int32_t in_norm);
+/* Batches of consecutive units for the workgroup-cooperative kernels: block_ptr_host[n_blocks+1]
+ * (NULL: count only), greedy in plan order: a batch closes before it would exceed max_edges edges
+ * (a single longer unit gets a batch of its own) or max_units units.                          */
+#define STAG_BLOCK_EDGES 256
+#define STAG_BLOCK_UNITS 32
+int stag_plan_blocks(const stag_unit* units_host, int32_t n_units, int32_t max_edges,
+                     int32_t max_units, int32_t* block_ptr_host, int32_t* n_blocks_out);
 
 /* ---- graph preprocessing on the device: COO -> stable destination-major CSR ----------------
  * Position order inside a row = ascending original edge id (the order `graph.edata` frames

@@ -18,6 +18,7 @@ NOISE_NONE, NOISE_EXPLICIT, NOISE_NORMAL, NOISE_UNIFORM, NOISE_BERNOULLI = range
 PARAM_SCALAR, PARAM_PER_CHANNEL, PARAM_PER_EDGE1, PARAM_PER_EDGE = range(4)
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 HEAVY_LEN = 16   # STAG_HEAVY_LEN (include/stag_hip.h)
+BLOCK_EDGES, BLOCK_UNITS = 256, 32   # STAG_BLOCK_EDGES / STAG_BLOCK_UNITS
 
 _vp = C.c_void_p
 
@@ -39,7 +40,7 @@ class Plan(C.Structure):
     _fields_ = [("seg_len", C.c_int32), ("n_units", C.c_int32), ("n_long", C.c_int32),
                 ("n_seg", C.c_int32), ("units", _vp), ("long_rows", _vp), ("long_seg_ptr", _vp),
                 ("seg_counters", _vp), ("workspace", _vp), ("workspace_bytes", C.c_size_t),
-                ("n_heavy", C.c_int32), ("reserved", C.c_int32)]
+                ("n_heavy", C.c_int32), ("n_blocks", C.c_int32), ("block_ptr", _vp)]
 
 
 class StagHipError(RuntimeError):
@@ -81,6 +82,7 @@ def lib():
     l.stag_strerror.argtypes = [C.c_int]
     l.stag_plan_count.argtypes = [_vp, C.c_int32, C.c_int32, ip, ip, ip, ip]
     l.stag_plan_fill.argtypes = [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]
+    l.stag_plan_blocks.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, ip]
     l.stag_plan_workspace_bytes.restype = C.c_size_t
     l.stag_plan_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     l.stag_csr_build_workspace_bytes.restype = C.c_size_t

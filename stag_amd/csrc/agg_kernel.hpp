@@ -815,6 +815,12 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
 template <int KIND>
 hipError_t agg_launch(const AggArgs& a, bool vec, hipStream_t stream);
 
+// Dynamic LDS the launch asks for although the kernel uses none: caps the workgroups a CU admits
+// (160 KB / bytes).  A/B knob (tools/ab_bench.py): the gather saturates the fabric with fewer waves in
+// flight than the register budget allows, and past that point more of them slow it down.
+#ifndef STAG_AGG_LDS_BYTES
+#define STAG_AGG_LDS_BYTES 0
+#endif
 template <int KIND, int LPE>
 inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles, hipStream_t s) {
   AggArgs a = a_in;
@@ -828,37 +834,37 @@ inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles
   const dim3 block(STAG_BLOCK_THREADS);
   if constexpr (KIND >= kNormal) {
     if (a.mc && a.outx[2]) {   // four Monte-Carlo samples per gathered row (validated on the host: !pedge)
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 4, true>), grid, block, 0, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 4, true>), grid, block, 0, s, a);
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 4, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 4, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
       return;
     }
     if (a.mc && a.outx[0]) {   // two
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 2, true>), grid, block, 0, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 2, true>), grid, block, 0, s, a);
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 2, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 2, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
       return;
     }
   }
   if constexpr (KIND == kNormal || KIND == kUniform) {
     if (a.outx[0]) {        // weight + both parameter derivatives in one pass (validated on the host: !pedge)
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 3>), grid, block, 0, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 3>), grid, block, 0, s, a);
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 3>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 3>), grid, block, STAG_AGG_LDS_BYTES, s, a);
       return;
     }
   }
   if constexpr (KIND >= kNormal) {
     if (pedge == 1) {       // [E, 1] parameters: one pair per edge
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 1>), grid, block, 0, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 1>), grid, block, 0, s, a);
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 1>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 1>), grid, block, STAG_AGG_LDS_BYTES, s, a);
       return;
     }
     if (pedge == 2) {       // [E, D] parameters: a row per edge
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 2>), grid, block, 0, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 2>), grid, block, 0, s, a);
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 2>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 2>), grid, block, STAG_AGG_LDS_BYTES, s, a);
       return;
     }
   }
-  if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0>), grid, block, 0, s, a);
-  else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0>), grid, block, 0, s, a);
+  if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+  else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0>), grid, block, STAG_AGG_LDS_BYTES, s, a);
 }
 
 template <int KIND>

@@ -543,6 +543,30 @@ int stag_plan_fill(const int32_t* indptr_host, int32_t n_dst, int32_t seg_len,
   return STAG_OK;
 }
 
+int stag_plan_blocks(const stag_unit* units_host, int32_t n_units, int32_t max_edges, int32_t max_units,
+                     int32_t* block_ptr_host, int32_t* n_blocks_out) {
+  if (n_units < 0 || max_edges <= 0 || max_units <= 0 || !n_blocks_out || (n_units > 0 && !units_host))
+    return STAG_EINVAL;
+  int32_t nb = 0, edges = 0, units = 0;
+  if (block_ptr_host) block_ptr_host[0] = 0;
+  for (int32_t i = 0; i < n_units; ++i) {
+    const int32_t len = units_host[i].len;
+    if (len < 0) return STAG_EINVAL;
+    if (units > 0 && (edges + len > max_edges || units == max_units)) {
+      ++nb;
+      if (block_ptr_host) block_ptr_host[nb] = i;
+      edges = 0; units = 0;
+    }
+    edges += len; ++units;
+  }
+  if (units > 0) {
+    ++nb;
+    if (block_ptr_host) block_ptr_host[nb] = n_units;
+  }
+  *n_blocks_out = nb;
+  return STAG_OK;
+}
+
 size_t stag_plan_workspace_bytes(int32_t n_seg, int32_t D, int32_t in_norm) {
   if (n_seg <= 0 || D <= 0) return 0;
   return (size_t)n_seg * (size_t)D * (in_norm ? 2u : 1u) * sizeof(float);

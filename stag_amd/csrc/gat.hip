@@ -57,6 +57,8 @@ struct GatArgs {
   int32_t n_seg;         // units [0, n_seg) are the segments of long rows
   int32_t ws_stride;
   uint32_t ws_bytes;
+  const int32_t* block_ptr;   // [n_blocks+1] unit batches of the workgroup-cooperative kernels
+  int32_t hvec;               // el / er / nscale are 16-byte aligned (rows of H % 4 == 0 heads load as dwordx4)
 };
 
 // the 4 weights of heads [4c, 4c+4) of the edge with noise index n and edge id ed
@@ -91,6 +93,19 @@ __device__ __forceinline__ void head_w4(const GatArgs& a, const PhiloxKey& key, 
       break;
     default: w[0] = w[1] = w[2] = w[3] = 1.0f;
   }
+}
+
+// The row output is written once and not read again by this launch: a non-temporal store keeps it from
+// displacing ft in the 256 MB Infinity Cache (cfg5: ft 173 MB + out 173 MB do not fit together; measured
+// 298 -> 289 us on the one-unit-per-team kernel).
+__device__ __forceinline__ void store4_out(float* p, int k0, int D, bool vec, const float (&v)[4]) {
+  if (vec) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 t = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p + k0));
+    return;
+  }
+  store4(p, k0, D, vec, v);
 }
 
 // LDS hand-off between lanes of ONE wave: the LDS unit serves a wave's requests in
@@ -232,7 +247,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatArgs a) {
         const float lq = l[VEC ? 0 : q];
         o[q] = acc[q] * ((lq > 0.f) ? 1.0f / lq : 0.f);
       }
-      store4(a.out + (int64_t)row * HF, k0, HF, VEC, o);
+      store4_out(a.out + (int64_t)row * HF, k0, HF, VEC, o);
     }
     // the lane holding a head's first channel publishes that head's statistics: the attention
     // values and the backward pass are computed from them (no [E, H] tensor leaves this kernel)
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatArgs a) {
         const float lq = L[VEC ? 0 : q];
         A[q] *= (lq > 0.f) ? 1.0f / lq : 0.f;
       }
-      store4(a.out + (int64_t)row * HF, k0, HF, VEC, A);
+      store4_out(a.out + (int64_t)row * HF, k0, HF, VEC, A);
     }
     if (a.stats && kin) {
 #pragma unroll
@@ -308,6 +323,241 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatArgs a) {
         }
     }
   }
+}
+
+// ---- workgroup-cooperative forward (the default with a block plan, F % 4 == 0, H <= 16) --------
+// gat_fwd_kernel gives a whole wave to one destination row: on a graph of mean in-degree 7 its
+// edge-parallel phase runs 7 of 64 lanes through a chain of dependent round trips (unit -> ids -> el ->
+// draw) while nothing is being gathered: 283 us at cfg5 for 1.5 GB, 5.4 TB/s, 5 waves per SIMD, each
+// alive ~14 us for one row.  Here a WORKGROUP takes a batch of consecutive units of the plan (stag_plan
+// block_ptr: <= 256 edges, <= 32 units):
+//   phase 1  thread t <-> edge t of the batch: draws its H weights, forms its H noisy logits -> LDS
+//            (every lane busy, one chain of round trips per batch instead of one per row);
+//   phase 1b thread <-> (unit, head): max and sum of exp over the unit's logits in LDS; the logits are
+//            replaced by p = exp(e - m) in place;
+//   phase 2  a team of LPE lanes per unit (the block's units dealt round robin): a plain weighted gather
+//            — ids and weights come from LDS, NR rows in flight — then normalise / publish.
+// A unit's arithmetic does not depend on which batch it rides in: m = max over its edges, l = sum of
+// exp in edge order, acc = fma(p_i, row_i, acc) in edge order — so shards reproduce the whole graph.
+constexpr int kBlkEdges = STAG_BLOCK_EDGES, kBlkUnits = STAG_BLOCK_UNITS, kBlkMaxH = 16;
+#ifndef STAG_GAT_DBG
+#define STAG_GAT_DBG 0    // 16: per-stage timestamps into the stats buffer (tools/gat_trace.py)
+#endif
+#ifndef STAG_GAT_NR
+#define STAG_GAT_NR 4     // rows in flight per team in phase 2
+#endif
+
+// (80 SGPRs: a CU admits 8 workgroups of 256 threads only up to that count — MI355X_MICROARCH.md,
+//  "Residency"; the argument block alone would take ~100, the rest spill to lanes of a VGPR.)
+#ifndef STAG_GAT_SGPR
+#define STAG_GAT_SGPR 0
+#endif
+#if STAG_GAT_SGPR
+#define STAG_GAT_SGPR_ATTR __attribute__((amdgpu_num_sgpr(STAG_GAT_SGPR)))
+#else
+#define STAG_GAT_SGPR_ATTR
+#endif
+#ifndef STAG_GAT_LDS_MIN
+#define STAG_GAT_LDS_MIN 40000  // bytes of LDS a workgroup asks for at least: caps the workgroups per CU (160 KB)
+#endif
+template <int LPE>
+__global__ __launch_bounds__(256) STAG_GAT_SGPR_ATTR void gat_fwd_block_kernel(const GatArgs a) {
+  extern __shared__ __align__(16) float lds[];
+  const int H = a.H, F = a.F, HF = a.HF;
+  float* s_w = lds;                                   // [kBlkEdges][H] logits, then p = exp(e - m)
+  float* s_m = s_w + kBlkEdges * H;                   // [kBlkUnits][H]
+  float* s_l = s_m + kBlkUnits * H;                   // [kBlkUnits][H]
+  int* s_u = reinterpret_cast<int*>(s_l + kBlkUnits * H);   // [kBlkEdges] source row of each edge
+  int* s_start = s_u + kBlkEdges;                     // [kBlkUnits + 1] first edge slot of each unit
+  int4* s_unit = reinterpret_cast<int4*>(s_start + kBlkUnits + 4);   // [kBlkUnits] (row, start, len, slot); 16-B aligned
+  const int t = threadIdx.x;
+#if STAG_GAT_DBG & 16
+  uint64_t* trace = reinterpret_cast<uint64_t*>(a.stats) + (int64_t)blockIdx.x * 8;
+  if (t == 0) trace[0] = wall_clock64();
+#define GAT_TS(i) if (t == 0) trace[i] = wall_clock64();
+#else
+#define GAT_TS(i)
+#endif
+  const int ub = a.block_ptr[blockIdx.x], nu = a.block_ptr[blockIdx.x + 1] - ub;
+
+  // ---- the batch: unit records, edge-slot prefix -----------------------------------------------
+  if (t < kBlkUnits) {
+    int4 q = make_int4(0, 0, 0, -1);
+    if (t < nu) q = *reinterpret_cast<const int4*>(a.units + ub + t);
+    s_unit[t] = q;
+    int incl = q.z;                                    // inclusive scan of the lengths over lanes 0..31
+#pragma unroll
+    for (int d = 1; d < kBlkUnits; d <<= 1) {
+      const int up = __shfl_up(incl, d, kBlkUnits);
+      if (t >= d) incl += up;
+    }
+    s_start[t + 1] = incl;
+    if (t == 0) s_start[0] = 0;
+  }
+  __syncthreads();
+  GAT_TS(1)
+  const int ne = s_start[nu];                          // edges of the batch (<= kBlkEdges by the plan)
+
+  // ---- phase 1: thread t <-> edge slot t ---------------------------------------------------------
+  if (t < ne) {
+    int lo = 0, hi = nu;                               // unit j with s_start[j] <= t < s_start[j+1]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_start[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int4 q = s_unit[lo];
+    const int row = (q.w >= 0) ? a.long_rows[q.x] : q.x;
+    const int p = q.y + (t - s_start[lo]);
+    const int u = a.indices[p];
+    s_u[t] = u;
+    const int64_t ed = a.eid ? a.eid[p] : p;
+    const uint32_t n = a.pos_lo + (a.nidx ? (uint32_t)a.nidx[p] : (uint32_t)p);
+    const PhiloxKey key = resolve_epoch(a.key);
+    const int nchunk = (H + 3) / 4;
+    const bool h4 = (H & 3) == 0 && a.hvec;           // el / er / nscale rows as dwordx4 (one L1 lookup per 4 heads)
+    for (int cc = 0; cc < nchunk; ++cc) {
+      float w[4], sl4[4], sr4[4], ns4[4] = {1.f, 1.f, 1.f, 1.f};
+      if (h4) {
+        load4(a.el + (int64_t)u * H, 4 * cc, H, true, sl4);
+        load4(a.er + (int64_t)row * H, 4 * cc, H, true, sr4);
+        if (a.nscale) load4(a.nscale + (int64_t)row * H, 4 * cc, H, true, ns4);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int h = 4 * cc + j;
+          sl4[j] = h < H ? a.el[(int64_t)u * H + h] : 0.f;
+          sr4[j] = h < H ? a.er[(int64_t)row * H + h] : 0.f;
+          if (a.nscale && h < H) ns4[j] = a.nscale[(int64_t)row * H + h];
+        }
+      }
+      head_w4(a, key, n, ed, (uint32_t)cc, w);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int h = 4 * cc + j;
+        if (h < H) {
+          const float sL = sl4[j] + sr4[j];
+          const float lr = sL > 0.f ? sL : a.neg_slope * sL;
+          s_w[t * H + h] = (w[j] * ns4[j]) * lr;
+        }
+      }
+    }
+  }
+  GAT_TS(2)
+  __syncthreads();
+  GAT_TS(3)
+
+  // ---- phase 1b: thread <-> (unit, head): softmax statistics, logits -> p ---------------------------
+  for (int i = t; i < nu * H; i += 256) {
+    const int j = i / H, h = i - j * H;
+    const int e0 = s_start[j], e1 = s_start[j + 1];
+    float m = -INFINITY;
+    for (int e = e0; e < e1; ++e) m = fmaxf(m, s_w[e * H + h]);
+    float l = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const float pe = __expf(s_w[e * H + h] - m);
+      s_w[e * H + h] = pe;
+      l += pe;
+    }
+    s_m[i] = m;
+    s_l[i] = l;
+  }
+  GAT_TS(4)
+  __syncthreads();
+  GAT_TS(5)
+
+  // ---- phase 2: a team per unit, weighted gather -------------------------------------------------------
+  constexpr int TEAMS = 256 / LPE, NR = STAG_GAT_NR;
+  const int team = t / LPE, c = t % LPE;
+  const int team_lane0 = (int)(t & 63) - c;
+  const int k0 = c * 4;
+  const bool kin = k0 < HF;
+  const int hl = kin ? k0 / F : 0;
+  const __amdgpu_buffer_rsrc_t rft =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ft), 0, (int)a.ft_bytes, 0x00020000);
+  const bool ft_buf = a.ft_bytes != 0;
+  for (int j = team; j < nu; j += TEAMS) {
+    const int4 q = s_unit[j];
+    const int e0 = s_start[j], e1 = s_start[j + 1];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int e = e0; e < e1; e += NR) {
+      float fv[NR][4];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (e + r < e1 && kin) {
+          const int u = s_u[e + r];
+          if (ft_buf) bufrow4(rft, u, (uint32_t)HF * 4u, (uint32_t)k0 * 4u, fv[r]);
+          else loadrow4(a.ft + (int64_t)u * HF + k0, k0, HF, true, fv[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (e + r < e1 && kin) {
+          const float pe = s_w[(e + r) * H + hl];
+#pragma unroll
+          for (int x = 0; x < 4; ++x) acc[x] = __builtin_fmaf(pe, fv[r][x], acc[x]);
+        }
+      }
+    }
+    const float m = s_m[j * H + hl], l = s_l[j * H + hl];
+    if (q.w < 0) {
+      // ---- whole row: normalise and store --------------------------------------------------------
+      if (kin) {
+        const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+        float o[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) o[x] = acc[x] * inv;
+        store4_out(a.out + (int64_t)q.x * HF, k0, HF, true, o);
+        if (a.stats && k0 % F == 0 && !(STAG_GAT_DBG & 16)) {
+          a.stats[(int64_t)q.x * 2 * H + hl] = m;
+          a.stats[(int64_t)q.x * 2 * H + H + hl] = l;
+        }
+      }
+      continue;
+    }
+    // ---- segment: publish (acc, m, l) write-through, take a ticket; the last arriver merges ----------
+    const int v = q.x, slot = q.w, row = a.long_rows[v];
+    const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)a.ws_bytes, 0x00020000);
+    const uint32_t base = (uint32_t)slot * ((uint32_t)a.ws_stride * 4u);
+    if (kin) {
+      store4_sc1(rws, base + (uint32_t)k0 * 4u, k0, HF, true, acc);
+      if (k0 % F == 0) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rws, (int)(base + (uint32_t)(HF + hl) * 4u), 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l), rws, (int)(base + (uint32_t)(HF + H + hl) * 4u), 0, 16);
+      }
+    }
+    const int s0 = a.long_seg_ptr[v], s1 = a.long_seg_ptr[v + 1];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int ticket = 0;
+    if (c == 0)
+      ticket = __hip_atomic_fetch_add(a.seg_counters + v, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_ds_bpermute(team_lane0 << 2, ticket);
+    if (ticket != (s1 - s0) - 1) continue;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (c == 0) a.seg_counters[v] = 0;
+    if (!kin) continue;
+    float M = -INFINITY, L = 0.f;
+    float A[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int sg = s0; sg < s1; ++sg) M = fmaxf(M, a.ws[(int64_t)sg * a.ws_stride + HF + hl]);
+    for (int sg = s0; sg < s1; ++sg) {
+      const float* wr = a.ws + (int64_t)sg * a.ws_stride;
+      float tt[4];
+      load4(wr, k0, HF, true, tt);
+      const float sc = __expf(wr[HF + hl] - M);
+      L += wr[HF + H + hl] * sc;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) A[x] = __builtin_fmaf(tt[x], sc, A[x]);
+    }
+    const float inv = (L > 0.f) ? 1.0f / L : 0.f;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) A[x] *= inv;
+    store4_out(a.out + (int64_t)row * HF, k0, HF, true, A);
+    if (a.stats && k0 % F == 0 && !(STAG_GAT_DBG & 16)) {
+      a.stats[(int64_t)row * 2 * H + hl] = M;
+      a.stats[(int64_t)row * 2 * H + H + hl] = L;
+    }
+  }
+  GAT_TS(6)
 }
 
 // Attention values a[eid, h] = exp(logit - m[v,h]) / l[v,h] (get_attention=True,
@@ -572,6 +822,23 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
   const dim3 grid((a.n_units + tpb - 1) / tpb);
   const size_t lds_bytes = (size_t)256 * H * sizeof(float);   // [teams][LPE][H]
   hipStream_t s = (hipStream_t)stream;
+  if (use_plan && plan->block_ptr && plan->n_blocks > 0 && vec && H <= kBlkMaxH && plan->seg_len <= kBlkEdges) {
+    // workgroup-cooperative form: batches of units (stag_plan_blocks with STAG_BLOCK_EDGES / _UNITS)
+    a.block_ptr = plan->block_ptr;
+    a.hvec = aligned16(el) && aligned16(er) && (!a.nscale || aligned16(a.nscale));
+    size_t lds_blk = (size_t)(kBlkEdges * H + 2 * kBlkUnits * H) * sizeof(float) +
+                     (size_t)(kBlkEdges + kBlkUnits + 4) * sizeof(int) + (size_t)kBlkUnits * sizeof(int4);
+    if (lds_blk < STAG_GAT_LDS_MIN) lds_blk = STAG_GAT_LDS_MIN;
+    const dim3 gb(plan->n_blocks);
+    switch (lpe) {
+      case 64: hipLaunchKernelGGL(gat_fwd_block_kernel<64>, gb, dim3(256), lds_blk, s, a); break;
+      case 32: hipLaunchKernelGGL(gat_fwd_block_kernel<32>, gb, dim3(256), lds_blk, s, a); break;
+      case 16: hipLaunchKernelGGL(gat_fwd_block_kernel<16>, gb, dim3(256), lds_blk, s, a); break;
+      case 8: hipLaunchKernelGGL(gat_fwd_block_kernel<8>, gb, dim3(256), lds_blk, s, a); break;
+      default: hipLaunchKernelGGL(gat_fwd_block_kernel<4>, gb, dim3(256), lds_blk, s, a); break;
+    }
+    return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+  }
 #define STAG_GAT_LAUNCH(L)                                                                         \
   do {                                                                                             \
     if (vec) hipLaunchKernelGGL((gat_fwd_kernel<L, true>), grid, dim3(256), lds_bytes, s, a);     \

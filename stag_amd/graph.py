@@ -70,7 +70,7 @@ class CsrView:
                 units=torch.from_numpy(units).to(dev),
                 long_rows=torch.from_numpy(long_rows).to(dev),
                 long_seg_ptr=torch.from_numpy(long_seg_ptr).to(dev),
-                counters={})
+                counters={}, **_block_plan(units, nu, dev))
         return self._plans[seg_len]
 
     def subplan(self, seg_len, keep):
@@ -90,7 +90,19 @@ class CsrView:
         return dict(seg_len=seg_len, n_units=int(len(sel)), n_long=full["n_long"] if n_seg else 0, n_seg=n_seg,
                     n_heavy=n_seg + int((sel[n_seg:, 2] > _lib.HEAVY_LEN).sum()) if len(sel) else 0,
                     units=torch.from_numpy(buf).to(dev), long_rows=full["long_rows"],
-                    long_seg_ptr=full["long_seg_ptr"], counters={})
+                    long_seg_ptr=full["long_seg_ptr"], counters={}, **_block_plan(buf, int(len(sel)), dev))
+
+
+def _block_plan(units_host, n_units, dev):
+    """block_ptr of a unit list (stag_plan_blocks): the workgroup batches of the cooperative GAT kernels."""
+    lib = _lib.lib()
+    units_host = np.ascontiguousarray(units_host, dtype=np.int32)
+    nb = C.c_int32(0)
+    args = (units_host.ctypes.data, n_units, _lib.BLOCK_EDGES, _lib.BLOCK_UNITS)
+    _lib.check(lib.stag_plan_blocks(*args, None, C.byref(nb)), "stag_plan_blocks")
+    ptr = np.zeros(nb.value + 1, np.int32)
+    _lib.check(lib.stag_plan_blocks(*args, ptr.ctypes.data, C.byref(nb)), "stag_plan_blocks")
+    return dict(n_blocks=nb.value, block_ptr=torch.from_numpy(ptr).to(dev))
 
 
 def build_csr(src, dst, n_src, n_dst):

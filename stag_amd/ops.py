@@ -65,7 +65,7 @@ def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None):
     plan_c = _lib.Plan(plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"],
                        _lib.ptr(plan_t["units"]), _lib.ptr(plan_t["long_rows"]),
                        _lib.ptr(plan_t["long_seg_ptr"]), _lib.ptr(counters), _lib.ptr(ws), nbytes,
-                       plan_t["n_heavy"], 0)
+                       plan_t["n_heavy"], plan_t["n_blocks"], _lib.ptr(plan_t["block_ptr"]))
     return plan_c, (ws, counters)
 
 

@@ -28,7 +28,7 @@ def test_abi_struct_layouts_match_header():
     from stag_amd import _lib
     assert ctypes.sizeof(_lib.Csr) == 48
     assert ctypes.sizeof(_lib.NoiseSpec) == 88
-    assert ctypes.sizeof(_lib.Plan) == 72
+    assert ctypes.sizeof(_lib.Plan) == 80
     assert _lib.NoiseSpec.deriv.offset == 40 and _lib.NoiseSpec.seed.offset == 48 and _lib.NoiseSpec.pos_base.offset == 64
 
 
@@ -348,7 +348,7 @@ def test_abi_argument_validation_without_gpu():
     bad = _lib.NoiseSpec(); bad.kind = _lib.NOISE_NORMAL; bad.pos_base = (1 << 32) - 1
     a = ok_args(); a[5] = C.byref(bad)
     assert lib.stag_agg_fwd(*a) == ENOSYS                                   # launch would straddle 2^32 positions
-    plan = _lib.Plan(64, 2, 1, 2, None, None, None, None, None, 0)
+    plan = _lib.Plan(64, 2, 1, 2, None, None, None, None, None, 0, 0, 0, None)
     a = ok_args(); a[1] = C.byref(plan)
     assert lib.stag_agg_fwd(*a) == EINVAL                                   # plan without units
     # GAT limits
