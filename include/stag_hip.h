@@ -330,6 +330,24 @@ int stag_gat_bwd_edge(const stag_csr* csr, const stag_plan* plan, const float* e
                       const stag_noise_spec* spec, const float* norm_scale, float* de,
                       float* dw, float* attn_out, void* stream);
 
+/* The whole backward of stag_gat_fwd in one call, for shapes with F % 4 == 0, F/4 a power of two,
+ * H <= 16, H*F <= 256 and block plans (stag_plan.block_ptr) on both orientations of the graph:
+ *   edge pass (csr, plan):     a, de per edge (the weight redrawn from its counters, a from `stats`),
+ *                              written to ade_ws[E, 2H] by forward position; d er[v,h] = sum_in de
+ *   source pass (csr_t, plan_t; csr_t.nidx = forward position of each transposed position):
+ *                              d el[u,h] = sum_out de;  d ft[u,h,:] = sum_out a[e,h] g[v,h,:]
+ * dw (may be NULL): [E, H] by edge id, the gradient w.r.t. explicit weights (ds * lrelu * norm_scale).
+ * Long rows leave per-segment partials in plan->workspace (>= stag_gat_bwd_workspace_bytes()) and a
+ * small launch adds them in segment order: no atomics, results do not depend on scheduling.
+ * STAG_ENOSYS for other shapes / plans: use stag_gat_bwd_edge + stag_agg_fwd on the transposed CSR.
+ * Replaces DGL's backward of u_add_v / edge_softmax / u_mul_e (stag/zoo/gat.py:114-126).          */
+size_t stag_gat_bwd_workspace_bytes(int32_t n_seg, int32_t n_seg_t, int32_t H, int32_t F);
+int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
+                 const stag_plan* plan_t, const float* el, const float* er, const float* ft,
+                 const float* stats, const float* g, const float* out, int32_t H, int32_t F,
+                 float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
+                 float* d_el, float* d_er, float* d_ft, float* dw, float* ade_ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

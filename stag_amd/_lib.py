@@ -117,6 +117,11 @@ def lib():
     l.stag_gat_bwd_edge.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp, _vp, _vp, _vp,
                                     C.c_int32, C.c_int32, C.c_float, C.POINTER(NoiseSpec), _vp, _vp,
                                     _vp, _vp, _vp]
+    l.stag_gat_bwd_workspace_bytes.restype = C.c_size_t
+    l.stag_gat_bwd_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    l.stag_gat_bwd.argtypes = [C.POINTER(Csr), C.POINTER(Plan), C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp,
+                               _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_float, C.POINTER(NoiseSpec), _vp,
+                               _vp, _vp, _vp, _vp, _vp, _vp]
     if l.stag_abi_version() != 11:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     _lib = l

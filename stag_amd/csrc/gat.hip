@@ -358,7 +358,14 @@ constexpr int kBlkEdges = STAG_BLOCK_EDGES, kBlkUnits = STAG_BLOCK_UNITS, kBlkMa
 #define STAG_GAT_SGPR_ATTR
 #endif
 #ifndef STAG_GAT_LDS_MIN
-#define STAG_GAT_LDS_MIN 40000  // bytes of LDS a workgroup asks for at least: caps the workgroups per CU (160 KB)
+// Bytes of LDS a workgroup asks for at least: caps the workgroups a CU admits (160 KB / bytes).  The
+// gather of 1-KB rows from a table beyond L2 is fastest with FEWER workgroups resident than registers
+// and the kernel's own LDS would allow (cfg5, us per forward: 6 per CU 250, 5: 235, 4: 224.5, 3: 252,
+// 2: 341; forward + backward with the two backward kernels at 4: 759, 5: 722, 6: 733).
+#define STAG_GAT_LDS_MIN 40000      // forward: 4 workgroups per CU
+#endif
+#ifndef STAG_GAT_LDS_MIN_BWD
+#define STAG_GAT_LDS_MIN_BWD 32000  // backward passes: 5
 #endif
 template <int LPE>
 __global__ __launch_bounds__(256) STAG_GAT_SGPR_ATTR void gat_fwd_block_kernel(const GatArgs a) {
@@ -747,6 +754,333 @@ __global__ __launch_bounds__(256) void gat_bwd_edge_kernel(const GatBwdArgs ba) 
   }
 }
 
+// ---- workgroup-cooperative backward (stag_gat_bwd) -------------------------------------------------
+// Two passes over batches of units, each shaped like gat_fwd_block_kernel:
+//   edge pass (destination-major batches): phase 1, thread <-> edge: the weight redrawn from its
+//     counters, a = exp(e - m[v]) / l[v] from the forward's statistics, c1 = w ns lrelu'(s),
+//     (c2 = lrelu(s) ns) -> LDS; phase 2, a team per unit: G[v] and gdo[v] = <G[v], out[v]> in registers,
+//     per in-edge the ft row, <G[v,h,:], ft[u,h,:]> reduced over the head's lanes, ds = a (da - gdo),
+//     de = ds c1 -> LDS; phase 3, thread <-> edge: (a, de) written BY FORWARD POSITION, [E, 2H], coalesced;
+//     thread <-> (unit, head): d er[v,h] = sum of de over the unit (segments: a partial per segment).
+//   source pass (source-major batches of the transposed CSR): phase 1, thread <-> out-edge: (a, de) of
+//     its forward position (csr_t.nidx) -> LDS; d el[u,h] = sum of de; phase 2: d ft[u] = sum a G[v],
+//     the forward kernel's weighted gather with G in the place of ft.
+// Long rows (segments) leave partial sums in the plan's workspace; gat_seg_finish_kernel adds them in
+// segment order (deterministic; nothing is accumulated with atomics).
+struct GatBwdBlkArgs {
+  GatArgs f;             // edge pass: the forward's arguments (graph, el, er, ft, noise, stats, plan batches)
+  const float* g;        // [n_rows, H*F]
+  const float* out;      // [n_rows, H*F] forward output
+  float* ade;            // [E, 2H] by forward position: a[H] then de[H]
+  float* d_er;           // [n_rows, H]
+  float* dw;             // [E, H] by edge id, or null
+  float* ws;             // segment partials of d er: [n_seg][H]
+};
+
+// the batch a workgroup owns: unit records and the edge-slot prefix in LDS; returns the unit count
+__device__ __forceinline__ int blk_prologue(const stag_unit* units, const int32_t* block_ptr, int4* s_unit,
+                                            int* s_start) {
+  const int t = threadIdx.x;
+  const int ub = block_ptr[blockIdx.x], nu = block_ptr[blockIdx.x + 1] - ub;
+  if (t < kBlkUnits) {
+    int4 q = make_int4(0, 0, 0, -1);
+    if (t < nu) q = *reinterpret_cast<const int4*>(units + ub + t);
+    s_unit[t] = q;
+    int incl = q.z;
+#pragma unroll
+    for (int d = 1; d < kBlkUnits; d <<= 1) {
+      const int up = __shfl_up(incl, d, kBlkUnits);
+      if (t >= d) incl += up;
+    }
+    s_start[t + 1] = incl;
+    if (t == 0) s_start[0] = 0;
+  }
+  __syncthreads();
+  return nu;
+}
+
+__device__ __forceinline__ int blk_unit_of(const int* s_start, int nu, int t) {
+  int lo = 0, hi = nu;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (s_start[mid] <= t) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// sum over the F/4 lanes of a head (lanes_per_head a power of two): DPP inside a row of 16 lanes
+__device__ __forceinline__ float gat_head_sum(float x, int lanes_per_head) {
+  if (lanes_per_head >= 2) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
+  if (lanes_per_head >= 4) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));
+  if (lanes_per_head >= 8) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));
+  if (lanes_per_head >= 16) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true));
+  if (lanes_per_head >= 32) x += __shfl_xor(x, 16);
+  if (lanes_per_head >= 64) x += __shfl_xor(x, 32);
+  return x;
+}
+
+template <int LPE>
+__global__ __launch_bounds__(256) void gat_bwd_edge_block_kernel(const GatBwdBlkArgs ba) {
+  extern __shared__ __align__(16) float lds[];
+  const GatArgs& a = ba.f;
+  const int H = a.H, F = a.F, HF = a.HF;
+  float* s_a = lds;                                   // [kBlkEdges][H] attention
+  float* s_c1 = s_a + kBlkEdges * H;                  // [kBlkEdges][H] w ns lrelu'(s), then de
+  float* s_c2 = s_c1 + kBlkEdges * H;                 // [kBlkEdges][H] lrelu(s) ns, then dw (only when wanted)
+  int* s_u = reinterpret_cast<int*>(s_c2 + (ba.dw ? kBlkEdges * H : 0));
+  int* s_start = s_u + kBlkEdges;
+  int4* s_unit = reinterpret_cast<int4*>(s_start + kBlkUnits + 4);
+  const int t = threadIdx.x;
+  const int nu = blk_prologue(a.units, a.block_ptr, s_unit, s_start);
+  const int ne = s_start[nu];
+
+  // ---- phase 1: thread <-> edge slot -------------------------------------------------------------
+  int my_p = 0;
+  int64_t my_ed = 0;
+  if (t < ne) {
+    const int j = blk_unit_of(s_start, nu, t);
+    const int4 q = s_unit[j];
+    const int row = (q.w >= 0) ? a.long_rows[q.x] : q.x;
+    const int p = q.y + (t - s_start[j]);
+    my_p = p;
+    const int u = a.indices[p];
+    s_u[t] = u;
+    const int64_t ed = a.eid ? a.eid[p] : p;
+    my_ed = ed;
+    const uint32_t n = a.pos_lo + (a.nidx ? (uint32_t)a.nidx[p] : (uint32_t)p);
+    const PhiloxKey key = resolve_epoch(a.key);
+    const int nchunk = (H + 3) / 4;
+    const bool h4 = (H & 3) == 0 && a.hvec;
+    for (int cc = 0; cc < nchunk; ++cc) {
+      float w[4], sl4[4], sr4[4], ns4[4] = {1.f, 1.f, 1.f, 1.f}, m4[4], l4[4];
+      if (h4) {
+        load4(a.el + (int64_t)u * H, 4 * cc, H, true, sl4);
+        load4(a.er + (int64_t)row * H, 4 * cc, H, true, sr4);
+        if (a.nscale) load4(a.nscale + (int64_t)row * H, 4 * cc, H, true, ns4);
+        load4(a.stats + (int64_t)row * 2 * H, 4 * cc, H, true, m4);
+        load4(a.stats + (int64_t)row * 2 * H + H, 4 * cc, H, true, l4);
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int h = 4 * cc + jj;
+          const bool in = h < H;
+          sl4[jj] = in ? a.el[(int64_t)u * H + h] : 0.f;
+          sr4[jj] = in ? a.er[(int64_t)row * H + h] : 0.f;
+          if (a.nscale && in) ns4[jj] = a.nscale[(int64_t)row * H + h];
+          m4[jj] = in ? a.stats[(int64_t)row * 2 * H + h] : 0.f;
+          l4[jj] = in ? a.stats[(int64_t)row * 2 * H + H + h] : 1.f;
+        }
+      }
+      head_w4(a, key, n, ed, (uint32_t)cc, w);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int h = 4 * cc + jj;
+        if (h < H) {
+          const float sL = sl4[jj] + sr4[jj];
+          const float lr = sL > 0.f ? sL : a.neg_slope * sL;
+          const float wn = w[jj] * ns4[jj];
+          s_a[t * H + h] = __expf(wn * lr - m4[jj]) / l4[jj];
+          s_c1[t * H + h] = wn * (sL > 0.f ? 1.0f : a.neg_slope);
+          if (ba.dw) s_c2[t * H + h] = lr * ns4[jj];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: a team per unit: <G[v,h,:], ft[u,h,:]> per in-edge -> ds -> de ---------------------------
+  constexpr int TEAMS = 256 / LPE, NR = STAG_GAT_NR;
+  const int team = t / LPE, c = t % LPE;
+  const int k0 = c * 4;
+  const bool kin = k0 < HF;
+  const int hl = kin ? k0 / F : 0;
+  const int lph = F / 4;
+  const bool head_lane = kin && (k0 % F) == 0;
+  const __amdgpu_buffer_rsrc_t rft =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ft), 0, (int)a.ft_bytes, 0x00020000);
+  const bool ft_buf = a.ft_bytes != 0;
+  for (int j = team; j < nu; j += TEAMS) {
+    const int4 q = s_unit[j];
+    const int row = (q.w >= 0) ? a.long_rows[q.x] : q.x;
+    const int e0 = s_start[j], e1 = s_start[j + 1];
+    if (e0 == e1) continue;
+    float gv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
+    if (kin) {
+      load4(ba.g + (int64_t)row * HF, k0, HF, true, gv);
+      load4(ba.out + (int64_t)row * HF, k0, HF, true, ov);
+    }
+    const float gdo = gat_head_sum((gv[0] * ov[0] + gv[1] * ov[1]) + (gv[2] * ov[2] + gv[3] * ov[3]), lph);
+    for (int e = e0; e < e1; e += NR) {
+      float fv[NR][4];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (e + r < e1 && kin) {
+          const int u = s_u[e + r];
+          if (ft_buf) bufrow4(rft, u, (uint32_t)HF * 4u, (uint32_t)k0 * 4u, fv[r]);
+          else loadrow4(a.ft + (int64_t)u * HF + k0, k0, HF, true, fv[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (e + r < e1) {                              // uniform over the team
+          float dot = 0.f;
+          if (kin) dot = (gv[0] * fv[r][0] + gv[1] * fv[r][1]) + (gv[2] * fv[r][2] + gv[3] * fv[r][3]);
+          dot = gat_head_sum(dot, lph);
+          if (head_lane) {
+            const float ds = s_a[(e + r) * H + hl] * (dot - gdo);
+            s_c1[(e + r) * H + hl] = ds * s_c1[(e + r) * H + hl];
+            if (ba.dw) s_c2[(e + r) * H + hl] = ds * s_c2[(e + r) * H + hl];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3: per-edge results by forward position (coalesced); d er per unit ------------------------
+  if (t < ne) {
+    float* dst = ba.ade + (int64_t)my_p * 2 * H;
+    if ((H & 3) == 0) {
+      for (int h = 0; h < H; h += 4) {
+        *reinterpret_cast<float4*>(dst + h) = *reinterpret_cast<const float4*>(s_a + t * H + h);
+        *reinterpret_cast<float4*>(dst + H + h) = *reinterpret_cast<const float4*>(s_c1 + t * H + h);
+      }
+    } else {
+      for (int h = 0; h < H; ++h) { dst[h] = s_a[t * H + h]; dst[H + h] = s_c1[t * H + h]; }
+    }
+    if (ba.dw)
+      for (int h = 0; h < H; ++h) ba.dw[my_ed * H + h] = s_c2[t * H + h];
+  }
+  for (int i = t; i < nu * H; i += 256) {
+    const int j = i / H, h = i - j * H;
+    const int4 q = s_unit[j];
+    float sum = 0.f;
+    for (int e = s_start[j]; e < s_start[j + 1]; ++e) sum += s_c1[e * H + h];
+    if (q.w < 0) ba.d_er[(int64_t)q.x * H + h] = sum;
+    else ba.ws[(int64_t)q.w * H + h] = sum;            // a segment's share; gat_seg_finish_kernel adds them
+  }
+}
+
+struct GatSrcBlkArgs {
+  const int32_t* indices;      // csr_t: destination row of each transposed position
+  const int32_t* nidx;         // csr_t: forward position of each transposed position
+  const stag_unit* units;
+  const int32_t* block_ptr;
+  const int32_t* long_rows;
+  const float* ade;            // [E, 2H] by forward position
+  const float* g;              // [n_dst rows of the forward, H*F]
+  int32_t H, F, HF;
+  uint32_t g_bytes;
+  float* d_ft;                 // [n_src, H*F]
+  float* d_el;                 // [n_src, H]
+  float* ws;                   // segment partials: [n_seg_t][HF + H]
+};
+
+template <int LPE>
+__global__ __launch_bounds__(256) void gat_bwd_src_block_kernel(const GatSrcBlkArgs a) {
+  extern __shared__ __align__(16) float lds[];
+  const int H = a.H, F = a.F, HF = a.HF;
+  float* s_a = lds;                                   // [kBlkEdges][H]
+  float* s_de = s_a + kBlkEdges * H;                  // [kBlkEdges][H]
+  int* s_v = reinterpret_cast<int*>(s_de + kBlkEdges * H);
+  int* s_start = s_v + kBlkEdges;
+  int4* s_unit = reinterpret_cast<int4*>(s_start + kBlkUnits + 4);
+  const int t = threadIdx.x;
+  const int nu = blk_prologue(a.units, a.block_ptr, s_unit, s_start);
+  const int ne = s_start[nu];
+  if (t < ne) {
+    const int j = blk_unit_of(s_start, nu, t);
+    const int4 q = s_unit[j];
+    const int qq = q.y + (t - s_start[j]);
+    s_v[t] = a.indices[qq];
+    const float* src = a.ade + (int64_t)a.nidx[qq] * 2 * H;
+    if ((H & 3) == 0) {
+      for (int h = 0; h < H; h += 4) {
+        *reinterpret_cast<float4*>(s_a + t * H + h) = *reinterpret_cast<const float4*>(src + h);
+        *reinterpret_cast<float4*>(s_de + t * H + h) = *reinterpret_cast<const float4*>(src + H + h);
+      }
+    } else {
+      for (int h = 0; h < H; ++h) { s_a[t * H + h] = src[h]; s_de[t * H + h] = src[H + h]; }
+    }
+  }
+  __syncthreads();
+  // d el[u,h] = sum of de over the out-edges, in transposed-position order
+  for (int i = t; i < nu * H; i += 256) {
+    const int j = i / H, h = i - j * H;
+    const int4 q = s_unit[j];
+    float sum = 0.f;
+    for (int e = s_start[j]; e < s_start[j + 1]; ++e) sum += s_de[e * H + h];
+    if (q.w < 0) a.d_el[(int64_t)q.x * H + h] = sum;
+    else a.ws[(int64_t)q.w * (HF + H) + HF + h] = sum;
+  }
+  // d ft[u,h,:] = sum over out-edges of a[e,h] G[v,h,:]
+  constexpr int TEAMS = 256 / LPE, NR = STAG_GAT_NR;
+  const int team = t / LPE, c = t % LPE;
+  const int k0 = c * 4;
+  const bool kin = k0 < HF;
+  const int hl = kin ? k0 / F : 0;
+  const __amdgpu_buffer_rsrc_t rg =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, (int)a.g_bytes, 0x00020000);
+  const bool g_buf = a.g_bytes != 0;
+  for (int j = team; j < nu; j += TEAMS) {
+    const int4 q = s_unit[j];
+    const int e0 = s_start[j], e1 = s_start[j + 1];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int e = e0; e < e1; e += NR) {
+      float fv[NR][4];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (e + r < e1 && kin) {
+          const int v = s_v[e + r];
+          if (g_buf) bufrow4(rg, v, (uint32_t)HF * 4u, (uint32_t)k0 * 4u, fv[r]);
+          else loadrow4(a.g + (int64_t)v * HF + k0, k0, HF, true, fv[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (e + r < e1 && kin) {
+          const float w = s_a[(e + r) * H + hl];
+#pragma unroll
+          for (int x = 0; x < 4; ++x) acc[x] = __builtin_fmaf(w, fv[r][x], acc[x]);
+        }
+      }
+    }
+    if (!kin) continue;
+    if (q.w < 0) store4_out(a.d_ft + (int64_t)q.x * HF, k0, HF, true, acc);
+    else store4(a.ws + (int64_t)q.w * (HF + H), k0, HF, true, acc);
+  }
+}
+
+// out[long_rows[r]][k] = sum over the row's segments of ws[s][ws_off + k], k < width.  A workgroup per
+// (long row, 16 columns): 16 slices of the segment list are summed side by side (slice i takes segments
+// i, i+16, ... in order, Kahan), then the 16 slice sums in slice order — a fixed order, and a hub row
+// of 200 segments costs 13 dependent loads instead of 200.
+__global__ __launch_bounds__(256) void gat_seg_finish_kernel(const float* ws, int ws_stride, int ws_off, int width,
+                                                             const int32_t* long_rows, const int32_t* long_seg_ptr,
+                                                             float* out, int ld_out) {
+  __shared__ float red[16][17];
+  const int r = blockIdx.x, kx = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int k = blockIdx.y * 16 + kx;
+  const int s0 = long_seg_ptr[r], s1 = long_seg_ptr[r + 1];
+  float sum = 0.f, comp = 0.f;
+  if (k < width) {
+    for (int s = s0 + slice; s < s1; s += 16) {
+      const float y = ws[(int64_t)s * ws_stride + ws_off + k] - comp;
+      const float n = sum + y;
+      comp = (n - sum) - y;
+      sum = n;
+    }
+  }
+  red[slice][kx] = sum;
+  __syncthreads();
+  if (slice == 0 && k < width) {
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += red[i][kx];
+    out[(int64_t)long_rows[r] * ld_out + k] = tot;
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
@@ -938,6 +1272,100 @@ extern "C" int stag_gat_bwd_edge(const stag_csr* csr, const stag_plan* plan, con
     case 16: hipLaunchKernelGGL(gat_bwd_edge_kernel<16>, grid, dim3(256), lds_bytes, s, ba); break;
     case 8: hipLaunchKernelGGL(gat_bwd_edge_kernel<8>, grid, dim3(256), lds_bytes, s, ba); break;
     default: hipLaunchKernelGGL(gat_bwd_edge_kernel<4>, grid, dim3(256), lds_bytes, s, ba); break;
+  }
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}
+
+// One call = the whole backward of stag_gat_fwd w.r.t. el, er, ft (and explicit weights): the edge pass
+// over the forward CSR and the source pass over its transpose (see gat_bwd_edge_block_kernel).
+extern "C" size_t stag_gat_bwd_workspace_bytes(int32_t n_seg, int32_t n_seg_t, int32_t H, int32_t F) {
+  if (H <= 0 || F <= 0) return 0;
+  const size_t a = n_seg > 0 ? (size_t)n_seg * (size_t)H : 0;
+  const size_t b = n_seg_t > 0 ? (size_t)n_seg_t * (size_t)(H * F + H) : 0;
+  return (a > b ? a : b) * sizeof(float);
+}
+
+extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
+                            const stag_plan* plan_t, const float* el, const float* er, const float* ft,
+                            const float* stats, const float* g, const float* out, int32_t H, int32_t F,
+                            float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
+                            float* d_el, float* d_er, float* d_ft, float* dw, float* ade_ws, void* stream) {
+  if (!csr || !csr_t || !csr->indptr || !csr_t->indptr || csr->n_dst < 0 || csr->n_edges < 0) return STAG_EINVAL;
+  if (csr_t->n_edges != csr->n_edges || csr_t->n_dst != csr->n_src || csr_t->n_src != csr->n_dst) return STAG_EINVAL;
+  if (!spec || spec->kind < STAG_NOISE_NONE || spec->kind > STAG_NOISE_BERNOULLI || spec->deriv) return STAG_EINVAL;
+  if (!d_el || !d_er || !d_ft || !ade_ws || H <= 0 || F <= 0) return STAG_EINVAL;
+  const int64_t HF64 = (int64_t)H * F;
+  const int lph = F / 4;
+  if (H > kBlkMaxH || HF64 > 256 || F % 4 != 0 || (lph & (lph - 1)) != 0) return STAG_ENOSYS;
+  if (spec->chunk_base != 0) return STAG_ENOSYS;
+  if (!plan || !plan_t || !plan->block_ptr || !plan_t->block_ptr || plan->n_blocks <= 0 || plan_t->n_blocks <= 0 ||
+      plan->seg_len > kBlkEdges || plan_t->seg_len > kBlkEdges)
+    return STAG_ENOSYS;                                   // needs the batch plans of both orientations
+  if (spec->in_norm && !norm_scale) return STAG_EINVAL;
+  if (csr->n_dst == 0 || csr->n_edges == 0) return STAG_OK;   // the caller zero-fills (no edge, no gradient)
+  if (!csr->indices || !csr_t->indices || !csr_t->nidx || !el || !er || !ft || !stats || !g || !out) return STAG_EINVAL;
+  if (!aligned16(ft) || !aligned16(g) || !aligned16(out) || !aligned16(d_ft) || !aligned16(ade_ws)) return STAG_EINVAL;
+  if (spec->kind == STAG_NOISE_EXPLICIT && !spec->p0) return STAG_EINVAL;
+  if (spec->kind >= STAG_NOISE_NORMAL && (uint64_t)((uint64_t)spec->pos_base & 0xFFFFFFFFull) + (uint64_t)csr->n_edges > (1ull << 32))
+    return STAG_ENOSYS;
+  const int HF = (int)HF64;
+  const size_t need = stag_gat_bwd_workspace_bytes(plan->n_seg, plan_t->n_seg, H, F);
+  if (need > 0 && (!plan->workspace || plan->workspace_bytes < need)) return STAG_ENOMEM;
+  hipStream_t s = (hipStream_t)stream;
+
+  GatBwdBlkArgs ba{};
+  GatArgs& a = ba.f;
+  int rc = fill_edge_args(a, csr, plan, el, er, H, neg_slope, spec, norm_scale, stats);
+  if (rc) return rc;
+  a.ft = ft; a.F = F; a.HF = HF;
+  const uint64_t ftb = (uint64_t)csr->n_src * (uint64_t)HF * 4u;
+  a.ft_bytes = (ftb < (1ull << 32) && csr->n_src < (1 << 24)) ? (uint32_t)ftb : 0u;
+  a.block_ptr = plan->block_ptr;
+  a.hvec = aligned16(el) && aligned16(er) && aligned16(stats) && (!a.nscale || aligned16(a.nscale));
+  ba.g = g; ba.out = out; ba.ade = ade_ws; ba.d_er = d_er; ba.dw = dw; ba.ws = plan->workspace;
+  const int nchunk = (HF + 3) / 4;
+  int lpe = 4;
+  while (lpe < nchunk) lpe <<= 1;
+  size_t lds_e = (size_t)kBlkEdges * H * (dw ? 3 : 2) * sizeof(float) +
+                 (size_t)(kBlkEdges + kBlkUnits + 4) * sizeof(int) + (size_t)kBlkUnits * sizeof(int4);
+  if (lds_e < STAG_GAT_LDS_MIN_BWD) lds_e = STAG_GAT_LDS_MIN_BWD;
+  const dim3 ge(plan->n_blocks);
+  switch (lpe) {
+    case 64: hipLaunchKernelGGL(gat_bwd_edge_block_kernel<64>, ge, dim3(256), lds_e, s, ba); break;
+    case 32: hipLaunchKernelGGL(gat_bwd_edge_block_kernel<32>, ge, dim3(256), lds_e, s, ba); break;
+    case 16: hipLaunchKernelGGL(gat_bwd_edge_block_kernel<16>, ge, dim3(256), lds_e, s, ba); break;
+    case 8: hipLaunchKernelGGL(gat_bwd_edge_block_kernel<8>, ge, dim3(256), lds_e, s, ba); break;
+    default: hipLaunchKernelGGL(gat_bwd_edge_block_kernel<4>, ge, dim3(256), lds_e, s, ba); break;
+  }
+  if (plan->n_long > 0)
+    hipLaunchKernelGGL(gat_seg_finish_kernel, dim3(plan->n_long, (H + 15) / 16), dim3(256), 0, s,
+                       plan->workspace, H, 0, H, plan->long_rows, plan->long_seg_ptr, d_er, H);
+
+  GatSrcBlkArgs sa{};
+  sa.indices = csr_t->indices; sa.nidx = csr_t->nidx;
+  sa.units = plan_t->units; sa.block_ptr = plan_t->block_ptr; sa.long_rows = plan_t->long_rows;
+  sa.ade = ade_ws; sa.g = g; sa.H = H; sa.F = F; sa.HF = HF;
+  const uint64_t gb = (uint64_t)csr->n_dst * (uint64_t)HF * 4u;
+  sa.g_bytes = (gb < (1ull << 32) && csr->n_dst < (1 << 24)) ? (uint32_t)gb : 0u;
+  sa.d_ft = d_ft; sa.d_el = d_el; sa.ws = plan->workspace;   // the edge pass's partials are consumed by now (stream order)
+  if (!plan_t->units || !aligned16(plan_t->units)) return STAG_EINVAL;
+  if (plan_t->n_seg > 0 && (!plan_t->long_rows || !plan_t->long_seg_ptr)) return STAG_EINVAL;
+  size_t lds_s = (size_t)kBlkEdges * H * 2 * sizeof(float) + (size_t)(kBlkEdges + kBlkUnits + 4) * sizeof(int) +
+                 (size_t)kBlkUnits * sizeof(int4);
+  if (lds_s < STAG_GAT_LDS_MIN_BWD) lds_s = STAG_GAT_LDS_MIN_BWD;
+  const dim3 gs(plan_t->n_blocks);
+  switch (lpe) {
+    case 64: hipLaunchKernelGGL(gat_bwd_src_block_kernel<64>, gs, dim3(256), lds_s, s, sa); break;
+    case 32: hipLaunchKernelGGL(gat_bwd_src_block_kernel<32>, gs, dim3(256), lds_s, s, sa); break;
+    case 16: hipLaunchKernelGGL(gat_bwd_src_block_kernel<16>, gs, dim3(256), lds_s, s, sa); break;
+    case 8: hipLaunchKernelGGL(gat_bwd_src_block_kernel<8>, gs, dim3(256), lds_s, s, sa); break;
+    default: hipLaunchKernelGGL(gat_bwd_src_block_kernel<4>, gs, dim3(256), lds_s, s, sa); break;
+  }
+  if (plan_t->n_long > 0) {
+    hipLaunchKernelGGL(gat_seg_finish_kernel, dim3(plan_t->n_long, (HF + 15) / 16), dim3(256), 0, s,
+                       plan->workspace, HF + H, 0, HF, plan_t->long_rows, plan_t->long_seg_ptr, d_ft, HF);
+    hipLaunchKernelGGL(gat_seg_finish_kernel, dim3(plan_t->n_long, (H + 15) / 16), dim3(256), 0, s,
+                       plan->workspace, HF + H, HF, H, plan_t->long_rows, plan_t->long_seg_ptr, d_el, H);
   }
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }

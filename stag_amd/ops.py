@@ -636,6 +636,12 @@ class _GatAggregate(torch.autograd.Function):
         else:
             spec = _none_spec()
         want_dw = w is not None and ctx.needs_input_grad[3]
+        fused = _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, ctx.neg_slope, spec, nscale,
+                               want_dw, ctx.seg_len, dev)
+        if fused is not None:
+            d_el, d_er, d_ft, dw = fused
+            return (d_el if ctx.needs_input_grad[0] else None, d_er if ctx.needs_input_grad[1] else None,
+                    d_ft if ctx.needs_input_grad[2] else None, dw, None, None, None, None, None)
         de = torch.empty((csrv.n_edges, H), dtype=torch.float32, device=dev)
         dw = torch.empty((csrv.n_edges, H), dtype=torch.float32, device=dev) if want_dw else None
         # a[E, H], a by-product of the edge pass: the weights of the d ft aggregation
@@ -666,6 +672,38 @@ class _GatAggregate(torch.autograd.Function):
             d_ft, _ = _agg_raw(csrt, G.reshape(-1, HF), HF, sa, _lib.REDUCE_SUM, None, None, ctx.seg_len)
             d_ft = d_ft.reshape(-1, H, F)
         return d_el, d_er, d_ft, dw, None, None, None, None, None
+
+
+def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec, nscale, want_dw, seg_len, dev):
+    """stag_gat_bwd: both passes of the backward on the workgroup-cooperative kernels; None when the
+    shape or the plans are outside what it covers (the caller then composes the older kernels)."""
+    lph = F // 4
+    E = csrv.n_edges
+    if not (_GAT_BWD_FUSED and F % 4 == 0 and lph & (lph - 1) == 0 and H <= 16 and H * F <= 256 and E > 0
+            and seg_len is not None and 0 < seg_len <= _lib.BLOCK_EDGES):
+        return None
+    plan_f, plan_b = csrv.plan(seg_len), csrt.plan(seg_len)
+    nbytes = _lib.lib().stag_gat_bwd_workspace_bytes(plan_f["n_seg"], plan_b["n_seg"], H, F)
+    pf, _k1 = _plan_struct(csrv, seg_len, 1, nbytes, dev)
+    pb, _k2 = _plan_struct(csrt, seg_len, 1, 0, dev)
+    d_el = torch.empty((csrt.n_dst, H), dtype=torch.float32, device=dev)
+    d_er = torch.empty((csrv.n_dst, H), dtype=torch.float32, device=dev)
+    d_ft = torch.empty((csrt.n_dst, H, F), dtype=torch.float32, device=dev)
+    dw = torch.empty((E, H), dtype=torch.float32, device=dev) if want_dw else None
+    ade = torch.empty((E, 2 * H), dtype=torch.float32, device=dev)
+    cs, ct = csrv.struct(), csrt.struct()
+    with _lib.on_device(dev):
+        rc = _lib.lib().stag_gat_bwd(C.byref(cs), C.byref(pf), C.byref(ct), C.byref(pb), _lib.ptr(el), _lib.ptr(er),
+                                     _lib.ptr(ft), _lib.ptr(stats), _lib.ptr(G), _lib.ptr(out), H, F, neg_slope,
+                                     C.byref(spec), _lib.ptr(nscale), _lib.ptr(d_el), _lib.ptr(d_er), _lib.ptr(d_ft),
+                                     _lib.ptr(dw), _lib.ptr(ade), _lib.stream_of(dev))
+    if rc == -38:
+        return None
+    _lib.check(rc, "stag_gat_bwd")
+    return d_el, d_er, d_ft, dw
+
+
+_GAT_BWD_FUSED = True      # tools/bench_configs.py --gat-old-bwd flips it for A/B runs
 
 
 def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False,

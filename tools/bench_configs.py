@@ -59,12 +59,12 @@ def main():
     ap.add_argument("--noise", default="normal", choices=["normal", "none"])
     ap.add_argument("--json", default=None)
     ap.add_argument("--lib", default=None, help="A/B: a build variant tools/_bin/libstag_<name>.so (tools/ab_bench.py build)")
-    ap.add_argument("--gat-one-launch", action="store_true",
-                    help="cfg5: the one-kernel GAT forward (logits kept in LDS) instead of logits + aggregation launches")
+    ap.add_argument("--gat-old-bwd", action="store_true",
+                    help="cfg5_train: the composed backward (stag_gat_bwd_edge + three stag_agg_fwd calls) for A/B")
     args = ap.parse_args()
     only = [s for s in args.only.split(",") if s]
-    if args.gat_one_launch:
-        ops._GAT_TWO_LAUNCH = False
+    if args.gat_old_bwd:
+        ops._GAT_BWD_FUSED = False
     if args.lib:
         _lib._SO = os.path.join(ROOT, "tools", "_bin", f"libstag_{args.lib}.so")
     dev = torch.device("cuda:0")
