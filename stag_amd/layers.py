@@ -143,12 +143,13 @@ class StagLayer(torch.nn.Module):
                 graph, sample_dimension, dist, relu=self.relu, in_norm=self.norm,
                 seed=gen.seed, offset=gen.next_offset(), epoch=gen.device_epoch)
         reparam = type(dist) in (torch.distributions.Normal, torch.distributions.Uniform)
-        if (fused_ok and self.vi and reparam and not self.norm
+        if (fused_ok and self.vi and reparam
                 and getattr(self.base_layer, "supports_edge_noise_grad", False)):
             # vi=True on the fused path: the descriptor keeps the live loc / scale tensors and
             # ops.aggregate returns their gradients by regenerating the noise in the backward
+            # (in-norm included: its factor is differentiated from two [N, D] tensors, ops._AggregateVI)
             return EdgeNoise.from_distribution(
-                graph, sample_dimension, dist, relu=self.relu, differentiable=True,
+                graph, sample_dimension, dist, relu=self.relu, in_norm=self.norm, differentiable=True,
                 seed=gen.seed, offset=gen.next_offset(), epoch=gen.device_epoch)
         if fusable(dist) and self.vi and type(dist) in (torch.distributions.Normal,
                                                        torch.distributions.Uniform):

@@ -123,19 +123,24 @@ class EdgeNoise:
         whatever is computed from it (the sample-based KL of stag/layers.py:141-143, whose reference form
         differentiates through `rsample`) sends gradients to loc / log_scale."""
         from . import ops
-        live = (self.grad_params is not None and torch.is_grad_enabled() and not self.in_norm
+        live = (self.grad_params is not None and torch.is_grad_enabled()
                 and any(torch.is_tensor(p) and p.requires_grad for p in self.grad_params))
         if not live:
             return ops.materialize_noise(self.graph, self)
         import copy
         std = copy.copy(self)
-        std.grad_params, std.relu, std.param_mode = None, False, _lib.PARAM_SCALAR
+        std.grad_params, std.relu, std.in_norm, std.param_mode = None, False, False, _lib.PARAM_SCALAR
         std.p0 = std.p1 = None
         std.p0_scalar, std.p1_scalar = 0.0, 1.0          # N(0, 1) | U[0, 1)
         z = ops.materialize_noise(self.graph, std)
         p0, p1 = (torch.as_tensor(p, dtype=torch.float32, device=z.device) for p in self.grad_params)
         w = p0 + p1 * z if self.kind == _lib.NOISE_NORMAL else p0 + (p1 - p0) * z
-        return w.relu() if self.relu else w
+        if self.relu:
+            w = w.relu()
+        if self.in_norm:
+            from .layers import _in_norm
+            w = _in_norm(self.graph, w)
+        return w
 
     def __repr__(self):
         names = {2: "Normal", 3: "Uniform", 4: "Bernoulli"}

@@ -288,21 +288,35 @@ class _AggregateVI(torch.autograd.Function):
         x = _f32c(x)
         D = x.shape[1]
         spec = noise.spec()
-        out, _ = _agg_raw(graph.csr, x, D, spec, reduce, src_scale, dst_scale, seg_len)
+        out, ns = _agg_raw(graph.csr, x, D, spec, reduce, src_scale, dst_scale, seg_len,
+                           want_norm_scale=bool(spec.in_norm))
         ctx.graph, ctx.noise, ctx.reduce, ctx.seg_len, ctx.D = _owner(graph), noise, reduce, seg_len, D
         ctx.shapes = (p0.shape, p1.shape)
-        ctx.save_for_backward(x, src_scale, dst_scale)
+        # in-norm (stag/layers.py:8-36) is differentiated too: its factor s = indeg / sum_in(w) and the
+        # output are kept ([N, D] each; nothing [E, D]-sized)
+        ctx.save_for_backward(x, src_scale, dst_scale, ns, out if ns is not None else None)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, src_scale, dst_scale = ctx.saved_tensors
+        x, src_scale, dst_scale, ns, out = ctx.saved_tensors
         graph, noise, D = ctx.graph, ctx.noise, ctx.D
         g = _f32c(grad_out)
         dvec = dst_scale
         if ctx.reduce == _lib.REDUCE_MEAN:
             inv = 1.0 / graph.csr.degrees.clamp(min=1).to(torch.float32)
             dvec = inv if dvec is None else dvec * inv
+        spec = noise.spec()
+        spec.in_norm = 0                  # the backward redraws the RAW weights; the factor rides in g
+        q = None
+        if ns is not None:
+            # out = dv * s * A, A = sum_e w x', s = indeg / W, W = sum_e w  =>  with g' = g * s (dv applied by
+            # the kernel):  dL/dw[e,k] = dv g'[v,k] (x'[u,k] - A/W),  A/W = out / (dv * indeg).
+            # The x' part is the usual pass with g'; the other part is the same aggregate of dw/dp with
+            #   q[v,k] = dv g' A/W = g[v,k] s[v,k] out[v,k] / indeg[v]   in the place of g and no x.
+            deg = graph.csr.degrees.clamp(min=1).to(torch.float32).unsqueeze(1)
+            q = (g * ns * out / deg).contiguous()
+            g = (g * ns).contiguous()
         dx = dp0 = dp1 = None
         per_edge = noise.param_mode >= _lib.PARAM_PER_EDGE1
         need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
@@ -310,20 +324,28 @@ class _AggregateVI(torch.autograd.Function):
             # scalar / per-channel parameters: ONE transposed pass yields dx and the two
             # derivative aggregates T_i[u,k] = ss[u] sum_p dw/dp_i[p,k] g'[v_p,k]; then
             # dp_i[k] = sum_u x[u,k] T_i[u,k]   (sum_e D[e,k] s_u x[u,k] g'[v,k] regrouped by u)
-            dx, t0, t1 = _agg_bwd_raw(graph.csr_t, g, D, noise.spec(), dvec, src_scale, ctx.seg_len, need_p)
+            dx, t0, t1 = _agg_bwd_raw(graph.csr_t, g, D, spec, dvec, src_scale, ctx.seg_len, need_p)
             if not ctx.needs_input_grad[0]:
                 dx = None
             if need_p:      # dp_i[k] = sum_u x[u,k] T_i[u,k], both in one pass over x
                 c0, c1 = coldot(x, t0, t1)
+                if q is not None:   # in-norm: minus sum_e dw/dp_i[e,k] q[v,k], the same pass over q
+                    _, n0, n1 = _agg_bwd_raw(graph.csr_t, q, D, spec, None, None, ctx.seg_len, True)
+                    c0, c1 = c0 - n0.sum(0), c1 - n1.sum(0)
                 rows = {1: c0, 2: c1}
         elif ctx.needs_input_grad[0]:
-            dx, _, _ = _agg_bwd_raw(graph.csr_t, g, D, noise.spec(), dvec, src_scale, ctx.seg_len, False)
+            dx, _, _ = _agg_bwd_raw(graph.csr_t, g, D, spec, dvec, src_scale, ctx.seg_len, False)
         if per_edge and need_p:
             # per-edge (amortised) parameters: both derivatives from ONE pass over the edges
             gg = (g if dvec is None else g * dvec.unsqueeze(1)).contiguous()
-            e0, e1 = _bwd_w_raw(graph.csr, x, gg, D, src_scale, spec=noise.spec(),
-                                reduce_k=noise.param_mode == _lib.PARAM_PER_EDGE1, both=True,
+            rk = noise.param_mode == _lib.PARAM_PER_EDGE1
+            e0, e1 = _bwd_w_raw(graph.csr, x, gg, D, src_scale, spec=spec, reduce_k=rk, both=True,
                                 seg_len=ctx.seg_len)
+            if q is not None:
+                ones = torch.ones(D, dtype=torch.float32, device=q.device)
+                m0, m1 = _bwd_w_raw(graph.csr, ones, q, D, None, broadcast_x=True, spec=spec, reduce_k=rk,
+                                    both=True, seg_len=ctx.seg_len)
+                e0, e1 = e0 - m0, e1 - m1
             rows = {1: e0, 2: e1}
         for which, need in ((1, ctx.needs_input_grad[1]), (2, ctx.needs_input_grad[2])):
             if not need:
@@ -393,9 +415,6 @@ def aggregate(graph, x, weight=None, reduce="sum", src_scale=None, dst_scale=Non
     if noise is not None and noise.grad_params is not None and torch.is_grad_enabled():
         p0, p1 = (torch.as_tensor(p, dtype=torch.float32, device=x.device) for p in noise.grad_params)
         if p0.requires_grad or p1.requires_grad:
-            if noise.in_norm:
-                raise ValueError("in-norm is not differentiated on the fused path; "
-                                 "StagLayer materialises the weights for vi=True with norm=True")
             return _AggregateVI.apply(x, p0, p1, graph, noise, _REDUCE[reduce], _f32c(src_scale),
                                       _f32c(dst_scale), seg_len)
     return _Aggregate.apply(x, w, graph, noise, _REDUCE[reduce], _f32c(src_scale),

@@ -359,6 +359,60 @@ def test_fused_vi_gradients(dev, oracle, kind, pmode, relu):
         assert_close(b.grad, ref, what="d p1 vs oracle")
 
 
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("pmode", ["scalar", "per_channel", "per_edge1", "per_edge"])
+@pytest.mark.parametrize("kind", ["normal", "uniform"])
+def test_fused_vi_gradients_with_in_norm(dev, kind, pmode, relu):
+    """vi=True AND norm=True (stag/layers.py:102-105 on top of :123-124) on the fused path: the in-degree
+    renormalisation s = indeg / sum_in(w) depends on the parameters through every weight of the row; its
+    derivative comes from two [N, D] tensors (the factor and the output), not from an [E, D] graph.  Against
+    autograd through the materialised statement: w = p0 + p1 z, relu, _in_norm, explicit-weight aggregation."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    from stag_amd.layers import _in_norm
+    from util import random_graph
+    rng = np.random.default_rng(17)
+    n, D = 150, 12
+    g = random_graph(n, 1100, seed=33, hub=160, device=dev)
+    E = g.number_of_edges()
+    shape = {"scalar": (), "per_channel": (D,), "per_edge1": (E, 1), "per_edge": (E, D)}[pmode]
+    a0 = torch.tensor(rng.uniform(0.8, 1.2, shape).astype(np.float32), device=dev)
+    b0 = torch.tensor(rng.uniform(0.2, 0.5, shape).astype(np.float32), device=dev)
+    if kind == "uniform":
+        b0 = a0 + b0 + 0.5
+    x0 = torch.tensor(rng.standard_normal((n, D)).astype(np.float32), device=dev)
+    gout = torch.tensor(rng.standard_normal((n, D)).astype(np.float32), device=dev)
+    ss = torch.tensor(rng.uniform(0.5, 1.5, n).astype(np.float32), device=dev)
+    ds = torch.tensor(rng.uniform(0.5, 1.5, n).astype(np.float32), device=dev)
+    K = _lib.NOISE_NORMAL if kind == "normal" else _lib.NOISE_UNIFORM
+    shift = -0.6 if relu else 0.0
+    for reduce in ("sum", "mean"):
+        x, a, b = (t.clone().requires_grad_(True) for t in (x0, a0, b0))
+        noise = stag_amd.EdgeNoise(g, D, K, a + shift, b, relu=relu, in_norm=True, seed=5, offset=2, differentiable=True)
+        out = ops.aggregate(g, x, noise, reduce=reduce, src_scale=ss, dst_scale=ds, seg_len=32)
+        out.backward(gout)
+        std = stag_amd.EdgeNoise(g, D, K, 0.0, 1.0, seed=5, offset=2).materialize()
+        x2, a2, b2 = (t.clone().requires_grad_(True) for t in (x0, a0, b0))
+        w = (a2 + shift) + b2 * std if kind == "normal" else (a2 + shift) + (b2 - (a2 + shift)) * std
+        if relu:
+            w = w.relu()
+        w = _in_norm(g, w.expand(E, D))
+        out2 = ops.aggregate(g, x2, w, reduce=reduce, src_scale=ss, dst_scale=ds, seg_len=32)
+        out2.backward(gout)
+        assert_close(out, out2.detach().cpu().numpy(), what=f"forward {reduce}")
+        assert_close(x.grad, x2.grad.cpu().numpy(), what=f"dx {reduce}")
+        for got, ref, nm in ((a.grad, a2.grad, "p0"), (b.grad, b2.grad, "p1")):
+            sc = max(1.0, float(ref.abs().max()))
+            assert_close(got / sc, (ref / sc).cpu().numpy(), what=f"d {nm} {pmode} {reduce}")
+    # and the layer: vi + norm stays on the fused path, with gradients into loc / log_scale
+    layer = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(D, 8), q_a=torch.distributions.Normal(1.0, 0.5), vi=True,
+                                      norm=True, relu=relu).to(dev)
+    y = layer(g, x0)
+    assert isinstance(layer._edge_weight_handle, stag_amd.EdgeNoise) and layer._edge_weight_handle.in_norm
+    y.square().mean().backward()
+    assert layer.q_a.loc.grad is not None and float(layer.q_a.log_scale.grad.abs()) > 0
+
+
 def test_sample_based_kl_reaches_q_a_on_the_fused_path(dev):
     """No closed-form KL (a MixtureSameFamily prior, which StagLayer accepts: stag/layers.py:66-67) => the
     regulariser is q.log_prob(w) - p.log_prob(w) on the LAST SAMPLE (stag/layers.py:141-143), and the
