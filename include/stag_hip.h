@@ -330,6 +330,26 @@ int stag_gat_bwd_edge(const stag_csr* csr, const stag_plan* plan, const float* e
                       const stag_noise_spec* spec, const float* norm_scale, float* de,
                       float* dw, float* attn_out, void* stream);
 
+/* ---- multi-GPU: the halo exchange of a node-range partition on RCCL over xGMI ---------
+ * The reference is single-process; BASELINE.json's north_star partitions the node range over the GPUs of
+ * a node.  One process per GPU; RCCL is bound at run time (the copy already in the process if there is
+ * one), so the library loads without it and these entry points then return STAG_ENOSYS.
+ *   stag_comm_unique_id  rank 0 makes a 128-byte id and hands it to the other ranks (any side channel);
+ *   stag_comm_init       every rank, its device current: joins the communicator (collective);
+ *   stag_halo_allgather  x_full[world * n_floats] = the ranks' x_local[n_floats] in rank order
+ *                        (equal-size padded row shards; backward = the caller's reduce-scatter);
+ *   stag_halo_exchange   all-to-all-v of exactly the rows each rank's edges reference: peer p receives
+ *                        send[off_p, off_p + send_counts[p]) and recv[...] fills with what p sends, in peer
+ *                        order; counts in FLOATS, host arrays of length world, own entry 0; ONE RCCL group,
+ *                        so every xGMI link carries its pair at the same time.
+ * All enqueue on `stream` and return.                                                               */
+int stag_comm_unique_id(void* id_out_host /* 128 bytes */);
+int stag_comm_init(const void* id_host, int32_t rank, int32_t world, void** comm_out);
+int stag_comm_destroy(void* comm);
+int stag_halo_allgather(void* comm, const float* x_local, int64_t n_floats, float* x_full, void* stream);
+int stag_halo_exchange(void* comm, const float* send, const int64_t* send_counts_host, float* recv,
+                       const int64_t* recv_counts_host, void* stream);
+
 /* The whole backward of stag_gat_fwd in one call, for shapes with F % 4 == 0, F/4 a power of two,
  * H <= 16, H*F <= 256 and block plans (stag_plan.block_ptr) on both orientations of the graph:
  *   edge pass (csr, plan):     a, de per edge (the weight redrawn from its counters, a from `stats`),

@@ -105,6 +105,68 @@ class _HaloGather(torch.autograd.Function):
         return out, None
 
 
+class NativeComm:
+    """An RCCL communicator owned by libstag_hip.so (include/stag_hip.h: stag_comm_*): the halo exchange
+    as calls into the C ABI on a HIP stream, without torch.distributed on the data path.  torch.distributed
+    (any backend) is used once, to hand rank 0's 128-byte id to the other ranks.  One process per GPU."""
+
+    def __init__(self, rank, world, device, group=None):
+        import ctypes as C
+        from . import _lib
+        self.rank, self.world, self.device = int(rank), int(world), torch.device(device)
+        lib = _lib.lib()
+        buf = (C.c_char * 128)()
+        if self.rank == 0:
+            _lib.check(lib.stag_comm_unique_id(buf), "stag_comm_unique_id")
+        box = [bytes(buf.raw)]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        self._handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.stag_comm_init(box[0], self.rank, self.world, C.byref(self._handle)), "stag_comm_init")
+        self._side = torch.cuda.Stream(device=self.device)
+
+    def close(self):
+        if self._handle:
+            from . import _lib
+            _lib.lib().stag_comm_destroy(self._handle)
+            self._handle = None
+
+    def allgather(self, x_pad, out=None):
+        """[rows, D] on every rank -> [world * rows, D] (stag_halo_allgather, on the current stream)."""
+        from . import _lib
+        x_pad = x_pad.contiguous()
+        if out is None:
+            out = torch.empty((self.world * x_pad.shape[0],) + tuple(x_pad.shape[1:]), dtype=torch.float32,
+                              device=x_pad.device)
+        _lib.check(_lib.lib().stag_halo_allgather(self._handle, x_pad.data_ptr(), x_pad.numel(), out.data_ptr(),
+                                                  _lib.stream_of(x_pad.device)), "stag_halo_allgather")
+        return out
+
+    def exchange_async(self, send, in_rows, recv, out_rows, width):
+        """All-to-all-v of rows on a side stream (stag_halo_exchange): -> an object whose wait() orders the
+        current stream behind it, so kernels launched in between overlap the transfer."""
+        import ctypes as C
+        from . import _lib
+        cur = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(cur)                       # the send rows are produced on the current stream
+        sc = (C.c_int64 * self.world)(*[int(r) * width for r in in_rows])
+        rc_ = (C.c_int64 * self.world)(*[int(r) * width for r in out_rows])
+        with torch.cuda.stream(self._side):
+            rc = _lib.lib().stag_halo_exchange(self._handle, send.data_ptr() if send.numel() else None, sc,
+                                               recv.data_ptr() if recv.numel() else None, rc_,
+                                               self._side.cuda_stream)
+        _lib.check(rc, "stag_halo_exchange")
+        send.record_stream(self._side)
+        recv.record_stream(self._side)
+        side = self._side
+
+        class _Work:
+            def wait(self_inner):
+                torch.cuda.current_stream(side.device).wait_stream(side)
+        return _Work()
+
+
 def _owner_of(ids, bounds_t, world):
     """Rank owning each node id (ids: int64 tensor; bounds_t: [world+1] int64 tensor on its device)."""
     return torch.bucketize(ids, bounds_t[1:-1], right=True).clamp_(max=world - 1)
@@ -211,6 +273,7 @@ class GraphShard:
         self._csr_t = None
         self._plan_split = {}
         self._origin = self
+        self.native_comm = None      # a NativeComm: the no-grad exchange then goes through stag_halo_* (C ABI)
 
     def _set_bounds(self, indptr):
         self.bounds = edge_balanced_bounds(indptr.cpu().numpy(), self.world)
@@ -372,16 +435,22 @@ class GraphShard:
         if x_local.shape[0] != self.n_rows:
             raise ValueError(f"rank {self.rank} owns {self.n_rows} rows, got {x_local.shape[0]}")
         tail = tuple(x_local.shape[1:])
+        native = self.native_comm if (x_local.is_cuda and x_local.dtype == torch.float32) else None
         if self.exchange == "halo":
             buf = torch.empty((self.n_buf,) + tail, dtype=x_local.dtype, device=x_local.device)
             buf[:self.n_rows].copy_(x_local)
             send = x_local.index_select(0, self.send_idx)
+            if native is not None:                      # RCCL through the C ABI, on a side stream
+                width = int(np.prod(tail)) if tail else 1
+                return buf, native.exchange_async(send, self.in_splits, buf[self.n_rows:], self.out_splits, width)
             work = dist.all_to_all_single(buf[self.n_rows:], send, self.out_splits, self.in_splits,
                                           group=self.group, async_op=True)
             return buf, work
         x_pad = self.pad_rows(x_local).contiguous()
-        if self.world == 1:
+        if self.world == 1 and native is None:
             return x_pad, None
+        if native is not None:
+            return native.allgather(x_pad), None
         buf = torch.empty((self.world * self.max_rows,) + tail, dtype=x_local.dtype, device=x_local.device)
         return buf, dist.all_gather_into_tensor(buf, x_pad, group=self.group, async_op=True)
 

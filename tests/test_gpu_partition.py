@@ -153,3 +153,31 @@ def test_layers_on_two_shards_match_the_whole_graph(dev, tmp_path):
             ref = p.grad.cpu().numpy()
             scale = max(1.0, float(np.abs(ref).max()))
             assert_close(parts[0][name]["grads"][k] / scale, ref / scale, TOL, f"{name}: d/d{k} summed over ranks")
+
+
+def test_native_rccl_comm_single_rank(dev):
+    """The RCCL path behind the C ABI (stag_comm_* / stag_halo_allgather / stag_halo_exchange) on the one GPU
+    of this box: the library finds RCCL at run time, a one-rank communicator forms, the all-gather is the
+    identity and an exchange with nothing to send completes; a world-1 shard with the native communicator
+    attached reproduces the whole-graph aggregation.  (More ranks need more GPUs: two RCCL ranks cannot
+    share a device; the torch.distributed twin of the same exchange runs with two ranks above.)"""
+    import stag_amd
+    from stag_amd import _lib, ops
+    from stag_amd.partition import GraphShard, NativeComm
+    comm = NativeComm(0, 1, dev)
+    try:
+        x = torch.randn(300, 40, device=dev)
+        assert torch.equal(comm.allgather(x), x)
+        w = comm.exchange_async(x[:0], [0], x[:0], [0], 40)
+        w.wait()
+        src, dst, n = _graph()
+        g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
+        xs = torch.randn(n, 32, device=dev)
+        mk = lambda gr: stag_amd.EdgeNoise(gr, 32, _lib.NOISE_NORMAL, 1.0, 0.5, seed=2, offset=1)
+        for ex in ("allgather", "halo"):
+            sh = GraphShard(src, dst, n, 0, 1, device=dev, exchange=ex)
+            sh.native_comm = comm
+            with torch.no_grad():
+                assert torch.equal(sh.aggregate(xs, mk(sh)), ops.aggregate(g, xs, mk(g)))
+    finally:
+        comm.close()
