@@ -64,6 +64,9 @@ def parse(argv=None):
     ap.add_argument("--no-overlap", action="store_true",
                     help="N>1, nodes: launch all rows behind the collective instead of overlapping the "
                          "local-source rows with it")
+    ap.add_argument("--native-comm", action="store_true",
+                    help="N>1, nodes: the exchange through the library's own RCCL communicator "
+                         "(stag_halo_exchange, include/stag_hip.h) instead of torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--rehearse", action="store_true",
@@ -261,6 +264,9 @@ def main():
                 f"no exchange in the step"), None
         shard = GraphShard(src, dst, n, rank, world, device=dev, exchange=args.exchange)
         x = x_host[shard.row_lo:shard.row_hi].to(dev)
+        if args.native_comm and not rehearse:
+            from stag_amd.partition import NativeComm
+            shard.native_comm = NativeComm(rank, world, dev)
         overlap = not args.no_overlap
         coll = "RCCL" if dist.get_backend() == "nccl" else f"{dist.get_backend()} (rehearsal backend, not RCCL)"
         desc = (f"node-range partition x{world}: dst-row ranges cut at equal edge counts, {coll} "
