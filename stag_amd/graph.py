@@ -40,6 +40,10 @@ class CsrView:
         return _lib.Csr(self.n_dst, self.n_src, self.n_edges, _lib.ptr(self.indptr),
                         _lib.ptr(self.indices), _lib.ptr(self.eid), _lib.ptr(self.nidx))
 
+    def torch_args(self):
+        """(indptr, indices, eid, nidx, n_src): the graph arguments of torch.ops.stag.*"""
+        return (self.indptr, self.indices, self.eid, self.nidx, self.n_src)
+
     @property
     def degrees(self):
         if self._degrees is None:

@@ -116,6 +116,14 @@ class EdgeNoise:
         s.epoch = _lib.ptr(self.epoch)
         return s
 
+    def torch_args(self, in_norm=None, group=0):
+        """(noise_ints, noise_u64, noise_floats, p0, p1, epoch) of torch.ops.stag.* — the same fields as spec()."""
+        s64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v          # 64-bit pattern in an int64
+        return ([self.kind, self.param_mode, int(self.relu), int(self.in_norm if in_norm is None else in_norm),
+                 int(self.deriv), group, self.chunk_base],
+                [s64(self.seed), s64(self.offset), self.pos_base], [self.p0_scalar, self.p1_scalar],
+                self.p0, self.p1, self.epoch)
+
     def materialize(self):
         """The [E, Dn] tensor this descriptor stands for.  With live parameters (vi=True, `grad_params`)
         and gradients enabled it is the reparameterised sample itself, w = p0 + p1 * z (Normal) or

@@ -10,7 +10,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, _torch_ext
 from .graph import DEFAULT_SEG_LEN
 from .noise import EdgeNoise
 
@@ -32,18 +32,44 @@ def _f32c(t):
     return t.contiguous()
 
 
+# A noise description travels to the library in one of two forms: the ctypes `stag_noise_spec`, or — when
+# the TORCH_LIBRARY front end is loaded (_torch_ext) — the argument tuple of torch.ops.stag.* (ints, 64-bit
+# patterns, floats, the parameter tensors themselves).  _agg_raw / _agg_bwd_raw take either.
 def _none_spec():
+    if _torch_ext.available():
+        return _NONE_ARGS
     s = _lib.NoiseSpec()
     s.kind = _lib.NOISE_NONE
     return s
 
 
-def _explicit_spec(w, relu=False, in_norm=False):
+def _explicit_spec(w, relu=False, in_norm=False, group=0):
+    if _torch_ext.available():
+        return ([_lib.NOISE_EXPLICIT, 0, int(relu), int(in_norm), 0, int(group), 0], [0, 0, 0], [0.0, 0.0], w, None, None)
     s = _lib.NoiseSpec()
     s.kind = _lib.NOISE_EXPLICIT
     s.p0 = w.data_ptr()
-    s.relu, s.in_norm = int(relu), int(in_norm)
+    s.relu, s.in_norm, s.group = int(relu), int(in_norm), int(group)
     return s
+
+
+def _noise_spec(noise, in_norm=None):
+    """The spec of an EdgeNoise (in_norm optionally overridden: the backward passes redraw the raw weights)."""
+    if _torch_ext.available():
+        return noise.torch_args(in_norm=in_norm)
+    s = noise.spec()
+    if in_norm is not None:
+        s.in_norm = int(in_norm)
+    return s
+
+
+def _targs_or_c(spec):
+    """The ctypes form, whichever form came in (entry points bound through ctypes only)."""
+    return _targs_to_ctypes(spec) if isinstance(spec, tuple) else spec
+
+
+def _spec_in_norm(spec):
+    return bool(spec[0][3]) if isinstance(spec, tuple) else bool(spec.in_norm)
 
 
 def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None):
@@ -69,10 +95,43 @@ def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None):
     return plan_c, (ws, counters)
 
 
+_NONE_ARGS = ([_lib.NOISE_NONE, 0, 0, 0, 0, 0, 0], [0, 0, 0], [0.0, 0.0], None, None, None)
+
+
+def _plan_args(csrv, plan_t, tiles, dev):
+    """(units, long_rows, long_seg_ptr, block_ptr, counters, plan_ints) of torch.ops.stag.*"""
+    if plan_t is None:
+        return (None, None, None, None, None, [0, 0, 0, 0, 0, 0])
+    key = (tiles, _lib.stream_of(dev))
+    counters = plan_t["counters"].get(key)
+    if counters is None:
+        counters = torch.zeros(max(plan_t["n_long"], 1) * tiles, dtype=torch.int32, device=dev)
+        plan_t["counters"][key] = counters
+    ints = plan_t.get("_ints")
+    if ints is None:
+        ints = plan_t["_ints"] = [plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"],
+                                  plan_t["n_heavy"], plan_t["n_blocks"]]
+    return (plan_t["units"], plan_t["long_rows"], plan_t["long_seg_ptr"], plan_t["block_ptr"], counters, ints)
+
+
+def _agg_fwd_torch(csrv, x, noise_args, reduce, src_scale, dst_scale, seg_len, want_norm_scale, broadcast_x):
+    """stag_agg_fwd through the dispatcher op (csrc/torch_ext.cpp): same library call, no ctypes."""
+    dev = _lib.require_device(x, csrv.indptr, src_scale, dst_scale)
+    D = x.numel() if broadcast_x else x.shape[1]
+    plan_t = csrv.plan(seg_len)
+    out, ns = torch.ops.stag.agg_fwd(*csrv.torch_args(), *_plan_args(csrv, plan_t, (D + 255) // 256, dev), x,
+                                     broadcast_x, *noise_args, reduce, src_scale, dst_scale, want_norm_scale)
+    return out, (ns if want_norm_scale else None)
+
+
 def _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len, want_norm_scale=False,
              broadcast_x=False, out=None, plan_t=None):
     """One stag_agg_fwd launch on csrv (a CsrView). x: [n_src, D] fp32 contiguous.
     out / plan_t: write the rows of a sub-plan's units into an existing [n_dst, D] tensor."""
+    if isinstance(spec, tuple):
+        if out is None and plan_t is None:
+            return _agg_fwd_torch(csrv, x, spec, reduce, src_scale, dst_scale, seg_len, want_norm_scale, broadcast_x)
+        spec = _targs_to_ctypes(spec)
     dev = _lib.require_device(x, csrv.indptr, src_scale, dst_scale)
     if out is None:
         out = torch.empty((csrv.n_dst, D), dtype=torch.float32, device=dev)
@@ -82,6 +141,7 @@ def _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len, want_norm_
     nbytes = (_lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], D, int(spec.in_norm))
               if plan_t is not None else 0)
     plan_c, _keep = _plan_struct(csrv, seg_len, (D + 255) // 256, nbytes, dev, plan_t)
+    # (spec is the ctypes form from here on)
     cs = csrv.struct()
     with _lib.on_device(dev):
         rc = _lib.lib().stag_agg_fwd(
@@ -92,9 +152,26 @@ def _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len, want_norm_
     return out, ns
 
 
+def _targs_to_ctypes(t):
+    """The torch-op argument tuple as a ctypes stag_noise_spec (for the entry points bound through ctypes)."""
+    ni, nu, nf, p0, p1, epoch = t
+    s = _lib.NoiseSpec()
+    s.kind, s.param_mode, s.relu, s.in_norm, s.deriv, s.group, s.chunk_base = ni
+    s.seed, s.offset, s.pos_base = nu[0] & ((1 << 64) - 1), nu[1] & ((1 << 64) - 1), nu[2]
+    s.p0_scalar, s.p1_scalar = nf
+    s.p0, s.p1, s.epoch = _lib.ptr(p0), _lib.ptr(p1), _lib.ptr(epoch)
+    return s
+
+
 def _agg_bwd_raw(csrv_t, g, D, spec, g_scale, row_scale, seg_len, want_dp):
     """One stag_agg_bwd launch on the source-major CSR: dx and, if want_dp, the two per-row
     parameter-derivative aggregates (same gather, same Philox block)."""
+    if isinstance(spec, tuple):
+        dev = _lib.require_device(g, csrv_t.indptr, g_scale, row_scale)
+        plan_t = csrv_t.plan(seg_len)
+        dx, t0, t1 = torch.ops.stag.agg_bwd(*csrv_t.torch_args(), *_plan_args(csrv_t, plan_t, (D + 255) // 256, dev),
+                                            g, *spec, g_scale, row_scale, want_dp)
+        return dx, (t0 if want_dp else None), (t1 if want_dp else None)
     dev = _lib.require_device(g, csrv_t.indptr, g_scale, row_scale)
     dx = torch.empty((csrv_t.n_dst, D), dtype=torch.float32, device=dev)
     t0 = torch.empty_like(dx) if want_dp else None
@@ -230,14 +307,14 @@ class _Aggregate(torch.autograd.Function):
         D = x.shape[1]
         csrv = graph.csr
         if noise is not None:
-            spec = noise.spec()        # ctx.noise keeps the parameter tensors alive
+            spec = _noise_spec(noise)  # ctx.noise keeps the parameter tensors alive
         elif w is not None:
             w = _f32c(w)
             spec = _explicit_spec(w)
         else:
             spec = _none_spec()
         # the in-norm factor is only kept (one more [N, D] store) when a backward can follow
-        want_ns = bool(spec.in_norm) and any(ctx.needs_input_grad[:2])
+        want_ns = _spec_in_norm(spec) and any(ctx.needs_input_grad[:2])
         out, ns = _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len,
                            want_norm_scale=want_ns, broadcast_x=broadcast_x)
         ctx.graph, ctx.noise, ctx.reduce, ctx.seg_len = _owner(graph), noise, reduce, seg_len
@@ -262,8 +339,7 @@ class _Aggregate(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0] and not ctx.broadcast_x:
             if noise is not None:
-                spec = noise.spec()
-                spec.in_norm = 0
+                spec = _noise_spec(noise, in_norm=0)
             elif w is not None:
                 spec = _explicit_spec(w)
             else:
@@ -287,9 +363,9 @@ class _AggregateVI(torch.autograd.Function):
     def forward(ctx, x, p0, p1, graph, noise, reduce, src_scale, dst_scale, seg_len):
         x = _f32c(x)
         D = x.shape[1]
-        spec = noise.spec()
+        spec = _noise_spec(noise)
         out, ns = _agg_raw(graph.csr, x, D, spec, reduce, src_scale, dst_scale, seg_len,
-                           want_norm_scale=bool(spec.in_norm))
+                           want_norm_scale=_spec_in_norm(spec))
         ctx.graph, ctx.noise, ctx.reduce, ctx.seg_len, ctx.D = _owner(graph), noise, reduce, seg_len, D
         ctx.shapes = (p0.shape, p1.shape)
         # in-norm (stag/layers.py:8-36) is differentiated too: its factor s = indeg / sum_in(w) and the
@@ -306,8 +382,8 @@ class _AggregateVI(torch.autograd.Function):
         if ctx.reduce == _lib.REDUCE_MEAN:
             inv = 1.0 / graph.csr.degrees.clamp(min=1).to(torch.float32)
             dvec = inv if dvec is None else dvec * inv
-        spec = noise.spec()
-        spec.in_norm = 0                  # the backward redraws the RAW weights; the factor rides in g
+        spec = _noise_spec(noise, in_norm=0)     # the backward redraws the RAW weights; the factor rides in g
+        spec_c = spec if not isinstance(spec, tuple) else _targs_to_ctypes(spec)   # stag_agg_bwd_w goes through ctypes
         q = None
         if ns is not None:
             # out = dv * s * A, A = sum_e w x', s = indeg / W, W = sum_e w  =>  with g' = g * s (dv applied by
@@ -339,11 +415,11 @@ class _AggregateVI(torch.autograd.Function):
             # per-edge (amortised) parameters: both derivatives from ONE pass over the edges
             gg = (g if dvec is None else g * dvec.unsqueeze(1)).contiguous()
             rk = noise.param_mode == _lib.PARAM_PER_EDGE1
-            e0, e1 = _bwd_w_raw(graph.csr, x, gg, D, src_scale, spec=spec, reduce_k=rk, both=True,
+            e0, e1 = _bwd_w_raw(graph.csr, x, gg, D, src_scale, spec=spec_c, reduce_k=rk, both=True,
                                 seg_len=ctx.seg_len)
             if q is not None:
                 ones = torch.ones(D, dtype=torch.float32, device=q.device)
-                m0, m1 = _bwd_w_raw(graph.csr, ones, q, D, None, broadcast_x=True, spec=spec, reduce_k=rk,
+                m0, m1 = _bwd_w_raw(graph.csr, ones, q, D, None, broadcast_x=True, spec=spec_c, reduce_k=rk,
                                     both=True, seg_len=ctx.seg_len)
                 e0, e1 = e0 - m0, e1 - m1
             rows = {1: e0, 2: e1}
@@ -371,7 +447,7 @@ def aggregate_into(csrv, x, out, weight, reduce, src_scale, dst_scale, plan_t):
     elif isinstance(weight, EdgeNoise):
         if weight.dn != x.shape[1]:
             raise ValueError(f"noise width {weight.dn} != feature width {x.shape[1]}")
-        spec = weight.spec()
+        spec = _noise_spec(weight)
     else:
         raise TypeError("aggregate_into takes None or an EdgeNoise")
     _agg_raw(csrv, x, x.shape[1], spec, _REDUCE[reduce], _f32c(src_scale), _f32c(dst_scale),
@@ -584,10 +660,9 @@ def segment_reduce(x, offsets, reduce="sum"):
 def _gat_norm_scale(csrv, noise, H, seg_len, dev):
     """in-norm factor [N, H] of H-wide weights (stag/layers.py:8-36): row sums on the aggregation
     kernel (a broadcast row of ones, same noise, in-norm off), then indeg / sum."""
-    s2 = noise.spec()
-    s2.in_norm = 0
     ones = torch.ones(1, H, dtype=torch.float32, device=dev)
-    sums, _ = _agg_raw(csrv, ones, H, s2, _lib.REDUCE_SUM, None, None, seg_len, broadcast_x=True)
+    sums, _ = _agg_raw(csrv, ones, H, _noise_spec(noise, in_norm=0), _lib.REDUCE_SUM, None, None, seg_len,
+                       broadcast_x=True)
     deg = csrv.degrees.to(torch.float32).unsqueeze(1)
     return torch.where(sums != 0, deg / sums, torch.ones_like(sums)).contiguous()
 
@@ -603,9 +678,9 @@ class _GatAggregate(torch.autograd.Function):
             spec = noise.spec()
         elif w is not None:
             w = _f32c(w)
-            spec = _explicit_spec(w)
+            spec = _targs_or_c(_explicit_spec(w))
         else:
-            spec = _none_spec()
+            spec = _targs_or_c(_none_spec())
         nscale = _gat_norm_scale(csrv, noise, H, seg_len, dev) if spec.in_norm else None
         need_grad = any(ctx.needs_input_grad[:4])
         out = torch.empty((csrv.n_dst, H, F), dtype=torch.float32, device=dev)
@@ -651,9 +726,9 @@ class _GatAggregate(torch.autograd.Function):
         if noise is not None:
             spec = noise.spec()
         elif w is not None:
-            spec = _explicit_spec(w)
+            spec = _targs_or_c(_explicit_spec(w))
         else:
-            spec = _none_spec()
+            spec = _targs_or_c(_none_spec())
         want_dw = w is not None and ctx.needs_input_grad[3]
         fused = _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, ctx.neg_slope, spec, nscale,
                                want_dw, ctx.seg_len, dev)
@@ -686,9 +761,8 @@ class _GatAggregate(torch.autograd.Function):
             d_el, _ = _agg_raw(csrt, ones, H, _explicit_spec(de), _lib.REDUCE_SUM, None, None,
                                ctx.seg_len, broadcast_x=True)
         if ctx.needs_input_grad[2]:      # d ft[u,h,:] = sum over out-edges of a[e,h] * G[v,h,:]
-            sa = _explicit_spec(attn)
-            sa.group = F
-            d_ft, _ = _agg_raw(csrt, G.reshape(-1, HF), HF, sa, _lib.REDUCE_SUM, None, None, ctx.seg_len)
+            d_ft, _ = _agg_raw(csrt, G.reshape(-1, HF), HF, _explicit_spec(attn, group=F), _lib.REDUCE_SUM, None, None,
+                               ctx.seg_len)
             d_ft = d_ft.reshape(-1, H, F)
         return d_el, d_er, d_ft, dw, None, None, None, None, None
 

@@ -35,6 +35,51 @@ def test_library_loaded_is_in_tree():
     assert "stag_amd/libstag_hip.so" in maps
 
 
+def test_torch_ops_equal_ctypes_binding(dev, monkeypatch):
+    """The dispatcher ops (torch.ops.stag.agg_fwd / agg_bwd, csrc/torch_ext.cpp) and the ctypes binding are two
+    front ends of the same library calls: outputs and gradients are bit-identical, plan or no plan, every noise
+    kind, explicit weights, in-norm, vi gradients."""
+    import stag_amd
+    from stag_amd import _lib, _torch_ext, ops
+    monkeypatch.setenv("STAG_TORCH_OPS", "1")
+    assert _torch_ext.available(), "the torch front end must be built and loaded on the GPU box"
+    g = random_graph(400, 5000, seed=2, hub=900, device=dev)
+    E, D = g.number_of_edges(), 48
+    x = torch.randn(400, D, device=dev)
+    gout = torch.randn(400, D, device=dev)
+    loc = torch.rand(D, device=dev) + 0.5
+    w = torch.rand(E, D, device=dev)
+
+    def run(kind):
+        xg = x.clone().requires_grad_(True)
+        extra = []
+        if kind == "explicit":
+            wg = w.clone().requires_grad_(True); extra = [wg]
+            out = ops.aggregate(g, xg, wg, reduce="mean")
+        elif kind == "none":
+            out = ops.aggregate(g, xg, None, src_scale=loc[:1].expand(400).contiguous())
+        elif kind == "vi":
+            a = loc.clone().requires_grad_(True); b = (loc * 0.3).requires_grad_(True); extra = [a, b]
+            out = ops.aggregate(g, xg, stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, a, b, relu=True, in_norm=True, seed=4,
+                                                          offset=1, differentiable=True), seg_len=32)
+        else:
+            k = {"normal": _lib.NOISE_NORMAL, "uniform": _lib.NOISE_UNIFORM, "bernoulli": _lib.NOISE_BERNOULLI}[kind]
+            out = ops.aggregate(g, xg, stag_amd.EdgeNoise(g, D, k, 0.6 if kind == "bernoulli" else loc,
+                                                          None if kind == "bernoulli" else loc + 1.0, seed=4, offset=1,
+                                                          in_norm=(kind == "bernoulli")), seg_len=0 if kind == "uniform" else 64)
+        out.backward(gout)
+        return [out.detach(), xg.grad] + [t.grad for t in extra]
+
+    for kind in ("none", "explicit", "normal", "uniform", "bernoulli", "vi"):
+        monkeypatch.setenv("STAG_TORCH_OPS", "1")
+        via_ops = run(kind)
+        monkeypatch.delenv("STAG_TORCH_OPS")
+        assert not _torch_ext.available()
+        via_ctypes = run(kind)
+        for a_, b_ in zip(via_ops, via_ctypes):
+            assert torch.equal(a_, b_), kind
+
+
 def test_philox_words_bit_exact(dev, oracle):
     from stag_amd import ops
     for seed, offset, pos0 in [(0, 0, 0), (0x5747A6, 3, 12345), (2**63 + 5, 2**40 + 9, 2**33 + 17)]:

@@ -24,6 +24,29 @@ def test_abi_exports_every_declared_symbol():
     assert lib.stag_strerror(-22) == b"invalid argument"
 
 
+def test_torch_library_front_end_loads_and_traces():
+    """stag_amd/_stag_torch.so (csrc/torch_ext.cpp): the TORCH_LIBRARY ops over the same C ABI load without a GPU,
+    agree with the library on the ABI version, and have Meta kernels (shape inference for tracing / torch.compile)."""
+    from stag_amd import _torch_ext
+    assert os.path.exists(os.path.join(ROOT, "stag_amd", "_stag_torch.so")), "build with make -C stag_amd/csrc"
+    assert _torch_ext.loaded() and not _torch_ext.available()      # eager mode keeps ctypes (it is faster)
+    assert int(torch.ops.stag.abi_version()) == 11
+    ip = torch.zeros(6, dtype=torch.int32, device="meta")
+    ix = torch.zeros(9, dtype=torch.int32, device="meta")
+    x = torch.zeros(5, 12, device="meta")
+    noise = ([2, 0, 0, 1, 0, 0, 0], [1, 2, 0], [1.0, 0.5], None, None, None)
+    plan = (None, None, None, None, None, [0] * 6)
+    out, ns = torch.ops.stag.agg_fwd(ip, ix, None, None, 5, *plan, x, False, *noise, 0, None, None, True)
+    assert out.shape == (5, 12) and ns.shape == (5, 12) and out.device.type == "meta"
+    dx, t0, t1 = torch.ops.stag.agg_bwd(ip, ix, None, None, 5, *plan, x, *noise, None, None, True)
+    assert dx.shape == t0.shape == t1.shape == (5, 12)
+    # a CPU tensor is refused by the Python layer before the dispatcher would fail to find a CPU kernel
+    import stag_amd
+    from stag_amd._lib import StagHipError
+    with pytest.raises(StagHipError):
+        stag_amd.ops.aggregate(stag_amd.rand_graph(3, 9), torch.randn(3, 4), None)
+
+
 def test_abi_struct_layouts_match_header():
     from stag_amd import _lib
     assert ctypes.sizeof(_lib.Csr) == 48
