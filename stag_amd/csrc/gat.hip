@@ -367,7 +367,7 @@ constexpr int kBlkEdges = STAG_BLOCK_EDGES, kBlkUnits = STAG_BLOCK_UNITS, kBlkMa
 #ifndef STAG_GAT_LDS_MIN_BWD
 #define STAG_GAT_LDS_MIN_BWD 32000  // backward passes: 5
 #endif
-template <int LPE>
+template <int LPE, int CPL>
 __global__ __launch_bounds__(256) STAG_GAT_SGPR_ATTR void gat_fwd_block_kernel(const GatArgs a) {
   extern __shared__ __align__(16) float lds[];
   const int H = a.H, F = a.F, HF = a.HF;
@@ -473,50 +473,70 @@ __global__ __launch_bounds__(256) STAG_GAT_SGPR_ATTR void gat_fwd_block_kernel(c
   GAT_TS(5)
 
   // ---- phase 2: a team per unit, weighted gather -------------------------------------------------------
-  constexpr int TEAMS = 256 / LPE, NR = STAG_GAT_NR;
+  // lane c owns CPL chunks of 4 channels: [4 (c + LPE j), +4), j < CPL  (H*F <= 256: one; up to 1024: 2 or 4)
+  constexpr int TEAMS = 256 / LPE, NR = CPL >= 4 ? 2 : STAG_GAT_NR;
   const int team = t / LPE, c = t % LPE;
   const int team_lane0 = (int)(t & 63) - c;
-  const int k0 = c * 4;
-  const bool kin = k0 < HF;
-  const int hl = kin ? k0 / F : 0;
+  int k0[CPL], hl[CPL];
+  bool kin[CPL];
+#pragma unroll
+  for (int cj = 0; cj < CPL; ++cj) {
+    k0[cj] = (c + LPE * cj) * 4;
+    kin[cj] = k0[cj] < HF;
+    hl[cj] = kin[cj] ? k0[cj] / F : 0;
+  }
   const __amdgpu_buffer_rsrc_t rft =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ft), 0, (int)a.ft_bytes, 0x00020000);
   const bool ft_buf = a.ft_bytes != 0;
   for (int j = team; j < nu; j += TEAMS) {
     const int4 q = s_unit[j];
     const int e0 = s_start[j], e1 = s_start[j + 1];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[CPL][4];
+#pragma unroll
+    for (int cj = 0; cj < CPL; ++cj) acc[cj][0] = acc[cj][1] = acc[cj][2] = acc[cj][3] = 0.f;
     for (int e = e0; e < e1; e += NR) {
-      float fv[NR][4];
+      float fv[NR][CPL][4];
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        if (e + r < e1 && kin) {
+        if (e + r < e1) {
           const int u = s_u[e + r];
-          if (ft_buf) bufrow4(rft, u, (uint32_t)HF * 4u, (uint32_t)k0 * 4u, fv[r]);
-          else loadrow4(a.ft + (int64_t)u * HF + k0, k0, HF, true, fv[r]);
+#pragma unroll
+          for (int cj = 0; cj < CPL; ++cj) {
+            if (kin[cj]) {
+              if (ft_buf) bufrow4(rft, u, (uint32_t)HF * 4u, (uint32_t)k0[cj] * 4u, fv[r][cj]);
+              else loadrow4(a.ft + (int64_t)u * HF + k0[cj], k0[cj], HF, true, fv[r][cj]);
+            }
+          }
         }
       }
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        if (e + r < e1 && kin) {
-          const float pe = s_w[(e + r) * H + hl];
+        if (e + r < e1) {
 #pragma unroll
-          for (int x = 0; x < 4; ++x) acc[x] = __builtin_fmaf(pe, fv[r][x], acc[x]);
+          for (int cj = 0; cj < CPL; ++cj) {
+            if (kin[cj]) {
+              const float pe = s_w[(e + r) * H + hl[cj]];
+#pragma unroll
+              for (int x = 0; x < 4; ++x) acc[cj][x] = __builtin_fmaf(pe, fv[r][cj][x], acc[cj][x]);
+            }
+          }
         }
       }
     }
-    const float m = s_m[j * H + hl], l = s_l[j * H + hl];
     if (q.w < 0) {
       // ---- whole row: normalise and store --------------------------------------------------------
-      if (kin) {
+#pragma unroll
+      for (int cj = 0; cj < CPL; ++cj) {
+        if (!kin[cj]) continue;
+        const float m = s_m[j * H + hl[cj]], l = s_l[j * H + hl[cj]];
         const float inv = (l > 0.f) ? 1.0f / l : 0.f;
         float o[4];
 #pragma unroll
-        for (int x = 0; x < 4; ++x) o[x] = acc[x] * inv;
-        store4_out(a.out + (int64_t)q.x * HF, k0, HF, true, o);
-        if (a.stats && k0 % F == 0 && !(STAG_GAT_DBG & 16)) {
-          a.stats[(int64_t)q.x * 2 * H + hl] = m;
-          a.stats[(int64_t)q.x * 2 * H + H + hl] = l;
+        for (int x = 0; x < 4; ++x) o[x] = acc[cj][x] * inv;
+        store4_out(a.out + (int64_t)q.x * HF, k0[cj], HF, true, o);
+        if (a.stats && k0[cj] % F == 0 && !(STAG_GAT_DBG & 16)) {
+          a.stats[(int64_t)q.x * 2 * H + hl[cj]] = m;
+          a.stats[(int64_t)q.x * 2 * H + H + hl[cj]] = l;
         }
       }
       continue;
@@ -525,11 +545,14 @@ __global__ __launch_bounds__(256) STAG_GAT_SGPR_ATTR void gat_fwd_block_kernel(c
     const int v = q.x, slot = q.w, row = a.long_rows[v];
     const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)a.ws_bytes, 0x00020000);
     const uint32_t base = (uint32_t)slot * ((uint32_t)a.ws_stride * 4u);
-    if (kin) {
-      store4_sc1(rws, base + (uint32_t)k0 * 4u, k0, HF, true, acc);
-      if (k0 % F == 0) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rws, (int)(base + (uint32_t)(HF + hl) * 4u), 0, 16);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l), rws, (int)(base + (uint32_t)(HF + H + hl) * 4u), 0, 16);
+#pragma unroll
+    for (int cj = 0; cj < CPL; ++cj) {
+      if (!kin[cj]) continue;
+      store4_sc1(rws, base + (uint32_t)k0[cj] * 4u, k0[cj], HF, true, acc[cj]);
+      if (k0[cj] % F == 0) {
+        const float m = s_m[j * H + hl[cj]], l = s_l[j * H + hl[cj]];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rws, (int)(base + (uint32_t)(HF + hl[cj]) * 4u), 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l), rws, (int)(base + (uint32_t)(HF + H + hl[cj]) * 4u), 0, 16);
       }
     }
     const int s0 = a.long_seg_ptr[v], s1 = a.long_seg_ptr[v + 1];
@@ -542,26 +565,29 @@ __global__ __launch_bounds__(256) STAG_GAT_SGPR_ATTR void gat_fwd_block_kernel(c
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (c == 0) a.seg_counters[v] = 0;
-    if (!kin) continue;
-    float M = -INFINITY, L = 0.f;
-    float A[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int sg = s0; sg < s1; ++sg) M = fmaxf(M, a.ws[(int64_t)sg * a.ws_stride + HF + hl]);
-    for (int sg = s0; sg < s1; ++sg) {
-      const float* wr = a.ws + (int64_t)sg * a.ws_stride;
-      float tt[4];
-      load4(wr, k0, HF, true, tt);
-      const float sc = __expf(wr[HF + hl] - M);
-      L += wr[HF + H + hl] * sc;
 #pragma unroll
-      for (int x = 0; x < 4; ++x) A[x] = __builtin_fmaf(tt[x], sc, A[x]);
-    }
-    const float inv = (L > 0.f) ? 1.0f / L : 0.f;
+    for (int cj = 0; cj < CPL; ++cj) {
+      if (!kin[cj]) continue;
+      float M = -INFINITY, L = 0.f;
+      float A[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int sg = s0; sg < s1; ++sg) M = fmaxf(M, a.ws[(int64_t)sg * a.ws_stride + HF + hl[cj]]);
+      for (int sg = s0; sg < s1; ++sg) {
+        const float* wr = a.ws + (int64_t)sg * a.ws_stride;
+        float tt[4];
+        load4(wr, k0[cj], HF, true, tt);
+        const float sc = __expf(wr[HF + hl[cj]] - M);
+        L += wr[HF + H + hl[cj]] * sc;
 #pragma unroll
-    for (int x = 0; x < 4; ++x) A[x] *= inv;
-    store4_out(a.out + (int64_t)row * HF, k0, HF, true, A);
-    if (a.stats && k0 % F == 0 && !(STAG_GAT_DBG & 16)) {
-      a.stats[(int64_t)row * 2 * H + hl] = M;
-      a.stats[(int64_t)row * 2 * H + H + hl] = L;
+        for (int x = 0; x < 4; ++x) A[x] = __builtin_fmaf(tt[x], sc, A[x]);
+      }
+      const float inv = (L > 0.f) ? 1.0f / L : 0.f;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) A[x] *= inv;
+      store4_out(a.out + (int64_t)row * HF, k0[cj], HF, true, A);
+      if (a.stats && k0[cj] % F == 0 && !(STAG_GAT_DBG & 16)) {
+        a.stats[(int64_t)row * 2 * H + hl[cj]] = M;
+        a.stats[(int64_t)row * 2 * H + H + hl[cj]] = L;
+      }
     }
   }
   GAT_TS(6)
@@ -819,7 +845,7 @@ __device__ __forceinline__ float gat_head_sum(float x, int lanes_per_head) {
   return x;
 }
 
-template <int LPE>
+template <int LPE, int CPL>
 __global__ __launch_bounds__(256) void gat_bwd_edge_block_kernel(const GatBwdBlkArgs ba) {
   extern __shared__ __align__(16) float lds[];
   const GatArgs& a = ba.f;
@@ -889,13 +915,17 @@ __global__ __launch_bounds__(256) void gat_bwd_edge_block_kernel(const GatBwdBlk
   __syncthreads();
 
   // ---- phase 2: a team per unit: <G[v,h,:], ft[u,h,:]> per in-edge -> ds -> de ---------------------------
-  constexpr int TEAMS = 256 / LPE, NR = STAG_GAT_NR;
+  constexpr int TEAMS = 256 / LPE, NR = CPL >= 4 ? 2 : STAG_GAT_NR;
   const int team = t / LPE, c = t % LPE;
-  const int k0 = c * 4;
-  const bool kin = k0 < HF;
-  const int hl = kin ? k0 / F : 0;
   const int lph = F / 4;
-  const bool head_lane = kin && (k0 % F) == 0;
+  int k0[CPL], hl[CPL];
+  bool kin[CPL];
+#pragma unroll
+  for (int cj = 0; cj < CPL; ++cj) {
+    k0[cj] = (c + LPE * cj) * 4;
+    kin[cj] = k0[cj] < HF;
+    hl[cj] = kin[cj] ? k0[cj] / F : 0;
+  }
   const __amdgpu_buffer_rsrc_t rft =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ft), 0, (int)a.ft_bytes, 0x00020000);
   const bool ft_buf = a.ft_bytes != 0;
@@ -904,32 +934,46 @@ __global__ __launch_bounds__(256) void gat_bwd_edge_block_kernel(const GatBwdBlk
     const int row = (q.w >= 0) ? a.long_rows[q.x] : q.x;
     const int e0 = s_start[j], e1 = s_start[j + 1];
     if (e0 == e1) continue;
-    float gv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
-    if (kin) {
-      load4(ba.g + (int64_t)row * HF, k0, HF, true, gv);
-      load4(ba.out + (int64_t)row * HF, k0, HF, true, ov);
+    float gv[CPL][4], gdo[CPL];
+#pragma unroll
+    for (int cj = 0; cj < CPL; ++cj) {
+      float ov[4] = {0.f, 0.f, 0.f, 0.f};
+      gv[cj][0] = gv[cj][1] = gv[cj][2] = gv[cj][3] = 0.f;
+      if (kin[cj]) {
+        load4(ba.g + (int64_t)row * HF, k0[cj], HF, true, gv[cj]);
+        load4(ba.out + (int64_t)row * HF, k0[cj], HF, true, ov);
+      }
+      gdo[cj] = gat_head_sum((gv[cj][0] * ov[0] + gv[cj][1] * ov[1]) + (gv[cj][2] * ov[2] + gv[cj][3] * ov[3]), lph);
     }
-    const float gdo = gat_head_sum((gv[0] * ov[0] + gv[1] * ov[1]) + (gv[2] * ov[2] + gv[3] * ov[3]), lph);
     for (int e = e0; e < e1; e += NR) {
-      float fv[NR][4];
+      float fv[NR][CPL][4];
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        if (e + r < e1 && kin) {
+        if (e + r < e1) {
           const int u = s_u[e + r];
-          if (ft_buf) bufrow4(rft, u, (uint32_t)HF * 4u, (uint32_t)k0 * 4u, fv[r]);
-          else loadrow4(a.ft + (int64_t)u * HF + k0, k0, HF, true, fv[r]);
+#pragma unroll
+          for (int cj = 0; cj < CPL; ++cj) {
+            if (kin[cj]) {
+              if (ft_buf) bufrow4(rft, u, (uint32_t)HF * 4u, (uint32_t)k0[cj] * 4u, fv[r][cj]);
+              else loadrow4(a.ft + (int64_t)u * HF + k0[cj], k0[cj], HF, true, fv[r][cj]);
+            }
+          }
         }
       }
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         if (e + r < e1) {                              // uniform over the team
-          float dot = 0.f;
-          if (kin) dot = (gv[0] * fv[r][0] + gv[1] * fv[r][1]) + (gv[2] * fv[r][2] + gv[3] * fv[r][3]);
-          dot = gat_head_sum(dot, lph);
-          if (head_lane) {
-            const float ds = s_a[(e + r) * H + hl] * (dot - gdo);
-            s_c1[(e + r) * H + hl] = ds * s_c1[(e + r) * H + hl];
-            if (ba.dw) s_c2[(e + r) * H + hl] = ds * s_c2[(e + r) * H + hl];
+#pragma unroll
+          for (int cj = 0; cj < CPL; ++cj) {
+            float dot = 0.f;
+            if (kin[cj])
+              dot = (gv[cj][0] * fv[r][cj][0] + gv[cj][1] * fv[r][cj][1]) + (gv[cj][2] * fv[r][cj][2] + gv[cj][3] * fv[r][cj][3]);
+            dot = gat_head_sum(dot, lph);
+            if (kin[cj] && (k0[cj] % F) == 0) {
+              const float ds = s_a[(e + r) * H + hl[cj]] * (dot - gdo[cj]);
+              s_c1[(e + r) * H + hl[cj]] = ds * s_c1[(e + r) * H + hl[cj]];
+              if (ba.dw) s_c2[(e + r) * H + hl[cj]] = ds * s_c2[(e + r) * H + hl[cj]];
+            }
           }
         }
       }
@@ -976,7 +1020,7 @@ struct GatSrcBlkArgs {
   float* ws;                   // segment partials: [n_seg_t][HF + H]
 };
 
-template <int LPE>
+template <int LPE, int CPL>
 __global__ __launch_bounds__(256) void gat_bwd_src_block_kernel(const GatSrcBlkArgs a) {
   extern __shared__ __align__(16) float lds[];
   const int H = a.H, F = a.F, HF = a.HF;
@@ -1014,40 +1058,60 @@ __global__ __launch_bounds__(256) void gat_bwd_src_block_kernel(const GatSrcBlkA
     else a.ws[(int64_t)q.w * (HF + H) + HF + h] = sum;
   }
   // d ft[u,h,:] = sum over out-edges of a[e,h] G[v,h,:]
-  constexpr int TEAMS = 256 / LPE, NR = STAG_GAT_NR;
+  constexpr int TEAMS = 256 / LPE, NR = CPL >= 4 ? 2 : STAG_GAT_NR;
   const int team = t / LPE, c = t % LPE;
-  const int k0 = c * 4;
-  const bool kin = k0 < HF;
-  const int hl = kin ? k0 / F : 0;
+  int k0[CPL], hl[CPL];
+  bool kin[CPL];
+#pragma unroll
+  for (int cj = 0; cj < CPL; ++cj) {
+    k0[cj] = (c + LPE * cj) * 4;
+    kin[cj] = k0[cj] < HF;
+    hl[cj] = kin[cj] ? k0[cj] / F : 0;
+  }
   const __amdgpu_buffer_rsrc_t rg =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, (int)a.g_bytes, 0x00020000);
   const bool g_buf = a.g_bytes != 0;
   for (int j = team; j < nu; j += TEAMS) {
     const int4 q = s_unit[j];
     const int e0 = s_start[j], e1 = s_start[j + 1];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[CPL][4];
+#pragma unroll
+    for (int cj = 0; cj < CPL; ++cj) acc[cj][0] = acc[cj][1] = acc[cj][2] = acc[cj][3] = 0.f;
     for (int e = e0; e < e1; e += NR) {
-      float fv[NR][4];
+      float fv[NR][CPL][4];
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        if (e + r < e1 && kin) {
+        if (e + r < e1) {
           const int v = s_v[e + r];
-          if (g_buf) bufrow4(rg, v, (uint32_t)HF * 4u, (uint32_t)k0 * 4u, fv[r]);
-          else loadrow4(a.g + (int64_t)v * HF + k0, k0, HF, true, fv[r]);
+#pragma unroll
+          for (int cj = 0; cj < CPL; ++cj) {
+            if (kin[cj]) {
+              if (g_buf) bufrow4(rg, v, (uint32_t)HF * 4u, (uint32_t)k0[cj] * 4u, fv[r][cj]);
+              else loadrow4(a.g + (int64_t)v * HF + k0[cj], k0[cj], HF, true, fv[r][cj]);
+            }
+          }
         }
       }
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        if (e + r < e1 && kin) {
-          const float w = s_a[(e + r) * H + hl];
+        if (e + r < e1) {
 #pragma unroll
-          for (int x = 0; x < 4; ++x) acc[x] = __builtin_fmaf(w, fv[r][x], acc[x]);
+          for (int cj = 0; cj < CPL; ++cj) {
+            if (kin[cj]) {
+              const float w = s_a[(e + r) * H + hl[cj]];
+#pragma unroll
+              for (int x = 0; x < 4; ++x) acc[cj][x] = __builtin_fmaf(w, fv[r][cj][x], acc[cj][x]);
+            }
+          }
         }
       }
     }
-    if (!kin) continue;
-    if (q.w < 0) store4_out(a.d_ft + (int64_t)q.x * HF, k0, HF, true, acc);
-    else store4(a.ws + (int64_t)q.w * (HF + H), k0, HF, true, acc);
+#pragma unroll
+    for (int cj = 0; cj < CPL; ++cj) {
+      if (!kin[cj]) continue;
+      if (q.w < 0) store4_out(a.d_ft + (int64_t)q.x * HF, k0[cj], HF, true, acc[cj]);
+      else store4(a.ws + (int64_t)q.w * (HF + H), k0[cj], HF, true, acc[cj]);
+    }
   }
 }
 
@@ -1087,7 +1151,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 extern "C" size_t stag_gat_workspace_bytes(int32_t n_seg, int32_t H, int32_t F) {
   if (n_seg <= 0 || H <= 0 || F <= 0) return 0;
-  return (size_t)n_seg * (size_t)(H * F + 2 * H) * sizeof(float);
+  return (size_t)n_seg * (size_t)((H * F + 2 * H + 3) & ~3) * sizeof(float);   // rows padded to 16 bytes
 }
 
 extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const float* el,
@@ -1098,7 +1162,9 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
   if (!spec || spec->kind < STAG_NOISE_NONE || spec->kind > STAG_NOISE_BERNOULLI) return STAG_EINVAL;
   if (!out || H <= 0 || F <= 0) return STAG_EINVAL;
   const int64_t HF64 = (int64_t)H * F;
-  if (H > 64 || HF64 > 256) return STAG_ENOSYS;   // one wave spans the H*F row; LDS tile is [64][H]
+  // one team spans the H*F row: 256 channels on the one-unit-per-team kernel, 1024 (4 chunks per lane) on the
+  // workgroup-cooperative one (which also wants H <= 16, F % 4 == 0 and a block plan: checked below)
+  if (H > 64 || HF64 > 1024) return STAG_ENOSYS;
   if (spec->chunk_base != 0) return STAG_ENOSYS;  // heads are not channel-sharded
   if (spec->in_norm && !norm_scale) return STAG_EINVAL;   // the caller runs the row-sum pass first
   if (csr->n_dst == 0) return STAG_OK;
@@ -1143,7 +1209,7 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
       if (need >= (1ull << 32)) return STAG_ENOSYS;
       a.long_rows = plan->long_rows; a.long_seg_ptr = plan->long_seg_ptr; a.n_long = plan->n_long;
       a.seg_counters = plan->seg_counters; a.ws = plan->workspace;
-      a.ws_stride = HF + 2 * H; a.ws_bytes = (uint32_t)need; a.n_seg = plan->n_seg;
+      a.ws_stride = (HF + 2 * H + 3) & ~3; a.ws_bytes = (uint32_t)need; a.n_seg = plan->n_seg;
     }
   }
   bool vec = (F % 4 == 0) && aligned16(ft) && aligned16(out);
@@ -1151,12 +1217,15 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
 
   const int nchunk = (HF + 3) / 4;
   int lpe = 4;
-  while (lpe < nchunk) lpe <<= 1;
+  while (lpe < nchunk && lpe < 64) lpe <<= 1;
+  const int cpl = nchunk <= 64 ? 1 : (nchunk <= 128 ? 2 : 4);   // chunks of 4 channels per lane
   const int tpb = 256 / lpe;
   const dim3 grid((a.n_units + tpb - 1) / tpb);
   const size_t lds_bytes = (size_t)256 * H * sizeof(float);   // [teams][LPE][H]
   hipStream_t s = (hipStream_t)stream;
-  if (use_plan && plan->block_ptr && plan->n_blocks > 0 && vec && H <= kBlkMaxH && plan->seg_len <= kBlkEdges) {
+  const bool blk_ok = use_plan && plan->block_ptr && plan->n_blocks > 0 && vec && H <= kBlkMaxH && plan->seg_len <= kBlkEdges;
+  if (HF > 256 && !blk_ok) return STAG_ENOSYS;
+  if (blk_ok) {
     // workgroup-cooperative form: batches of units (stag_plan_blocks with STAG_BLOCK_EDGES / _UNITS)
     a.block_ptr = plan->block_ptr;
     a.hvec = aligned16(el) && aligned16(er) && (!a.nscale || aligned16(a.nscale));
@@ -1164,13 +1233,17 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
                      (size_t)(kBlkEdges + kBlkUnits + 4) * sizeof(int) + (size_t)kBlkUnits * sizeof(int4);
     if (lds_blk < STAG_GAT_LDS_MIN) lds_blk = STAG_GAT_LDS_MIN;
     const dim3 gb(plan->n_blocks);
-    switch (lpe) {
-      case 64: hipLaunchKernelGGL(gat_fwd_block_kernel<64>, gb, dim3(256), lds_blk, s, a); break;
-      case 32: hipLaunchKernelGGL(gat_fwd_block_kernel<32>, gb, dim3(256), lds_blk, s, a); break;
-      case 16: hipLaunchKernelGGL(gat_fwd_block_kernel<16>, gb, dim3(256), lds_blk, s, a); break;
-      case 8: hipLaunchKernelGGL(gat_fwd_block_kernel<8>, gb, dim3(256), lds_blk, s, a); break;
-      default: hipLaunchKernelGGL(gat_fwd_block_kernel<4>, gb, dim3(256), lds_blk, s, a); break;
+#define STAG_BLK_LAUNCH(L, Cc) hipLaunchKernelGGL((gat_fwd_block_kernel<L, Cc>), gb, dim3(256), lds_blk, s, a)
+    if (cpl == 4) STAG_BLK_LAUNCH(64, 4);
+    else if (cpl == 2) STAG_BLK_LAUNCH(64, 2);
+    else switch (lpe) {
+      case 64: STAG_BLK_LAUNCH(64, 1); break;
+      case 32: STAG_BLK_LAUNCH(32, 1); break;
+      case 16: STAG_BLK_LAUNCH(16, 1); break;
+      case 8: STAG_BLK_LAUNCH(8, 1); break;
+      default: STAG_BLK_LAUNCH(4, 1); break;
     }
+#undef STAG_BLK_LAUNCH
     return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
   }
 #define STAG_GAT_LAUNCH(L)                                                                         \
@@ -1296,7 +1369,7 @@ extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const st
   if (!d_el || !d_er || !d_ft || !ade_ws || H <= 0 || F <= 0) return STAG_EINVAL;
   const int64_t HF64 = (int64_t)H * F;
   const int lph = F / 4;
-  if (H > kBlkMaxH || HF64 > 256 || F % 4 != 0 || (lph & (lph - 1)) != 0) return STAG_ENOSYS;
+  if (H > kBlkMaxH || HF64 > 1024 || F % 4 != 0 || lph > 64 || (lph & (lph - 1)) != 0) return STAG_ENOSYS;
   if (spec->chunk_base != 0) return STAG_ENOSYS;
   if (!plan || !plan_t || !plan->block_ptr || !plan_t->block_ptr || plan->n_blocks <= 0 || plan_t->n_blocks <= 0 ||
       plan->seg_len > kBlkEdges || plan_t->seg_len > kBlkEdges)
@@ -1325,18 +1398,23 @@ extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const st
   ba.g = g; ba.out = out; ba.ade = ade_ws; ba.d_er = d_er; ba.dw = dw; ba.ws = plan->workspace;
   const int nchunk = (HF + 3) / 4;
   int lpe = 4;
-  while (lpe < nchunk) lpe <<= 1;
+  while (lpe < nchunk && lpe < 64) lpe <<= 1;
+  const int cpl = nchunk <= 64 ? 1 : (nchunk <= 128 ? 2 : 4);
   size_t lds_e = (size_t)kBlkEdges * H * (dw ? 3 : 2) * sizeof(float) +
                  (size_t)(kBlkEdges + kBlkUnits + 4) * sizeof(int) + (size_t)kBlkUnits * sizeof(int4);
   if (lds_e < STAG_GAT_LDS_MIN_BWD) lds_e = STAG_GAT_LDS_MIN_BWD;
   const dim3 ge(plan->n_blocks);
-  switch (lpe) {
-    case 64: hipLaunchKernelGGL(gat_bwd_edge_block_kernel<64>, ge, dim3(256), lds_e, s, ba); break;
-    case 32: hipLaunchKernelGGL(gat_bwd_edge_block_kernel<32>, ge, dim3(256), lds_e, s, ba); break;
-    case 16: hipLaunchKernelGGL(gat_bwd_edge_block_kernel<16>, ge, dim3(256), lds_e, s, ba); break;
-    case 8: hipLaunchKernelGGL(gat_bwd_edge_block_kernel<8>, ge, dim3(256), lds_e, s, ba); break;
-    default: hipLaunchKernelGGL(gat_bwd_edge_block_kernel<4>, ge, dim3(256), lds_e, s, ba); break;
-  }
+#define STAG_BLK_LAUNCH(L, Cc) hipLaunchKernelGGL((gat_bwd_edge_block_kernel<L, Cc>), ge, dim3(256), lds_e, s, ba)
+    if (cpl == 4) STAG_BLK_LAUNCH(64, 4);
+    else if (cpl == 2) STAG_BLK_LAUNCH(64, 2);
+    else switch (lpe) {
+      case 64: STAG_BLK_LAUNCH(64, 1); break;
+      case 32: STAG_BLK_LAUNCH(32, 1); break;
+      case 16: STAG_BLK_LAUNCH(16, 1); break;
+      case 8: STAG_BLK_LAUNCH(8, 1); break;
+      default: STAG_BLK_LAUNCH(4, 1); break;
+    }
+#undef STAG_BLK_LAUNCH
   if (plan->n_long > 0)
     hipLaunchKernelGGL(gat_seg_finish_kernel, dim3(plan->n_long, (H + 15) / 16), dim3(256), 0, s,
                        plan->workspace, H, 0, H, plan->long_rows, plan->long_seg_ptr, d_er, H);
@@ -1354,13 +1432,17 @@ extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const st
                  (size_t)kBlkUnits * sizeof(int4);
   if (lds_s < STAG_GAT_LDS_MIN_BWD) lds_s = STAG_GAT_LDS_MIN_BWD;
   const dim3 gs(plan_t->n_blocks);
-  switch (lpe) {
-    case 64: hipLaunchKernelGGL(gat_bwd_src_block_kernel<64>, gs, dim3(256), lds_s, s, sa); break;
-    case 32: hipLaunchKernelGGL(gat_bwd_src_block_kernel<32>, gs, dim3(256), lds_s, s, sa); break;
-    case 16: hipLaunchKernelGGL(gat_bwd_src_block_kernel<16>, gs, dim3(256), lds_s, s, sa); break;
-    case 8: hipLaunchKernelGGL(gat_bwd_src_block_kernel<8>, gs, dim3(256), lds_s, s, sa); break;
-    default: hipLaunchKernelGGL(gat_bwd_src_block_kernel<4>, gs, dim3(256), lds_s, s, sa); break;
-  }
+#define STAG_BLK_LAUNCH(L, Cc) hipLaunchKernelGGL((gat_bwd_src_block_kernel<L, Cc>), gs, dim3(256), lds_s, s, sa)
+    if (cpl == 4) STAG_BLK_LAUNCH(64, 4);
+    else if (cpl == 2) STAG_BLK_LAUNCH(64, 2);
+    else switch (lpe) {
+      case 64: STAG_BLK_LAUNCH(64, 1); break;
+      case 32: STAG_BLK_LAUNCH(32, 1); break;
+      case 16: STAG_BLK_LAUNCH(16, 1); break;
+      case 8: STAG_BLK_LAUNCH(8, 1); break;
+      default: STAG_BLK_LAUNCH(4, 1); break;
+    }
+#undef STAG_BLK_LAUNCH
   if (plan_t->n_long > 0) {
     hipLaunchKernelGGL(gat_seg_finish_kernel, dim3(plan_t->n_long, (HF + 15) / 16), dim3(256), 0, s,
                        plan->workspace, HF + H, 0, HF, plan_t->long_rows, plan_t->long_seg_ptr, d_ft, HF);

@@ -772,7 +772,7 @@ def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec,
     shape or the plans are outside what it covers (the caller then composes the older kernels)."""
     lph = F // 4
     E = csrv.n_edges
-    if not (_GAT_BWD_FUSED and F % 4 == 0 and lph & (lph - 1) == 0 and H <= 16 and H * F <= 256 and E > 0
+    if not (_GAT_BWD_FUSED and F % 4 == 0 and lph <= 64 and lph & (lph - 1) == 0 and H <= 16 and H * F <= 1024 and E > 0
             and seg_len is not None and 0 < seg_len <= _lib.BLOCK_EDGES):
         return None
     plan_f, plan_b = csrv.plan(seg_len), csrt.plan(seg_len)
@@ -811,8 +811,13 @@ def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False
     if w is not None and w.shape[0] != graph.number_of_edges():
         raise AssertionError("edge_weight.shape[0] != number_of_edges")
     H, F = ft.shape[1], ft.shape[2]
-    if (attn_fn is not None or H > 64 or H * F > 256
-            or (F % 4 != 0 or ((F // 4) & (F // 4 - 1)) != 0) and torch.is_grad_enabled()):
+    lph = F // 4
+    # the fused kernels: H*F <= 256 always; up to 1024 channels on the workgroup-cooperative forms (F % 4 == 0,
+    # H <= 16, the default plan); the backward wants F/4 a power of two (<= 64)
+    wide_ok = F % 4 == 0 and H <= 16 and seg_len is not None and 0 < seg_len <= _lib.BLOCK_EDGES
+    if (attn_fn is not None or H > 64 or H * F > (1024 if wide_ok else 256)
+            or (F % 4 != 0 or lph > 64 or (lph & (lph - 1)) != 0) and torch.is_grad_enabled()
+            or (H * F > 256 and torch.is_grad_enabled() and not _GAT_BWD_FUSED)):
         if getattr(graph, "is_shard", False):
             raise NotImplementedError("the composed GAT path (attention dropout, H > 64 or H*F > 256) is not partitioned")
         return _gat_composed(graph, el, er, ft, neg_slope, noise, w, want_attn, seg_len, attn_fn)

@@ -70,6 +70,36 @@ def test_gpus2_real_kernels_two_gloo_ranks_on_one_card():
     assert ex["exchange_only_us"] > 0 and ex["kernels_only_us"] > 0 and ex["local_units"] + ex["remote_units"] > 0
 
 
+def _torchrun(args, env=None, timeout=600):
+    """The driver's own launch line: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", *args]
+    return subprocess.run(cmd, env=e, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+
+
+def test_gpus2_under_torchrun_rehearsal_on_cpu():
+    r = _torchrun(["--rehearse", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = _line(r)
+    assert line["n_gpus"] == 2 and line["rehearsal"] is True and line["config"]["partition"] == "nodes"
+
+
+@pytest.mark.gpu
+def test_gpus2_under_torchrun_real_kernels():
+    r = _torchrun(["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-alt"], env={"STAG_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = _line(r)
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["exchange"]["kernels_only_us"] > 0
+
+
 @pytest.mark.gpu
 def test_single_gpu_line_contract():
     r = _run(["--steps", "20", "--warmup", "5", "--cpu-budget-s", "4"])

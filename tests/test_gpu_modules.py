@@ -789,11 +789,13 @@ def test_no_memory_growth_across_training_steps(dev):
         gc.collect()
 
 
-@pytest.mark.parametrize("H,F", [(4, 128), (2, 6), (3, 12)])
+@pytest.mark.parametrize("H,F", [(4, 128), (8, 64), (16, 64), (3, 256), (8, 96), (2, 6), (3, 12), (20, 16)])
 def test_gat_outside_the_fused_kernel_limits(dev, oracle, H, F):
-    """H*F > 256 (one wave no longer spans the row) and, under autograd, F/4 not a power of two:
-    the layer is composed from the aggregation kernel and [E, H] torch ops; forward against the
-    oracle, gradients against a float64 torch restatement."""
+    """Beyond 256 channels per row.  Up to H*F = 1024 (H <= 16, F % 4 == 0) the workgroup-cooperative kernels
+    give every lane 2 or 4 chunks of 4 channels ((4,128), (8,64), (16,64), (3,256)); F/4 not a power of two
+    under autograd ((8,96), (2,6), (3,12)) or H > 16 with more than 256 channels ((20,16)) is composed from
+    the aggregation kernel and [E, H] torch ops.  Forward against the oracle, gradients against a float64
+    torch restatement — the same bar either way."""
     import stag_amd
     from stag_amd import _lib, ops
     from util import random_graph
