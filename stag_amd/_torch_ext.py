@@ -1,11 +1,12 @@
 """PyTorch-ROCm front end of the hot calls (stag_amd/csrc/torch_ext.cpp): `torch.ops.stag.agg_fwd` /
 `agg_bwd` — dispatcher ops with Meta kernels over the same C ABI as the ctypes binding (include/stag_hip.h).
 
-Which front end runs: measured on the GPU box (tools/host_probe.py, a Cora-sized graph, 5000 calls), one
-`ops.aggregate` costs 16.1 us of host time through ctypes and 23.6 us through the dispatcher (23 arguments to
-parse, box and match against the schema) — so eager mode keeps ctypes.  The dispatcher ops are what a traced or
-compiled graph needs (they are visible to it, and their Meta kernels give it the output shapes), so they are used
-while `torch.compiler.is_compiling()`, or always with STAG_TORCH_OPS=1.  The HIP library underneath is the same.
+Which front end runs: measured on the GPU box (tools/host_probe.py, a Cora-sized graph, 5000 calls, no autograd
+node), one `ops.aggregate` costs 12.6 us of host time through ctypes and 12.5 us through the dispatcher (23
+arguments to parse, box and match against the schema cost what ctypes' marshalling costs) — no gain, so eager mode
+keeps ctypes and does not depend on a second shared object.  The dispatcher ops are what a traced or compiled graph
+needs (they are visible to it, and their Meta kernels give it the output shapes), so they are used while
+`torch.compiler.is_compiling()`, or always with STAG_TORCH_OPS=1.  The HIP library underneath is the same.
 """
 import os
 

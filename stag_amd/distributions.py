@@ -169,20 +169,19 @@ class AmortizedDistribution(Distribution):
         if feat.is_cuda and feat.dim() == 2 and isinstance(lin, torch.nn.Linear):
             from . import ops
             k = feat.shape[1]
+            # the Linear's bias joins the destination half on the N node rows, not the E edge rows
             h = (ops.gather_rows(graph, ops.node_linear(feat, lin.weight[:, :k].t()), "src")
-                 + ops.gather_rows(graph, ops.node_linear(feat, lin.weight[:, k:].t()), "dst"))
-            if lin.bias is not None:
-                h = h + lin.bias
+                 + ops.gather_rows(graph, ops.node_linear(feat, lin.weight[:, k:].t(), lin.bias), "dst"))
             for mod in list(self.embedding_mlp)[1:]:
                 h = mod(h)
             heads = [self.parameters_mlp[n] for n in self.new_parameter_names]
             if sum(hd.out_features for hd in heads) <= 64:
                 # narrow heads ([E, 1] parameters): ONE product over the E rows of h, then split
-                y = ops.node_linear(h, torch.cat([hd.weight for hd in heads], 0).t())
-                y = y + torch.cat([hd.bias for hd in heads], 0)
+                y = ops.node_linear(h, torch.cat([hd.weight for hd in heads], 0).t(),
+                                    torch.cat([hd.bias for hd in heads], 0))
                 outs = torch.split(y, [hd.out_features for hd in heads], dim=1)
             else:   # wide heads stay separate: their outputs are consumed as contiguous [E, D] rows
-                outs = [ops.node_linear(h, hd.weight.t()) + hd.bias for hd in heads]
+                outs = [ops.node_linear(h, hd.weight.t(), hd.bias) for hd in heads]
             self.new_parameters = dict(zip(self.new_parameter_names, outs))
             self._base = None
             return self

@@ -35,10 +35,14 @@ class CsrView:
         self.n_edges = int(indices.shape[0])
         self._plans = {}
         self._degrees = None
+        self._struct = None
 
     def struct(self):
-        return _lib.Csr(self.n_dst, self.n_src, self.n_edges, _lib.ptr(self.indptr),
-                        _lib.ptr(self.indices), _lib.ptr(self.eid), _lib.ptr(self.nidx))
+        """The ctypes stag_csr (built once: the tensors it points into live as long as this view)."""
+        if self._struct is None:
+            self._struct = _lib.Csr(self.n_dst, self.n_src, self.n_edges, _lib.ptr(self.indptr),
+                                    _lib.ptr(self.indices), _lib.ptr(self.eid), _lib.ptr(self.nidx))
+        return self._struct
 
     def torch_args(self):
         """(indptr, indices, eid, nidx, n_src): the graph arguments of torch.ops.stag.*"""

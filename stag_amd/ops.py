@@ -88,10 +88,16 @@ def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None):
     if counters is None:
         counters = torch.zeros(max(plan_t["n_long"], 1) * tiles, dtype=torch.int32, device=dev)
         plan_t["counters"][key] = counters
-    plan_c = _lib.Plan(plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"],
-                       _lib.ptr(plan_t["units"]), _lib.ptr(plan_t["long_rows"]),
-                       _lib.ptr(plan_t["long_seg_ptr"]), _lib.ptr(counters), _lib.ptr(ws), nbytes,
-                       plan_t["n_heavy"], plan_t["n_blocks"], _lib.ptr(plan_t["block_ptr"]))
+    # the struct is kept per (tiles, stream): only the workspace changes from call to call (host time of a
+    # call matters on launch-bound graphs).  Safe to reuse: the library reads it during the call only.
+    plan_c = plan_t.setdefault("_structs", {}).get(key)
+    if plan_c is None:
+        plan_c = _lib.Plan(plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"],
+                           _lib.ptr(plan_t["units"]), _lib.ptr(plan_t["long_rows"]),
+                           _lib.ptr(plan_t["long_seg_ptr"]), _lib.ptr(counters), None, 0,
+                           plan_t["n_heavy"], plan_t["n_blocks"], _lib.ptr(plan_t["block_ptr"]))
+        plan_t["_structs"][key] = plan_c
+    plan_c.workspace, plan_c.workspace_bytes = _lib.ptr(ws), nbytes
     return plan_c, (ws, counters)
 
 
@@ -218,14 +224,17 @@ class _NodeLinear(torch.autograd.Function):
     SPLIT = 64
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, bias=None):
         ctx.save_for_backward(x, w)
-        return x @ w
+        ctx.has_bias = bias is not None
+        # the bias rides in the GEMM's epilogue (one pass over the [rows, out] result instead of two)
+        return torch.addmm(bias, x, w) if bias is not None else x @ w
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         dx = g @ w.t() if ctx.needs_input_grad[0] else None
+        db = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         dw = None
         if ctx.needs_input_grad[1]:
             n, S = x.shape[0], _NodeLinear.SPLIT
@@ -238,14 +247,14 @@ class _NodeLinear(torch.autograd.Function):
                     dw = dw + x[n1:].t() @ g[n1:]
             else:
                 dw = x.t() @ g
-        return dx, dw
+        return dx, dw, db
 
 
-def node_linear(x, w):
-    """x [N, in] @ w [in, out] with a split-K weight gradient (see _NodeLinear)."""
+def node_linear(x, w, bias=None):
+    """x [N, in] @ w [in, out] (+ bias, in the GEMM's epilogue) with a split-K weight gradient (see _NodeLinear)."""
     if x.dim() != 2 or not x.is_contiguous():
-        return x @ w
-    return _NodeLinear.apply(x, w)
+        return x @ w if bias is None else x @ w + bias
+    return _NodeLinear.apply(x, w, bias)
 
 
 class _GatherRows(torch.autograd.Function):
@@ -493,6 +502,18 @@ def aggregate(graph, x, weight=None, reduce="sum", src_scale=None, dst_scale=Non
         if p0.requires_grad or p1.requires_grad:
             return _AggregateVI.apply(x, p0, p1, graph, noise, _REDUCE[reduce], _f32c(src_scale),
                                       _f32c(dst_scale), seg_len)
+    if not (torch.is_grad_enabled() and (x.requires_grad or (w is not None and w.requires_grad))):
+        # nothing to differentiate: straight to the library (no autograd node; host time of a call matters on
+        # launch-bound graphs)
+        x = _f32c(x)
+        if noise is not None:
+            spec = _noise_spec(noise)
+        elif w is not None:
+            spec = _explicit_spec(_f32c(w))
+        else:
+            spec = _none_spec()
+        return _agg_raw(graph.csr, x, D, spec, _REDUCE[reduce], _f32c(src_scale), _f32c(dst_scale), seg_len,
+                        broadcast_x=_broadcast_x)[0]
     return _Aggregate.apply(x, w, graph, noise, _REDUCE[reduce], _f32c(src_scale),
                             _f32c(dst_scale), seg_len, _broadcast_x)
 

@@ -58,10 +58,13 @@ class GCN(torch.nn.Module):
         rst = ops.aggregate(graph, feat_src.reshape(lead[0], -1), edge_weight, reduce="sum",
                             src_scale=src_scale, dst_scale=dst_scale)
         rst = rst.reshape(lead if rst.dim() == 2 else (rst.shape[0],) + tuple(lead))   # [S, ...]: MC samples
-        if weight is not None:
-            rst = ops.node_linear(rst, weight)
-        if self.bias is not None:
-            rst = rst + self.bias
+        if weight is not None and self.bias is not None and rst.dim() == 2:
+            rst = ops.node_linear(rst, weight, self.bias)        # bias in the GEMM's epilogue
+        else:
+            if weight is not None:
+                rst = ops.node_linear(rst, weight)
+            if self.bias is not None:
+                rst = rst + self.bias
         if self._activation is not None:
             rst = self._activation(rst)
         return rst

@@ -29,9 +29,7 @@ class GIN(torch.nn.Module):
         neigh = ops.aggregate(graph, feat, edge_weight, reduce=self._aggregator_type)
         h = (1 + self.eps) * feat + neigh
         if isinstance(self.apply_func, torch.nn.Linear):      # split-K weight gradient (ops.node_linear)
-            rst = ops.node_linear(h, self.apply_func.weight.t())
-            if self.apply_func.bias is not None:
-                rst = rst + self.apply_func.bias
+            rst = ops.node_linear(h, self.apply_func.weight.t(), self.apply_func.bias)
         else:
             rst = self.apply_func(h)
         if self.activation is not None:

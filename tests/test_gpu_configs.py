@@ -216,3 +216,50 @@ def test_amortized_condition_on_device_golden(dev, golden, tag, of):
     w = torch.from_numpy(golden[f"amort_{tag}_w"]).to(dev)
     out = ops.aggregate(g, x.detach(), w.expand(g.number_of_edges(), 16).contiguous())
     assert_close(out, golden[f"amort_{tag}_out"], what=f"{tag} layer output (SumBase)")
+
+
+def test_cfg1_cora_two_layer_gcn_model(dev, oracle):
+    """BASELINE configs[0] — Cora-sized 2-layer GCN, hidden 16 (scripts/citation_mle/gcn/run.py:44-66: remove +
+    add self loops, StagLayer(GCN(1433, 16, relu)), StagLayer(GCN(16, 7))) — on the HIP path: every layer's output
+    against `((sum_in w (.) x outdeg^-1/2) W) indeg^-1/2 + b` (stag/zoo/gcn.py:67-111) from the oracle's aggregation,
+    the StagModel loss and its backward."""
+    import stag_amd
+    rng = np.random.default_rng(0)
+    n, e0 = 2708, 10556
+    src = rng.integers(0, n, e0)
+    dst = rng.integers(0, n, e0)
+    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
+    g.ndata["feat"] = (torch.rand(n, 1433, generator=torch.Generator().manual_seed(1)) < 0.012).float().to(dev)   # bag of words
+    g = stag_amd.add_self_loop(stag_amd.remove_self_loop(g))
+    assert g.number_of_edges() == int((src != dst).sum()) + n and g.ndata["feat"].shape == (n, 1433)
+    x = g.ndata["feat"]
+    torch.manual_seed(5)
+    l1 = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(1433, 16, activation=torch.relu), q_a=torch.distributions.Normal(1.0, 0.5)).to(dev)
+    l2 = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(16, 7), q_a=torch.distributions.Normal(1.0, 0.5)).to(dev)
+    og = oracle_graph(oracle, g)
+    ind = np.maximum(g.in_degrees().cpu().numpy(), 1).astype(np.float64)
+    outd = np.maximum(g.out_degrees().cpu().numpy(), 1).astype(np.float64)
+    stag_amd.manual_seed(77)
+    h = x
+    with torch.no_grad(), hw_normals(oracle, dev):
+        for layer, act in ((l1, True), (l2, False)):
+            out = layer(g, h)
+            nz = layer._edge_weight_handle
+            D = h.shape[1]
+            spec = oracle.make_spec("normal", 1.0, 0.5, seed=nz.seed, offset=nz.offset, Dn=D, n_edges=g.number_of_edges())
+            agg = oracle.agg_fwd(og, h.cpu().numpy(), spec, src_scale=(outd ** -0.5).astype(np.float32)).astype(np.float64)
+            W = layer.base_layer.weight.detach().cpu().numpy().astype(np.float64)
+            ref = (agg @ W) * (ind ** -0.5)[:, None] + layer.base_layer.bias.detach().cpu().numpy().astype(np.float64)
+            if act:
+                ref = np.maximum(ref, 0.0)
+            assert_close(out, ref, what=f"cfg1 GCN layer {D}->{out.shape[1]}")
+            h = out
+    model = stag_amd.models.StagModel([l1, l2, stag_amd.layers.FeatOnlyLayer(torch.nn.Softmax(dim=-1))])
+    y = torch.randint(0, 7, (n,), generator=torch.Generator().manual_seed(2)).to(dev)
+    mask = torch.zeros(n, dtype=torch.bool, device=dev)
+    mask[:140] = True
+    loss = model.loss(g, x, y, mask=mask, n_samples=2)
+    loss.backward()
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in l1.base_layer.parameters())
+    pred = model(g, x, n_samples=4, return_parameters=True)
+    assert pred.shape == (n, 7) and torch.allclose(pred.sum(-1), torch.ones(n, device=dev), atol=1e-5)
