@@ -23,7 +23,7 @@ def build(specs):
         name, _, flags = spec.partition("=")
         out = os.path.join(BIN, f"libstag_{name}.so")
         subprocess.run(["make", "-C", os.path.join(ROOT, "stag_amd", "csrc"), "-j", "8",
-                        f"EXTRA={flags}", f"OBJDIR=_obj_{name}", f"OUT={out}"], check=True,
+                        f"EXTRA={flags}", f"OBJDIR=_obj_{name}", f"OUT={out}", out], check=True,   # the library only
                        stdout=subprocess.DEVNULL)
         print("built", out, flags)
 
