@@ -132,6 +132,35 @@ def test_plan_covers_every_edge_once(seg_len):
     assert set(units[units[:, 3] >= 0][:, 3]) == set(range(p["n_seg"]))
 
 
+@pytest.mark.parametrize("seg_len", [64, 16, 300])
+def test_block_plan_batches_units(seg_len):
+    """stag_plan_blocks: consecutive units of the plan in batches of at most STAG_BLOCK_EDGES edges and
+    STAG_BLOCK_UNITS units (a unit longer than the budget gets a batch of its own) — what the workgroup-cooperative
+    GAT kernels walk."""
+    import stag_amd
+    from stag_amd import _lib
+    rng = np.random.default_rng(4)
+    n = 2000
+    dst = np.concatenate([rng.integers(0, n - 50, 9000), np.full(1500, 5), np.full(300, 77)])   # hubs + 50 empty rows
+    src = rng.integers(0, n, len(dst))
+    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n)
+    plan = g.csr.plan(seg_len)
+    bp = plan["block_ptr"].numpy()
+    units = plan["units"].numpy()[:plan["n_units"]]
+    assert bp[0] == 0 and bp[-1] == plan["n_units"] and len(bp) == plan["n_blocks"] + 1 and (np.diff(bp) > 0).all()
+    for b0, b1 in zip(bp[:-1], bp[1:]):
+        lens = units[b0:b1, 2]
+        assert b1 - b0 <= _lib.BLOCK_UNITS
+        assert lens.sum() <= _lib.BLOCK_EDGES or b1 - b0 == 1
+        if b1 < plan["n_units"] and b1 - b0 < _lib.BLOCK_UNITS:           # closed because the next unit did not fit
+            assert lens.sum() + units[b1, 2] > _lib.BLOCK_EDGES
+    assert units[:, 2].sum() == g.number_of_edges()
+    lib = _lib.lib()
+    nb = ctypes.c_int32()
+    assert lib.stag_plan_blocks(None, 3, 256, 32, None, ctypes.byref(nb)) == -22           # units missing
+    assert lib.stag_plan_blocks(None, 0, 256, 32, None, ctypes.byref(nb)) == 0 and nb.value == 0
+
+
 def test_subplan_partitions_the_units():
     """CsrView.subplan: complementary masks over the plan's units give two plans that cover every unit once,
     keep the plan's order, keep the segments together and the heavy units a prefix."""
