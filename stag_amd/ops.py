@@ -831,6 +831,11 @@ def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False
     w = weight if torch.is_tensor(weight) else None
     if w is not None and w.shape[0] != graph.number_of_edges():
         raise AssertionError("edge_weight.shape[0] != number_of_edges")
+    if (noise is not None and noise.grad_params is not None and torch.is_grad_enabled()
+            and any(torch.is_tensor(p) and p.requires_grad for p in noise.grad_params)):
+        # vi=True: the H-wide weights are formed from the kernel's standard draw and the live parameters
+        # ([E, H]: 37 MB at cfg5); they enter as explicit weights and the edge pass returns dw[E, H]
+        w, noise = noise.materialize(), None
     H, F = ft.shape[1], ft.shape[2]
     lph = F // 4
     # the fused kernels: H*F <= 256 always; up to 1024 channels on the workgroup-cooperative forms (F % 4 == 0,

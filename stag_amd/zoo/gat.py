@@ -9,6 +9,7 @@ from .. import ops
 
 class GAT(torch.nn.Module):
     supports_edge_noise = True
+    supports_edge_noise_grad = True   # vi=True: ops.gat_aggregate forms the [E, H] weights from the descriptor
 
     def __init__(self, in_feats, out_feats, num_heads=4, feat_drop=0.0, attn_drop=0.0,
                  negative_slope=0.2, residual=False, activation=None, allow_zero_in_degree=False,

@@ -454,6 +454,39 @@ def test_sample_based_kl_reaches_q_a_on_the_fused_path(dev):
         assert_close(got[1], ls.grad.cpu().numpy(), what="d KL / d log_scale")
 
 
+@pytest.mark.parametrize("norm", [False, True])
+def test_gat_vi_descriptor_gradients(dev, norm):
+    """StagLayer(GAT, vi=True) hands the GAT layer a differentiable descriptor; the gradients into loc / log_scale
+    equal those of the reference's dataflow (rsample -> [E, H] tensor -> relu -> _in_norm -> edge_weight=)."""
+    import stag_amd
+    from stag_amd import _lib
+    from stag_amd.layers import _in_norm
+    from util import random_graph
+    g = random_graph(200, 1500, seed=8, hub=150, device=dev)
+    x = torch.randn(200, 16, device=dev)
+    torch.manual_seed(1)
+    gat = stag_amd.zoo.GAT(16, 8, num_heads=4).to(dev)
+    layer = stag_amd.layers.StagLayer(gat, q_a=torch.distributions.Normal(1.0, 0.5), vi=True, relu=True, norm=norm).to(dev)
+    stag_amd.manual_seed(3)
+    out = layer(g, x)
+    h = layer._edge_weight_handle
+    assert isinstance(h, stag_amd.EdgeNoise) and h.grad_params is not None and h.in_norm == norm
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    got = (layer.q_a.loc.grad.clone(), layer.q_a.log_scale.grad.clone(), gat.fc.weight.grad.clone())
+    layer.zero_grad()
+    z = stag_amd.EdgeNoise(g, 4, _lib.NOISE_NORMAL, 0.0, 1.0, seed=3, offset=h.offset).materialize()
+    w = (layer.q_a.loc + layer.q_a.log_scale.exp() * z).relu()
+    if norm:
+        w = _in_norm(g, w)
+    ref = gat(g, x, edge_weight=w)
+    assert_close(out, ref.detach().cpu().numpy(), what="vi GAT forward")
+    ref.backward(gout)
+    for a_, b_, nm in zip(got, (layer.q_a.loc.grad, layer.q_a.log_scale.grad, gat.fc.weight.grad), ("loc", "log_scale", "fc.weight")):
+        sc = max(1.0, float(b_.abs().max()))
+        assert_close(a_ / sc, (b_ / sc).cpu().numpy(), what=f"vi GAT d {nm}")
+
+
 def test_gat_attention_dropout(dev):
     """zoo.GAT(attn_drop=0.6) — what the reference's GAT scripts construct (scripts/citation_mle/gat/run.py:40)
     — builds, trains through the composed path (dropout between softmax and sum, stag/zoo/gat.py:122) and is
