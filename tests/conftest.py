@@ -31,3 +31,17 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _seeded(request):
+    """Every test starts from generators seeded by its own name: inputs drawn with torch.randn(..., device=dev) or
+    the global numpy generator are the same numbers on every run, so a comparison that passes once passes always
+    (the bars are tight: 1e-5)."""
+    import zlib
+    import numpy as np
+    import torch
+    seed = zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF
+    torch.manual_seed(seed)            # seeds the device generators too
+    np.random.seed(seed)
+    yield
