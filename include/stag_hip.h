@@ -116,7 +116,13 @@ typedef struct stag_noise_spec {
   int64_t pos_base; /* global CSR position of this shard's position 0 (node-range shards) */
   int32_t chunk_base; /* first global channel / 4 of this shard's channel 0 (channel shards:
                          every GPU holds the whole CSR and D/P of the channels, no exchange) */
-  int32_t reserved;
+  int32_t p1_log;   /* NORMAL only, 0 | 1: p1 (p1_scalar) holds log(scale) — how a vi=True ParametrizedDistribution and an
+                       AmortizedDistribution store it (stag/distributions.py:108-121, 235-242).  The kernels
+                       exponentiate it where they load it, so the [E, Dn] exp pass and the tensor autograd would keep
+                       for it never exist; every derivative w.r.t. p1 (deriv = 2, the dp1 / dw1 outputs) is then the
+                       one w.r.t. the LOG: dw/dlog_scale = z * scale.  param_mode SCALAR, PER_EDGE1, PER_EDGE
+                       (PER_CHANNEL: STAG_ENOSYS — a [Dn] row is exponentiated by the caller; it would cost the
+                       hot kernel a wave per SIMD).                                                                */
   const uint64_t* epoch; /* NULL, or a DEVICE counter read at run time: the launch draws with
                             offset + *epoch.  Lets a captured hipGraph draw fresh noise on every
                             replay: its kernel nodes keep the offsets they were captured with, and

@@ -33,7 +33,7 @@ class NoiseSpec(C.Structure):
                 ("p0_scalar", C.c_float), ("p1_scalar", C.c_float),
                 ("relu", C.c_int32), ("in_norm", C.c_int32), ("deriv", C.c_int32),
                 ("group", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64), ("pos_base", C.c_int64),
-                ("chunk_base", C.c_int32), ("reserved", C.c_int32), ("epoch", C.c_void_p)]
+                ("chunk_base", C.c_int32), ("p1_log", C.c_int32), ("epoch", C.c_void_p)]
 
 
 def build(force=False):
@@ -168,13 +168,14 @@ def csr_build(src, dst, n_src, n_dst):
 
 
 def make_spec(kind="none", p0=None, p1=None, relu=False, in_norm=False, seed=0, offset=0,
-              pos_base=0, Dn=None, n_edges=None, deriv=0, chunk_base=0):
+              pos_base=0, Dn=None, n_edges=None, deriv=0, chunk_base=0, p1_log=False):
     """Build a NoiseSpec; p0/p1 may be python floats or arrays ([Dn], [E,1], [E,Dn])."""
     k = KIND[kind] if isinstance(kind, str) else int(kind)
     keep = []
     s = NoiseSpec()
     s.kind, s.relu, s.in_norm, s.deriv = k, int(relu), int(in_norm), int(deriv)
     s.seed, s.offset, s.pos_base, s.chunk_base = int(seed), int(offset), int(pos_base), int(chunk_base)
+    s.p1_log = int(p1_log)
     s.param_mode = PARAM_SCALAR
 
     def classify(a):

@@ -170,6 +170,10 @@ static void edge_weights4(const stag_csr* csr, const stag_noise_spec* s,
       float d1 = 1.0f, d2 = t[j];                     /* dw/dp0, dw/dp1 */
       if (s->kind == STAG_NOISE_NORMAL) {
         float b = param_at(s->p1, s->p1_scalar, s->param_mode, eid, k, Dn);
+        if (s->p1_log) {                              /* p1 = log(scale): d/dlog_scale = z * scale */
+          b = expf(b);
+          d2 = t[j] * b;
+        }
         w[j] = fmaf(b, t[j], a);                      /* loc + scale * z */
       } else if (s->kind == STAG_NOISE_UNIFORM) {
         float b = param_at(s->p1, s->p1_scalar, s->param_mode, eid, k, Dn);

@@ -33,7 +33,7 @@ class NoiseSpec(C.Structure):
                 ("p0_scalar", C.c_float), ("p1_scalar", C.c_float),
                 ("relu", C.c_int32), ("in_norm", C.c_int32), ("deriv", C.c_int32),
                 ("group", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64), ("pos_base", C.c_int64),
-                ("chunk_base", C.c_int32), ("reserved", C.c_int32), ("epoch", C.c_void_p)]
+                ("chunk_base", C.c_int32), ("p1_log", C.c_int32), ("epoch", C.c_void_p)]
 
 
 class Plan(C.Structure):

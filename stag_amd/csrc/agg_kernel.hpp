@@ -58,7 +58,7 @@ struct AggArgs {
   const float* p1;
   float p0s, p1s;
   int32_t pmode;   // STAG_PARAM_*
-  int32_t relu, in_norm;   // relu: noise flags = relu | deriv << 1 (noise.hpp)
+  int32_t relu, in_norm;   // relu: noise flags = relu | deriv << 1 | log-scale << 3 (noise.hpp)
   int32_t wgroup;          // EXPLICIT: channels sharing one weight column (<= 1: one per channel)
   PhiloxKey key;
   uint32_t pos_lo, pos_hi;   // lo32 / hi32 of the shard's global position base
@@ -520,12 +520,20 @@ struct AggTeam {
       }
     } else {
       if constexpr (PEDGE == 1) {
+        const float s1 = (a.relu & kFlagLogScale) ? exp_scale(R.P.q1[j]) : R.P.q1[j];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { pa[q] = R.P.q0[j]; pb[q] = R.P.q1[j]; }
+        for (int q = 0; q < 4; ++q) { pa[q] = R.P.q0[j]; pb[q] = s1; }
         draw4<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w);
         return;
       } else if constexpr (PEDGE == 2) {
-        draw4<KIND>(I.nn[j], c1, key, R.P.pa[j], R.P.pb[j], a.relu, w);
+        if (a.relu & kFlagLogScale) {         // [E, D] log-scales exponentiated where they are used: no [E, D] exp pass
+          float pbe[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pbe[q] = exp_scale(R.P.pb[j][q]);
+          draw4<KIND>(I.nn[j], c1, key, R.P.pa[j], pbe, a.relu, w);
+        } else {
+          draw4<KIND>(I.nn[j], c1, key, R.P.pa[j], R.P.pb[j], a.relu, w);
+        }
         return;
       }
       draw4<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w);

@@ -2,6 +2,7 @@
 // planning, and the auxiliary kernels (noise materialisation, weight gradient,
 // readout, raw Philox test hook).  The hot kernel lives in agg_kernel.hpp.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -26,6 +27,8 @@ int check_spec(const stag_noise_spec* s) {
   if (s->deriv < 0 || s->deriv > 2 || s->chunk_base < 0 || s->chunk_base >= (1 << 20)) return STAG_EINVAL;
   if (s->deriv != 0 && (s->in_norm || (s->kind != STAG_NOISE_NORMAL && s->kind != STAG_NOISE_UNIFORM)))
     return STAG_EINVAL;   // only reparameterised draws have a derivative; in-norm is not differentiated here
+  if (s->p1_log != 0 && (s->p1_log != 1 || s->kind != STAG_NOISE_NORMAL)) return STAG_EINVAL;   // a log-scale is a Normal's
+  if (s->p1_log && s->param_mode == STAG_PARAM_PER_CHANNEL) return STAG_ENOSYS;   // exponentiate a [Dn] row yourself
   if (s->kind >= STAG_NOISE_NORMAL) {
     if (s->param_mode < STAG_PARAM_SCALAR || s->param_mode > STAG_PARAM_PER_EDGE) return STAG_EINVAL;
     if (s->param_mode != STAG_PARAM_SCALAR) {
@@ -118,6 +121,7 @@ __device__ __forceinline__ void edge_params4(const NoiseArgs& a, int64_t ed, int
     if (a.pmode == 1) { q0 = in ? a.p0[k] : 0.f; q1 = (in && a.p1) ? a.p1[k] : 0.f; }
     else if (a.pmode == 2) { q0 = a.p0[ed]; q1 = a.p1 ? a.p1[ed] : 0.f; }
     else if (a.pmode == 3) { q0 = in ? a.p0[ed * a.Dn + k] : 0.f; q1 = (in && a.p1) ? a.p1[ed * a.Dn + k] : 0.f; }
+    if (a.pmode != 0 && (a.nflags & kFlagLogScale)) q1 = exp_scale(q1);     // scalar: exponentiated on the host
     pa[j] = q0; pb[j] = q1;
   }
 }
@@ -168,6 +172,7 @@ __device__ __forceinline__ void edge_w4(const NoiseArgs& a, int p, int64_t ed, u
     if (a.pmode == 1) { q0 = in ? a.p0[k] : 0.f; q1 = (in && a.p1) ? a.p1[k] : 0.f; }
     else if (a.pmode == 2) { q0 = a.p0[ed]; q1 = a.p1 ? a.p1[ed] : 0.f; }
     else if (a.pmode == 3) { q0 = in ? a.p0[ed * a.Dn + k] : 0.f; q1 = (in && a.p1) ? a.p1[ed * a.Dn + k] : 0.f; }
+    if (a.pmode != 0 && (a.nflags & kFlagLogScale)) q1 = exp_scale(q1);     // scalar: exponentiated on the host
     pa[j] = q0; pb[j] = q1;
   }
   const int64_t gpos = a.pos_base + (a.nidx ? (int64_t)a.nidx[p] : (int64_t)p);
@@ -289,7 +294,8 @@ __device__ __forceinline__ void agg_bwd_w_body(const BwdWArgs& b) {
           if constexpr (both) {
             float w[4], d0[4], d1[4];
             if (a.pmode == 2) {
-              const float pa[4] = {q0[j], q0[j], q0[j], q0[j]}, pb[4] = {q1[j], q1[j], q1[j], q1[j]};
+              const float s1 = (a.nflags & kFlagLogScale) ? exp_scale(q1[j]) : q1[j];
+              const float pa[4] = {q0[j], q0[j], q0[j], q0[j]}, pb[4] = {s1, s1, s1, s1};
               edge_w4_grad_p(a, key, p0 + j, chunk, pa, pb, w, d0, d1);
             } else {
               edge_w4_grad(a, key, p0 + j, ed[j], chunk, w, d0, d1);
@@ -620,9 +626,11 @@ static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x
     a.wide = (x_narrow ? 0 : 1) | (w_narrow ? 0 : 2);
     a.x_bytes = x_narrow ? (uint32_t)(ldx == 0 ? (uint64_t)D * 4u : xbytes) : 0u;
   }
-  a.p0 = spec->p0; a.p1 = spec->p1; a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar;
+  const bool logs = spec->kind == STAG_NOISE_NORMAL && spec->p1_log;
+  a.p0 = spec->p0; a.p1 = spec->p1; a.p0s = spec->p0_scalar; a.p1s = logs ? expf(spec->p1_scalar) : spec->p1_scalar;
   a.pmode = spec->kind >= STAG_NOISE_NORMAL ? spec->param_mode : 0;
-  a.relu = (spec->relu ? kFlagRelu : 0) | (spec->deriv << kDerivShift); a.in_norm = spec->in_norm;
+  a.relu = (spec->relu ? kFlagRelu : 0) | (spec->deriv << kDerivShift) | (logs ? kFlagLogScale : 0);
+  a.in_norm = spec->in_norm;
   a.wgroup = (spec->kind == STAG_NOISE_EXPLICIT && spec->group > 1) ? spec->group : 1;
   if (a.wgroup > 1 && (D % a.wgroup != 0 || spec->in_norm)) return STAG_EINVAL;
   a.key = make_key(spec);
@@ -791,9 +799,11 @@ int stag_noise_materialize(const stag_csr* csr, const stag_plan* plan, const sta
   NoiseArgs a{};
   a.indptr = csr->indptr; a.eid = csr->eid; a.nidx = csr->nidx; a.n_rows = csr->n_dst;
   a.Dn = Dn; a.kind = spec->kind; a.p0 = spec->p0; a.p1 = spec->p1;
-  a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar;
+  const bool logs = spec->kind == STAG_NOISE_NORMAL && spec->p1_log;
+  a.p0s = spec->p0_scalar; a.p1s = logs ? expf(spec->p1_scalar) : spec->p1_scalar;
   a.pmode = spec->kind >= STAG_NOISE_NORMAL ? spec->param_mode : 0;
-  a.nflags = (spec->relu ? kFlagRelu : 0) | (spec->deriv << kDerivShift); a.in_norm = spec->in_norm;
+  a.nflags = (spec->relu ? kFlagRelu : 0) | (spec->deriv << kDerivShift) | (logs ? kFlagLogScale : 0);
+  a.in_norm = spec->in_norm;
   a.key = make_key(spec); a.pos_base = spec->pos_base; a.chunk_base = (uint32_t)spec->chunk_base;
   a.w = w; a.ldw = ldw; a.norm_scale = spec->in_norm ? norm_scale : nullptr;
   rc = set_units(a, csr, plan);
@@ -824,8 +834,9 @@ int stag_agg_bwd_w(const stag_csr* csr, const stag_plan* plan, const float* x, i
   a.indptr = csr->indptr; a.eid = csr->eid; a.nidx = csr->nidx; a.n_rows = csr->n_dst; a.Dn = D;
   if (spec && spec->kind >= STAG_NOISE_NORMAL && (spec->deriv != 0 || dw1)) {
     a.kind = spec->kind; a.p0 = spec->p0; a.p1 = spec->p1;
-    a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar; a.pmode = spec->param_mode;
-    a.nflags = (spec->relu ? kFlagRelu : 0) | ((dw1 ? 0 : spec->deriv) << kDerivShift);
+    const bool logs = spec->kind == STAG_NOISE_NORMAL && spec->p1_log;
+    a.p0s = spec->p0_scalar; a.p1s = logs ? expf(spec->p1_scalar) : spec->p1_scalar; a.pmode = spec->param_mode;
+    a.nflags = (spec->relu ? kFlagRelu : 0) | ((dw1 ? 0 : spec->deriv) << kDerivShift) | (logs ? kFlagLogScale : 0);
     a.key = make_key(spec); a.pos_base = spec->pos_base; a.chunk_base = (uint32_t)spec->chunk_base;
   }
   a.w = dw; a.ldw = ldw;

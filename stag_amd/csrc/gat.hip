@@ -77,6 +77,7 @@ __device__ __forceinline__ void head_w4(const GatArgs& a, const PhiloxKey& key, 
       q0 = in ? a.p0[ed * a.H + h] : 0.f;
       q1 = (in && a.p1) ? a.p1[ed * a.H + h] : 0.f;
     }
+    if (a.pmode != STAG_PARAM_SCALAR && (a.relu & kFlagLogScale)) q1 = exp_scale(q1);
     pa[j] = q0; pb[j] = q1;
   }
   const uint32_t c1 = chunk | (a.pos_hi << 20);
@@ -1181,9 +1182,10 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
   a.nscale = spec->in_norm ? norm_scale : nullptr;
   a.H = H; a.F = F; a.HF = HF;
   a.neg_slope = neg_slope; a.kind = spec->kind; a.p0 = spec->p0; a.p1 = spec->p1;
-  a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar;
+  const bool logs = spec->kind == STAG_NOISE_NORMAL && spec->p1_log;
+  a.p0s = spec->p0_scalar; a.p1s = logs ? expf(spec->p1_scalar) : spec->p1_scalar;
   a.pmode = spec->kind >= STAG_NOISE_NORMAL ? spec->param_mode : 0;
-  a.relu = spec->relu ? kFlagRelu : 0;
+  a.relu = (spec->relu ? kFlagRelu : 0) | (logs ? kFlagLogScale : 0);
   if (spec->deriv != 0) return STAG_EINVAL;
   a.key.k0 = (uint32_t)(spec->seed & 0xFFFFFFFFull); a.key.k1 = (uint32_t)(spec->seed >> 32);
   a.key.o0 = (uint32_t)(spec->offset & 0xFFFFFFFFull); a.key.o1 = (uint32_t)(spec->offset >> 32);
@@ -1270,9 +1272,11 @@ static int fill_edge_args(GatArgs& a, const stag_csr* csr, const stag_plan* plan
   a.n_rows = csr->n_dst; a.el = el; a.er = er;
   a.nscale = spec->in_norm ? norm_scale : nullptr;
   a.H = H; a.neg_slope = neg_slope;
-  a.kind = spec->kind; a.p0 = spec->p0; a.p1 = spec->p1; a.p0s = spec->p0_scalar; a.p1s = spec->p1_scalar;
+  const bool logs = spec->kind == STAG_NOISE_NORMAL && spec->p1_log;
+  a.kind = spec->kind; a.p0 = spec->p0; a.p1 = spec->p1; a.p0s = spec->p0_scalar;
+  a.p1s = logs ? expf(spec->p1_scalar) : spec->p1_scalar;
   a.pmode = spec->kind >= STAG_NOISE_NORMAL ? spec->param_mode : 0;
-  a.relu = spec->relu ? kFlagRelu : 0;
+  a.relu = (spec->relu ? kFlagRelu : 0) | (logs ? kFlagLogScale : 0);
   a.key.k0 = (uint32_t)(spec->seed & 0xFFFFFFFFull); a.key.k1 = (uint32_t)(spec->seed >> 32);
   a.key.o0 = (uint32_t)(spec->offset & 0xFFFFFFFFull); a.key.o1 = (uint32_t)(spec->offset >> 32);
   a.key.epoch = spec->epoch;

@@ -112,7 +112,11 @@ enum : int { kNone = 0, kExplicit = 1, kNormal = 2, kUniform = 3, kBernoulli = 4
 // flags (wave-uniform): bit 0 = relu; bits 1-2 = derivative selector for the backward pass of
 // a reparameterised draw (stag/layers.py:123-124, `rsample`): 0 -> w itself,
 // 1 -> dw/dp0 (loc | low), 2 -> dw/dp1 (scale | high), each times 1[w > 0] under relu.
-enum : int { kFlagRelu = 1, kDerivShift = 1 };
+// bit 3 = the scale came in as its logarithm (spec.p1_log; NORMAL): the callers hand draw4 the exponentiated
+// value, and the derivative w.r.t. the parameter is then the one w.r.t. the LOG: dw/dlog_scale = z * scale.
+enum : int { kFlagRelu = 1, kDerivShift = 1, kDerivMask = 3, kFlagLogScale = 8 };
+
+__device__ __forceinline__ float exp_scale(float log_scale) { return __expf(log_scale); }
 
 template <int KIND>
 __device__ __forceinline__ void draw4(uint32_t c0, uint32_t c1, const PhiloxKey& key,
@@ -134,11 +138,12 @@ __device__ __forceinline__ void draw4(uint32_t c0, uint32_t c1, const PhiloxKey&
 #pragma unroll
     for (int j = 0; j < 4; ++j) w[j] = u01(r[j]) < a[j] ? 1.0f : 0.0f;
   }
-  if (flags == 0) return;
-  const int deriv = flags >> kDerivShift;
+  const int deriv = (flags >> kDerivShift) & kDerivMask;
   if (deriv == 0) {
+    if (flags & kFlagRelu) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = fmaxf(w[j], 0.0f);
+      for (int j = 0; j < 4; ++j) w[j] = fmaxf(w[j], 0.0f);
+    }
     return;
   }
   if constexpr (KIND != kBernoulli) {
@@ -146,7 +151,8 @@ __device__ __forceinline__ void draw4(uint32_t c0, uint32_t c1, const PhiloxKey&
     for (int j = 0; j < 4; ++j) {
       const float mask = ((flags & kFlagRelu) && !(w[j] > 0.0f)) ? 0.0f : 1.0f;
       float d;
-      if constexpr (KIND == kNormal) d = (deriv == 1) ? 1.0f : t[j];           // w = loc + scale z
+      if constexpr (KIND == kNormal)                                           // w = loc + scale z
+        d = (deriv == 1) ? 1.0f : ((flags & kFlagLogScale) ? t[j] * b[j] : t[j]);
       else d = (deriv == 1) ? 1.0f - t[j] : t[j];                             // w = low + (high-low) u
       w[j] = d * mask;
     }
@@ -178,7 +184,7 @@ __device__ __forceinline__ void draw4_grad(uint32_t c0, uint32_t c1, const Philo
     const float mask = ((flags & kFlagRelu) && !(w[j] > 0.0f)) ? 0.0f : 1.0f;
     if (flags & kFlagRelu) w[j] = fmaxf(w[j], 0.0f);
     d0[j] = ((KIND == kNormal) ? 1.0f : 1.0f - t[j]) * mask;
-    d1[j] = t[j] * mask;
+    d1[j] = (KIND == kNormal && (flags & kFlagLogScale)) ? t[j] * b[j] * mask : t[j] * mask;
   }
 }
 

@@ -67,13 +67,13 @@ Graph make_graph(const Tensor& indptr, const Tensor& indices, OptT eid, OptT nid
   return g;
 }
 
-// noise_ints = [kind, param_mode, relu, in_norm, deriv, group, chunk_base]; noise_u64 = [seed, offset, pos_base]
+// noise_ints = [kind, param_mode, relu, in_norm, deriv, group, chunk_base, p1_log]; noise_u64 = [seed, offset, pos_base]
 // (64-bit patterns carried in int64); noise_floats = [p0_scalar, p1_scalar]
 stag_noise_spec make_spec(at::IntArrayRef ni, at::IntArrayRef nu, at::ArrayRef<double> nf, OptT p0, OptT p1, OptT epoch) {
-  TORCH_CHECK(ni.size() == 7 && nu.size() == 3 && nf.size() == 2, "noise descriptor: 7 ints, 3 x 64 bit, 2 floats");
+  TORCH_CHECK(ni.size() == 8 && nu.size() == 3 && nf.size() == 2, "noise descriptor: 8 ints, 3 x 64 bit, 2 floats");
   stag_noise_spec s{};
   s.kind = (int32_t)ni[0]; s.param_mode = (int32_t)ni[1]; s.relu = (int32_t)ni[2]; s.in_norm = (int32_t)ni[3];
-  s.deriv = (int32_t)ni[4]; s.group = (int32_t)ni[5]; s.chunk_base = (int32_t)ni[6];
+  s.deriv = (int32_t)ni[4]; s.group = (int32_t)ni[5]; s.chunk_base = (int32_t)ni[6]; s.p1_log = (int32_t)ni[7];
   s.seed = (uint64_t)nu[0]; s.offset = (uint64_t)nu[1]; s.pos_base = nu[2];
   s.p0_scalar = (float)nf[0]; s.p1_scalar = (float)nf[1];
   s.p0 = ptr_of<float>(p0); s.p1 = ptr_of<float>(p1);

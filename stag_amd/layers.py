@@ -130,6 +130,18 @@ class StagLayer(torch.nn.Module):
         self._edge_weight_handle = None      # no single [E, Dn] sample stands for this call
         return self.base_layer.forward(graph=graph, feat=feat, edge_weight=w)
 
+    def _descriptor(self, graph, dn, dist, **kw):
+        """EdgeNoise of q_a.  An AmortizedDistribution's Normal hands over its heads' outputs as they are —
+        `loc` and `log_scale`, [E, 1 | Dn] — and the kernels exponentiate the log-scale where they load it
+        (stag_noise_spec.p1_log): the [E, Dn] exp pass of stag/distributions.py:235-242 and the tensor autograd
+        would keep for it do not exist, and the gradient comes back w.r.t. `log_scale` directly."""
+        q = self.q_a
+        params = getattr(q, "new_parameters", None)
+        if (isinstance(dist, torch.distributions.Normal) and isinstance(params, dict)
+                and set(params) == {"loc", "log_scale"}):
+            return EdgeNoise(graph, dn, _lib.NOISE_NORMAL, params["loc"], params["log_scale"], p1_log=True, **kw)
+        return EdgeNoise.from_distribution(graph, dn, dist, **kw)
+
     def rsample_noise(self, graph, sample_dimension):
         """Edge weights of shape [E, sample_dimension] (stag/layers.py:115-129): an
         EdgeNoise descriptor when the draw can be fused into the aggregation (relu and
@@ -139,7 +151,7 @@ class StagLayer(torch.nn.Module):
         gen = self._generator()
         fused_ok = fusable(dist) and getattr(self.base_layer, "supports_edge_noise", False)
         if fused_ok and not self.vi:
-            return EdgeNoise.from_distribution(
+            return self._descriptor(
                 graph, sample_dimension, dist, relu=self.relu, in_norm=self.norm,
                 seed=gen.seed, offset=gen.next_offset(), epoch=gen.device_epoch)
         reparam = type(dist) in (torch.distributions.Normal, torch.distributions.Uniform)
@@ -148,7 +160,7 @@ class StagLayer(torch.nn.Module):
             # vi=True on the fused path: the descriptor keeps the live loc / scale tensors and
             # ops.aggregate returns their gradients by regenerating the noise in the backward
             # (in-norm included: its factor is differentiated from two [N, D] tensors, ops._AggregateVI)
-            return EdgeNoise.from_distribution(
+            return self._descriptor(
                 graph, sample_dimension, dist, relu=self.relu, in_norm=self.norm, differentiable=True,
                 seed=gen.seed, offset=gen.next_offset(), epoch=gen.device_epoch)
         if fusable(dist) and self.vi and type(dist) in (torch.distributions.Normal,

@@ -40,7 +40,7 @@ def _param_mode(p, n_edges, dn):
 
 class EdgeNoise:
     def __init__(self, graph, dn, kind, p0, p1=None, relu=False, in_norm=False, seed=0, offset=0,
-                 pos_base=0, differentiable=False, chunk_base=0, epoch=None):
+                 pos_base=0, differentiable=False, chunk_base=0, epoch=None, p1_log=False):
         # the owner of the cached structure, not a local_var() copy (whose frames hold step tensors)
         self.graph = graph._cache_owner() if hasattr(graph, "_cache_owner") else graph
         self.dn, self.kind = int(dn), int(kind)
@@ -50,6 +50,9 @@ class EdgeNoise:
         if differentiable and kind in (_lib.NOISE_NORMAL, _lib.NOISE_UNIFORM):
             self.grad_params = (p0, p1)
         self.deriv = 0
+        # p1 is log(scale) (Normal): the kernels exponentiate it where they load it and gradients come back
+        # w.r.t. the log — what an AmortizedDistribution's [E, Dn] `log_scale` head wants (no exp pass, no saved tensor)
+        self.p1_log = bool(p1_log) and kind == _lib.NOISE_NORMAL
         self.relu, self.in_norm = bool(relu), bool(in_norm)
         self.seed, self.offset, self.pos_base = int(seed), int(offset), int(pos_base)
         # channel shards (partition.ChannelShard): this tensor's channel 0 is global channel 4*chunk_base
@@ -77,6 +80,11 @@ class EdgeNoise:
                 # hipGraph, so it travels as a per-channel row instead
                 mode = _lib.PARAM_PER_CHANNEL
             self.param_mode = mode
+            if self.p1_log and mode == _lib.PARAM_PER_CHANNEL:      # the library takes log-scales per edge or scalar
+                ps[1] = ps[1].exp()
+                self.p1_log = False
+                if self.grad_params is not None:
+                    raise ValueError("a per-channel log-scale with gradients: exponentiate it yourself (p1_log=False)")
             if mode == _lib.PARAM_SCALAR:
                 self.p0_scalar = float(ps[0].detach().reshape(()))
                 if p1 is not None:
@@ -113,6 +121,7 @@ class EdgeNoise:
         s.relu, s.in_norm, s.deriv = int(self.relu), int(self.in_norm), int(self.deriv)
         s.seed, s.offset, s.pos_base = self.seed, self.offset, self.pos_base
         s.chunk_base = self.chunk_base
+        s.p1_log = int(self.p1_log)
         s.epoch = _lib.ptr(self.epoch)
         return s
 
@@ -120,7 +129,7 @@ class EdgeNoise:
         """(noise_ints, noise_u64, noise_floats, p0, p1, epoch) of torch.ops.stag.* — the same fields as spec()."""
         s64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v          # 64-bit pattern in an int64
         return ([self.kind, self.param_mode, int(self.relu), int(self.in_norm if in_norm is None else in_norm),
-                 int(self.deriv), group, self.chunk_base],
+                 int(self.deriv), group, self.chunk_base, int(self.p1_log)],
                 [s64(self.seed), s64(self.offset), self.pos_base], [self.p0_scalar, self.p1_scalar],
                 self.p0, self.p1, self.epoch)
 
@@ -137,11 +146,13 @@ class EdgeNoise:
             return ops.materialize_noise(self.graph, self)
         import copy
         std = copy.copy(self)
-        std.grad_params, std.relu, std.in_norm, std.param_mode = None, False, False, _lib.PARAM_SCALAR
+        std.grad_params, std.relu, std.in_norm, std.param_mode, std.p1_log = None, False, False, _lib.PARAM_SCALAR, False
         std.p0 = std.p1 = None
         std.p0_scalar, std.p1_scalar = 0.0, 1.0          # N(0, 1) | U[0, 1)
         z = ops.materialize_noise(self.graph, std)
         p0, p1 = (torch.as_tensor(p, dtype=torch.float32, device=z.device) for p in self.grad_params)
+        if self.p1_log:
+            p1 = p1.exp()
         w = p0 + p1 * z if self.kind == _lib.NOISE_NORMAL else p0 + (p1 - p0) * z
         if self.relu:
             w = w.relu()

@@ -45,7 +45,7 @@ def _none_spec():
 
 def _explicit_spec(w, relu=False, in_norm=False, group=0):
     if _torch_ext.available():
-        return ([_lib.NOISE_EXPLICIT, 0, int(relu), int(in_norm), 0, int(group), 0], [0, 0, 0], [0.0, 0.0], w, None, None)
+        return ([_lib.NOISE_EXPLICIT, 0, int(relu), int(in_norm), 0, int(group), 0, 0], [0, 0, 0], [0.0, 0.0], w, None, None)
     s = _lib.NoiseSpec()
     s.kind = _lib.NOISE_EXPLICIT
     s.p0 = w.data_ptr()
@@ -101,7 +101,7 @@ def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None):
     return plan_c, (ws, counters)
 
 
-_NONE_ARGS = ([_lib.NOISE_NONE, 0, 0, 0, 0, 0, 0], [0, 0, 0], [0.0, 0.0], None, None, None)
+_NONE_ARGS = ([_lib.NOISE_NONE, 0, 0, 0, 0, 0, 0, 0], [0, 0, 0], [0.0, 0.0], None, None, None)
 
 
 def _plan_args(csrv, plan_t, tiles, dev):
@@ -162,7 +162,7 @@ def _targs_to_ctypes(t):
     """The torch-op argument tuple as a ctypes stag_noise_spec (for the entry points bound through ctypes)."""
     ni, nu, nf, p0, p1, epoch = t
     s = _lib.NoiseSpec()
-    s.kind, s.param_mode, s.relu, s.in_norm, s.deriv, s.group, s.chunk_base = ni
+    s.kind, s.param_mode, s.relu, s.in_norm, s.deriv, s.group, s.chunk_base, s.p1_log = ni
     s.seed, s.offset, s.pos_base = nu[0] & ((1 << 64) - 1), nu[1] & ((1 << 64) - 1), nu[2]
     s.p0_scalar, s.p1_scalar = nf
     s.p0, s.p1, s.epoch = _lib.ptr(p0), _lib.ptr(p1), _lib.ptr(epoch)

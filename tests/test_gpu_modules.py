@@ -413,6 +413,92 @@ def test_fused_vi_gradients_with_in_norm(dev, kind, pmode, relu):
     assert layer.q_a.loc.grad is not None and float(layer.q_a.log_scale.grad.abs()) > 0
 
 
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("pmode", ["scalar", "per_edge1", "per_edge"])
+def test_log_scale_parameters(dev, oracle, pmode, relu):
+    """stag_noise_spec.p1_log: the scale handed over as its logarithm (what AmortizedDistribution's `log_scale`
+    head produces, stag/distributions.py:235-242) and exponentiated where the kernels load it.  Forward and the
+    materialised field against the oracle, gradients w.r.t. x, loc and LOG-scale against autograd through
+    w = loc + exp(log_scale) z."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    from util import random_graph
+    rng = np.random.default_rng(23)
+    n, D = 160, 12
+    g = random_graph(n, 1200, seed=41, hub=170, device=dev)
+    E = g.number_of_edges()
+    shape = {"scalar": (), "per_edge1": (E, 1), "per_edge": (E, D)}[pmode]
+    a0 = torch.tensor(rng.uniform(0.5, 1.0, shape).astype(np.float32), device=dev)
+    l0 = torch.tensor(np.log(rng.uniform(0.3, 0.8, shape)).astype(np.float32), device=dev)
+    x0 = torch.tensor(rng.standard_normal((n, D)).astype(np.float32), device=dev)
+    gout = torch.tensor(rng.standard_normal((n, D)).astype(np.float32), device=dev)
+    shift = -0.9 if relu else 0.0
+    og = oracle_graph(oracle, g)
+    p0n, p1n = (a0 + shift).cpu().numpy(), l0.cpu().numpy()
+    if pmode == "scalar":
+        p0n, p1n = float(p0n), float(p1n)
+    spec = oracle.make_spec("normal", p0n, p1n, relu=relu, seed=5, offset=2, Dn=D, n_edges=E, p1_log=True)
+    mk = lambda a, l, **kw: stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, (a + shift) if pmode != "scalar" else float(a + shift),
+                                                l if pmode != "scalar" else float(l), relu=relu, seed=5, offset=2,
+                                                p1_log=True, **kw)
+    assert_close(ops.aggregate(g, x0, mk(a0, l0)), oracle.agg_fwd(og, x0.cpu().numpy(), spec), what=f"p1_log forward {pmode}")
+    assert_close(mk(a0, l0).materialize(), oracle.noise_materialize(og, spec, D), what=f"p1_log materialised {pmode}")
+    if pmode == "scalar":
+        return
+    x, a, l = (t.clone().requires_grad_(True) for t in (x0, a0, l0))
+    out = ops.aggregate(g, x, stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, a + shift, l, relu=relu, seed=5, offset=2,
+                                                 p1_log=True, differentiable=True), reduce="mean", seg_len=32)
+    out.backward(gout)
+    z = stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, 0.0, 1.0, seed=5, offset=2).materialize()
+    x2, a2, l2 = (t.clone().requires_grad_(True) for t in (x0, a0, l0))
+    w = (a2 + shift) + l2.exp() * z
+    if relu:
+        w = w.relu()
+    out2 = ops.aggregate(g, x2, w.expand(E, D), reduce="mean", seg_len=32)
+    out2.backward(gout)
+    assert_close(out, out2.detach().cpu().numpy(), what="p1_log vi forward")
+    assert_close(x.grad, x2.grad.cpu().numpy(), what="p1_log dx")
+    assert_close(a.grad, a2.grad.cpu().numpy(), what=f"p1_log d loc {pmode}")
+    assert_close(l.grad, l2.grad.cpu().numpy(), what=f"p1_log d log_scale {pmode}")
+
+
+@pytest.mark.parametrize("of", [1, 16])
+def test_amortized_layer_uses_log_scale_descriptor(dev, of):
+    """StagLayer(GCN, q_a=AmortizedDistribution) hands the kernel loc / log_scale as the heads produce them: the
+    descriptor carries p1_log, no [E, Dn] exp tensor is formed, and the MLP's gradients equal those of the
+    reference's dataflow (exp, rsample, edge_weight=)."""
+    import stag_amd
+    from stag_amd import _lib
+    from stag_amd.distributions import AmortizedDistribution
+    from util import random_graph
+    g = random_graph(120, 900, seed=6, hub=90, device=dev)
+    x = torch.randn(120, 16, device=dev)
+    torch.manual_seed(4)
+    q = AmortizedDistribution(16, of, init_like=torch.distributions.Normal(1.0, 0.3))
+    gcn = stag_amd.zoo.GCN(16, 8)
+    layer = stag_amd.layers.StagLayer(gcn, q_a=q, vi=True).to(dev)
+    stag_amd.manual_seed(9)
+    out = layer(g, x)
+    h = layer._edge_weight_handle
+    assert isinstance(h, stag_amd.EdgeNoise) and h.p1_log and h.param_mode in (_lib.PARAM_PER_EDGE1, _lib.PARAM_PER_EDGE)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    got = {k: p.grad.clone() for k, p in layer.named_parameters() if p.grad is not None}
+    layer.zero_grad()
+    q.condition(g, x)
+    z = stag_amd.EdgeNoise(g, 16, _lib.NOISE_NORMAL, 0.0, 1.0, seed=9, offset=h.offset).materialize()
+    w = q.new_parameters["loc"] + q.new_parameters["log_scale"].exp() * z
+    ref = gcn(g, x, edge_weight=w)
+    assert_close(out, ref.detach().cpu().numpy(), what="amortised layer forward")
+    ref.backward(gout)
+    assert any("parameters_mlp.log_scale" in k for k in got)
+    for k, p in layer.named_parameters():
+        if p.grad is None:
+            continue
+        sc = max(1.0, float(p.grad.abs().max()))
+        assert_close(got[k] / sc, (p.grad / sc).cpu().numpy(), what=f"amortised d {k}")
+
+
 def test_sample_based_kl_reaches_q_a_on_the_fused_path(dev):
     """No closed-form KL (a MixtureSameFamily prior, which StagLayer accepts: stag/layers.py:66-67) => the
     regulariser is q.log_prob(w) - p.log_prob(w) on the LAST SAMPLE (stag/layers.py:141-143), and the

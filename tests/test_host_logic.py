@@ -34,7 +34,7 @@ def test_torch_library_front_end_loads_and_traces():
     ip = torch.zeros(6, dtype=torch.int32, device="meta")
     ix = torch.zeros(9, dtype=torch.int32, device="meta")
     x = torch.zeros(5, 12, device="meta")
-    noise = ([2, 0, 0, 1, 0, 0, 0], [1, 2, 0], [1.0, 0.5], None, None, None)
+    noise = ([2, 0, 0, 1, 0, 0, 0, 0], [1, 2, 0], [1.0, 0.5], None, None, None)
     plan = (None, None, None, None, None, [0] * 6)
     out, ns = torch.ops.stag.agg_fwd(ip, ix, None, None, 5, *plan, x, False, *noise, 0, None, None, True)
     assert out.shape == (5, 12) and ns.shape == (5, 12) and out.device.type == "meta"
