@@ -579,3 +579,54 @@ def test_fuzz_agg_against_oracle(dev, oracle):
                              src_scale=ss, dst_scale=ds)
         assert_close(got, ref,
                      what=f"fuzz {it}: n={n} E={E} D={D} {kind} seg={seg_len} {reduce} relu={relu}")
+
+
+def test_fuzz_gat_against_oracle_and_composed_backward(dev, oracle):
+    """Seeded sweep over graphs x head shapes x weight kinds x plans for the GAT entry points: the forward
+    (workgroup-cooperative kernel, 1 / 2 / 4 chunks per lane, or the one-unit-per-team fallback) against the
+    oracle, the backward (stag_gat_bwd or the composed calls) against autograd through the composed statement
+    of the same layer (ops._gat_composed: torch ops over [E, H] + the aggregation kernel)."""
+    from stag_amd import ops
+    rng = np.random.default_rng(20261004)
+    shapes = [(1, 4), (2, 8), (3, 4), (4, 16), (8, 32), (8, 64), (16, 64), (5, 12), (4, 5), (2, 256), (16, 8), (6, 40)]
+    kinds = ["none", "explicit", "normal", "uniform", "bernoulli"]
+    for it in range(36):
+        n = int(rng.integers(2, 500))
+        e = int(rng.integers(1, 4000))
+        hub = int(rng.choice([0, 0, 90, 700]))
+        H, F = shapes[it % len(shapes)]
+        kind = kinds[it % 5]
+        seg_len = int(rng.choice([64, 64, 16, 256, 0]))
+        g = random_graph(n, e, seed=3000 + it, hub=hub if n > 4 else 0, device=dev)
+        E = g.number_of_edges()
+        og = oracle_graph(oracle, g)
+        el = rng.standard_normal((n, H)).astype(np.float32)
+        er = rng.standard_normal((n, H)).astype(np.float32)
+        ft = rng.standard_normal((n, H, F)).astype(np.float32)
+        relu = bool(rng.random() < 0.3)
+        if kind == "none":
+            w, spec = None, oracle.make_spec("none")
+        elif kind == "explicit":
+            wt = rng.uniform(-0.5, 1.5, (E, H)).astype(np.float32)
+            w, spec = torch.from_numpy(wt).to(dev), oracle.make_spec("explicit", wt)
+        else:
+            p0, p1 = {"normal": (1.0, 0.5), "uniform": (0.2, 1.7), "bernoulli": (0.7, None)}[kind]
+            norm = kind == "bernoulli" and bool(rng.random() < 0.5)
+            kw = dict(relu=relu, in_norm=norm, seed=int(rng.integers(0, 2**40)), offset=int(rng.integers(0, 99)))
+            w = _noise(g, H, kind, p0, p1, **kw)
+            spec = _ospec(oracle, g, H, kind, p0, p1, **kw)
+        what = f"gat fuzz {it}: n={n} E={E} H={H} F={F} {kind} seg={seg_len} relu={relu}"
+        t = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (el, er, ft)]
+        out, attn = ops.gat_aggregate(g, *t, 0.2, w, want_attn=True, seg_len=seg_len)
+        ref, ref_attn = oracle.gat_fwd(og, el, er, ft, 0.2, spec, want_attn=True)
+        tol = TOL if 0 < seg_len <= 64 else 2 * TOL
+        assert_close(out, ref, tol=tol, what=what + " out")
+        assert_close(attn, ref_attn, tol=tol, what=what + " attn")
+        G = torch.from_numpy(rng.standard_normal((n, H, F)).astype(np.float32)).to(dev)
+        out.backward(G)
+        t2 = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (el, er, ft)]
+        out2 = ops.gat_aggregate(g, *t2, 0.2, w, seg_len=seg_len if seg_len else 64, attn_fn=lambda a_: a_)   # the composed path
+        out2.backward(G)
+        for a_, b_, nm in zip(t, t2, ("d el", "d er", "d ft")):
+            sc = max(1.0, float(b_.grad.abs().max()))
+            assert_close(a_.grad / sc, (b_.grad / sc).cpu().numpy(), what=what + " " + nm)
