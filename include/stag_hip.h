@@ -183,8 +183,12 @@ size_t stag_plan_workspace_bytes(int32_t n_seg, int32_t D, int32_t in_norm);
 /* Batches of consecutive units for the workgroup-cooperative kernels: block_ptr_host[n_blocks+1]
  * (NULL: count only), greedy in plan order: a batch closes before it would exceed max_edges edges
  * (a single longer unit gets a batch of its own) or max_units units.                          */
+#ifndef STAG_BLOCK_EDGES
 #define STAG_BLOCK_EDGES 256
+#endif
+#ifndef STAG_BLOCK_UNITS
 #define STAG_BLOCK_UNITS 32
+#endif
 int stag_plan_blocks(const stag_unit* units_host, int32_t n_units, int32_t max_edges,
                      int32_t max_units, int32_t* block_ptr_host, int32_t* n_blocks_out);
 

@@ -341,6 +341,8 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const GatArgs a) {
 // A unit's arithmetic does not depend on which batch it rides in: m = max over its edges, l = sum of
 // exp in edge order, acc = fma(p_i, row_i, acc) in edge order — so shards reproduce the whole graph.
 constexpr int kBlkEdges = STAG_BLOCK_EDGES, kBlkUnits = STAG_BLOCK_UNITS, kBlkMaxH = 16;
+constexpr int kBlkThreads = STAG_BLOCK_EDGES;     // a thread per edge of the batch
+static_assert(kBlkUnits <= 64 && kBlkThreads % 64 == 0 && kBlkThreads <= 1024, "the unit prefix is one wave's scan");
 #ifndef STAG_GAT_DBG
 #define STAG_GAT_DBG 0    // 16: per-stage timestamps into the stats buffer (tools/gat_trace.py)
 #endif
@@ -369,7 +371,7 @@ constexpr int kBlkEdges = STAG_BLOCK_EDGES, kBlkUnits = STAG_BLOCK_UNITS, kBlkMa
 #define STAG_GAT_LDS_MIN_BWD 32000  // backward passes: 5
 #endif
 template <int LPE, int CPL>
-__global__ __launch_bounds__(256) STAG_GAT_SGPR_ATTR void gat_fwd_block_kernel(const GatArgs a) {
+__global__ __launch_bounds__(kBlkThreads) STAG_GAT_SGPR_ATTR void gat_fwd_block_kernel(const GatArgs a) {
   extern __shared__ __align__(16) float lds[];
   const int H = a.H, F = a.F, HF = a.HF;
   float* s_w = lds;                                   // [kBlkEdges][H] logits, then p = exp(e - m)
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(256) STAG_GAT_SGPR_ATTR void gat_fwd_block_kernel(c
     int incl = q.z;                                    // inclusive scan of the lengths over lanes 0..31
 #pragma unroll
     for (int d = 1; d < kBlkUnits; d <<= 1) {
-      const int up = __shfl_up(incl, d, kBlkUnits);
+      const int up = __shfl_up(incl, d, kBlkUnits);          // lanes 0..kBlkUnits-1 of wave 0
       if (t >= d) incl += up;
     }
     s_start[t + 1] = incl;
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(256) STAG_GAT_SGPR_ATTR void gat_fwd_block_kernel(c
   GAT_TS(3)
 
   // ---- phase 1b: thread <-> (unit, head): softmax statistics, logits -> p ---------------------------
-  for (int i = t; i < nu * H; i += 256) {
+  for (int i = t; i < nu * H; i += kBlkThreads) {
     const int j = i / H, h = i - j * H;
     const int e0 = s_start[j], e1 = s_start[j + 1];
     float m = -INFINITY;
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(256) STAG_GAT_SGPR_ATTR void gat_fwd_block_kernel(c
 
   // ---- phase 2: a team per unit, weighted gather -------------------------------------------------------
   // lane c owns CPL chunks of 4 channels: [4 (c + LPE j), +4), j < CPL  (H*F <= 256: one; up to 1024: 2 or 4)
-  constexpr int TEAMS = 256 / LPE, NR = CPL >= 4 ? 2 : STAG_GAT_NR;
+  constexpr int TEAMS = kBlkThreads / LPE, NR = CPL >= 4 ? 2 : STAG_GAT_NR;
   const int team = t / LPE, c = t % LPE;
   const int team_lane0 = (int)(t & 63) - c;
   int k0[CPL], hl[CPL];
@@ -816,7 +818,7 @@ __device__ __forceinline__ int blk_prologue(const stag_unit* units, const int32_
     int incl = q.z;
 #pragma unroll
     for (int d = 1; d < kBlkUnits; d <<= 1) {
-      const int up = __shfl_up(incl, d, kBlkUnits);
+      const int up = __shfl_up(incl, d, kBlkUnits);          // lanes 0..kBlkUnits-1 of wave 0
       if (t >= d) incl += up;
     }
     s_start[t + 1] = incl;
@@ -847,7 +849,7 @@ __device__ __forceinline__ float gat_head_sum(float x, int lanes_per_head) {
 }
 
 template <int LPE, int CPL>
-__global__ __launch_bounds__(256) void gat_bwd_edge_block_kernel(const GatBwdBlkArgs ba) {
+__global__ __launch_bounds__(kBlkThreads) void gat_bwd_edge_block_kernel(const GatBwdBlkArgs ba) {
   extern __shared__ __align__(16) float lds[];
   const GatArgs& a = ba.f;
   const int H = a.H, F = a.F, HF = a.HF;
@@ -916,7 +918,7 @@ __global__ __launch_bounds__(256) void gat_bwd_edge_block_kernel(const GatBwdBlk
   __syncthreads();
 
   // ---- phase 2: a team per unit: <G[v,h,:], ft[u,h,:]> per in-edge -> ds -> de ---------------------------
-  constexpr int TEAMS = 256 / LPE, NR = CPL >= 4 ? 2 : STAG_GAT_NR;
+  constexpr int TEAMS = kBlkThreads / LPE, NR = CPL >= 4 ? 2 : STAG_GAT_NR;
   const int team = t / LPE, c = t % LPE;
   const int lph = F / 4;
   int k0[CPL], hl[CPL];
@@ -996,7 +998,7 @@ __global__ __launch_bounds__(256) void gat_bwd_edge_block_kernel(const GatBwdBlk
     if (ba.dw)
       for (int h = 0; h < H; ++h) ba.dw[my_ed * H + h] = s_c2[t * H + h];
   }
-  for (int i = t; i < nu * H; i += 256) {
+  for (int i = t; i < nu * H; i += kBlkThreads) {
     const int j = i / H, h = i - j * H;
     const int4 q = s_unit[j];
     float sum = 0.f;
@@ -1022,7 +1024,7 @@ struct GatSrcBlkArgs {
 };
 
 template <int LPE, int CPL>
-__global__ __launch_bounds__(256) void gat_bwd_src_block_kernel(const GatSrcBlkArgs a) {
+__global__ __launch_bounds__(kBlkThreads) void gat_bwd_src_block_kernel(const GatSrcBlkArgs a) {
   extern __shared__ __align__(16) float lds[];
   const int H = a.H, F = a.F, HF = a.HF;
   float* s_a = lds;                                   // [kBlkEdges][H]
@@ -1050,7 +1052,7 @@ __global__ __launch_bounds__(256) void gat_bwd_src_block_kernel(const GatSrcBlkA
   }
   __syncthreads();
   // d el[u,h] = sum of de over the out-edges, in transposed-position order
-  for (int i = t; i < nu * H; i += 256) {
+  for (int i = t; i < nu * H; i += kBlkThreads) {
     const int j = i / H, h = i - j * H;
     const int4 q = s_unit[j];
     float sum = 0.f;
@@ -1059,7 +1061,7 @@ __global__ __launch_bounds__(256) void gat_bwd_src_block_kernel(const GatSrcBlkA
     else a.ws[(int64_t)q.w * (HF + H) + HF + h] = sum;
   }
   // d ft[u,h,:] = sum over out-edges of a[e,h] G[v,h,:]
-  constexpr int TEAMS = 256 / LPE, NR = CPL >= 4 ? 2 : STAG_GAT_NR;
+  constexpr int TEAMS = kBlkThreads / LPE, NR = CPL >= 4 ? 2 : STAG_GAT_NR;
   const int team = t / LPE, c = t % LPE;
   int k0[CPL], hl[CPL];
   bool kin[CPL];
@@ -1235,7 +1237,7 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
                      (size_t)(kBlkEdges + kBlkUnits + 4) * sizeof(int) + (size_t)kBlkUnits * sizeof(int4);
     if (lds_blk < STAG_GAT_LDS_MIN) lds_blk = STAG_GAT_LDS_MIN;
     const dim3 gb(plan->n_blocks);
-#define STAG_BLK_LAUNCH(L, Cc) hipLaunchKernelGGL((gat_fwd_block_kernel<L, Cc>), gb, dim3(256), lds_blk, s, a)
+#define STAG_BLK_LAUNCH(L, Cc) hipLaunchKernelGGL((gat_fwd_block_kernel<L, Cc>), gb, dim3(kBlkThreads), lds_blk, s, a)
     if (cpl == 4) STAG_BLK_LAUNCH(64, 4);
     else if (cpl == 2) STAG_BLK_LAUNCH(64, 2);
     else switch (lpe) {
@@ -1408,7 +1410,7 @@ extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const st
                  (size_t)(kBlkEdges + kBlkUnits + 4) * sizeof(int) + (size_t)kBlkUnits * sizeof(int4);
   if (lds_e < STAG_GAT_LDS_MIN_BWD) lds_e = STAG_GAT_LDS_MIN_BWD;
   const dim3 ge(plan->n_blocks);
-#define STAG_BLK_LAUNCH(L, Cc) hipLaunchKernelGGL((gat_bwd_edge_block_kernel<L, Cc>), ge, dim3(256), lds_e, s, ba)
+#define STAG_BLK_LAUNCH(L, Cc) hipLaunchKernelGGL((gat_bwd_edge_block_kernel<L, Cc>), ge, dim3(kBlkThreads), lds_e, s, ba)
     if (cpl == 4) STAG_BLK_LAUNCH(64, 4);
     else if (cpl == 2) STAG_BLK_LAUNCH(64, 2);
     else switch (lpe) {
@@ -1436,7 +1438,7 @@ extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const st
                  (size_t)kBlkUnits * sizeof(int4);
   if (lds_s < STAG_GAT_LDS_MIN_BWD) lds_s = STAG_GAT_LDS_MIN_BWD;
   const dim3 gs(plan_t->n_blocks);
-#define STAG_BLK_LAUNCH(L, Cc) hipLaunchKernelGGL((gat_bwd_src_block_kernel<L, Cc>), gs, dim3(256), lds_s, s, sa)
+#define STAG_BLK_LAUNCH(L, Cc) hipLaunchKernelGGL((gat_bwd_src_block_kernel<L, Cc>), gs, dim3(kBlkThreads), lds_s, s, sa)
     if (cpl == 4) STAG_BLK_LAUNCH(64, 4);
     else if (cpl == 2) STAG_BLK_LAUNCH(64, 2);
     else switch (lpe) {

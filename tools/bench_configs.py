@@ -59,10 +59,13 @@ def main():
     ap.add_argument("--noise", default="normal", choices=["normal", "none"])
     ap.add_argument("--json", default=None)
     ap.add_argument("--lib", default=None, help="A/B: a build variant tools/_bin/libstag_<name>.so (tools/ab_bench.py build)")
+    ap.add_argument("--blk", default=None, help="A/B: batch budget of the cooperative GAT kernels, 'edges,units' (at most the library's STAG_BLOCK_EDGES, STAG_BLOCK_UNITS)")
     ap.add_argument("--gat-old-bwd", action="store_true",
                     help="cfg5_train: the composed backward (stag_gat_bwd_edge + three stag_agg_fwd calls) for A/B")
     args = ap.parse_args()
     only = [s for s in args.only.split(",") if s]
+    if args.blk:
+        _lib.BLOCK_EDGES, _lib.BLOCK_UNITS = (int(v) for v in args.blk.split(","))
     if args.gat_old_bwd:
         ops._GAT_BWD_FUSED = False
     if args.lib:
