@@ -69,6 +69,10 @@ def parse(argv=None):
                          "(stag_halo_exchange, include/stag_hip.h) instead of torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--settle-ms", type=float, default=300.0,
+                    help="untimed launches of the same step before the W warm-up steps, until this much wall time "
+                         "has passed: the card raises its clocks over the first ~100 ms of load, and a 20-step run "
+                         "(2 ms of work) would otherwise time the ramp (DESIGN.md section 5); 0 = none")
     ap.add_argument("--rehearse", action="store_true",
                     help="plumbing check without a GPU: ranks, rendezvous (gloo), partition and exchange run on "
                          "CPU tensors, NO kernel is launched; the line carries rehearsal=true and value=null")
@@ -319,8 +323,26 @@ def main():
         assert torch.isfinite(out).all()
         return wall, dev_ms
 
+    def settle(step):
+        """Untimed launches of the step until --settle-ms of wall time has gone by (every rank, same count)."""
+        if rehearse or args.settle_ms <= 0:
+            return 0
+        done, t_end = 0, time.perf_counter() + args.settle_ms * 1e-3
+        with torch.no_grad():
+            while True:
+                for i in range(50):
+                    step(i)
+                sync()
+                done += 50
+                more = torch.tensor([1.0 if time.perf_counter() < t_end else 0.0], device=dev)
+                if world > 1:
+                    dist.all_reduce(more, op=dist.ReduceOp.MIN)   # ranks must agree: the step is a collective
+                if float(more) == 0.0:
+                    return done
+
     partition = args.partition
     step, parallelism, parts = make_step(partition)
+    settle_steps = settle(step)
     wall, dev_ms = timed(step, args.steps, args.warmup)
 
     exchange = None
@@ -367,7 +389,8 @@ def main():
         line = {
             "metric": "aggregated edges/sec, stochastic-aggregation layer-forward, ogbn-arxiv-shaped CSR",
             "value": None if rehearse else E / (wall / args.steps), "unit": "edges/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "steps": args.steps, "warmup": args.warmup, "settle_ms": args.settle_ms, "settle_steps": settle_steps,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: ogbn-arxiv-shaped synthetic CSR "

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 11
+#define STAG_ABI_VERSION 12
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -263,6 +263,22 @@ int stag_agg_bwd(const stag_csr* csr_t, const stag_plan* plan_t, const float* g,
                  int32_t D, const stag_noise_spec* spec, const float* g_scale,
                  const float* row_scale, float* dx, float* dp0_rows, float* dp1_rows,
                  int64_t ldo, void* stream);
+
+/* Backward of stag_agg_fwd for [E, 1] (amortised) parameters, param_mode PER_EDGE1, kind NORMAL | UNIFORM:
+ * dx AND the gradient of every edge's parameter pair from ONE pass over the source-major CSR — the row of
+ * x the pair needs is the unit's own row there, the row of g is the one the pass gathers anyway:
+ *     dx[u,:]      = row_scale[u] * sum_{p: src_p = u} w[p,:] * g_scale[v_p] * g[v_p,:]
+ *     dp0_edge[e]  = sum_k dw/dp0[e,k] * g_scale[v] * g[v,k] * row_scale[u] * x[u,k]       (e = csr_t->eid[p])
+ *     dp1_edge[e]  = ... dw/dp1 ...   (with spec->p1_log: the gradient w.r.t. the log-scale, dw/dp1 * p1)
+ * dx may be NULL (parameter gradients only); dp1_edge may be NULL.  The channel sum is one team sum, so the
+ * row must fit one channel tile: D <= 256, else STAG_ENOSYS (the caller then runs stag_agg_bwd +
+ * stag_agg_bwd_w, three gathers instead of one).  csr_t->eid and csr_t->nidx must be set.  in_norm 0.
+ * The reference gets these from autograd through `rsample` on [E, D] tensors
+ * (stag/layers.py:123-124, stag/distributions.py:229-242).                                          */
+int stag_agg_bwd_edge(const stag_csr* csr_t, const stag_plan* plan_t, const float* g, int64_t ldg,
+                      int32_t D, const stag_noise_spec* spec, const float* g_scale,
+                      const float* row_scale, const float* x, int64_t ldx, float* dx, int64_t ldo,
+                      float* dp0_edge, float* dp1_edge, void* stream);
 
 /* w[eid, k] for every edge of the shard: what the reference keeps in
  * `self._edge_weight_sample` (stag/layers.py:107). relu and in_norm applied.

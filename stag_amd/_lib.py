@@ -102,6 +102,8 @@ def lib():
                                   C.c_int64, C.c_int64, _vp]
     l.stag_agg_bwd.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, C.c_int64, C.c_int32,
                                C.POINTER(NoiseSpec), _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]
+    l.stag_agg_bwd_edge.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, C.c_int64, C.c_int32,
+                                    C.POINTER(NoiseSpec), _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, _vp]
     l.stag_coldot_workspace_bytes.restype = C.c_size_t
     l.stag_coldot_workspace_bytes.argtypes = [C.c_int32]
     l.stag_coldot.argtypes = [_vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, _vp,
@@ -127,7 +129,7 @@ def lib():
     l.stag_comm_destroy.argtypes = [_vp]
     l.stag_halo_allgather.argtypes = [_vp, _vp, C.c_int64, _vp, _vp]
     l.stag_halo_exchange.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
-    if l.stag_abi_version() != 11:
+    if l.stag_abi_version() != 12:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     _lib = l
     return l

@@ -77,6 +77,13 @@ struct AggArgs {
   uint64_t mc_stride;
   int64_t ldo;
   float* norm_scale_out;   // [n_rows, D] or null
+  // per-edge parameter gradients out of the same pass (stag_agg_bwd_edge; PEDGE 3): the unit's OWN row of
+  // xown times the gathered row, summed over the channels, times each derivative of the draw
+  const float* xown;       // [n_rows, ldxo]
+  int64_t ldxo;
+  const float* own_scale;  // [n_rows] or null: factor on the own row
+  float* eg0;              // [E] by edge id: d / d p0
+  float* eg1;              // [E] by edge id: d / d p1 (d / d log p1 under the log-scale flag); may be null
   // plan
   const stag_unit* units;  // null: unit i = row i, unsplit
   int32_t n_units;
@@ -308,6 +315,34 @@ constexpr int kKahanMinLen = STAG_KAHAN_MIN_LEN;
 #define STAG_MULT_WIDE 1
 #endif
 
+// sum over the LPE lanes of a team, result in every lane: DPP inside a row of 16 lanes (quad
+// swaps, half-row and row mirrors: 4 full-rate ops), ds_bpermute only across rows
+template <int LPE>
+__device__ __forceinline__ float team_sum(float v) {
+  if constexpr (LPE >= 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm 1,0,3,2
+  if constexpr (LPE >= 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm 2,3,0,1
+  if constexpr (LPE >= 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  if constexpr (LPE >= 16) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)); // row_mirror
+  if constexpr (LPE >= 32) v += __shfl_xor(v, 16);
+  if constexpr (LPE >= 64) v += __shfl_xor(v, 32);
+  return v;
+}
+
+// The same sum when lanes at the END of the team may have left (channel chunks past the row's end):
+// a shift-down tree, whose reads only ever go to higher lanes, valid in lane 0 only.  c = this lane's
+// index in the team, nlive = the lanes that stayed.  (A butterfly needs every lane's partial sums.)
+template <int LPE>
+__device__ __forceinline__ float team_sum_lane0(float v, int c, int nlive) {
+  // row_shl:n — lane i of a row of 16 reads lane i + n; past the row or from a lane that left: 0 (bound_ctrl)
+  if constexpr (LPE >= 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, true));
+  if constexpr (LPE >= 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x102, 0xF, 0xF, true));
+  if constexpr (LPE >= 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xF, 0xF, true));
+  if constexpr (LPE >= 16) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x108, 0xF, 0xF, true));
+  if constexpr (LPE >= 32) { const float t = __shfl_down(v, 16); v += (c + 16 < nlive) ? t : 0.f; }
+  if constexpr (LPE >= 64) { const float t = __shfl_down(v, 32); v += (c + 32 < nlive) ? t : 0.f; }
+  return v;
+}
+
 // Register image of one block of BLK edges of a unit.
 template <int BLK>
 struct EdgeIdx {        // what the index fetch brings in
@@ -323,6 +358,13 @@ template <int BLK>
 struct EdgeParams<BLK, 1> { float q0[BLK], q1[BLK]; };
 template <int BLK>
 struct EdgeParams<BLK, 2> { float pa[BLK][4], pb[BLK][4]; };
+// PEDGE 3 = PEDGE 1 whose pass also returns the gradients of the pair (stag_agg_bwd_edge)
+template <int BLK>
+struct EdgeParams<BLK, 3> : EdgeParams<BLK, 1> {};
+template <bool ON>
+struct OwnRow { float v[4]; };
+template <>
+struct OwnRow<false> {};
 
 template <int BLK, int PEDGE = 0>
 struct EdgeRows {       // what the row fetch brings in
@@ -371,6 +413,8 @@ struct AggTeam {
   const bool kahan;
   [[no_unique_address]] ExtraAcc<NX> X;
   [[no_unique_address]] ExtraKeys<MC ? NX : 0> KX;
+  [[no_unique_address]] OwnRow<PEDGE == 3> XO;     // the unit's own row of a.xown (times own_scale)
+  static constexpr bool P1 = PEDGE == 1 || PEDGE == 3;
 
   // every lane of the team reads the same BLK column ids: broadcast dword loads with
   // immediate offsets, no per-edge vector arithmetic
@@ -393,7 +437,7 @@ struct AggTeam {
         if (x_buf) bufrow4(rx, I.u[j], a.ldxb, koff, R.xv[j]);
         else loadrow4(row_at(a.x, I.u[j], a.ldxb, koff, (a.wide & 1) != 0), k0, a.D, VEC, R.xv[j]);
         if (a.src_scale) R.xs[j] = a.src_scale[I.u[j]];
-        if constexpr (KIND >= kNormal && PEDGE == 1) {
+        if constexpr (KIND >= kNormal && P1) {
           R.P.q0[j] = a.p0[I.ee[j]];
           R.P.q1[j] = a.p1 ? a.p1[I.ee[j]] : 0.0f;
         } else if constexpr (KIND >= kNormal && PEDGE == 2) {
@@ -417,7 +461,13 @@ struct AggTeam {
       if (p0 + j < pend) {
         float w[4];
         [[maybe_unused]] ExtraAcc<NX> dd;          // dd.acc[o] = derivative o of this edge's draw
-        if constexpr (NX == 0) {
+        [[maybe_unused]] float g0[4], g1[4];        // PEDGE 3: the two derivatives of this edge's draw
+        if constexpr (PEDGE == 3) {
+          const float s1 = (a.relu & kFlagLogScale) ? exp_scale(R.P.q1[j]) : R.P.q1[j];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { pa[q] = R.P.q0[j]; pb[q] = s1; }
+          draw4_grad<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w, g0, g1);
+        } else if constexpr (NX == 0) {
           edge_weight(R, I, j, w);
         } else if constexpr (!MC) {
           draw4_grad<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w, dd.acc[0], dd.acc[1]);
@@ -438,6 +488,23 @@ struct AggTeam {
           for (int o = 0; o < NX; ++o)
 #pragma unroll
             for (int q = 0; q < 4; ++q) TX.acc[o][q] = __builtin_fmaf(dd.acc[o][q], R.xv[j][q], TX.acc[o][q]);
+        }
+        if constexpr (PEDGE == 3) {
+          // d L / d p_i of this edge = sum_k dw/dp_i[k] * (gathered row)[k] * (own row)[k]: the channel
+          // tile is the whole row (one tile: checked on the host), so one team sum finishes it
+          float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float gx = R.xv[j][q] * XO.v[q];
+            e0 = __builtin_fmaf(g0[q], gx, e0);
+            e1 = __builtin_fmaf(g1[q], gx, e1);
+          }
+          e0 = team_sum_lane0<LPE>(e0, k0 >> 2, (a.D + 3) >> 2);
+          e1 = team_sum_lane0<LPE>(e1, k0 >> 2, (a.D + 3) >> 2);
+          if (k0 == 0) {
+            a.eg0[I.ee[j]] = e0;
+            if (a.eg1) a.eg1[I.ee[j]] = e1;
+          }
         }
         if (a.in_norm) {
           asm volatile("" ::: "memory");
@@ -554,7 +621,9 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
 
   const uint32_t chunk = blockIdx.y * LPE + c;
   const int k0 = (int)chunk * 4;
-  if (k0 >= a.D) return;                          // lanes past the row's end (units never talk: no barrier below)
+  // lanes past the row's end (units never talk: no barrier below; the team sums of PEDGE 3 are written
+  // for teams whose last lanes have left: team_sum_lane0)
+  if (k0 >= a.D) return;
 
   int v, b, len, slot = -1;
   if (a.units) {
@@ -592,6 +661,13 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   if constexpr (MC) {
 #pragma unroll
     for (int o = 0; o < NOUT - 1; ++o) T.KX.k[o] = key_plus(T.key, (uint64_t)(o + 1) * a.mc_stride);
+  }
+  if constexpr (PEDGE == 3) {
+    const int row = slot >= 0 ? a.long_rows[v] : v;
+    const float os = a.own_scale ? a.own_scale[row] : 1.0f;
+    load4(a.xown + (int64_t)row * a.ldxo, k0, a.D, VEC, T.XO.v);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) T.XO.v[q] *= os;
   }
   if constexpr (KIND >= kNormal) {
     if (a.pmode == STAG_PARAM_PER_CHANNEL) {   // distribution parameters of this lane's 4 channels
@@ -800,7 +876,7 @@ constexpr int heavy_slots_of() {
 
 template <int KIND, int LPE, bool VEC, int PEDGE, int NOUT = 1, bool MC = false>
 __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_kernel(const AggArgs a) {
-  constexpr int HS = NOUT == 1 ? heavy_slots_of<LPE>() : 1;
+  constexpr int HS = (NOUT == 1 && PEDGE != 3) ? heavy_slots_of<LPE>() : 1;
   const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
   int first = 0, blk = blockIdx.x;
   if constexpr (HS > 1) {
@@ -835,7 +911,7 @@ inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles
   constexpr int TPB = STAG_BLOCK_THREADS / LPE;
   constexpr int HS = heavy_slots_of<LPE>();
   constexpr int TPBH = STAG_BLOCK_THREADS / (LPE * HS);
-  if (HS == 1 || a.outx[0]) a.n_heavy = 0;
+  if (HS == 1 || a.outx[0] || pedge == 3) a.n_heavy = 0;
   a.n_heavy_blocks = (a.n_heavy + TPBH - 1) / TPBH;
   dim3 grid(a.n_heavy_blocks + (a.n_units - a.n_heavy + TPB - 1) / TPB, tiles);
   if (grid.x == 0) return;
@@ -859,6 +935,13 @@ inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles
       return;
     }
   }
+  if constexpr (KIND == kNormal || KIND == kUniform) {
+    if (pedge == 3) {       // [E, 1] parameters and their gradients (stag_agg_bwd_edge)
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 3>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 3>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      return;
+    }
+  }
   if constexpr (KIND >= kNormal) {
     if (pedge == 1) {       // [E, 1] parameters: one pair per edge
       if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 1>), grid, block, STAG_AGG_LDS_BYTES, s, a);
@@ -878,7 +961,8 @@ inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles
 template <int KIND>
 inline hipError_t agg_launch_impl(const AggArgs& a, bool vec, hipStream_t s) {
   const int nchunk = (a.D + 3) / 4;
-  const int pedge = (KIND < kNormal) ? 0 : a.pmode == STAG_PARAM_PER_EDGE1 ? 1 : a.pmode == STAG_PARAM_PER_EDGE ? 2 : 0;
+  const int pedge = (KIND < kNormal) ? 0 : a.pmode == STAG_PARAM_PER_EDGE1 ? (a.eg0 ? 3 : 1)
+                    : a.pmode == STAG_PARAM_PER_EDGE ? 2 : 0;
   // lanes per unit: smallest power of two covering the row, capped at a wave
   int lpe = 1;
   while (lpe < nchunk && lpe < 64) lpe <<= 1;

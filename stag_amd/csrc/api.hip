@@ -147,19 +147,6 @@ __device__ __forceinline__ void edge_w4_grad_p(const NoiseArgs& a, const PhiloxK
   else draw4_grad<kUniform>((uint32_t)gpos, ctr1_of(gpos, chunk), key, pa, pb, a.nflags, w, d0, d1);
 }
 
-// sum over the LPE lanes of a team, result in every lane: DPP inside a row of 16 lanes (quad
-// swaps, half-row and row mirrors: 4 full-rate ops), ds_bpermute only across rows
-template <int LPE>
-__device__ __forceinline__ float team_sum(float v) {
-  if constexpr (LPE >= 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm 1,0,3,2
-  if constexpr (LPE >= 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm 2,3,0,1
-  if constexpr (LPE >= 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-  if constexpr (LPE >= 16) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)); // row_mirror
-  if constexpr (LPE >= 32) v += __shfl_xor(v, 16);
-  if constexpr (LPE >= 64) v += __shfl_xor(v, 32);
-  return v;
-}
-
 __device__ __forceinline__ void edge_w4(const NoiseArgs& a, int p, int64_t ed, uint32_t chunk,
                                         float (&w)[4]) {
   const int k0 = (int)chunk * 4;
@@ -598,16 +585,23 @@ int stag_normal_tables(float* rad, float* cosv, float* sinv, void* stream) {
 
 // one aggregation launch; nout > 1: extra outputs ride along — the two parameter-derivative
 // aggregates (nout = 3, mc = 0) or Monte-Carlo samples 1.. (nout = 2 | 4, mc = 1)
+struct EdgeGradOut {      // stag_agg_bwd_edge: per-edge parameter gradients out of the same pass
+  const float* xown;      // [n_dst, ldxo]: the rows the units own
+  int64_t ldxo;
+  float* eg0;
+  float* eg1;
+};
 static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x, int64_t ldx,
                       int32_t D, const stag_noise_spec* spec, int32_t reduce, const float* src_scale,
                       const float* dst_scale, float* out, int64_t ldo, float* norm_scale_out,
-                      int nout, float* const* extra, int mc, uint64_t mc_stride, void* stream) {
+                      int nout, float* const* extra, int mc, uint64_t mc_stride, void* stream,
+                      const EdgeGradOut* eg = nullptr) {
   int rc = check_csr(csr);
   if (rc) return rc;
   rc = check_spec(spec);
   if (rc) return rc;
-  // ldx == 0: one broadcast row; out may be NULL when only the in-norm factor is wanted
-  if ((!out && !norm_scale_out) || D <= 0 || (ldx != 0 && ldx < D) || ldo < D) return STAG_EINVAL;
+  // ldx == 0: one broadcast row; out may be NULL when only the in-norm factor (or the edge gradients) is wanted
+  if ((!out && !norm_scale_out && !eg) || D <= 0 || (ldx != 0 && ldx < D) || ldo < D) return STAG_EINVAL;
   if (csr->n_edges > 0 && !x) return STAG_EINVAL;
   if (reduce != STAG_REDUCE_SUM && reduce != STAG_REDUCE_MEAN) return STAG_EINVAL;
   if (csr->n_dst == 0) return STAG_OK;
@@ -646,6 +640,7 @@ static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x
   a.out = out; a.ldo = ldo; a.norm_scale_out = norm_scale_out;
   for (int o = 0; o + 1 < nout; ++o) a.outx[o] = extra[o];
   a.mc = mc; a.mc_stride = mc_stride;
+  if (eg) { a.xown = eg->xown; a.ldxo = eg->ldxo; a.own_scale = dst_scale; a.eg0 = eg->eg0; a.eg1 = eg->eg1; }
 
   const bool use_plan = plan && plan->n_units > 0;
   const bool has_segs = use_plan && plan->n_seg > 0;
@@ -679,6 +674,7 @@ static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x
       spec->param_mode != STAG_PARAM_PER_EDGE1)
     vec = vec && aligned16(spec->p0) && (!spec->p1 || aligned16(spec->p1));
   if (has_segs) vec = vec && aligned16(plan->workspace);
+  if (eg) vec = vec && aligned16(eg->xown) && (eg->ldxo % 4 == 0);
 
   hipStream_t s = (hipStream_t)stream;
   auto launch = [&](const AggArgs& args) -> hipError_t {
@@ -743,6 +739,21 @@ int stag_agg_bwd(const stag_csr* csr_t, const stag_plan* plan_t, const float* g,
   float* extra[2] = {dp0_rows, dp1_rows};
   return agg_common(csr_t, plan_t, g, ldg, D, spec, STAG_REDUCE_SUM, g_scale, row_scale, dx, ldo, nullptr,
                     dp0_rows ? 3 : 1, extra, 0, 0, stream);
+}
+
+int stag_agg_bwd_edge(const stag_csr* csr_t, const stag_plan* plan_t, const float* g, int64_t ldg,
+                      int32_t D, const stag_noise_spec* spec, const float* g_scale,
+                      const float* row_scale, const float* x, int64_t ldx, float* dx, int64_t ldo,
+                      float* dp0_edge, float* dp1_edge, void* stream) {
+  if (!spec || !csr_t || !x || !dp0_edge || ldx < D) return STAG_EINVAL;
+  if (spec->kind != STAG_NOISE_NORMAL && spec->kind != STAG_NOISE_UNIFORM) return STAG_EINVAL;
+  if (spec->param_mode != STAG_PARAM_PER_EDGE1 || spec->in_norm || spec->deriv) return STAG_EINVAL;
+  // the parameters and their gradients live at edge ids, the noise at forward positions
+  if (csr_t->n_edges > 0 && (!csr_t->nidx || !csr_t->eid)) return STAG_EINVAL;
+  if (D > 256) return STAG_ENOSYS;      // the channel sum of an edge is one team sum: one channel tile
+  const EdgeGradOut eg{x, ldx, dp0_edge, dp1_edge};
+  return agg_common(csr_t, plan_t, g, ldg, D, spec, STAG_REDUCE_SUM, g_scale, row_scale, dx, ldo, nullptr,
+                    1, nullptr, 0, 0, stream, &eg);
 }
 
 // plan fields the unit-walking auxiliary kernels need

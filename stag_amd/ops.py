@@ -196,6 +196,29 @@ def _agg_bwd_raw(csrv_t, g, D, spec, g_scale, row_scale, seg_len, want_dp):
     return dx, t0, t1
 
 
+def _agg_bwd_edge_raw(csrv_t, g, x, D, spec, g_scale, row_scale, seg_len, want_dx=True):
+    """One stag_agg_bwd_edge launch on the source-major CSR: dx (if wanted) and the gradients of the
+    [E, 1] parameter pair of every edge, by edge id.  None when the shape has no one-pass form
+    (D > 256: the caller takes stag_agg_bwd + stag_agg_bwd_w)."""
+    if D > 256:
+        return None
+    dev = _lib.require_device(g, x, csrv_t.indptr, g_scale, row_scale)
+    dx = torch.empty((csrv_t.n_dst, D), dtype=torch.float32, device=dev) if want_dx else None
+    e0 = torch.empty((csrv_t.n_edges, 1), dtype=torch.float32, device=dev)
+    e1 = torch.empty_like(e0)
+    plan_t = csrv_t.plan(seg_len)
+    nbytes = _lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], D, 0) if plan_t is not None else 0
+    plan_c, _keep = _plan_struct(csrv_t, seg_len, 1, nbytes, dev)
+    cs = csrv_t.struct()
+    with _lib.on_device(dev):
+        rc = _lib.lib().stag_agg_bwd_edge(
+            C.byref(cs), C.byref(plan_c) if plan_c is not None else None, _lib.ptr(g), g.stride(0), D,
+            C.byref(spec), _lib.ptr(g_scale), _lib.ptr(row_scale), _lib.ptr(x), x.stride(0),
+            _lib.ptr(dx), D, _lib.ptr(e0), _lib.ptr(e1), _lib.stream_of(dev))
+    _lib.check(rc, "stag_agg_bwd_edge")
+    return dx, e0, e1
+
+
 def coldot(x, t0, t1=None):
     """out_i[k] = sum_n x[n,k] * t_i[n,k]  (stag_coldot; no autograd — a backward-pass helper)."""
     dev = _lib.require_device(x, t0, t1)
@@ -418,6 +441,13 @@ class _AggregateVI(torch.autograd.Function):
                     _, n0, n1 = _agg_bwd_raw(graph.csr_t, q, D, spec, None, None, ctx.seg_len, True)
                     c0, c1 = c0 - n0.sum(0), c1 - n1.sum(0)
                 rows = {1: c0, 2: c1}
+        elif need_p and q is None and noise.param_mode == _lib.PARAM_PER_EDGE1 and D <= 256:
+            # [E, 1] (amortised) parameters: dx and both per-edge gradients from ONE transposed pass — the
+            # row of x an edge's gradient needs is the unit's own row there
+            dx, e0, e1 = _agg_bwd_edge_raw(graph.csr_t, g, x, D, spec_c, dvec, src_scale, ctx.seg_len,
+                                           want_dx=ctx.needs_input_grad[0])
+            rows = {1: e0, 2: e1}
+            need_p = False
         elif ctx.needs_input_grad[0]:
             dx, _, _ = _agg_bwd_raw(graph.csr_t, g, D, spec, dvec, src_scale, ctx.seg_len, False)
         if per_edge and need_p:

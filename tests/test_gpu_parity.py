@@ -630,3 +630,53 @@ def test_fuzz_gat_against_oracle_and_composed_backward(dev, oracle):
         for a_, b_, nm in zip(t, t2, ("d el", "d er", "d ft")):
             sc = max(1.0, float(b_.grad.abs().max()))
             assert_close(a_.grad / sc, (b_.grad / sc).cpu().numpy(), what=what + " " + nm)
+
+
+@pytest.mark.parametrize("kind,relu,logs", [("normal", False, False), ("normal", True, True), ("uniform", True, False)])
+@pytest.mark.parametrize("D", [1, 4, 12, 50, 100, 128, 256])
+def test_agg_bwd_edge_one_pass(dev, oracle, kind, relu, logs, D):
+    """stag_agg_bwd_edge: dx and the gradients of [E, 1] parameters from ONE pass over the source-major CSR
+    against the two-kernel statement (stag_agg_bwd for dx: bit for bit; stag_agg_bwd_w with reduce_k for the
+    per-edge sums) and against the oracle's dw/dp summed over the channels.  Widths that leave lanes of the
+    team idle (50, 100), a hub source row (segments), and the dx == NULL form included."""
+    from stag_amd import _lib, ops
+    import stag_amd
+    rng = np.random.default_rng(23)
+    n = 150
+    g = random_graph(n, 1500, seed=6, hub=300, device=dev)
+    E = g.number_of_edges()
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    gout = rng.standard_normal((n, D)).astype(np.float32)
+    gs = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    rs = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    p0 = rng.uniform(-0.3 if relu else 0.5, 1.0, (E, 1)).astype(np.float32)
+    p1 = rng.uniform(0.3, 0.9, (E, 1)).astype(np.float32)
+    if kind == "uniform":
+        p1 = p0 + p1 + 0.5
+    p1_in = np.log(p1) if logs else p1
+    xd, gd, gsd, rsd, p0d, p1d = (torch.from_numpy(a).to(dev) for a in (x, gout, gs, rs, p0, p1_in))
+    K = _lib.NOISE_NORMAL if kind == "normal" else _lib.NOISE_UNIFORM
+    noise = stag_amd.EdgeNoise(g, D, K, p0d, p1d, relu=relu, seed=3, offset=11, p1_log=logs)
+    spec = noise.spec()
+    spec = spec if not isinstance(spec, tuple) else ops._targs_to_ctypes(spec)
+    dx, e0, e1 = ops._agg_bwd_edge_raw(g.csr_t, gd, xd, D, spec, gsd, rsd, 32)
+    ref_dx, _, _ = ops._agg_bwd_raw(g.csr_t, gd, D, noise.spec(), gsd, rsd, 32, False)
+    assert_close(dx, ref_dx.cpu().numpy(), what="dx")
+    none_dx, f0, f1 = ops._agg_bwd_edge_raw(g.csr_t, gd, xd, D, spec, gsd, rsd, 32, want_dx=False)
+    assert none_dx is None and torch.equal(e0, f0) and torch.equal(e1, f1)
+    # the two-kernel statement: gradient rows scaled on the host, destination-major pass
+    gg = (gd * gsd.unsqueeze(1)).contiguous()
+    r0, r1 = ops._bwd_w_raw(g.csr, xd, gg, D, rsd, spec=spec, reduce_k=True, both=True, seg_len=32)
+    for got, ref, nm in ((e0, r0, "d p0"), (e1, r1, "d p1")):
+        sc = max(1.0, float(ref.abs().max()))
+        assert_close(got / sc, (ref / sc).cpu().numpy(), what=f"{nm} vs stag_agg_bwd_w")
+    # the oracle: dw/dp_i [E, D] rows, summed over the channels here
+    og = oracle_graph(oracle, g)
+    for deriv, got in ((1, e0), (2, e1)):
+        ospec = oracle.make_spec(kind, p0, p1_in, relu=relu, seed=3, offset=11, Dn=D, n_edges=E, deriv=deriv,
+                                 **({"p1_log": True} if logs else {}))
+        ref = oracle.agg_bwd_w(og, x, gout * gs[:, None], src_scale=rs, spec=ospec).astype(np.float64).sum(1, keepdims=True)
+        sc = max(1.0, float(np.abs(ref).max()))
+        assert_close(got / sc, ref / sc, what=f"deriv {deriv} vs oracle")
+    # wider than one channel tile: no one-pass form
+    assert ops._agg_bwd_edge_raw(g.csr_t, gd, xd, 300, spec, gsd, rsd, 32) is None
