@@ -317,6 +317,51 @@ int stag_coldot(const float* x, int64_t ldx, const float* t0, const float* t1, i
                 int64_t n_rows, int32_t D, float* out0, float* out1, void* workspace,
                 size_t workspace_bytes, void* stream);
 
+/* ---- amortised per-edge parameters with narrow heads ---------------------------------
+ * AmortizedDistribution(in_features, 1) — what every scripts/*_rec/run.py builds (scripts/arxiv_rec/gcn/run.py:85);
+ * hidden_features defaults to out_features = 1 (stag/distributions.py:158-159):
+ *     h_e   = SiLU(W_e [feat[src_e] || feat[dst_e]] + b_e)        stag/distributions.py:178-183, 225-227
+ *     par_c = W_c h_e + b_c   (c = loc, log_scale, ...)            stag/distributions.py:186-191, 229-231
+ *     KL(N(loc, exp(log_scale)) || prior).mean()                   stag/layers.py:132-145
+ * As dense torch these are GEMMs with 1-2 output columns and ~40 elementwise launches over [E, 1] tensors.
+ * Three small kernels instead, every reduction in a fixed order:
+ *
+ * stag_node_project_fwd   y [n_rows, C] = x [n_rows, K] . w [K, C] + b [C]   (b may be NULL), C <= 16.
+ *     W_e [feat_src || feat_dst] = feat W_src^T [src] + feat W_dst^T [dst]: with w = [W_src^T | W_dst^T]
+ *     (C = 2 hidden) ONE pass over feat yields both projected tables.
+ * stag_node_project_bwd   dx [n_rows, K] = gy . w^T (NULL: skipped), dw [K, C] = x^T . gy, db [C] = column sums of
+ *     gy, one pass over x; workspace >= stag_amort_workspace_bytes((K + 1) * C).
+ * stag_edge_mlp_fwd       par[c * n_edges + e] = b_c + sum_j SiLU(ps[src_e, j] + pd[dst_e, j]) wh[j, c];
+ *     ps / pd: the two projected tables, row stride ldp floats, hidden <= 8 columns each; wh [hidden, n_par],
+ *     n_par <= 4; one planar [n_edges] array per parameter (an [E, 1] tensor each, by edge id).
+ * stag_edge_mlp_bwd       from gpar (planar like par): dpre [n_edges, hidden] (d / d of the pre-activation; its
+ *     sums over the out-edges of a source / in-edges of a destination are the gradients of ps / pd — an
+ *     aggregation of explicit rows, stag_agg_fwd), dwh [hidden, n_par], dbh [n_par];
+ *     workspace >= stag_amort_workspace_bytes(36).
+ * stag_normal_kl_fwd/bwd  kl_mean = mean_i KL(N(loc_i, exp(log_scale_i)) || N(p_loc, p_scale)) and its gradients
+ *     (torch.distributions.kl._kl_normal_normal); p_loc, p_scale, kl_mean, g (the incoming gradient of kl_mean)
+ *     are ONE-element device arrays: no host round trip; dloc / dlog_scale [n] and dp_loc / dp_scale [1] may be
+ *     NULL; workspace >= stag_amort_workspace_bytes(2).                                                       */
+size_t stag_amort_workspace_bytes(int32_t n_values);
+int stag_node_project_fwd(const float* x, int64_t ldx, int64_t n_rows, int32_t K, const float* w,
+                          const float* b, int32_t C, float* y, void* stream);
+int stag_node_project_bwd(const float* x, int64_t ldx, int64_t n_rows, int32_t K, const float* w, int32_t C,
+                          const float* gy, float* dx, int64_t lddx, float* dw, float* db, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int stag_edge_mlp_fwd(const int32_t* src, const int32_t* dst, int64_t n_edges, const float* ps,
+                      const float* pd, int64_t ldp, int32_t hidden, const float* wh, const float* bh,
+                      int32_t n_par, float* par, void* stream);
+int stag_edge_mlp_bwd(const int32_t* src, const int32_t* dst, int64_t n_edges, const float* ps,
+                      const float* pd, int64_t ldp, int32_t hidden, const float* wh, int32_t n_par,
+                      const float* gpar, float* dpre, float* dwh, float* dbh, void* workspace,
+                      size_t workspace_bytes, void* stream);
+int stag_normal_kl_fwd(const float* loc, const float* log_scale, int64_t n, const float* p_loc,
+                       const float* p_scale, float* kl_mean, void* workspace, size_t workspace_bytes,
+                       void* stream);
+int stag_normal_kl_bwd(const float* loc, const float* log_scale, int64_t n, const float* p_loc,
+                       const float* p_scale, const float* g, float* dloc, float* dlog_scale, float* dp_loc,
+                       float* dp_scale, void* workspace, size_t workspace_bytes, void* stream);
+
 /* GAT edge attention with noisy logits + softmax + aggregation, one launch:
  *   e[p,h]  = w[p,h] * leaky_relu(el[u_p,h] + er[v,h])     stag/zoo/gat.py:114-119
  *   a[p,h]  = softmax over the in-edges of v                stag/zoo/gat.py:122

@@ -104,6 +104,16 @@ def lib():
                                C.POINTER(NoiseSpec), _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]
     l.stag_agg_bwd_edge.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, C.c_int64, C.c_int32,
                                     C.POINTER(NoiseSpec), _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, _vp]
+    l.stag_amort_workspace_bytes.restype = C.c_size_t
+    l.stag_amort_workspace_bytes.argtypes = [C.c_int32]
+    l.stag_node_project_fwd.argtypes = [_vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, C.c_int32, _vp, _vp]
+    l.stag_node_project_bwd.argtypes = [_vp, C.c_int64, C.c_int64, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int64,
+                                        _vp, _vp, _vp, C.c_size_t, _vp]
+    l.stag_edge_mlp_fwd.argtypes = [_vp, _vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int32, _vp, _vp, C.c_int32, _vp, _vp]
+    l.stag_edge_mlp_bwd.argtypes = [_vp, _vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int32, _vp, C.c_int32, _vp, _vp,
+                                    _vp, _vp, _vp, C.c_size_t, _vp]
+    l.stag_normal_kl_fwd.argtypes = [_vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_size_t, _vp]
+    l.stag_normal_kl_bwd.argtypes = [_vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]
     l.stag_coldot_workspace_bytes.restype = C.c_size_t
     l.stag_coldot_workspace_bytes.argtypes = [C.c_int32]
     l.stag_coldot.argtypes = [_vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, _vp,

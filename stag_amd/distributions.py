@@ -166,6 +166,24 @@ class AmortizedDistribution(Distribution):
         and the E-row work is two gathers — no [E, 2 in] concatenation, no E-row GEMM — and the
         gathers' backward is the aggregation kernel, not a scatter-add."""
         lin = self.embedding_mlp[0]
+        if feat.is_cuda and feat.dim() == 2 and isinstance(lin, torch.nn.Linear) and self._narrow(graph, lin):
+            # narrow heads — AmortizedDistribution(in, 1), hidden_features = 1 by default: what every
+            # scripts/*_rec/run.py builds — as three kernels: both projections of feat in ONE pass over it
+            # (w = [W_src^T | W_dst^T], the bias on the destination half), then a thread per edge for
+            # SiLU and the heads (ops.node_project / ops.edge_mlp, csrc/amort.hip)
+            from . import ops
+            k, hid = feat.shape[1], lin.out_features
+            w = torch.cat([lin.weight[:, :k].t(), lin.weight[:, k:].t()], 1)
+            b = None if lin.bias is None else torch.cat([torch.zeros_like(lin.bias), lin.bias])
+            heads = [self.parameters_mlp[n] for n in self.new_parameter_names]
+            wh = torch.cat([hd.weight for hd in heads], 0).t()
+            bs = [hd.bias for hd in heads]
+            bh = (None if all(t is None for t in bs) else
+                  torch.cat([t if t is not None else torch.zeros(1, device=feat.device) for t in bs]))
+            outs = ops.edge_mlp(graph, ops.node_project(feat, w, b), wh, bh)
+            self.new_parameters = dict(zip(self.new_parameter_names, outs))
+            self._base = None
+            return self
         if feat.is_cuda and feat.dim() == 2 and isinstance(lin, torch.nn.Linear):
             from . import ops
             k = feat.shape[1]
@@ -190,6 +208,17 @@ class AmortizedDistribution(Distribution):
         self.new_parameters = {k: self.parameters_mlp[k](h) for k in self.new_parameter_names}
         self._base = None
         return self
+
+    def _narrow(self, graph, lin):
+        """The three-kernel form applies: Sequential(Linear, SiLU), hidden <= 8, every head one column wide,
+        at most 4 heads, a whole graph (a node-range shard keeps the dense form)."""
+        from . import ops
+        mods = list(self.embedding_mlp)
+        heads = [self.parameters_mlp[n] for n in self.new_parameter_names]
+        return (len(mods) == 2 and type(mods[1]) is torch.nn.SiLU and lin.out_features <= ops.NARROW_MAX_HIDDEN
+                and len(heads) <= ops.NARROW_MAX_PAR
+                and all(isinstance(hd, torch.nn.Linear) and hd.out_features == 1 for hd in heads)
+                and hasattr(graph, "_src") and not getattr(graph, "is_shard", False))
 
     def arguments(self):
         if self.new_parameters is None:

@@ -312,6 +312,172 @@ def gather_rows(graph, x, which):
     return _GatherRows.apply(x, graph, which)
 
 
+# ---- amortised per-edge parameters with narrow heads (csrc/amort.hip) ---------------------------------------
+NARROW_MAX_HIDDEN, NARROW_MAX_PAR, NARROW_MAX_COLS = 8, 4, 16
+
+
+def _amort_ws(n_values, dev):
+    nbytes = _lib.lib().stag_amort_workspace_bytes(n_values)
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=dev), nbytes
+
+
+class _NodeProject(torch.autograd.Function):
+    """y = x [N, K] . w [K, C] + b for C <= 16 columns: one pass over x forward, one pass backward (dx, dw, db
+    together) — the library GEMMs take 75 us per call at N = 169,343, K = 128, C = 1 and run one such call per
+    projected column and per gradient (stag_node_project_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        dev = _lib.require_device(x, w, b)
+        x, w, b = _f32c(x), _f32c(w), _f32c(b)
+        n, K = x.shape
+        C_ = w.shape[1]
+        y = torch.empty((n, C_), dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            rc = _lib.lib().stag_node_project_fwd(_lib.ptr(x), x.stride(0), n, K, _lib.ptr(w), _lib.ptr(b), C_,
+                                                  _lib.ptr(y), _lib.stream_of(dev))
+        _lib.check(rc, "stag_node_project_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        dev = x.device
+        gy = _f32c(gy)
+        n, K = x.shape
+        C_ = w.shape[1]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        want_w = ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if dx is None and not want_w and not want_b:
+            return None, None, None
+        dw = torch.empty_like(w) if want_w else None
+        db = torch.empty(C_, dtype=torch.float32, device=dev) if want_b else None
+        ws, nbytes = _amort_ws((K + 1) * C_, dev)
+        with _lib.on_device(dev):
+            rc = _lib.lib().stag_node_project_bwd(_lib.ptr(x), x.stride(0), n, K, _lib.ptr(w), C_, _lib.ptr(gy),
+                                                  _lib.ptr(dx), K, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), nbytes,
+                                                  _lib.stream_of(dev))
+        _lib.check(rc, "stag_node_project_bwd")
+        return dx, dw, db
+
+
+def node_project(x, w, b=None):
+    """x [N, K] @ w [K, C] (+ b) for a handful of output columns (C <= 16)."""
+    if w.shape[1] > NARROW_MAX_COLS or not x.is_cuda or x.dim() != 2:
+        return node_linear(x, w, b)
+    return _NodeProject.apply(x, w, b)
+
+
+class _EdgeMlp(torch.autograd.Function):
+    """par_c[e] = b_c + sum_j SiLU(P[src_e, j] + P[dst_e, hidden + j]) wh[j, c]: the heads of an
+    AmortizedDistribution with narrow hidden / output widths (stag/distributions.py:178-191, 225-231) on the two
+    projected node tables, a thread per edge (stag_edge_mlp_fwd / _bwd).  Returns one [E, 1] tensor per head."""
+
+    @staticmethod
+    def forward(ctx, graph, P, wh, bh):
+        dev = _lib.require_device(P, wh, bh)
+        P, wh, bh = _f32c(P), _f32c(wh), _f32c(bh)
+        hidden, n_par = wh.shape
+        g = _owner(graph)
+        src, dst = g._src, g._dst
+        E = src.shape[0]
+        par = torch.empty((n_par, E), dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            rc = _lib.lib().stag_edge_mlp_fwd(_lib.ptr(src), _lib.ptr(dst), E, _lib.ptr(P), _lib.ptr(P[:, hidden:]),
+                                              P.stride(0), hidden, _lib.ptr(wh), _lib.ptr(bh), n_par, _lib.ptr(par),
+                                              _lib.stream_of(dev))
+        _lib.check(rc, "stag_edge_mlp_fwd")
+        ctx.graph = g
+        ctx.has_bias = bh is not None
+        ctx.save_for_backward(P, wh)
+        return tuple(par[c].unsqueeze(1) for c in range(n_par))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        P, wh = ctx.saved_tensors
+        g = ctx.graph
+        dev = P.device
+        hidden, n_par = wh.shape
+        src, dst = g._src, g._dst
+        E = src.shape[0]
+        gpar = torch.stack([_f32c(t).reshape(E) for t in gs], 0)
+        dpre = torch.empty((E, hidden), dtype=torch.float32, device=dev)
+        dwh = torch.empty_like(wh) if ctx.needs_input_grad[2] else None
+        dbh = torch.empty(n_par, dtype=torch.float32, device=dev) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+        ws, nbytes = _amort_ws(NARROW_MAX_HIDDEN * NARROW_MAX_PAR + NARROW_MAX_PAR, dev)
+        with _lib.on_device(dev):
+            rc = _lib.lib().stag_edge_mlp_bwd(_lib.ptr(src), _lib.ptr(dst), E, _lib.ptr(P), _lib.ptr(P[:, hidden:]),
+                                              P.stride(0), hidden, _lib.ptr(wh), n_par, _lib.ptr(gpar), _lib.ptr(dpre),
+                                              _lib.ptr(dwh), _lib.ptr(dbh), _lib.ptr(ws), nbytes, _lib.stream_of(dev))
+        _lib.check(rc, "stag_edge_mlp_bwd")
+        dP = None
+        if ctx.needs_input_grad[1]:
+            # d P[u, j] = sum over the out-edges of u, d P[v, hidden + j] = sum over the in-edges of v of dpre[e, j]:
+            # the aggregation kernel over explicit rows and one broadcast row of ones, written side by side
+            ones = torch.ones(hidden, dtype=torch.float32, device=dev)
+            spec = _explicit_spec(dpre)
+            d_src, _ = _agg_raw(g.csr_t, ones, hidden, spec, _lib.REDUCE_SUM, None, None, DEFAULT_SEG_LEN, broadcast_x=True)
+            d_dst, _ = _agg_raw(g.csr, ones, hidden, spec, _lib.REDUCE_SUM, None, None, DEFAULT_SEG_LEN, broadcast_x=True)
+            dP = torch.cat([d_src, d_dst], 1)
+        return None, dP, dwh, dbh
+
+
+def edge_mlp(graph, P, wh, bh=None):
+    """The per-edge heads of a narrow AmortizedDistribution: P [N, 2 hidden] (source half | destination half),
+    wh [hidden, n_par], bh [n_par]  ->  n_par tensors [E, 1] by edge id."""
+    return _EdgeMlp.apply(graph, P, wh, bh)
+
+
+class _NormalKlMean(torch.autograd.Function):
+    """mean over all elements of KL(N(loc, exp(log_scale)) || N(p_loc, p_scale)) with one-element prior parameters
+    (torch.distributions.kl._kl_normal_normal; stag/layers.py:132-145): one pass forward, one backward, against
+    ~25 elementwise passes over the [E, out] tensors (stag_normal_kl_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, loc, log_scale, p_loc, p_scale):
+        dev = _lib.require_device(loc, log_scale, p_loc, p_scale)
+        loc, log_scale = _f32c(loc), _f32c(log_scale)
+        p_loc, p_scale = _f32c(p_loc.reshape(1)), _f32c(p_scale.reshape(1))
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        ws, nbytes = _amort_ws(2, dev)
+        with _lib.on_device(dev):
+            rc = _lib.lib().stag_normal_kl_fwd(_lib.ptr(loc), _lib.ptr(log_scale), loc.numel(), _lib.ptr(p_loc),
+                                               _lib.ptr(p_scale), _lib.ptr(out), _lib.ptr(ws), nbytes, _lib.stream_of(dev))
+        _lib.check(rc, "stag_normal_kl_fwd")
+        ctx.save_for_backward(loc, log_scale, p_loc, p_scale)
+        ctx.shapes = (loc.shape, log_scale.shape)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        loc, log_scale, p_loc, p_scale = ctx.saved_tensors
+        dev = loc.device
+        g = _f32c(g.reshape(1))
+        need = ctx.needs_input_grad
+        dloc = torch.empty_like(loc) if need[0] else None
+        dls = torch.empty_like(log_scale) if need[1] else None
+        dpl = torch.empty(1, dtype=torch.float32, device=dev) if need[2] else None
+        dps = torch.empty(1, dtype=torch.float32, device=dev) if need[3] else None
+        ws, nbytes = _amort_ws(2, dev)
+        with _lib.on_device(dev):
+            rc = _lib.lib().stag_normal_kl_bwd(_lib.ptr(loc), _lib.ptr(log_scale), loc.numel(), _lib.ptr(p_loc),
+                                               _lib.ptr(p_scale), _lib.ptr(g), _lib.ptr(dloc), _lib.ptr(dls),
+                                               _lib.ptr(dpl), _lib.ptr(dps), _lib.ptr(ws), nbytes, _lib.stream_of(dev))
+        _lib.check(rc, "stag_normal_kl_bwd")
+        return dloc, dls, dpl, dps
+
+
+def normal_kl_mean(loc, log_scale, p_loc, p_scale):
+    """KL(N(loc, exp(log_scale)) || N(p_loc, p_scale)).mean(), loc / log_scale of one shape, the prior's two
+    parameters one-element tensors (their original shapes get their gradients back)."""
+    if loc.shape != log_scale.shape or p_loc.numel() != 1 or p_scale.numel() != 1 or loc.numel() == 0:
+        raise ValueError("normal_kl_mean: same-shape loc / log_scale and a one-element prior")
+    return _NormalKlMean.apply(loc, log_scale, p_loc, p_scale)
+
+
 def _bwd_w_raw(csrv, x, g, D, src_scale, broadcast_x=False, spec=None, reduce_k=False, both=False,
                seg_len=DEFAULT_SEG_LEN):
     """stag_agg_bwd_w over the plan's units.  both=True: (d/dp0, d/dp1) of a Normal | Uniform spec

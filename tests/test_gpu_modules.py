@@ -985,3 +985,135 @@ def test_sage_pool_and_max_reducer(dev):
                                                          include_self=False)
     assert torch.equal(gl.dstdata["o"], want)
     assert (gl.dstdata["o"][g.in_degrees() == 0] == 0).all()
+
+
+# ---- amortised per-edge parameters with narrow heads (csrc/amort.hip) ----------------------------------------
+
+@pytest.mark.parametrize("n,K,C", [(0, 8, 2), (1, 1, 1), (1000, 9, 2), (5000, 128, 2), (3000, 50, 4), (2000, 256, 8),
+                                   (700, 1433, 16), (40000, 128, 3)])
+def test_node_project(dev, n, K, C):
+    """stag_node_project_fwd / _bwd: y = x w + b, and (dx, dw, db) from one pass, against float64 torch."""
+    from stag_amd import ops
+    rng = np.random.default_rng(3)
+    x = torch.tensor(rng.standard_normal((n, K)).astype(np.float32), device=dev, requires_grad=True)
+    w = torch.tensor((rng.standard_normal((K, C)) / np.sqrt(K)).astype(np.float32), device=dev, requires_grad=True)
+    b = torch.tensor(rng.standard_normal(C).astype(np.float32), device=dev, requires_grad=True)
+    gy = torch.tensor(rng.standard_normal((n, C)).astype(np.float32), device=dev)
+    y = ops.node_project(x, w, b)
+    y.backward(gy)
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    ref = xd @ wd + bd
+    ref.backward(gy.double())
+    assert_close(y, ref.detach().cpu().numpy(), what="y")
+    assert_close(x.grad, xd.grad.cpu().numpy(), what="dx")
+    for got, r, nm in ((w.grad, wd.grad, "dw"), (b.grad, bd.grad, "db")):
+        sc = max(1.0, float(r.abs().max()))
+        assert_close(got / sc, (r / sc).cpu().numpy(), what=nm)
+    if n:
+        # no bias, no dx; and twice the same bits
+        w2 = w.detach().clone().requires_grad_(True)
+        y2 = ops.node_project(x.detach(), w2)
+        y2.backward(gy)
+        assert_close(y2, (xd.detach() @ wd.detach()).cpu().numpy(), what="y, no bias")
+        assert torch.equal(w2.grad, w.grad)
+
+
+@pytest.mark.parametrize("hidden,n_par", [(1, 2), (1, 1), (2, 2), (3, 4), (8, 2)])
+def test_edge_mlp(dev, hidden, n_par):
+    """stag_edge_mlp_fwd / _bwd against the reference's dataflow in float64: SiLU(P_src[src] + P_dst[dst]) then
+    one Linear(hidden -> 1) per parameter (stag/distributions.py:178-191, 225-231), with gradients to the
+    projected tables and to the heads; hub rows on both sides."""
+    from stag_amd import ops
+    from util import random_graph
+    rng = np.random.default_rng(8)
+    n = 300
+    g = random_graph(n, 4000, seed=12, hub=500, device=dev)
+    src, dst = g.edges()
+    E = g.number_of_edges()
+    P = torch.tensor(rng.standard_normal((n, 2 * hidden)).astype(np.float32), device=dev, requires_grad=True)
+    wh = torch.tensor(rng.standard_normal((hidden, n_par)).astype(np.float32), device=dev, requires_grad=True)
+    bh = torch.tensor(rng.standard_normal(n_par).astype(np.float32), device=dev, requires_grad=True)
+    gs = [torch.tensor(rng.standard_normal((E, 1)).astype(np.float32), device=dev) for _ in range(n_par)]
+    outs = ops.edge_mlp(g, P, wh, bh)
+    assert len(outs) == n_par and all(o.shape == (E, 1) for o in outs)
+    torch.autograd.backward(outs, gs)
+    Pd, whd, bhd = (t.detach().double().requires_grad_(True) for t in (P, wh, bh))
+    h = torch.nn.functional.silu(Pd[src, :hidden] + Pd[dst, hidden:])
+    ref = h @ whd + bhd
+    ref.backward(torch.cat(gs, 1).double())
+    for c in range(n_par):
+        assert_close(outs[c], ref[:, c:c + 1].detach().cpu().numpy(), what=f"head {c}")
+    for got, r, nm in ((P.grad, Pd.grad, "dP"), (wh.grad, whd.grad, "dwh"), (bh.grad, bhd.grad, "dbh")):
+        sc = max(1.0, float(r.abs().max()))
+        assert_close(got / sc, (r / sc).cpu().numpy(), what=nm)
+
+
+@pytest.mark.parametrize("shape", [(5000, 1), (700, 16)])
+@pytest.mark.parametrize("learn_prior", [False, True])
+def test_normal_kl_mean(dev, shape, learn_prior):
+    """stag_normal_kl_fwd / _bwd against torch.distributions.kl_divergence(...).mean() in float64
+    (stag/layers.py:132-145), gradients to the heads and — when it is learned — to the prior."""
+    from stag_amd import ops
+    rng = np.random.default_rng(4)
+    loc = torch.tensor(rng.normal(1.0, 0.4, shape).astype(np.float32), device=dev, requires_grad=True)
+    ls = torch.tensor(rng.normal(-1.0, 0.5, shape).astype(np.float32), device=dev, requires_grad=True)
+    pl = torch.tensor(0.8, device=dev, requires_grad=learn_prior)
+    pls = torch.tensor(-0.4, device=dev, requires_grad=learn_prior)
+    kl = ops.normal_kl_mean(loc, ls, pl, pls.exp())
+    (kl * 1.7).backward()
+    N = torch.distributions.Normal
+    locd, lsd, pld, plsd = (t.detach().double().requires_grad_(t.requires_grad) for t in (loc, ls, pl, pls))
+    ref = torch.distributions.kl_divergence(N(locd, lsd.exp()), N(pld, plsd.exp())).mean()
+    (ref * 1.7).backward()
+    assert_close(kl, ref.detach().cpu().numpy(), what="kl")
+    n = loc.numel()
+    assert_close(loc.grad * n, (locd.grad * n).cpu().numpy(), what="d loc")
+    assert_close(ls.grad * n, (lsd.grad * n).cpu().numpy(), what="d log_scale")
+    if learn_prior:
+        assert_close(pl.grad, pld.grad.cpu().numpy(), what="d prior loc")
+        assert_close(pls.grad, plsd.grad.cpu().numpy(), what="d prior log_scale")
+
+
+@pytest.mark.parametrize("hidden", [None, 4])
+def test_narrow_amortized_distribution_equals_dense_dataflow(dev, hidden):
+    """AmortizedDistribution(in, 1) on a HIP device takes the three-kernel form (ops.node_project, ops.edge_mlp);
+    its parameters and every gradient equal the reference's dataflow — cat([feat[src], feat[dst]]), Linear, SiLU,
+    one Linear per head (stag/distributions.py:221-233) — evaluated in float64; and StagLayer.kl_divergence of the
+    pair equals torch's closed form."""
+    import copy
+    import stag_amd
+    from stag_amd.distributions import AmortizedDistribution
+    from util import random_graph
+    n, D = 200, 24
+    g = random_graph(n, 2500, seed=3, hub=300, device=dev)
+    src, dst = g.edges()
+    torch.manual_seed(2)
+    q = AmortizedDistribution(D, 1, hidden_features=hidden, init_like=torch.distributions.Normal(1.0, 0.3)).to(dev)
+    for p in q.parameters():       # the default heads are near-constant: make every weight matter
+        torch.nn.init.normal_(p, 0.0, 0.5)
+    qd = copy.deepcopy(q).double()
+    x = torch.randn(n, D, device=dev, requires_grad=True)
+    xd = x.detach().double().requires_grad_(True)
+    q.condition(g, x)
+    assert q.new_parameters["loc"].grad_fn is not None and "EdgeMlp" in type(q.new_parameters["loc"].grad_fn).__name__
+    h = qd.embedding_mlp(torch.cat([xd[src], xd[dst]], -1))
+    ref = {k: qd.parameters_mlp[k](h) for k in qd.new_parameter_names}
+    gl, gs = torch.randn(g.number_of_edges(), 1, device=dev), torch.randn(g.number_of_edges(), 1, device=dev)
+    (q.new_parameters["loc"] * gl + q.new_parameters["log_scale"] * gs).sum().backward()
+    (ref["loc"] * gl.double() + ref["log_scale"] * gs.double()).sum().backward()
+    for k in ("loc", "log_scale"):
+        assert_close(q.new_parameters[k], ref[k].detach().cpu().numpy(), what=k)
+    sc = max(1.0, float(xd.grad.abs().max()))
+    assert_close(x.grad / sc, (xd.grad / sc).cpu().numpy(), what="d feat")
+    for (k, p), (_, pd) in zip(q.named_parameters(), qd.named_parameters()):
+        sc = max(1.0, float(pd.grad.abs().max()))
+        assert_close(p.grad / sc, (pd.grad / sc).cpu().numpy(), what=f"d {k}")
+    # the layer's KL term
+    layer = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(D, 8), q_a=q, vi=True).to(dev)
+    layer(g, x.detach())
+    kl = layer.kl_divergence()
+    assert "NormalKlMean" in type(kl.grad_fn).__name__
+    ref_kl = torch.distributions.kl_divergence(layer.q_a.base_distribution, layer.p_a.base_distribution).mean()
+    assert_close(kl, ref_kl.detach().cpu().numpy(), what="layer KL")
+    kl.backward()
+    assert layer.p_a.loc.grad is not None and layer.q_a.parameters_mlp["log_scale"].weight.grad is not None

@@ -48,8 +48,8 @@ def step():
     layer.zero_grad(set_to_none=True)
     xg.grad = None
     y = layer(g, xg)
-    if args.kl:
-        ((y * gout).sum() + layer.kl_divergence()).backward()
+    if args.kl:      # d loss = <gout, dy> + d kl, without an [N, D] product on the way
+        torch.autograd.backward([y, layer.kl_divergence()], [gout, torch.ones((), device=dev)])
     else:
         y.backward(gout)
 
