@@ -343,6 +343,16 @@ int stag_coldot(const float* x, int64_t ldx, const float* t0, const float* t1, i
  *     are ONE-element device arrays: no host round trip; dloc / dlog_scale [n] and dp_loc / dp_scale [1] may be
  *     NULL; workspace >= stag_amort_workspace_bytes(2).                                                       */
 size_t stag_amort_workspace_bytes(int32_t n_values);
+/* Per-head dots of a [n_rows, G * F] matrix with C <= 2 vectors w [C][G * F]:
+ *     y[c][n][g] = sum_f x[n, g F + f] * w[c][g F + f]
+ * GAT's el / er = (ft * attn_l).sum(-1), (ft * attn_r).sum(-1) (stag/zoo/gat.py:109-110) from ONE pass over ft; the
+ * backward (dx [n_rows, G F] = sum_c gy[c][n][g] w[c][k]; dw [C][G F] = sum_n gy[c][n][g] x[n, k]) from one pass too.
+ * F a power of two in [4, 256]; rows 16-byte aligned; workspace >= stag_amort_workspace_bytes(C * G * F).       */
+int stag_head_dot_fwd(const float* x, int64_t ldx, int64_t n_rows, int32_t G, int32_t F, const float* w, int32_t C,
+                      float* y, void* stream);
+int stag_head_dot_bwd(const float* x, int64_t ldx, int64_t n_rows, int32_t G, int32_t F, const float* w, int32_t C,
+                      const float* gy, float* dx, int64_t lddx, float* dw, void* workspace,
+                      size_t workspace_bytes, void* stream);
 int stag_node_project_fwd(const float* x, int64_t ldx, int64_t n_rows, int32_t K, const float* w,
                           const float* b, int32_t C, float* y, void* stream);
 int stag_node_project_bwd(const float* x, int64_t ldx, int64_t n_rows, int32_t K, const float* w, int32_t C,

@@ -106,6 +106,9 @@ def lib():
                                     C.POINTER(NoiseSpec), _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, _vp]
     l.stag_amort_workspace_bytes.restype = C.c_size_t
     l.stag_amort_workspace_bytes.argtypes = [C.c_int32]
+    l.stag_head_dot_fwd.argtypes = [_vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp]
+    l.stag_head_dot_bwd.argtypes = [_vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp,
+                                    C.c_int64, _vp, _vp, C.c_size_t, _vp]
     l.stag_node_project_fwd.argtypes = [_vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, C.c_int32, _vp, _vp]
     l.stag_node_project_bwd.argtypes = [_vp, C.c_int64, C.c_int64, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int64,
                                         _vp, _vp, _vp, C.c_size_t, _vp]

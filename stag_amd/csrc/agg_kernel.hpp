@@ -506,7 +506,7 @@ struct AggTeam {
             if (a.eg1) a.eg1[I.ee[j]] = e1;
           }
         }
-        if (a.in_norm) {
+        if (PEDGE != 3 && a.in_norm) {                   // (stag_agg_bwd_edge: in_norm 0, checked on the host)
           asm volatile("" ::: "memory");
 #pragma unroll
           for (int q = 0; q < 4; ++q) wsum[q] += w[q];   // edge order; 0/1 draws (Bernoulli + norm): exact
@@ -616,7 +616,12 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   static_assert(NOUT == 1 || SLOTS == 1, "the derivative outputs take the one-slot loop");
   // edges per block: the RNG kinds are VALU-bound and register-hungry, the others want
   // more rows in flight
-  constexpr int BLK = (KIND >= kNormal) ? STAG_BLK_RNG : STAG_BLK_MEM;
+  // with the per-edge gradients one edge per block: 66 VGPRs = 7 waves per SIMD instead of 76 = 6 (the layer step
+  // of tools/layer_step.py --mode re --kl: 988 against 1019 us)
+#ifndef STAG_BLK_EG
+#define STAG_BLK_EG 1
+#endif
+  constexpr int BLK = PEDGE == 3 ? STAG_BLK_EG : (KIND >= kNormal) ? STAG_BLK_RNG : STAG_BLK_MEM;
   constexpr int NB = BLK * MULT;
 
   const uint32_t chunk = blockIdx.y * LPE + c;
@@ -788,7 +793,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   const uint32_t woff = (uint32_t)slot * ((uint32_t)a.ws_stride * 4u) + (uint32_t)k0 * 4u;
   if (sl == 0) {
     store4_sc1(rws, woff, k0, a.D, VEC, T.acc);
-    if (a.in_norm) store4_sc1(rws, woff + (uint32_t)a.D * 4u, k0, a.D, VEC, T.wsum);
+    if (PEDGE != 3 && a.in_norm) store4_sc1(rws, woff + (uint32_t)a.D * 4u, k0, a.D, VEC, T.wsum);
     if constexpr (NOUT > 1) {
 #pragma unroll
       for (int o = 0; o < NOUT - 1; ++o)
@@ -825,7 +830,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   float facc[4], fws[4] = {0.f, 0.f, 0.f, 0.f};
   const int slot0 = lane0 + (c << 2);   // slot 0's lane of my channels
   two_level_sum<NF, VEC, LPE, SLOTS>(a.ws, a.ws_stride, s0, s1, k0, a.D, sl, slot0, facc);
-  if (a.in_norm) two_level_sum<NF, VEC, LPE, SLOTS>(a.ws + a.D, a.ws_stride, s0, s1, k0, a.D, sl, slot0, fws);
+  if (PEDGE != 3 && a.in_norm) two_level_sum<NF, VEC, LPE, SLOTS>(a.ws + a.D, a.ws_stride, s0, s1, k0, a.D, sl, slot0, fws);
   if (sl != 0) return;
   agg_epilogue(a, row, deg, k0, VEC, facc, fws);
 #pragma unroll

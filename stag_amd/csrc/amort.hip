@@ -180,6 +180,108 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const float* part, in
   else if (out1) out1[i - n0] = s;
 }
 
+// ---- per-head dots: y[c][n][g] = sum_f x[n, g F + f] w[c][g F + f]  (GAT's el / er, stag/zoo/gat.py:109-110) ------
+// The block-diagonal special case of node_project: a lane's 4 columns belong to ONE head, so a row costs CG dots
+// per lane and a sum over the F / 4 lanes of the head.  Same team / row walk as above.
+__device__ __forceinline__ float lanes_sum(float v, int nl) {     // aligned groups of nl = 2^i lanes, all alive
+  if (nl > 1) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  if (nl > 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  if (nl > 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+  if (nl > 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+  if (nl > 16) v += __shfl_xor(v, 16);
+  if (nl > 32) v += __shfl_xor(v, 32);
+  return v;
+}
+
+template <int LPE, int CG>
+__global__ __launch_bounds__(256) void head_dot_fwd_kernel(const float* x, int64_t ldx, int n, int K, int F,
+                                                           const float* w, float* y) {
+  constexpr int R = kFwdRows;
+  const int c = threadIdx.x % LPE;
+  const int row0 = (blockIdx.x * (256 / LPE) + threadIdx.x / LPE) * R;
+  const int G = K / F, gl = F >> 2;                 // heads; lanes per head
+  for (int kt = 0; kt < K; kt += LPE * 4) {
+    const int k0 = kt + c * 4;
+    const bool in = k0 < K;
+    float wv[CG][4], xv[R][4];
+#pragma unroll
+    for (int cc = 0; cc < CG; ++cc) {
+      wv[cc][0] = wv[cc][1] = wv[cc][2] = wv[cc][3] = 0.f;
+      if (in) load4(w + (int64_t)cc * K, k0, K, true, wv[cc]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      xv[r][0] = xv[r][1] = xv[r][2] = xv[r][3] = 0.f;
+      if (row0 + r < n && in) load4(x + (int64_t)(row0 + r) * ldx, k0, K, true, xv[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int cc = 0; cc < CG; ++cc) {
+        float d = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d = __builtin_fmaf(xv[r][q], wv[cc][q], d);
+        d = lanes_sum(d, gl);
+        if (in && row0 + r < n && (c % gl) == 0) y[((int64_t)cc * n + (row0 + r)) * G + k0 / F] = d;
+      }
+  }
+}
+
+// dx[n, k] = sum_c gy[c][n][g(k)] w[c][k];  dw[c][k] = sum_n gy[c][n][g(k)] x[n, k]: one pass over x
+template <int LPE, int CG>
+__global__ __launch_bounds__(256) void head_dot_bwd_kernel(const float* x, int64_t ldx, int n, int K, int F,
+                                                           const float* w, const float* gy, float* dx, int64_t lddx,
+                                                           float* part) {
+  constexpr int TEAMS = 256 / LPE;
+  __shared__ float s_red[TEAMS][LPE * 4 * CG];
+  const int c = threadIdx.x % LPE, tm = threadIdx.x / LPE;
+  const int T = gridDim.x * TEAMS;
+  const int t0 = blockIdx.x * TEAMS + tm;
+  const int G = K / F;
+  float* mypart = part + (int64_t)blockIdx.x * CG * K;
+  for (int kt = 0; kt < K; kt += LPE * 4) {
+    const int k0 = kt + c * 4;
+    const bool in = k0 < K;
+    const int g = in ? k0 / F : 0;
+    float wv[CG][4], dwacc[CG][4];
+#pragma unroll
+    for (int cc = 0; cc < CG; ++cc) {
+      wv[cc][0] = wv[cc][1] = wv[cc][2] = wv[cc][3] = 0.f;
+      if (in) load4(w + (int64_t)cc * K, k0, K, true, wv[cc]);
+      dwacc[cc][0] = dwacc[cc][1] = dwacc[cc][2] = dwacc[cc][3] = 0.f;
+    }
+    if (in) {
+      for (int row = t0; row < n; row += T) {
+        float gv[CG], xv[4], d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < CG; ++cc) gv[cc] = gy[((int64_t)cc * n + row) * G + g];
+        load4(x + (int64_t)row * ldx, k0, K, true, xv);
+#pragma unroll
+        for (int cc = 0; cc < CG; ++cc)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            d[q] = __builtin_fmaf(gv[cc], wv[cc][q], d[q]);
+            dwacc[cc][q] = __builtin_fmaf(gv[cc], xv[q], dwacc[cc][q]);
+          }
+        if (dx) stag::store4(dx + (int64_t)row * lddx, k0, K, true, d);
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < CG; ++cc)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s_red[tm][(cc * LPE + c) * 4 + q] = dwacc[cc][q];
+    __syncthreads();
+    for (int i = threadIdx.x; i < LPE * 4 * CG; i += 256) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < TEAMS; ++j) s += s_red[j][i];
+      const int cc = i / (LPE * 4), k = kt + i % (LPE * 4);
+      if (k < K) mypart[(int64_t)cc * K + k] = s;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- per-edge heads -----------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
 
@@ -405,6 +507,70 @@ int stag_node_project_bwd(const float* x, int64_t ldx, int64_t n_rows, int32_t K
   STAG_NP_DISPATCH(node_project_bwd_kernel, lpe, ct, dim3(nb), s, x, ldx, (int)n_rows, K, w, C, gy, vec, dx, lddx, part);
   hipLaunchKernelGGL(reduce_final_kernel, dim3(nv), dim3(256), 0, s, part, nb, nv, dw, K * C, db,
                      (const float*)nullptr, 1.0f);
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}
+
+int stag_head_dot_fwd(const float* x, int64_t ldx, int64_t n_rows, int32_t G, int32_t F, const float* w, int32_t C,
+                      float* y, void* stream) {
+  if (n_rows < 0 || G <= 0 || F < 4 || F > 256 || (F & (F - 1)) != 0 || C < 1 || C > 2 || n_rows >= (1ll << 31))
+    return STAG_EINVAL;
+  if (n_rows == 0) return STAG_OK;
+  const int K = G * F;
+  if (!x || !w || !y || ldx < K || ldx % 4 != 0 || !aligned16(x) || !aligned16(w)) return STAG_EINVAL;
+  const int lpe = lpe_for(K, 1) < F / 4 ? F / 4 : lpe_for(K, 1);
+  const int64_t rows_per_block = (int64_t)(256 / lpe) * kFwdRows;
+  const dim3 grid((unsigned)((n_rows + rows_per_block - 1) / rows_per_block));
+  hipStream_t s = (hipStream_t)stream;
+#define STAG_HD_FWD(L)                                                                                          \
+  do {                                                                                                          \
+    if (C == 1) hipLaunchKernelGGL((head_dot_fwd_kernel<L, 1>), grid, dim3(256), 0, s, x, ldx, (int)n_rows, K, F, w, y); \
+    else        hipLaunchKernelGGL((head_dot_fwd_kernel<L, 2>), grid, dim3(256), 0, s, x, ldx, (int)n_rows, K, F, w, y); \
+  } while (0)
+  switch (lpe) {
+    case 8: STAG_HD_FWD(8); break;
+    case 16: STAG_HD_FWD(16); break;
+    case 32: STAG_HD_FWD(32); break;
+    default: STAG_HD_FWD(64); break;
+  }
+#undef STAG_HD_FWD
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}
+
+int stag_head_dot_bwd(const float* x, int64_t ldx, int64_t n_rows, int32_t G, int32_t F, const float* w, int32_t C,
+                      const float* gy, float* dx, int64_t lddx, float* dw, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+  if (n_rows < 0 || G <= 0 || F < 4 || F > 256 || (F & (F - 1)) != 0 || C < 1 || C > 2 || n_rows >= (1ll << 31))
+    return STAG_EINVAL;
+  if (!dx && !dw) return STAG_EINVAL;
+  const int K = G * F, nv = C * K;
+  hipStream_t s = (hipStream_t)stream;
+  if (n_rows == 0) {
+    if (dw && hipMemsetAsync(dw, 0, sizeof(float) * nv, s) != hipSuccess) return STAG_EIO;
+    return STAG_OK;
+  }
+  if (!x || !w || !gy || ldx < K || ldx % 4 != 0 || !aligned16(x) || !aligned16(w)) return STAG_EINVAL;
+  if (dx && (lddx < K || lddx % 4 != 0 || !aligned16(dx))) return STAG_EINVAL;
+  const int lpe = lpe_for(K, 1) < F / 4 ? F / 4 : lpe_for(K, 1);
+  int nb = kRedBlocks;
+  while (nb > 16 && (size_t)nb * nv * sizeof(float) > (32u << 20)) nb >>= 1;
+  while (nb > 1 && (int64_t)(nb / 2) * (256 / lpe) >= n_rows) nb >>= 1;
+  if (!workspace || workspace_bytes < (size_t)nb * nv * sizeof(float)) return STAG_ENOMEM;
+  float* part = static_cast<float*>(workspace);
+#define STAG_HD_BWD(L)                                                                                          \
+  do {                                                                                                          \
+    if (C == 1) hipLaunchKernelGGL((head_dot_bwd_kernel<L, 1>), dim3(nb), dim3(256), 0, s, x, ldx, (int)n_rows, K, F, w, gy, dx, lddx, part); \
+    else        hipLaunchKernelGGL((head_dot_bwd_kernel<L, 2>), dim3(nb), dim3(256), 0, s, x, ldx, (int)n_rows, K, F, w, gy, dx, lddx, part); \
+  } while (0)
+  switch (lpe) {
+    case 8: STAG_HD_BWD(8); break;
+    case 16: STAG_HD_BWD(16); break;
+    case 32: STAG_HD_BWD(32); break;
+    default: STAG_HD_BWD(64); break;
+  }
+#undef STAG_HD_BWD
+  if (dw)
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(nv), dim3(256), 0, s, part, nb, nv, dw, nv, (float*)nullptr,
+                       (const float*)nullptr, 1.0f);
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }
 

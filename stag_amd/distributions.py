@@ -210,7 +210,7 @@ class AmortizedDistribution(Distribution):
         return self
 
     def _narrow(self, graph, lin):
-        """The three-kernel form applies: Sequential(Linear, SiLU), hidden <= 8, every head one column wide,
+        """The three-kernel form applies: Sequential(Linear, SiLU), hidden <= 4, every head one column wide,
         at most 4 heads, a whole graph (a node-range shard keeps the dense form)."""
         from . import ops
         mods = list(self.embedding_mlp)

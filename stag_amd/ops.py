@@ -256,7 +256,9 @@ class _NodeLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        dx = g @ w.t() if ctx.needs_input_grad[0] else None
+        # g @ w^T as an NN product on a transposed copy of w (64 KB): 75 against 92 us for the NT form at
+        # N = 169,343, 128 x 128 (tools/gemm_probe.py)
+        dx = g @ w.t().contiguous() if ctx.needs_input_grad[0] else None
         db = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         dw = None
         if ctx.needs_input_grad[1]:
@@ -313,7 +315,9 @@ def gather_rows(graph, x, which):
 
 
 # ---- amortised per-edge parameters with narrow heads (csrc/amort.hip) ---------------------------------------
-NARROW_MAX_HIDDEN, NARROW_MAX_PAR, NARROW_MAX_COLS = 8, 4, 16
+# MI355X, N = 169,343, K = 128, forward + backward: 122 | 125 | 137 | 238 us for 2 | 4 | 8 | 16 columns against
+# 193-273 us for the library GEMMs: the one-pass kernels take up to 8 columns (the library builds them for 16)
+NARROW_MAX_HIDDEN, NARROW_MAX_PAR, NARROW_MAX_COLS = 4, 4, 8
 
 
 def _amort_ws(n_values, dev):
@@ -365,10 +369,61 @@ class _NodeProject(torch.autograd.Function):
 
 
 def node_project(x, w, b=None):
-    """x [N, K] @ w [K, C] (+ b) for a handful of output columns (C <= 16)."""
+    """x [N, K] @ w [K, C] (+ b) for a handful of output columns (C <= 8; wider: node_linear)."""
     if w.shape[1] > NARROW_MAX_COLS or not x.is_cuda or x.dim() != 2:
         return node_linear(x, w, b)
     return _NodeProject.apply(x, w, b)
+
+
+class _HeadDot(torch.autograd.Function):
+    """(ft * attn_l).sum(-1) and (ft * attn_r).sum(-1) — GAT's el / er (stag/zoo/gat.py:109-110) — from one pass over
+    ft [N, H, F], and d ft, d attn_l, d attn_r from one pass back (stag_head_dot_fwd / _bwd).  As elementwise
+    multiply + reduce: 2 x 242 us at cfg5 and as much again backward; as a GEMM with a block-diagonal right side:
+    53 + 168 + 47 us in the library."""
+
+    @staticmethod
+    def forward(ctx, ft, al, ar):
+        dev = _lib.require_device(ft, al, ar)
+        n, H, F = ft.shape
+        ft = _f32c(ft)
+        w = torch.stack([al.reshape(H * F), ar.reshape(H * F)], 0).float().contiguous()
+        y = torch.empty((2, n, H), dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            rc = _lib.lib().stag_head_dot_fwd(_lib.ptr(ft), H * F, n, H, F, _lib.ptr(w), 2, _lib.ptr(y),
+                                              _lib.stream_of(dev))
+        _lib.check(rc, "stag_head_dot_fwd")
+        ctx.save_for_backward(ft, w)
+        ctx.wshape = (al.shape, ar.shape)
+        return y[0], y[1]
+
+    @staticmethod
+    def backward(ctx, gl, gr):
+        ft, w = ctx.saved_tensors
+        dev = ft.device
+        n, H, F = ft.shape
+        gy = torch.stack([_f32c(gl), _f32c(gr)], 0)
+        dft = torch.empty_like(ft) if ctx.needs_input_grad[0] else None
+        want_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dw = torch.empty_like(w) if want_w else None
+        ws, nbytes = _amort_ws(2 * H * F, dev)
+        with _lib.on_device(dev):
+            rc = _lib.lib().stag_head_dot_bwd(_lib.ptr(ft), H * F, n, H, F, _lib.ptr(w), 2, _lib.ptr(gy), _lib.ptr(dft),
+                                              H * F, _lib.ptr(dw), _lib.ptr(ws), nbytes, _lib.stream_of(dev))
+        _lib.check(rc, "stag_head_dot_bwd")
+        dal = dw[0].reshape(ctx.wshape[0]) if (want_w and ctx.needs_input_grad[1]) else None
+        dar = dw[1].reshape(ctx.wshape[1]) if (want_w and ctx.needs_input_grad[2]) else None
+        return dft, dal, dar
+
+
+def head_dot(ft, attn_l, attn_r):
+    """el, er [N, H] = (ft * attn_l).sum(-1), (ft * attn_r).sum(-1) for ft [N, H, F], attn_* [1, H, F] | [H, F].
+    None when the shape has no one-pass form (F not a power of two in [4, 256]): the caller takes the GEMM form."""
+    if ft.dim() != 3 or not ft.is_cuda or ft.shape[0] == 0:
+        return None
+    F = ft.shape[2]
+    if F < 4 or F > 256 or (F & (F - 1)) != 0:
+        return None
+    return _HeadDot.apply(ft, attn_l, attn_r)
 
 
 class _EdgeMlp(torch.autograd.Function):
@@ -407,7 +462,7 @@ class _EdgeMlp(torch.autograd.Function):
         dpre = torch.empty((E, hidden), dtype=torch.float32, device=dev)
         dwh = torch.empty_like(wh) if ctx.needs_input_grad[2] else None
         dbh = torch.empty(n_par, dtype=torch.float32, device=dev) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
-        ws, nbytes = _amort_ws(NARROW_MAX_HIDDEN * NARROW_MAX_PAR + NARROW_MAX_PAR, dev)
+        ws, nbytes = _amort_ws(36, dev)      # 8 hidden x 4 parameters + 4: the library's largest shape
         with _lib.on_device(dev):
             rc = _lib.lib().stag_edge_mlp_bwd(_lib.ptr(src), _lib.ptr(dst), E, _lib.ptr(P), _lib.ptr(P[:, hidden:]),
                                               P.stride(0), hidden, _lib.ptr(wh), n_par, _lib.ptr(gpar), _lib.ptr(dpre),

@@ -47,14 +47,19 @@ class GAT(torch.nn.Module):
         H, F = self._num_heads, self._out_feats
         h = self.feat_drop(feat)
         ft = ops.node_linear(h, self.fc.weight.t()).view(-1, H, F)
-        # el[n,h] = sum_f ft[n,h,f] attn_l[h,f], er likewise (zoo/gat.py:109-110), as ONE [N, HF] x
-        # [HF, 2H] product with a block-diagonal right side: the elementwise-multiply + reduce form
-        # costs 2 x 242 us at cfg5 (and as much again in the backward), this ~40 us
-        eye = torch.eye(H, dtype=ft.dtype, device=ft.device)
-        w_lr = torch.cat([(self.attn_l.reshape(H, F, 1) * eye.reshape(H, 1, H)).reshape(H * F, H),
-                          (self.attn_r.reshape(H, F, 1) * eye.reshape(H, 1, H)).reshape(H * F, H)], 1)
-        elr = ops.node_linear(ft.reshape(-1, H * F), w_lr)
-        el, er = elr[:, :H], elr[:, H:]
+        # el[n,h] = sum_f ft[n,h,f] attn_l[h,f], er likewise (zoo/gat.py:109-110).  The elementwise-multiply +
+        # reduce form costs 2 x 242 us at cfg5 (and as much again in the backward); ops.head_dot is one pass
+        # over ft forward and one back.  Head widths it does not take go through ONE [N, HF] x [HF, 2H]
+        # product with a block-diagonal right side.
+        lr = ops.head_dot(ft, self.attn_l, self.attn_r)
+        if lr is not None:
+            el, er = lr
+        else:
+            eye = torch.eye(H, dtype=ft.dtype, device=ft.device)
+            w_lr = torch.cat([(self.attn_l.reshape(H, F, 1) * eye.reshape(H, 1, H)).reshape(H * F, H),
+                              (self.attn_r.reshape(H, F, 1) * eye.reshape(H, 1, H)).reshape(H * F, H)], 1)
+            elr = ops.node_linear(ft.reshape(-1, H * F), w_lr)
+            el, er = elr[:, :H], elr[:, H:]
         if edge_weight is not None:
             assert edge_weight.shape[0] == graph.number_of_edges()
         # attention dropout (the reference's scripts train with attn_drop=0.6) needs a[E, H] between the

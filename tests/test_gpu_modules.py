@@ -999,7 +999,7 @@ def test_node_project(dev, n, K, C):
     w = torch.tensor((rng.standard_normal((K, C)) / np.sqrt(K)).astype(np.float32), device=dev, requires_grad=True)
     b = torch.tensor(rng.standard_normal(C).astype(np.float32), device=dev, requires_grad=True)
     gy = torch.tensor(rng.standard_normal((n, C)).astype(np.float32), device=dev)
-    y = ops.node_project(x, w, b)
+    y = ops._NodeProject.apply(x, w, b)      # (ops.node_project hands more than 8 columns to the library GEMM)
     y.backward(gy)
     xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
     ref = xd @ wd + bd
@@ -1012,7 +1012,7 @@ def test_node_project(dev, n, K, C):
     if n:
         # no bias, no dx; and twice the same bits
         w2 = w.detach().clone().requires_grad_(True)
-        y2 = ops.node_project(x.detach(), w2)
+        y2 = ops._NodeProject.apply(x.detach(), w2, None)
         y2.backward(gy)
         assert_close(y2, (xd.detach() @ wd.detach()).cpu().numpy(), what="y, no bias")
         assert torch.equal(w2.grad, w.grad)
@@ -1117,3 +1117,28 @@ def test_narrow_amortized_distribution_equals_dense_dataflow(dev, hidden):
     assert_close(kl, ref_kl.detach().cpu().numpy(), what="layer KL")
     kl.backward()
     assert layer.p_a.loc.grad is not None and layer.q_a.parameters_mlp["log_scale"].weight.grad is not None
+
+
+@pytest.mark.parametrize("n,H,F", [(1, 1, 4), (1000, 8, 32), (777, 3, 32), (500, 4, 64), (300, 2, 256), (2000, 16, 8),
+                                   (900, 1, 128)])
+def test_head_dot(dev, n, H, F):
+    """stag_head_dot_fwd / _bwd: GAT's el / er = (ft * attn).sum(-1) (stag/zoo/gat.py:109-110) and the gradients
+    to ft, attn_l, attn_r against float64 torch."""
+    from stag_amd import ops
+    rng = np.random.default_rng(11)
+    ft = torch.tensor(rng.standard_normal((n, H, F)).astype(np.float32), device=dev, requires_grad=True)
+    al = torch.tensor(rng.standard_normal((1, H, F)).astype(np.float32), device=dev, requires_grad=True)
+    ar = torch.tensor(rng.standard_normal((1, H, F)).astype(np.float32), device=dev, requires_grad=True)
+    gl, gr = (torch.tensor(rng.standard_normal((n, H)).astype(np.float32), device=dev) for _ in range(2))
+    el, er = ops.head_dot(ft, al, ar)
+    torch.autograd.backward([el, er], [gl, gr])
+    ftd, ald, ard = (t.detach().double().requires_grad_(True) for t in (ft, al, ar))
+    rl, rr = (ftd * ald).sum(-1), (ftd * ard).sum(-1)
+    torch.autograd.backward([rl, rr], [gl.double(), gr.double()])
+    assert_close(el, rl.detach().cpu().numpy(), what="el")
+    assert_close(er, rr.detach().cpu().numpy(), what="er")
+    assert_close(ft.grad, ftd.grad.cpu().numpy(), what="d ft")
+    for got, r, nm in ((al.grad, ald.grad, "d attn_l"), (ar.grad, ard.grad, "d attn_r")):
+        sc = max(1.0, float(r.abs().max()))
+        assert_close(got / sc, (r / sc).cpu().numpy(), what=nm)
+    assert ops.head_dot(torch.zeros(4, 2, 12, device=dev), al, ar) is None      # F = 12: the GEMM form

@@ -9,6 +9,7 @@
   rec      AmortizedDistribution(128, 128): [E, 128] parameters
   vi_norm  vi=True, norm=True
   fixed    Normal(1, 0.5), not learned
+  gat | sage | gin   the other base layers with the fixed Normal (GAT: 8 heads x 32)
 --kl adds the layer's KL term to the loss (stag/layers.py:132-145), as the training scripts do.
 The totals of the trace are per `--steps` steps plus 3 warm-up steps.
 """
@@ -22,10 +23,14 @@ import stag_amd
 from stag_amd import synthetic
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--mode", default="r1", choices=["r1", "re", "rec", "vi_norm", "fixed"])
+ap.add_argument("--mode", default="r1", choices=["r1", "re", "rec", "vi_norm", "fixed", "gat", "sage", "gin"])
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--kl", action="store_true")
+ap.add_argument("--lib", default=None, help="A/B: a build variant tools/_bin/libstag_<name>.so (tools/ab_bench.py build)")
 args = ap.parse_args()
+if args.lib:
+    from stag_amd import _lib
+    _lib._SO = os.path.join(os.getcwd(), "tools", "_bin", f"libstag_{args.lib}.so")
 
 dev = torch.device("cuda:0")
 src, dst = synthetic.arxiv_like(seed=1)
@@ -39,8 +44,10 @@ kw = {"r1": dict(q_a=N(1.0, 0.5), vi=True, relu=True),
       "re": dict(q_a=stag_amd.distributions.AmortizedDistribution(D, 1, init_like=N(1.0, 0.3)), vi=True),
       "rec": dict(q_a=stag_amd.distributions.AmortizedDistribution(D, D, init_like=N(1.0, 0.3)), vi=True),
       "vi_norm": dict(q_a=N(1.0, 0.5), vi=True, norm=True),
-      "fixed": dict(q_a=N(1.0, 0.5))}[args.mode]
-layer = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(D, D), **kw).to(dev)
+      "fixed": dict(q_a=N(1.0, 0.5))}.get(args.mode, dict(q_a=N(1.0, 0.5)))
+base = {"gat": lambda: stag_amd.zoo.GAT(D, 32, num_heads=8), "sage": lambda: stag_amd.zoo.GraphSAGE(D, D),
+        "gin": lambda: stag_amd.zoo.GIN(D, D)}.get(args.mode, lambda: stag_amd.zoo.GCN(D, D))()
+layer = stag_amd.layers.StagLayer(base, **kw).to(dev)
 xg = x.clone().requires_grad_(True)
 
 
@@ -48,6 +55,10 @@ def step():
     layer.zero_grad(set_to_none=True)
     xg.grad = None
     y = layer(g, xg)
+    if y.dim() == 3:
+        y = y.flatten(1)
+    if y.shape[1] != gout.shape[1]:
+        y = y[:, :gout.shape[1]] if y.shape[1] > gout.shape[1] else torch.nn.functional.pad(y, (0, gout.shape[1] - y.shape[1]))
     if args.kl:      # d loss = <gout, dy> + d kl, without an [N, D] product on the way
         torch.autograd.backward([y, layer.kl_divergence()], [gout, torch.ones((), device=dev)])
     else:
