@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 12
+#define STAG_ABI_VERSION 13
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -432,22 +432,36 @@ int stag_halo_exchange(void* comm, const float* send, const int64_t* send_counts
                        const int64_t* recv_counts_host, void* stream);
 
 /* The whole backward of stag_gat_fwd in one call, for shapes with F % 4 == 0, F/4 a power of two,
- * H <= 16, H*F <= 256 and block plans (stag_plan.block_ptr) on both orientations of the graph:
- *   edge pass (csr, plan):     a, de per edge (the weight redrawn from its counters, a from `stats`),
- *                              written to ade_ws[E, 2H] by forward position; d er[v,h] = sum_in de
- *   source pass (csr_t, plan_t; csr_t.nidx = forward position of each transposed position):
- *                              d el[u,h] = sum_out de;  d ft[u,h,:] = sum_out a[e,h] g[v,h,:]
- * dw (may be NULL): [E, H] by edge id, the gradient w.r.t. explicit weights (ds * lrelu * norm_scale).
- * Long rows leave per-segment partials in plan->workspace (>= stag_gat_bwd_workspace_bytes()) and a
- * small launch adds them in segment order: no atomics, results do not depend on scheduling.
+ * H <= 16, H*F <= 1024 and a block plan (stag_plan.block_ptr) on the source-major orientation.
+ *
+ * stag_gat_bwd — ONE gather of the [H*F] rows (the forward has one, autograd through DGL's ops has four):
+ *   1. sdot[v,h] = <g[v,h,:], out[v,h,:]>, the softmax's correction term, from one streaming pass;
+ *   2. source pass (csr_t, plan_t; csr_t.nidx = forward position, csr_t.eid = edge id of each transposed
+ *      position): per out-edge of u the weight is redrawn from its counters and a[e,h] rebuilt from `stats`;
+ *      the team that owns u gathers g[v], forms <g[v,h,:], ft[u,h,:]> with its own row of ft, and gets
+ *      d s[e,h] = a (dot - sdot[v,h]) w ns lrelu'(.), d ft[u,h,:] = sum_out a g[v,h,:], d el[u,h] = sum_out d s;
+ *      d s goes to scratch by FORWARD position, dw (may be NULL: [E, H] by edge id) = d s-factor * lrelu * ns;
+ *   3. d er[v,h] = sum of d s over the row's positions, which are contiguous there.
+ * stag_gat_bwd_two_pass — the form it replaces: an edge pass over csr (gathers ft[u]; a, de to scratch, d er)
+ * and a source pass over csr_t (gathers g[v]; d ft, d el): two gathers; needs block plans on both orientations.
+ * scratch: stag_gat_bwd_scratch_bytes(n_dst, n_edges, H) bytes, 16-byte aligned.
+ * Long rows leave per-segment partials in plan->workspace (>= stag_gat_bwd_workspace_bytes(); the forward
+ * plan's workspace serves both orientations, one after the other) and a small launch adds them in segment
+ * order: no atomics, results do not depend on scheduling.
  * STAG_ENOSYS for other shapes / plans: use stag_gat_bwd_edge + stag_agg_fwd on the transposed CSR.
  * Replaces DGL's backward of u_add_v / edge_softmax / u_mul_e (stag/zoo/gat.py:114-126).          */
 size_t stag_gat_bwd_workspace_bytes(int32_t n_seg, int32_t n_seg_t, int32_t H, int32_t F);
+size_t stag_gat_bwd_scratch_bytes(int64_t n_dst, int64_t n_edges, int32_t H);
 int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
                  const stag_plan* plan_t, const float* el, const float* er, const float* ft,
                  const float* stats, const float* g, const float* out, int32_t H, int32_t F,
                  float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
-                 float* d_el, float* d_er, float* d_ft, float* dw, float* ade_ws, void* stream);
+                 float* d_el, float* d_er, float* d_ft, float* dw, float* scratch, void* stream);
+int stag_gat_bwd_two_pass(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
+                          const stag_plan* plan_t, const float* el, const float* er, const float* ft,
+                          const float* stats, const float* g, const float* out, int32_t H, int32_t F,
+                          float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
+                          float* d_el, float* d_er, float* d_ft, float* dw, float* scratch, void* stream);
 
 #ifdef __cplusplus
 }

@@ -137,12 +137,15 @@ def lib():
     l.stag_gat_bwd.argtypes = [C.POINTER(Csr), C.POINTER(Plan), C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp,
                                _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_float, C.POINTER(NoiseSpec), _vp,
                                _vp, _vp, _vp, _vp, _vp, _vp]
+    l.stag_gat_bwd_two_pass.argtypes = l.stag_gat_bwd.argtypes
+    l.stag_gat_bwd_scratch_bytes.restype = C.c_size_t
+    l.stag_gat_bwd_scratch_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32]
     l.stag_comm_unique_id.argtypes = [_vp]
     l.stag_comm_init.argtypes = [_vp, C.c_int32, C.c_int32, C.POINTER(_vp)]
     l.stag_comm_destroy.argtypes = [_vp]
     l.stag_halo_allgather.argtypes = [_vp, _vp, C.c_int64, _vp, _vp]
     l.stag_halo_exchange.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
-    if l.stag_abi_version() != 12:
+    if l.stag_abi_version() != 13:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     _lib = l
     return l

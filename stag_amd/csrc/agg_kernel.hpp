@@ -621,6 +621,8 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
 #ifndef STAG_BLK_EG
 #define STAG_BLK_EG 1
 #endif
+  // (the three-accumulator backward, NOUT 3, at one edge per block: 84 VGPRs = 5 waves instead of 104 = 4, and
+  // no faster: 915-1040 against 869-885 us for the r1 layer step; it keeps the block of its separate passes)
   constexpr int BLK = PEDGE == 3 ? STAG_BLK_EG : (KIND >= kNormal) ? STAG_BLK_RNG : STAG_BLK_MEM;
   constexpr int NB = BLK * MULT;
 

@@ -367,6 +367,9 @@ static_assert(kBlkUnits <= 64 && kBlkThreads % 64 == 0 && kBlkThreads <= 1024, "
 // 2: 341; forward + backward with the two backward kernels at 4: 759, 5: 722, 6: 733).
 #define STAG_GAT_LDS_MIN 40000      // forward: 4 workgroups per CU
 #endif
+#ifndef STAG_GAT_LDS_MIN_ONE
+#define STAG_GAT_LDS_MIN_ONE 32000  // the one-gather backward
+#endif
 #ifndef STAG_GAT_LDS_MIN_BWD
 #define STAG_GAT_LDS_MIN_BWD 32000  // backward passes: 5
 #endif
@@ -1118,6 +1121,263 @@ __global__ __launch_bounds__(kBlkThreads) void gat_bwd_src_block_kernel(const Ga
   }
 }
 
+// ---- backward with ONE gather of [H*F] rows ---------------------------------------------------------------
+// The two kernels above gather 1-KB rows twice: ft[u] by destination (for <G[v], ft[u]>) and G[v] by source (for
+// d ft[u] = sum a G[v]).  The dot product is symmetric in where it is formed: on the SOURCE-major CSR ft[u] is the
+// unit's own row and G[v] is the row the d ft sum gathers anyway.  What the source-major side lacks is the softmax
+// correction sum_e' a[e',h] <G[v,h], ft[u',h]> = <G[v,h], out[v,h]> of the destination row — a per-node quantity,
+// sdot [N, H], that one streaming pass over G and out provides (gat_rowdot_kernel) — and d er[v], whose terms it
+// leaves in dsl [E, H] by forward position, where the in-edges of v are contiguous (gat_der_kernel).
+//   gat_rowdot_kernel       sdot[v,h] = sum_f G[v,h,f] out[v,h,f]                       (2 N H F floats read)
+//   gat_bwd_one_kernel      per batch of the source-major plan: phase 1 (thread per edge) a[e,h], the leaky-relu /
+//                           noise factors and sdot[v,h] into LDS; phase 2 (team per source row) gathers G[v], forms
+//                           the per-head dot with the own ft row, d s[e,h] = a (dot - sdot) c1, and d ft[u] += a G[v];
+//                           phase 3 writes dsl (by forward position), dw (by edge id), d el[u]
+//   gat_der_kernel          d er[v,h] = sum of dsl over the row's positions
+struct GatBwd1Args {
+  GatArgs f;             // graph fields: the SOURCE-major CSR (indices = destination, eid, nidx) and its block plan
+  const float* g;        // [n_dst of the forward, H*F]
+  uint32_t g_bytes;
+  const float* pack;     // [n_dst of the forward, 4H]: er | m | l | sdot per destination (gat_rowdot_kernel)
+  float* d_ft;           // [n_src, H*F]
+  float* d_el;           // [n_src, H]
+  float* dsl;            // [E, H] by forward position
+  float* dw;             // [E, H] by edge id, or null
+  float* ws;             // segment partials: [n_seg_t][HF + H]
+  int32_t eid_is_pos;    // the forward CSR has no eid: edge id = forward position
+};
+
+constexpr int kRowdotRows = 4;
+// sdot goes into a per-node record next to the other per-destination inputs of the edge phase — er, the softmax
+// statistics m and l — so that an edge fetches ONE line of 4H floats instead of three separate rows:
+// pack[v] = er[H] | m[H] | l[H] | sdot[H]
+template <int LPE>
+__global__ __launch_bounds__(256) void gat_rowdot_kernel(const float* g, const float* out, int n, int H, int F, int HF,
+                                                         const float* er, const float* stats, float* pack) {
+  constexpr int R = kRowdotRows;
+  const int c = threadIdx.x % LPE;
+  const int row0 = (blockIdx.x * (256 / LPE) + threadIdx.x / LPE) * R;
+  const int lph = F / 4;
+  for (int kt = 0; kt < HF; kt += LPE * 4) {            // every lane makes every trip (the head sums are DPP)
+    const int k0 = kt + c * 4;
+    const bool in = k0 < HF;
+    float gv[R][4], ov[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      gv[r][0] = gv[r][1] = gv[r][2] = gv[r][3] = 0.f;
+      ov[r][0] = ov[r][1] = ov[r][2] = ov[r][3] = 0.f;
+      if (in && row0 + r < n) {
+        load4(g + (int64_t)(row0 + r) * HF, k0, HF, true, gv[r]);
+        load4(out + (int64_t)(row0 + r) * HF, k0, HF, true, ov[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float d = gat_head_sum((gv[r][0] * ov[r][0] + gv[r][1] * ov[r][1]) + (gv[r][2] * ov[r][2] + gv[r][3] * ov[r][3]), lph);
+      if (in && row0 + r < n && (k0 % F) == 0) {
+        const int64_t row = row0 + r;
+        const int h = k0 / F;
+        float* rec = pack + row * 4 * H;
+        rec[h] = er[row * H + h];
+        rec[H + h] = stats[row * 2 * H + h];
+        rec[2 * H + h] = stats[row * 2 * H + H + h];
+        rec[3 * H + h] = d;
+      }
+    }
+  }
+}
+
+template <int LPE, int CPL>
+__global__ __launch_bounds__(kBlkThreads) void gat_bwd_one_kernel(const GatBwd1Args ba) {
+  extern __shared__ __align__(16) float lds[];
+  const GatArgs& a = ba.f;
+  const int H = a.H, F = a.F, HF = a.HF;
+  float* s_a = lds;                                   // [kBlkEdges][H] attention
+  float* s_c1 = s_a + kBlkEdges * H;                  // [kBlkEdges][H] w ns lrelu'(s), then d s
+  float* s_sd = s_c1 + kBlkEdges * H;                 // [kBlkEdges][H] sdot of the edge's destination
+  float* s_c2 = s_sd + kBlkEdges * H;                 // [kBlkEdges][H] lrelu(s) ns, then dw (only when wanted)
+  int* s_v = reinterpret_cast<int*>(s_c2 + (ba.dw ? kBlkEdges * H : 0));
+  int* s_start = s_v + kBlkEdges;
+  int4* s_unit = reinterpret_cast<int4*>(s_start + kBlkUnits + 4);
+  const int t = threadIdx.x;
+  const int nu = blk_prologue(a.units, a.block_ptr, s_unit, s_start);
+  const int ne = s_start[nu];
+
+  // ---- phase 1: thread <-> out-edge slot -----------------------------------------------------------------
+  int my_fp = 0;
+  int64_t my_ed = 0;
+  if (t < ne) {
+    const int j = blk_unit_of(s_start, nu, t);
+    const int4 q = s_unit[j];
+    const int u = (q.w >= 0) ? a.long_rows[q.x] : q.x;          // the source node: this unit's row
+    const int qq = q.y + (t - s_start[j]);
+    const int v = a.indices[qq];
+    s_v[t] = v;
+    const int fp = a.nidx[qq];                                  // forward position: the noise index, the dsl slot
+    my_fp = fp;
+    const int64_t ed = (ba.eid_is_pos || !a.eid) ? (int64_t)fp : (int64_t)a.eid[qq];
+    my_ed = ed;
+    const uint32_t n = a.pos_lo + (uint32_t)fp;
+    const PhiloxKey key = resolve_epoch(a.key);
+    const int nchunk = (H + 3) / 4;
+    const bool h4 = (H & 3) == 0 && a.hvec;
+    for (int cc = 0; cc < nchunk; ++cc) {
+      float w[4], sl4[4], sr4[4], ns4[4] = {1.f, 1.f, 1.f, 1.f}, m4[4], l4[4], sd4[4];
+      const float* rec = ba.pack + (int64_t)v * 4 * H;          // er | m | l | sdot of the destination
+      if (h4) {
+        load4(a.el + (int64_t)u * H, 4 * cc, H, true, sl4);
+        if (a.nscale) load4(a.nscale + (int64_t)v * H, 4 * cc, H, true, ns4);
+        load4(rec, 4 * cc, H, true, sr4);
+        load4(rec + H, 4 * cc, H, true, m4);
+        load4(rec + 2 * H, 4 * cc, H, true, l4);
+        load4(rec + 3 * H, 4 * cc, H, true, sd4);
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int h = 4 * cc + jj;
+          const bool in = h < H;
+          sl4[jj] = in ? a.el[(int64_t)u * H + h] : 0.f;
+          if (a.nscale && in) ns4[jj] = a.nscale[(int64_t)v * H + h];
+          sr4[jj] = in ? rec[h] : 0.f;
+          m4[jj] = in ? rec[H + h] : 0.f;
+          l4[jj] = in ? rec[2 * H + h] : 1.f;
+          sd4[jj] = in ? rec[3 * H + h] : 0.f;
+        }
+      }
+      head_w4(a, key, n, ed, (uint32_t)cc, w);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int h = 4 * cc + jj;
+        if (h < H) {
+          const float sL = sl4[jj] + sr4[jj];
+          const float lr = sL > 0.f ? sL : a.neg_slope * sL;
+          const float wn = w[jj] * ns4[jj];
+          s_a[t * H + h] = __expf(wn * lr - m4[jj]) / l4[jj];
+          s_c1[t * H + h] = wn * (sL > 0.f ? 1.0f : a.neg_slope);
+          s_sd[t * H + h] = sd4[jj];
+          if (ba.dw) s_c2[t * H + h] = lr * ns4[jj];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: a team per source row: gather G[v]; <G[v,h,:], ft[u,h,:]> -> d s; d ft[u] += a G[v] ----------
+  constexpr int TEAMS = kBlkThreads / LPE, NR = CPL >= 4 ? 2 : STAG_GAT_NR;
+  const int team = t / LPE, c = t % LPE;
+  const int lph = F / 4;
+  int k0[CPL], hl[CPL];
+  bool kin[CPL];
+#pragma unroll
+  for (int cj = 0; cj < CPL; ++cj) {
+    k0[cj] = (c + LPE * cj) * 4;
+    kin[cj] = k0[cj] < HF;
+    hl[cj] = kin[cj] ? k0[cj] / F : 0;
+  }
+  const __amdgpu_buffer_rsrc_t rg =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ba.g), 0, (int)ba.g_bytes, 0x00020000);
+  const bool g_buf = ba.g_bytes != 0;
+  for (int j = team; j < nu; j += TEAMS) {
+    const int4 q = s_unit[j];
+    const int u = (q.w >= 0) ? a.long_rows[q.x] : q.x;
+    const int e0 = s_start[j], e1 = s_start[j + 1];
+    float fu[CPL][4], acc[CPL][4];
+#pragma unroll
+    for (int cj = 0; cj < CPL; ++cj) {
+      fu[cj][0] = fu[cj][1] = fu[cj][2] = fu[cj][3] = 0.f;
+      acc[cj][0] = acc[cj][1] = acc[cj][2] = acc[cj][3] = 0.f;
+      if (kin[cj] && e0 < e1) load4(a.ft + (int64_t)u * HF, k0[cj], HF, true, fu[cj]);
+    }
+    for (int e = e0; e < e1; e += NR) {
+      float fv[NR][CPL][4];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (e + r < e1) {
+          const int v = s_v[e + r];
+#pragma unroll
+          for (int cj = 0; cj < CPL; ++cj) {
+            if (kin[cj]) {
+              if (g_buf) bufrow4(rg, v, (uint32_t)HF * 4u, (uint32_t)k0[cj] * 4u, fv[r][cj]);
+              else loadrow4(ba.g + (int64_t)v * HF + k0[cj], k0[cj], HF, true, fv[r][cj]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (e + r < e1) {                              // uniform over the team
+#pragma unroll
+          for (int cj = 0; cj < CPL; ++cj) {
+            float dot = 0.f;
+            if (kin[cj])
+              dot = (fu[cj][0] * fv[r][cj][0] + fu[cj][1] * fv[r][cj][1]) + (fu[cj][2] * fv[r][cj][2] + fu[cj][3] * fv[r][cj][3]);
+            dot = gat_head_sum(dot, lph);
+            if (kin[cj]) {
+              const float w = s_a[(e + r) * H + hl[cj]];
+#pragma unroll
+              for (int x = 0; x < 4; ++x) acc[cj][x] = __builtin_fmaf(w, fv[r][cj][x], acc[cj][x]);
+              if ((k0[cj] % F) == 0) {
+                const float ds = w * (dot - s_sd[(e + r) * H + hl[cj]]);
+                s_c1[(e + r) * H + hl[cj]] = ds * s_c1[(e + r) * H + hl[cj]];
+                if (ba.dw) s_c2[(e + r) * H + hl[cj]] = ds * s_c2[(e + r) * H + hl[cj]];
+              }
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int cj = 0; cj < CPL; ++cj) {
+      if (!kin[cj]) continue;
+      if (q.w < 0) store4_out(ba.d_ft + (int64_t)q.x * HF, k0[cj], HF, true, acc[cj]);
+      else store4(ba.ws + (int64_t)q.w * (HF + H), k0[cj], HF, true, acc[cj]);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3: d s by forward position, dw by edge id; d el per unit ---------------------------------------
+  if (t < ne) {
+    float* dst = ba.dsl + (int64_t)my_fp * H;
+    if ((H & 3) == 0) {
+      for (int h = 0; h < H; h += 4)
+        *reinterpret_cast<float4*>(dst + h) = *reinterpret_cast<const float4*>(s_c1 + t * H + h);
+    } else {
+      for (int h = 0; h < H; ++h) dst[h] = s_c1[t * H + h];
+    }
+    if (ba.dw)
+      for (int h = 0; h < H; ++h) ba.dw[my_ed * H + h] = s_c2[t * H + h];
+  }
+  for (int i = t; i < nu * H; i += kBlkThreads) {
+    const int j = i / H, h = i - j * H;
+    const int4 q = s_unit[j];
+    float sum = 0.f;
+    for (int e = s_start[j]; e < s_start[j + 1]; ++e) sum += s_c1[e * H + h];
+    if (q.w < 0) ba.d_el[(int64_t)q.x * H + h] = sum;
+    else ba.ws[(int64_t)q.w * (HF + H) + HF + h] = sum;
+  }
+}
+
+// d er[v,h] = sum over the positions of row v of dsl[p,h]: a thread per (unit of the forward plan, head), the
+// unit's <= seg_len positions in order; segments leave partials for gat_seg_finish_kernel
+__global__ __launch_bounds__(256) void gat_der_kernel(const stag_unit* units, int n_units, const int32_t* indptr,
+                                                      const float* dsl, int H, float* d_er, float* ws) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t unit = i / H;
+  const int h = (int)(i - unit * H);
+  if (unit >= n_units) return;
+  int row, b, len, slot = -1;
+  if (units) {
+    const int4 q = *reinterpret_cast<const int4*>(units + unit);
+    row = q.x; b = q.y; len = q.z; slot = q.w;
+  } else {
+    row = (int)unit; b = indptr[row]; len = indptr[row + 1] - b;
+  }
+  float sum = 0.f;
+  for (int p = b; p < b + len; ++p) sum += dsl[(int64_t)p * H + h];
+  if (slot < 0) d_er[(int64_t)row * H + h] = sum;
+  else ws[(int64_t)slot * H + h] = sum;
+}
+
 // out[long_rows[r]][k] = sum over the row's segments of ws[s][ws_off + k], k < width.  A workgroup per
 // (long row, 16 columns): 16 slices of the segment list are summed side by side (slice i takes segments
 // i, i+16, ... in order, Kahan), then the 16 slice sums in slice order — a fixed order, and a hub row
@@ -1364,7 +1624,7 @@ extern "C" size_t stag_gat_bwd_workspace_bytes(int32_t n_seg, int32_t n_seg_t, i
   return (a > b ? a : b) * sizeof(float);
 }
 
-extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
+extern "C" int stag_gat_bwd_two_pass(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
                             const stag_plan* plan_t, const float* el, const float* er, const float* ft,
                             const float* stats, const float* g, const float* out, int32_t H, int32_t F,
                             float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
@@ -1455,5 +1715,113 @@ extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const st
     hipLaunchKernelGGL(gat_seg_finish_kernel, dim3(plan_t->n_long, (H + 15) / 16), dim3(256), 0, s,
                        plan->workspace, HF + H, HF, H, plan_t->long_rows, plan_t->long_seg_ptr, d_el, H);
   }
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}
+
+extern "C" size_t stag_gat_bwd_scratch_bytes(int64_t n_dst, int64_t n_edges, int32_t H) {
+  if (n_dst < 0 || n_edges < 0 || H <= 0) return 0;
+  // two-pass form: a and de by forward position [E, 2H]; one-gather form: dsl [E, H] then the per-destination
+  // records [n_dst, 4H]
+  return ((size_t)2 * (size_t)n_edges + (size_t)4 * (size_t)n_dst) * (size_t)H * sizeof(float);
+}
+
+extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
+                            const stag_plan* plan_t, const float* el, const float* er, const float* ft,
+                            const float* stats, const float* g, const float* out, int32_t H, int32_t F,
+                            float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
+                            float* d_el, float* d_er, float* d_ft, float* dw, float* scratch, void* stream) {
+  if (!csr || !csr_t || !csr->indptr || !csr_t->indptr || csr->n_dst < 0 || csr->n_edges < 0) return STAG_EINVAL;
+  if (csr_t->n_edges != csr->n_edges || csr_t->n_dst != csr->n_src || csr_t->n_src != csr->n_dst) return STAG_EINVAL;
+  if (!spec || spec->kind < STAG_NOISE_NONE || spec->kind > STAG_NOISE_BERNOULLI || spec->deriv) return STAG_EINVAL;
+  if (!d_el || !d_er || !d_ft || !scratch || H <= 0 || F <= 0) return STAG_EINVAL;
+  const int64_t HF64 = (int64_t)H * F;
+  const int lph = F / 4;
+  if (H > kBlkMaxH || HF64 > 1024 || F % 4 != 0 || lph > 64 || (lph & (lph - 1)) != 0) return STAG_ENOSYS;
+  if (spec->chunk_base != 0) return STAG_ENOSYS;
+  if (!plan_t || !plan_t->block_ptr || plan_t->n_blocks <= 0 || plan_t->seg_len > kBlkEdges) return STAG_ENOSYS;
+  if (spec->in_norm && !norm_scale) return STAG_EINVAL;
+  if (csr->n_dst == 0 || csr->n_edges == 0) return STAG_OK;   // the caller zero-fills (no edge, no gradient)
+  if (!csr->indices || !csr_t->indices || !csr_t->nidx || !el || !er || !ft || !stats || !g || !out) return STAG_EINVAL;
+  if (csr->eid && !csr_t->eid) return STAG_EINVAL;            // edge ids of the transposed positions
+  if (!aligned16(ft) || !aligned16(g) || !aligned16(out) || !aligned16(d_ft) || !aligned16(scratch)) return STAG_EINVAL;
+  if (spec->kind == STAG_NOISE_EXPLICIT && !spec->p0) return STAG_EINVAL;
+  if (spec->kind >= STAG_NOISE_NORMAL && (uint64_t)((uint64_t)spec->pos_base & 0xFFFFFFFFull) + (uint64_t)csr->n_edges > (1ull << 32))
+    return STAG_ENOSYS;
+  if (!plan_t->units || !aligned16(plan_t->units)) return STAG_EINVAL;
+  if (plan_t->n_seg > 0 && (!plan_t->long_rows || !plan_t->long_seg_ptr)) return STAG_EINVAL;
+  const bool fplan = plan && plan->n_units > 0;
+  if (fplan && (!plan->units || !aligned16(plan->units))) return STAG_EINVAL;
+  if (fplan && plan->n_seg > 0 && (!plan->long_rows || !plan->long_seg_ptr)) return STAG_EINVAL;
+  const int HF = (int)HF64;
+  const size_t need = stag_gat_bwd_workspace_bytes(fplan ? plan->n_seg : 0, plan_t->n_seg, H, F);
+  // segment partials of BOTH orientations live in the forward plan's workspace, one after the other
+  if (need > 0 && (!plan || !plan->workspace || plan->workspace_bytes < need)) return STAG_ENOMEM;
+  hipStream_t s = (hipStream_t)stream;
+  float* dsl = scratch;
+  float* pack = scratch + (size_t)csr->n_edges * H;        // 16-byte aligned whenever H % 4 == 0 (the vector form)
+
+  const int nchunk = (HF + 3) / 4;
+  int lpe = 4;
+  while (lpe < nchunk && lpe < 64) lpe <<= 1;
+  const int cpl = nchunk <= 64 ? 1 : (nchunk <= 128 ? 2 : 4);
+
+  // 1. sdot[v,h] = <G[v,h,:], out[v,h,:]>
+  {
+    const int rl = lpe < lph ? lph : lpe;                       // a head's lanes inside one team
+    const int64_t rpb = (int64_t)(256 / rl) * kRowdotRows;
+    const dim3 gr((unsigned)((csr->n_dst + rpb - 1) / rpb));
+    switch (rl) {
+      case 64: hipLaunchKernelGGL((gat_rowdot_kernel<64>), gr, dim3(256), 0, s, g, out, csr->n_dst, H, F, HF, er, stats, pack); break;
+      case 32: hipLaunchKernelGGL((gat_rowdot_kernel<32>), gr, dim3(256), 0, s, g, out, csr->n_dst, H, F, HF, er, stats, pack); break;
+      case 16: hipLaunchKernelGGL((gat_rowdot_kernel<16>), gr, dim3(256), 0, s, g, out, csr->n_dst, H, F, HF, er, stats, pack); break;
+      case 8: hipLaunchKernelGGL((gat_rowdot_kernel<8>), gr, dim3(256), 0, s, g, out, csr->n_dst, H, F, HF, er, stats, pack); break;
+      default: hipLaunchKernelGGL((gat_rowdot_kernel<4>), gr, dim3(256), 0, s, g, out, csr->n_dst, H, F, HF, er, stats, pack); break;
+    }
+  }
+
+  // 2. the source-major pass
+  GatBwd1Args ba{};
+  GatArgs& a = ba.f;
+  int rc = fill_edge_args(a, csr_t, plan_t, el, er, H, neg_slope, spec, norm_scale, stats);
+  if (rc) return rc;
+  a.ft = ft; a.F = F; a.HF = HF;
+  a.block_ptr = plan_t->block_ptr;
+  a.hvec = aligned16(el) && aligned16(pack) && (!a.nscale || aligned16(a.nscale));
+  ba.g = g; ba.pack = pack; ba.d_ft = d_ft; ba.d_el = d_el; ba.dsl = dsl; ba.dw = dw;
+  ba.ws = plan ? plan->workspace : nullptr;
+  ba.eid_is_pos = csr->eid ? 0 : 1;
+  const uint64_t gb = (uint64_t)csr->n_dst * (uint64_t)HF * 4u;
+  ba.g_bytes = (gb < (1ull << 32) && csr->n_dst < (1 << 24)) ? (uint32_t)gb : 0u;
+  size_t lds_s = (size_t)kBlkEdges * H * (dw ? 4 : 3) * sizeof(float) + (size_t)(kBlkEdges + kBlkUnits + 4) * sizeof(int) +
+                 (size_t)kBlkUnits * sizeof(int4);
+  if (lds_s < STAG_GAT_LDS_MIN_ONE) lds_s = STAG_GAT_LDS_MIN_ONE;
+  const dim3 gs(plan_t->n_blocks);
+#define STAG_BLK_LAUNCH(L, Cc) hipLaunchKernelGGL((gat_bwd_one_kernel<L, Cc>), gs, dim3(kBlkThreads), lds_s, s, ba)
+    if (cpl == 4) STAG_BLK_LAUNCH(64, 4);
+    else if (cpl == 2) STAG_BLK_LAUNCH(64, 2);
+    else switch (lpe) {
+      case 64: STAG_BLK_LAUNCH(64, 1); break;
+      case 32: STAG_BLK_LAUNCH(32, 1); break;
+      case 16: STAG_BLK_LAUNCH(16, 1); break;
+      case 8: STAG_BLK_LAUNCH(8, 1); break;
+      default: STAG_BLK_LAUNCH(4, 1); break;
+    }
+#undef STAG_BLK_LAUNCH
+  if (plan_t->n_long > 0) {
+    hipLaunchKernelGGL(gat_seg_finish_kernel, dim3(plan_t->n_long, (HF + 15) / 16), dim3(256), 0, s,
+                       plan->workspace, HF + H, 0, HF, plan_t->long_rows, plan_t->long_seg_ptr, d_ft, HF);
+    hipLaunchKernelGGL(gat_seg_finish_kernel, dim3(plan_t->n_long, (H + 15) / 16), dim3(256), 0, s,
+                       plan->workspace, HF + H, HF, H, plan_t->long_rows, plan_t->long_seg_ptr, d_el, H);
+  }
+
+  // 3. d er: the in-edges of a row are contiguous in dsl (the source pass's partials are consumed by now)
+  const int n_units_f = fplan ? plan->n_units : csr->n_dst;
+  const int64_t nth = (int64_t)n_units_f * H;
+  hipLaunchKernelGGL(gat_der_kernel, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, s,
+                     fplan ? static_cast<const stag_unit*>(plan->units) : nullptr, n_units_f, csr->indptr, dsl, H, d_er,
+                     plan ? plan->workspace : nullptr);
+  if (fplan && plan->n_long > 0)
+    hipLaunchKernelGGL(gat_seg_finish_kernel, dim3(plan->n_long, (H + 15) / 16), dim3(256), 0, s,
+                       plan->workspace, H, 0, H, plan->long_rows, plan->long_seg_ptr, d_er, H);
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }

@@ -1040,8 +1040,9 @@ class _GatAggregate(torch.autograd.Function):
 
 
 def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec, nscale, want_dw, seg_len, dev):
-    """stag_gat_bwd: both passes of the backward on the workgroup-cooperative kernels; None when the
-    shape or the plans are outside what it covers (the caller then composes the older kernels)."""
+    """stag_gat_bwd: the whole backward on the workgroup-cooperative kernels (one gather of the [H*F] rows; the
+    two-gather form stag_gat_bwd_two_pass stays for A/B); None when the shape or the plans are outside what it
+    covers (the caller then composes the older kernels)."""
     lph = F // 4
     E = csrv.n_edges
     if not (_GAT_BWD_FUSED and F % 4 == 0 and lph <= 64 and lph & (lph - 1) == 0 and H <= 16 and H * F <= 1024 and E > 0
@@ -1055,13 +1056,14 @@ def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec,
     d_er = torch.empty((csrv.n_dst, H), dtype=torch.float32, device=dev)
     d_ft = torch.empty((csrt.n_dst, H, F), dtype=torch.float32, device=dev)
     dw = torch.empty((E, H), dtype=torch.float32, device=dev) if want_dw else None
-    ade = torch.empty((E, 2 * H), dtype=torch.float32, device=dev)
+    scratch = torch.empty(_lib.lib().stag_gat_bwd_scratch_bytes(csrv.n_dst, E, H) // 4, dtype=torch.float32, device=dev)
     cs, ct = csrv.struct(), csrt.struct()
+    fn = _lib.lib().stag_gat_bwd if _GAT_BWD_ONE_GATHER else _lib.lib().stag_gat_bwd_two_pass
     with _lib.on_device(dev):
-        rc = _lib.lib().stag_gat_bwd(C.byref(cs), C.byref(pf), C.byref(ct), C.byref(pb), _lib.ptr(el), _lib.ptr(er),
-                                     _lib.ptr(ft), _lib.ptr(stats), _lib.ptr(G), _lib.ptr(out), H, F, neg_slope,
-                                     C.byref(spec), _lib.ptr(nscale), _lib.ptr(d_el), _lib.ptr(d_er), _lib.ptr(d_ft),
-                                     _lib.ptr(dw), _lib.ptr(ade), _lib.stream_of(dev))
+        rc = fn(C.byref(cs), C.byref(pf), C.byref(ct), C.byref(pb), _lib.ptr(el), _lib.ptr(er),
+                _lib.ptr(ft), _lib.ptr(stats), _lib.ptr(G), _lib.ptr(out), H, F, neg_slope,
+                C.byref(spec), _lib.ptr(nscale), _lib.ptr(d_el), _lib.ptr(d_er), _lib.ptr(d_ft),
+                _lib.ptr(dw), _lib.ptr(scratch), _lib.stream_of(dev))
     if rc == -38:
         return None
     _lib.check(rc, "stag_gat_bwd")
@@ -1069,6 +1071,7 @@ def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec,
 
 
 _GAT_BWD_FUSED = True      # tools/bench_configs.py --gat-old-bwd flips it for A/B runs
+_GAT_BWD_ONE_GATHER = True  # stag_gat_bwd (one gather of [H*F] rows) | stag_gat_bwd_two_pass; --gat-two-pass for A/B
 
 
 def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False,

@@ -584,7 +584,7 @@ def test_fuzz_agg_against_oracle(dev, oracle):
 def test_fuzz_gat_against_oracle_and_composed_backward(dev, oracle):
     """Seeded sweep over graphs x head shapes x weight kinds x plans for the GAT entry points: the forward
     (workgroup-cooperative kernel, 1 / 2 / 4 chunks per lane, or the one-unit-per-team fallback) against the
-    oracle, the backward (stag_gat_bwd or the composed calls) against autograd through the composed statement
+    oracle, the backward (stag_gat_bwd, stag_gat_bwd_two_pass, or the composed calls) against autograd through the composed statement
     of the same layer (ops._gat_composed: torch ops over [E, H] + the aggregation kernel)."""
     from stag_amd import ops
     rng = np.random.default_rng(20261004)
@@ -630,6 +630,16 @@ def test_fuzz_gat_against_oracle_and_composed_backward(dev, oracle):
         for a_, b_, nm in zip(t, t2, ("d el", "d er", "d ft")):
             sc = max(1.0, float(b_.grad.abs().max()))
             assert_close(a_.grad / sc, (b_.grad / sc).cpu().numpy(), what=what + " " + nm)
+        # the two-gather form of the same backward (stag_gat_bwd_two_pass) stays covered
+        t3 = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (el, er, ft)]
+        ops._GAT_BWD_ONE_GATHER = False
+        try:
+            ops.gat_aggregate(g, *t3, 0.2, w, seg_len=seg_len).backward(G)
+        finally:
+            ops._GAT_BWD_ONE_GATHER = True
+        for a_, b_, nm in zip(t3, t2, ("d el", "d er", "d ft")):
+            sc = max(1.0, float(b_.grad.abs().max()))
+            assert_close(a_.grad / sc, (b_.grad / sc).cpu().numpy(), what=what + " two-pass " + nm)
 
 
 @pytest.mark.parametrize("kind,relu,logs", [("normal", False, False), ("normal", True, True), ("uniform", True, False)])

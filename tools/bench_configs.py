@@ -62,8 +62,12 @@ def main():
     ap.add_argument("--blk", default=None, help="A/B: batch budget of the cooperative GAT kernels, 'edges,units' (at most the library's STAG_BLOCK_EDGES, STAG_BLOCK_UNITS)")
     ap.add_argument("--gat-old-bwd", action="store_true",
                     help="cfg5_train: the composed backward (stag_gat_bwd_edge + three stag_agg_fwd calls) for A/B")
+    ap.add_argument("--gat-two-pass", action="store_true",
+                    help="cfg5_train: stag_gat_bwd_two_pass (edge pass + source pass: two gathers) for A/B")
     args = ap.parse_args()
     only = [s for s in args.only.split(",") if s]
+    if args.gat_two_pass:
+        ops._GAT_BWD_ONE_GATHER = False
     if args.blk:
         _lib.BLOCK_EDGES, _lib.BLOCK_UNITS = (int(v) for v in args.blk.split(","))
     if args.gat_old_bwd:
