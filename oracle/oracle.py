@@ -324,3 +324,27 @@ def agg_fwd_mc(g, x, spec, n_samples, offset_stride=1, **kw):
         s.offset = spec.offset + s_i * offset_stride
         outs.append(agg_fwd(g, x, s, **kw))
     return np.stack(outs, 0)
+
+
+# ---- amortised per-edge parameters and their KL term (float64 numpy; no C twin: dense arithmetic) -----------
+def amortized_parameters(src, dst, feat, w_embed, b_embed, heads):
+    """AmortizedDistribution.condition (stag/distributions.py:221-233) restated:
+        h_e   = SiLU(W_e [feat[src_e] || feat[dst_e]] + b_e)       :225-227 (embedding_mlp = Linear + SiLU, :178-183)
+        par_c = W_c h_e + b_c  for every head c                    :229-231 (parameters_mlp, :186-191)
+    heads: {name: (weight [out, hidden], bias [out])} -> {name: [E, out]} in float64."""
+    f = np.asarray(feat, np.float64)
+    cat = np.concatenate([f[np.asarray(src)], f[np.asarray(dst)]], 1)
+    pre = cat @ np.asarray(w_embed, np.float64).T + (0.0 if b_embed is None else np.asarray(b_embed, np.float64))
+    h = pre / (1.0 + np.exp(-pre))
+    return {k: h @ np.asarray(w, np.float64).T + (0.0 if b is None else np.asarray(b, np.float64))
+            for k, (w, b) in heads.items()}
+
+
+def normal_kl_mean(loc, log_scale, p_loc, p_scale):
+    """StagLayer.kl_divergence for a Normal pair (stag/layers.py:132-139): torch's closed form
+    (torch/distributions/kl.py _kl_normal_normal: 0.5 (vr + t1 - 1 - log vr), vr = (s_q / s_p)^2,
+    t1 = ((m_q - m_p) / s_p)^2), averaged over every element."""
+    m, ls = np.asarray(loc, np.float64), np.asarray(log_scale, np.float64)
+    vr = (np.exp(ls) / float(p_scale)) ** 2
+    t1 = ((m - float(p_loc)) / float(p_scale)) ** 2
+    return float((0.5 * (vr + t1 - 1.0 - np.log(vr))).mean())

@@ -332,6 +332,33 @@ def main():
         fx[f"amort_{tag}_w"] = layer._edge_weight_sample.numpy()
         fx[f"amort_{tag}_out"] = out.detach().numpy()
 
+    # ---- (b'') amortised + vi=True: the KL term against a learned Normal prior and every gradient of
+    #      loss = <gout, out> + kl  (stag/layers.py:132-145; scripts/arxiv_rec/gcn/run.py:85, 148-155)
+    torch.manual_seed(53)
+    g = G("hub40")
+    x = torch.randn(40, 16, requires_grad=True)
+    q = AmortizedDistribution(16, 1, init_like=torch.distributions.Normal(1.0, 0.3))
+    with torch.no_grad():           # the default heads are near-constant: make every weight matter
+        for prm in q.parameters():
+            prm.copy_(torch.randn_like(prm) * 0.5)
+    layer = StagLayer(SumBase(), q_a=q, p_a=torch.distributions.Normal(0.8, 0.6), vi=True)
+    for k, v in layer.state_dict().items():
+        fx[f"amort_kl_sd_{k}"] = v.numpy().copy()
+    torch.manual_seed(78)
+    out = quiet(layer, g, x)
+    kl = layer.kl_divergence()
+    gout = torch.randn(40, 16)
+    ((out * gout).sum() + kl).backward()
+    fx["amort_kl_x"], fx["amort_kl_gout"] = x.detach().numpy(), gout.numpy()
+    fx["amort_kl_w"] = layer._edge_weight_sample.detach().numpy()
+    fx["amort_kl_out"] = out.detach().numpy()
+    fx["amort_kl_value"] = np.array([kl.item()], np.float32)
+    fx["amort_kl_loc"] = q.new_parameters["loc"].detach().numpy()
+    fx["amort_kl_log_scale"] = q.new_parameters["log_scale"].detach().numpy()
+    fx["amort_kl_grad_x"] = x.grad.numpy()
+    for k, prm in layer.named_parameters():
+        fx[f"amort_kl_grad_{k}"] = prm.grad.numpy().copy()
+
     # ---- (c) zoo layers with an explicit edge_weight ---------------------------
     torch.manual_seed(5)
     g = G("hub40")

@@ -263,3 +263,45 @@ def test_cfg1_cora_two_layer_gcn_model(dev, oracle):
     assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in l1.base_layer.parameters())
     pred = model(g, x, n_samples=4, return_parameters=True)
     assert pred.shape == (n, 7) and torch.allclose(pred.sum(-1), torch.ones(n, device=dev), atol=1e-5)
+
+
+def test_amortized_vi_layer_kl_and_gradients_golden(dev, golden, oracle):
+    """The reference's amortised vi=True layer (fixture amort_kl: AmortizedDistribution(16, 1), a learned Normal
+    prior, loss = <gout, out> + kl_divergence(); stag/layers.py:93-145) through the HIP path: condition() on the
+    device (ops.node_project + ops.edge_mlp), the fused KL (ops.normal_kl_mean), and every gradient of the loss
+    with the reference's own noise draw injected (eps = (w - loc) / scale from the fixture)."""
+    import stag_amd
+    from stag_amd import ops
+    from stag_amd.distributions import AmortizedDistribution
+    g = stag_amd.Graph(torch.from_numpy(golden["hub40_src"]), torch.from_numpy(golden["hub40_dst"]), 40, device=dev)
+    q = AmortizedDistribution(16, 1)
+    layer = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(16, 16), q_a=q, p_a=torch.distributions.Normal(0.8, 0.6), vi=True)
+    sd = {k[len("amort_kl_sd_"):]: torch.from_numpy(golden[k]) for k in golden.files if k.startswith("amort_kl_sd_")}
+    missing = layer.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all(k.startswith("base_layer.") for k in missing.missing_keys)
+    layer = layer.to(dev)
+    x = torch.from_numpy(golden["amort_kl_x"]).to(dev).requires_grad_(True)
+    q = layer.q_a
+    q.condition(g, x)
+    loc, ls = q.new_parameters["loc"], q.new_parameters["log_scale"]
+    assert "EdgeMlp" in type(loc.grad_fn).__name__
+    assert_close(loc, golden["amort_kl_loc"], what="loc vs reference")
+    assert_close(ls, golden["amort_kl_log_scale"], what="log_scale vs reference")
+    kl = layer.kl_divergence()
+    assert "NormalKlMean" in type(kl.grad_fn).__name__
+    ref_kl = float(golden["amort_kl_value"][0])
+    assert abs(float(kl.detach()) - ref_kl) <= 1e-5 * abs(ref_kl)
+    assert abs(oracle.normal_kl_mean(loc.detach().cpu().numpy(), ls.detach().cpu().numpy(), 0.8, 0.6) - ref_kl) <= 1e-5 * abs(ref_kl)
+    # the reference's draw: w = loc + exp(log_scale) * eps, [E, 16]
+    w_ref = torch.from_numpy(golden["amort_kl_w"]).to(dev)
+    eps = (w_ref - torch.from_numpy(golden["amort_kl_loc"]).to(dev)) / torch.from_numpy(golden["amort_kl_log_scale"]).to(dev).exp()
+    w = loc + ls.exp() * eps
+    out = ops.aggregate(g, x, w)                       # SumBase: sum_e w_e * x[src_e]
+    assert_close(out, golden["amort_kl_out"], what="layer output")
+    gout = torch.from_numpy(golden["amort_kl_gout"]).to(dev)
+    ((out * gout).sum() + kl).backward()
+    checks = [("x", x.grad)] + [(k, p.grad) for k, p in layer.named_parameters() if not k.startswith("base_layer.")]
+    for k, got in checks:
+        ref = golden[f"amort_kl_grad_{k}"]
+        sc = max(1.0, float(np.abs(ref).max()))
+        assert_close(got / sc, ref / sc, tol=2e-5, what=f"d loss / d {k}")

@@ -314,6 +314,23 @@ def test_amortized_distribution_condition_golden(golden, tag, of):
     assert torch.allclose(init.parameters_mlp["log_scale"].bias, torch.full((2,), float(np.log(0.3))))
 
 
+def test_oracle_amortized_parameters_and_kl_golden(golden, oracle):
+    """The oracle's restatement of AmortizedDistribution.condition and of the Normal KL term against what the
+    reference computed (fixtures amort_re, amort_rec, amort_kl: tests/golden/make_golden.py b', b'')."""
+    src, dst = golden["hub40_src"], golden["hub40_dst"]
+    for tag, pre in (("re", "amort_re_sd_"), ("rec", "amort_rec_sd_"), ("kl", "amort_kl_sd_q_a.")):
+        sd = {k[len(pre):]: golden[k] for k in golden.files if k.startswith(pre)}
+        got = oracle.amortized_parameters(
+            src, dst, golden[f"amort_{tag}_x"], sd["embedding_mlp.0.weight"], sd["embedding_mlp.0.bias"],
+            {n: (sd[f"parameters_mlp.{n}.weight"], sd[f"parameters_mlp.{n}.bias"]) for n in ("loc", "log_scale")})
+        for n in ("loc", "log_scale"):
+            ref = golden[f"amort_{tag}_{n}"]
+            assert np.abs(got[n] - ref).max() <= 1e-5 * (1 + np.abs(ref).max()), (tag, n)
+    kl = oracle.normal_kl_mean(golden["amort_kl_loc"], golden["amort_kl_log_scale"], golden["amort_kl_sd_p_a.loc"],
+                               np.exp(golden["amort_kl_sd_p_a.log_scale"]))
+    assert abs(kl - float(golden["amort_kl_value"][0])) <= 1e-5 * abs(kl)
+
+
 def test_stag_layer_construction_and_state_dict():
     import stag_amd
     L = stag_amd.layers.StagLayer
