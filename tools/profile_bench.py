@@ -98,7 +98,7 @@ def main():
             f.write("\n")
 
     summary = {}
-    short = ["--steps", "20", "--warmup", "5", *common]
+    short = ["--steps", "20", "--warmup", "5", "--settle-ms", "0", *common]     # counters do not need warm clocks
     for tag, ctrs in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_sq", SQ)):
         out, _ = run_prof(tag, ["--pmc", *ctrs], short, scratch)
         name, nd, avg = counters(out, kernel_sub)
