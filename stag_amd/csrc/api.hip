@@ -20,10 +20,11 @@ namespace {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-int check_spec(const stag_noise_spec* s) {
+// n_edges: per-edge arrays (explicit weights, [E, 1 | Dn] parameters) of a graph without edges have no address
+int check_spec(const stag_noise_spec* s, int64_t n_edges = 1) {
   if (!s) return STAG_EINVAL;
   if (s->kind < STAG_NOISE_NONE || s->kind > STAG_NOISE_BERNOULLI) return STAG_EINVAL;
-  if (s->kind == STAG_NOISE_EXPLICIT && !s->p0) return STAG_EINVAL;
+  if (s->kind == STAG_NOISE_EXPLICIT && !s->p0 && n_edges > 0) return STAG_EINVAL;
   if (s->deriv < 0 || s->deriv > 2 || s->chunk_base < 0 || s->chunk_base >= (1 << 20)) return STAG_EINVAL;
   if (s->deriv != 0 && (s->in_norm || (s->kind != STAG_NOISE_NORMAL && s->kind != STAG_NOISE_UNIFORM)))
     return STAG_EINVAL;   // only reparameterised draws have a derivative; in-norm is not differentiated here
@@ -31,7 +32,8 @@ int check_spec(const stag_noise_spec* s) {
   if (s->p1_log && s->param_mode == STAG_PARAM_PER_CHANNEL) return STAG_ENOSYS;   // exponentiate a [Dn] row yourself
   if (s->kind >= STAG_NOISE_NORMAL) {
     if (s->param_mode < STAG_PARAM_SCALAR || s->param_mode > STAG_PARAM_PER_EDGE) return STAG_EINVAL;
-    if (s->param_mode != STAG_PARAM_SCALAR) {
+    const bool per_edge = s->param_mode == STAG_PARAM_PER_EDGE1 || s->param_mode == STAG_PARAM_PER_EDGE;
+    if (s->param_mode != STAG_PARAM_SCALAR && !(per_edge && n_edges == 0)) {
       if (!s->p0) return STAG_EINVAL;
       if (s->kind != STAG_NOISE_BERNOULLI && !s->p1) return STAG_EINVAL;
     }
@@ -598,7 +600,7 @@ static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x
                       const EdgeGradOut* eg = nullptr) {
   int rc = check_csr(csr);
   if (rc) return rc;
-  rc = check_spec(spec);
+  rc = check_spec(spec, csr->n_edges);
   if (rc) return rc;
   // ldx == 0: one broadcast row; out may be NULL when only the in-norm factor (or the edge gradients) is wanted
   if ((!out && !norm_scale_out && !eg) || D <= 0 || (ldx != 0 && ldx < D) || ldo < D) return STAG_EINVAL;
@@ -745,7 +747,8 @@ int stag_agg_bwd_edge(const stag_csr* csr_t, const stag_plan* plan_t, const floa
                       int32_t D, const stag_noise_spec* spec, const float* g_scale,
                       const float* row_scale, const float* x, int64_t ldx, float* dx, int64_t ldo,
                       float* dp0_edge, float* dp1_edge, void* stream) {
-  if (!spec || !csr_t || !x || !dp0_edge || ldx < D) return STAG_EINVAL;
+  if (!spec || !csr_t || ldx < D) return STAG_EINVAL;
+  if (csr_t->n_edges > 0 && (!x || !dp0_edge)) return STAG_EINVAL;     // (no edge: nothing per edge to write)
   if (spec->kind != STAG_NOISE_NORMAL && spec->kind != STAG_NOISE_UNIFORM) return STAG_EINVAL;
   if (spec->param_mode != STAG_PARAM_PER_EDGE1 || spec->in_norm || spec->deriv) return STAG_EINVAL;
   // the parameters and their gradients live at edge ids, the noise at forward positions
@@ -791,7 +794,7 @@ int stag_noise_materialize(const stag_csr* csr, const stag_plan* plan, const sta
                            int32_t Dn, float* w, int64_t ldw, float* norm_scale, void* stream) {
   int rc = check_csr(csr);
   if (rc) return rc;
-  rc = check_spec(spec);
+  rc = check_spec(spec, csr->n_edges);
   if (rc) return rc;
   if (!w || Dn <= 0 || ldw < Dn) return STAG_EINVAL;
   if (spec->in_norm && !norm_scale) return STAG_EINVAL;   // [n_dst, Dn] scratch for the row factors
@@ -835,7 +838,7 @@ int stag_agg_bwd_w(const stag_csr* csr, const stag_plan* plan, const float* x, i
                    void* stream) {
   int rc = check_csr(csr);
   if (rc) return rc;
-  if (spec) { rc = check_spec(spec); if (rc) return rc; }
+  if (spec) { rc = check_spec(spec, csr->n_edges); if (rc) return rc; }
   if (!x || !g || !dw || D <= 0 || (ldx != 0 && ldx < D) || ldg < D) return STAG_EINVAL;
   if (ldw < (reduce_k ? 1 : D)) return STAG_EINVAL;
   if (dw1 && !(spec && (spec->kind == STAG_NOISE_NORMAL || spec->kind == STAG_NOISE_UNIFORM))) return STAG_EINVAL;

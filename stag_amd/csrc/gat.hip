@@ -1432,8 +1432,8 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
   if (spec->in_norm && !norm_scale) return STAG_EINVAL;   // the caller runs the row-sum pass first
   if (csr->n_dst == 0) return STAG_OK;
   if (csr->n_edges > 0 && (!csr->indices || !el || !er || !ft)) return STAG_EINVAL;
-  if (spec->kind == STAG_NOISE_EXPLICIT && !spec->p0) return STAG_EINVAL;
-  if (spec->kind >= STAG_NOISE_NORMAL && spec->param_mode != STAG_PARAM_SCALAR &&
+  if (spec->kind == STAG_NOISE_EXPLICIT && !spec->p0 && csr->n_edges > 0) return STAG_EINVAL;
+  if (spec->kind >= STAG_NOISE_NORMAL && spec->param_mode != STAG_PARAM_SCALAR && csr->n_edges > 0 &&
       (!spec->p0 || (spec->kind != STAG_NOISE_BERNOULLI && !spec->p1)))
     return STAG_EINVAL;
   const int HF = (int)HF64;
@@ -1565,7 +1565,7 @@ extern "C" int stag_gat_attn(const stag_csr* csr, const stag_plan* plan, const f
   if (spec->in_norm && !norm_scale) return STAG_EINVAL;
   if (csr->n_dst == 0 || csr->n_edges == 0) return STAG_OK;
   if (!csr->indices || !el || !er) return STAG_EINVAL;
-  if (spec->kind == STAG_NOISE_EXPLICIT && !spec->p0) return STAG_EINVAL;
+  if (spec->kind == STAG_NOISE_EXPLICIT && !spec->p0 && csr->n_edges > 0) return STAG_EINVAL;
   GatArgs a{};
   const int rc = fill_edge_args(a, csr, plan, el, er, H, neg_slope, spec, norm_scale, stats);
   if (rc) return rc;
@@ -1590,7 +1590,7 @@ extern "C" int stag_gat_bwd_edge(const stag_csr* csr, const stag_plan* plan, con
   if (csr->n_dst == 0 || csr->n_edges == 0) return STAG_OK;
   if (!csr->indices || !el || !er || !ft || !stats || !g || !out) return STAG_EINVAL;
   if (!aligned16(ft) || !aligned16(g) || !aligned16(out)) return STAG_EINVAL;
-  if (spec->kind == STAG_NOISE_EXPLICIT && !spec->p0) return STAG_EINVAL;
+  if (spec->kind == STAG_NOISE_EXPLICIT && !spec->p0 && csr->n_edges > 0) return STAG_EINVAL;
   const int HF = (int)HF64;
   GatBwdArgs ba{};
   GatArgs& a = ba.f;
@@ -1644,7 +1644,7 @@ extern "C" int stag_gat_bwd_two_pass(const stag_csr* csr, const stag_plan* plan,
   if (csr->n_dst == 0 || csr->n_edges == 0) return STAG_OK;   // the caller zero-fills (no edge, no gradient)
   if (!csr->indices || !csr_t->indices || !csr_t->nidx || !el || !er || !ft || !stats || !g || !out) return STAG_EINVAL;
   if (!aligned16(ft) || !aligned16(g) || !aligned16(out) || !aligned16(d_ft) || !aligned16(ade_ws)) return STAG_EINVAL;
-  if (spec->kind == STAG_NOISE_EXPLICIT && !spec->p0) return STAG_EINVAL;
+  if (spec->kind == STAG_NOISE_EXPLICIT && !spec->p0 && csr->n_edges > 0) return STAG_EINVAL;
   if (spec->kind >= STAG_NOISE_NORMAL && (uint64_t)((uint64_t)spec->pos_base & 0xFFFFFFFFull) + (uint64_t)csr->n_edges > (1ull << 32))
     return STAG_ENOSYS;
   const int HF = (int)HF64;
@@ -1744,7 +1744,7 @@ extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const st
   if (!csr->indices || !csr_t->indices || !csr_t->nidx || !el || !er || !ft || !stats || !g || !out) return STAG_EINVAL;
   if (csr->eid && !csr_t->eid) return STAG_EINVAL;            // edge ids of the transposed positions
   if (!aligned16(ft) || !aligned16(g) || !aligned16(out) || !aligned16(d_ft) || !aligned16(scratch)) return STAG_EINVAL;
-  if (spec->kind == STAG_NOISE_EXPLICIT && !spec->p0) return STAG_EINVAL;
+  if (spec->kind == STAG_NOISE_EXPLICIT && !spec->p0 && csr->n_edges > 0) return STAG_EINVAL;
   if (spec->kind >= STAG_NOISE_NORMAL && (uint64_t)((uint64_t)spec->pos_base & 0xFFFFFFFFull) + (uint64_t)csr->n_edges > (1ull << 32))
     return STAG_ENOSYS;
   if (!plan_t->units || !aligned16(plan_t->units)) return STAG_EINVAL;

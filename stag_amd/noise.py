@@ -25,6 +25,8 @@ def fusable(dist):
 
 def _param_mode(p, n_edges, dn):
     """Classify how a parameter tensor broadcasts against [E, Dn] (`.expand([E, Dn])`)."""
+    if p.dim() == 2 and p.shape == (n_edges, 1) and n_edges == 1:
+        return _lib.PARAM_PER_EDGE1          # the [E, 1] head of a one-edge graph is still one value per edge
     if p.dim() == 0 or p.numel() == 1:
         return _lib.PARAM_SCALAR
     if p.dim() == 1 and p.shape[0] == dn:

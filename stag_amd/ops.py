@@ -1002,6 +1002,11 @@ class _GatAggregate(torch.autograd.Function):
         else:
             spec = _targs_or_c(_none_spec())
         want_dw = w is not None and ctx.needs_input_grad[3]
+        if csrv.n_edges == 0:        # no edge, no gradient
+            return (torch.zeros_like(el) if ctx.needs_input_grad[0] else None,
+                    torch.zeros_like(er) if ctx.needs_input_grad[1] else None,
+                    torch.zeros_like(ft) if ctx.needs_input_grad[2] else None,
+                    torch.zeros_like(w) if want_dw else None, None, None, None, None, None)
         fused = _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, ctx.neg_slope, spec, nscale,
                                want_dw, ctx.seg_len, dev)
         if fused is not None:

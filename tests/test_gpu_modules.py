@@ -1142,3 +1142,34 @@ def test_head_dot(dev, n, H, F):
         sc = max(1.0, float(r.abs().max()))
         assert_close(got / sc, (r / sc).cpu().numpy(), what=nm)
     assert ops.head_dot(torch.zeros(4, 2, 12, device=dev), al, ar) is None      # F = 12: the GEMM form
+
+
+@pytest.mark.parametrize("n,E", [(5, 0), (1, 0), (3, 1)])
+def test_layers_on_edgeless_and_one_edge_graphs(dev, n, E):
+    """Degenerate graphs through whole layers, forward and backward: no edges at all (per-edge arrays without an
+    address; every gradient that flows through an edge is zero; the KL mean over zero edges is NaN as in the
+    reference, stag/layers.py:136-139) and a single edge (an [E, 1] head of one element is still per edge)."""
+    import stag_amd
+    from stag_amd.distributions import AmortizedDistribution
+    N = torch.distributions.Normal
+    g = stag_amd.Graph(torch.zeros(E, dtype=torch.int64), torch.full((E,), min(1, n - 1), dtype=torch.int64), n, device=dev)
+    x = torch.randn(n, 8, device=dev, requires_grad=True)
+    q = AmortizedDistribution(8, 1, init_like=N(1.0, 0.3)).to(dev)
+    layer = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(8, 4, allow_zero_in_degree=True), q_a=q, vi=True).to(dev)
+    y = layer(g, x)
+    kl = layer.kl_divergence()
+    assert y.shape == (n, 4) and torch.isfinite(y).all()
+    assert torch.isnan(kl) if E == 0 else torch.isfinite(kl)
+    (y.sum() + (kl if E else 0.0)).backward()
+    assert torch.isfinite(x.grad).all()
+    if E == 0:
+        assert float(x.grad.abs().sum()) == 0.0 and float(layer.base_layer.weight.grad.abs().sum()) == 0.0
+    else:
+        assert float(q.embedding_mlp[0].weight.grad.abs().sum()) > 0.0
+    for base in (stag_amd.zoo.GAT(8, 4, num_heads=2, allow_zero_in_degree=True),
+                 stag_amd.zoo.GraphSAGE(8, 4, aggregator_type="mean"), stag_amd.zoo.GIN(8, 4)):
+        lay = stag_amd.layers.StagLayer(base, q_a=N(1.0, 0.5)).to(dev)
+        x2 = torch.randn(n, 8, device=dev, requires_grad=True)
+        o = lay(g, x2)
+        o.sum().backward()
+        assert torch.isfinite(o).all() and torch.isfinite(x2.grad).all()
