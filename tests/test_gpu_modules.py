@@ -1173,3 +1173,42 @@ def test_layers_on_edgeless_and_one_edge_graphs(dev, n, E):
         o = lay(g, x2)
         o.sum().backward()
         assert torch.isfinite(o).all() and torch.isfinite(x2.grad).all()
+
+
+def test_new_backward_paths_are_bit_reproducible(dev):
+    """Fixed-order reductions everywhere: the one-pass [E,1] backward, the narrow amortised heads, the KL, GAT's
+    per-head dots and its one-gather backward give the same bits on every run (hub rows, segments, block partials
+    included) — nothing is accumulated with atomics."""
+    import stag_amd
+    from stag_amd.distributions import AmortizedDistribution
+    from util import random_graph
+    N = torch.distributions.Normal
+    n, D = 3000, 64
+    g = random_graph(n, 40000, seed=5, hub=2500, device=dev)
+    torch.manual_seed(3)
+    x0 = torch.randn(n, D, device=dev)
+    gout = torch.randn(n, D, device=dev)
+    q = AmortizedDistribution(D, 1, init_like=N(1.0, 0.3)).to(dev)
+    for p in q.parameters():
+        torch.nn.init.normal_(p, 0.0, 0.3)
+    re_layer = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(D, D), q_a=q, vi=True).to(dev)
+    gat_layer = stag_amd.layers.StagLayer(stag_amd.zoo.GAT(D, 16, num_heads=4), q_a=N(1.0, 0.5)).to(dev)
+
+    def run(layer, with_kl):
+        stag_amd.manual_seed(11)
+        layer.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        y = layer(g, x)
+        outs, grads = [y], [gout[:, :y.shape[1]]]
+        if with_kl:
+            outs.append(layer.kl_divergence())
+            grads.append(torch.ones((), device=dev))
+        torch.autograd.backward(outs, grads)
+        return [y.detach().clone(), x.grad.clone()] + [o.detach().clone() for o in outs[1:]] + \
+               [p.grad.clone() for p in layer.parameters() if p.grad is not None]
+
+    for layer, with_kl in ((re_layer, True), (gat_layer, False)):
+        first = run(layer, with_kl)
+        for _ in range(3):
+            again = run(layer, with_kl)
+            assert len(again) == len(first) and all(torch.equal(a, b) for a, b in zip(first, again))
