@@ -37,7 +37,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ---- y[n, c] = sum_k x[n, k] w[k, c] + b[c] ---------------------------------------------------------------
 // A team of LPE lanes per kFwdRows consecutive rows (that many row loads in flight per lane), 4 columns of x per
 // lane and tile; the lane's 4 x C slice of w sits in registers.
-constexpr int kFwdRows = 4;
+constexpr int kFwdRows = 4, kBwdRows = 4;
 template <int LPE, int CT>
 __global__ __launch_bounds__(256) void node_project_fwd_kernel(const float* x, int64_t ldx, int n, int K,
                                                                const float* w, const float* b, int C, bool vec,
@@ -109,24 +109,35 @@ __global__ __launch_bounds__(256) void node_project_bwd_kernel(const float* x, i
         wv[q][cc] = (k0 + q < K && cc < C) ? w[(k0 + q) * C + cc] : 0.f;
         dwacc[q][cc] = 0.f;
       }
-    for (int row = t0; row < n; row += T) {
-      float g[CT];
+    // kBwdRows of the team's rows per trip (that many row loads in flight per lane), folded in row order
+    constexpr int RB = CT <= 4 ? kBwdRows : 1;
+    for (int row0 = t0; row0 < n; row0 += RB * T) {
+      float g[RB][CT], xv[RB][4];
 #pragma unroll
-      for (int cc = 0; cc < CT; ++cc) g[cc] = cc < C ? gy[(int64_t)row * C + cc] : 0.f;
-      float xv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (k0 < K) load4(x + (int64_t)row * ldx, k0, K, vec, xv);
-      float d[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < RB; ++r) {
+        const int row = row0 + r * T;
+        xv[r][0] = xv[r][1] = xv[r][2] = xv[r][3] = 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+        for (int cc = 0; cc < CT; ++cc) g[r][cc] = (cc < C && row < n) ? gy[(int64_t)row * C + cc] : 0.f;
+        if (k0 < K && row < n) load4(x + (int64_t)row * ldx, k0, K, vec, xv[r]);
+      }
 #pragma unroll
-        for (int cc = 0; cc < CT; ++cc) {
-          d[q] = __builtin_fmaf(g[cc], wv[q][cc], d[q]);
-          dwacc[q][cc] = __builtin_fmaf(xv[q], g[cc], dwacc[q][cc]);
+      for (int r = 0; r < RB; ++r) {
+        const int row = row0 + r * T;
+        if (row >= n) break;
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int cc = 0; cc < CT; ++cc) {
+            d[q] = __builtin_fmaf(g[r][cc], wv[q][cc], d[q]);
+            dwacc[q][cc] = __builtin_fmaf(xv[r][q], g[r][cc], dwacc[q][cc]);
+          }
+        if (dx && k0 < K) stag::store4(dx + (int64_t)row * lddx, k0, K, vec, d);
+        if (kt == 0 && c == 0) {
+#pragma unroll
+          for (int cc = 0; cc < CT; ++cc) dbacc[cc] += g[r][cc];
         }
-      if (dx && k0 < K) stag::store4(dx + (int64_t)row * lddx, k0, K, vec, d);
-      if (kt == 0 && c == 0) {
-#pragma unroll
-        for (int cc = 0; cc < CT; ++cc) dbacc[cc] += g[cc];
       }
     }
     // the block's teams, in team order
@@ -251,19 +262,32 @@ __global__ __launch_bounds__(256) void head_dot_bwd_kernel(const float* x, int64
       dwacc[cc][0] = dwacc[cc][1] = dwacc[cc][2] = dwacc[cc][3] = 0.f;
     }
     if (in) {
-      for (int row = t0; row < n; row += T) {
-        float gv[CG], xv[4], d[4] = {0.f, 0.f, 0.f, 0.f};
+      constexpr int RB = kBwdRows;       // rows of the team per trip, folded in row order
+      for (int row0 = t0; row0 < n; row0 += RB * T) {
+        float gv[RB][CG], xv[RB][4];
 #pragma unroll
-        for (int cc = 0; cc < CG; ++cc) gv[cc] = gy[((int64_t)cc * n + row) * G + g];
-        load4(x + (int64_t)row * ldx, k0, K, true, xv);
+        for (int r = 0; r < RB; ++r) {
+          const int row = row0 + r * T;
+          if (row < n) {
 #pragma unroll
-        for (int cc = 0; cc < CG; ++cc)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            d[q] = __builtin_fmaf(gv[cc], wv[cc][q], d[q]);
-            dwacc[cc][q] = __builtin_fmaf(gv[cc], xv[q], dwacc[cc][q]);
+            for (int cc = 0; cc < CG; ++cc) gv[r][cc] = gy[((int64_t)cc * n + row) * G + g];
+            load4(x + (int64_t)row * ldx, k0, K, true, xv[r]);
           }
-        if (dx) stag::store4(dx + (int64_t)row * lddx, k0, K, true, d);
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const int row = row0 + r * T;
+          if (row >= n) break;
+          float d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int cc = 0; cc < CG; ++cc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              d[q] = __builtin_fmaf(gv[r][cc], wv[cc][q], d[q]);
+              dwacc[cc][q] = __builtin_fmaf(gv[r][cc], xv[r][q], dwacc[cc][q]);
+            }
+          if (dx) stag::store4(dx + (int64_t)row * lddx, k0, K, true, d);
+        }
       }
     }
 #pragma unroll
