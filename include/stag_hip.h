@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 13
+#define STAG_ABI_VERSION 14
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -263,6 +263,20 @@ int stag_agg_bwd(const stag_csr* csr_t, const stag_plan* plan_t, const float* g,
                  int32_t D, const stag_noise_spec* spec, const float* g_scale,
                  const float* row_scale, float* dx, float* dp0_rows, float* dp1_rows,
                  int64_t ldo, void* stream);
+
+/* stag_agg_bwd with the parameter gradients FINISHED in the same pass (scalar | per-channel parameters, kind
+ * NORMAL | UNIFORM, in_norm 0): on the source-major CSR the row of x an edge's term needs is the unit's own row, so
+ *     dp_i[k] = sum_e dw/dp_i[e,k] * g_scale[v] g[v,k] * row_scale[u] x[u,k]
+ * is summed where the edges are walked — every lane keeps its share, a block adds its teams and leaves one partial,
+ * two small launches add the blocks in a fixed order — instead of two [n_dst, D] aggregates (stag_agg_bwd) and a
+ * column-dot pass over them (stag_coldot).  dp0, dp1: [D] (a scalar parameter's gradient is their sum over k);
+ * x == NULL: ones (the in-norm term of ops._AggregateVI); dx may be NULL; any D.
+ * workspace >= stag_agg_bwd_dp_workspace_bytes(n_units, D), n_units = plan_t->n_units (no plan: csr_t->n_dst).     */
+size_t stag_agg_bwd_dp_workspace_bytes(int64_t n_units, int32_t D);
+int stag_agg_bwd_dp(const stag_csr* csr_t, const stag_plan* plan_t, const float* g, int64_t ldg,
+                    int32_t D, const stag_noise_spec* spec, const float* g_scale,
+                    const float* row_scale, const float* x, int64_t ldx, float* dx, int64_t ldo,
+                    float* dp0, float* dp1, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of stag_agg_fwd for [E, 1] (amortised) parameters, param_mode PER_EDGE1, kind NORMAL | UNIFORM:
  * dx AND the gradient of every edge's parameter pair from ONE pass over the source-major CSR — the row of

@@ -104,6 +104,10 @@ def lib():
                                C.POINTER(NoiseSpec), _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]
     l.stag_agg_bwd_edge.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, C.c_int64, C.c_int32,
                                     C.POINTER(NoiseSpec), _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, _vp]
+    l.stag_agg_bwd_dp_workspace_bytes.restype = C.c_size_t
+    l.stag_agg_bwd_dp_workspace_bytes.argtypes = [C.c_int64, C.c_int32]
+    l.stag_agg_bwd_dp.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, C.c_int64, C.c_int32, C.POINTER(NoiseSpec),
+                                  _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, _vp, C.c_size_t, _vp]
     l.stag_amort_workspace_bytes.restype = C.c_size_t
     l.stag_amort_workspace_bytes.argtypes = [C.c_int32]
     l.stag_head_dot_fwd.argtypes = [_vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp]
@@ -145,7 +149,7 @@ def lib():
     l.stag_comm_destroy.argtypes = [_vp]
     l.stag_halo_allgather.argtypes = [_vp, _vp, C.c_int64, _vp, _vp]
     l.stag_halo_exchange.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
-    if l.stag_abi_version() != 13:
+    if l.stag_abi_version() != 14:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     _lib = l
     return l

@@ -84,6 +84,9 @@ struct AggArgs {
   const float* own_scale;  // [n_rows] or null: factor on the own row
   float* eg0;              // [E] by edge id: d / d p0
   float* eg1;              // [E] by edge id: d / d p1 (d / d log p1 under the log-scale flag); may be null
+  // gradients of scalar / per-channel parameters out of the same pass (stag_agg_bwd_dp; PEDGE 4): every lane sums
+  // dw/dp_i * (gathered row) * (own row of xown; null: ones) over the edges it walks, the block adds its teams
+  float* dp_part;          // [gridDim.y][gridDim.x][2][LPE * 4] block partials, or null
   // plan
   const stag_unit* units;  // null: unit i = row i, unsplit
   int32_t n_units;
@@ -361,6 +364,11 @@ struct EdgeParams<BLK, 2> { float pa[BLK][4], pb[BLK][4]; };
 // PEDGE 3 = PEDGE 1 whose pass also returns the gradients of the pair (stag_agg_bwd_edge)
 template <int BLK>
 struct EdgeParams<BLK, 3> : EdgeParams<BLK, 1> {};
+// PEDGE 4 = PEDGE 0 (scalar / per-channel parameters) whose pass also sums their gradients (stag_agg_bwd_dp)
+template <bool ON>
+struct DpAcc { float v[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}; };
+template <>
+struct DpAcc<false> {};
 template <bool ON>
 struct OwnRow { float v[4]; };
 template <>
@@ -399,7 +407,7 @@ struct AggTeam {
   static_assert(NOUT == 1 || PEDGE == 0, "extra outputs: scalar / per-channel parameters");
   static_assert(NOUT == 1 || MC || (NOUT == 3 && (KIND == kNormal || KIND == kUniform)), "derivatives: reparameterised draws");
   static_assert(!MC || KIND >= kNormal, "Monte-Carlo samples need sampled noise");
-  static constexpr bool NEED_EID = (KIND == kExplicit) || PEDGE != 0;
+  static constexpr bool NEED_EID = (KIND == kExplicit) || (PEDGE != 0 && PEDGE != 4);
   const AggArgs& a;
   const PhiloxKey key;     // a.key with the device epoch folded in
   const int k0;
@@ -413,7 +421,8 @@ struct AggTeam {
   const bool kahan;
   [[no_unique_address]] ExtraAcc<NX> X;
   [[no_unique_address]] ExtraKeys<MC ? NX : 0> KX;
-  [[no_unique_address]] OwnRow<PEDGE == 3> XO;     // the unit's own row of a.xown (times own_scale)
+  [[no_unique_address]] OwnRow<PEDGE == 3 || PEDGE == 4> XO;     // the unit's own row of a.xown (times own_scale)
+  [[no_unique_address]] DpAcc<PEDGE == 4> DP;      // this lane's share of the two parameter gradients
   static constexpr bool P1 = PEDGE == 1 || PEDGE == 3;
 
   // every lane of the team reads the same BLK column ids: broadcast dword loads with
@@ -467,6 +476,8 @@ struct AggTeam {
 #pragma unroll
           for (int q = 0; q < 4; ++q) { pa[q] = R.P.q0[j]; pb[q] = s1; }
           draw4_grad<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w, g0, g1);
+        } else if constexpr (PEDGE == 4) {
+          draw4_grad<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w, g0, g1);
         } else if constexpr (NX == 0) {
           edge_weight(R, I, j, w);
         } else if constexpr (!MC) {
@@ -489,6 +500,14 @@ struct AggTeam {
 #pragma unroll
             for (int q = 0; q < 4; ++q) TX.acc[o][q] = __builtin_fmaf(dd.acc[o][q], R.xv[j][q], TX.acc[o][q]);
         }
+        if constexpr (PEDGE == 4) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float gx = R.xv[j][q] * XO.v[q];
+            DP.v[0][q] = __builtin_fmaf(g0[q], gx, DP.v[0][q]);
+            DP.v[1][q] = __builtin_fmaf(g1[q], gx, DP.v[1][q]);
+          }
+        }
         if constexpr (PEDGE == 3) {
           // d L / d p_i of this edge = sum_k dw/dp_i[k] * (gathered row)[k] * (own row)[k]: the channel
           // tile is the whole row (one tile: checked on the host), so one team sum finishes it
@@ -506,7 +525,7 @@ struct AggTeam {
             if (a.eg1) a.eg1[I.ee[j]] = e1;
           }
         }
-        if (PEDGE != 3 && a.in_norm) {                   // (stag_agg_bwd_edge: in_norm 0, checked on the host)
+        if (PEDGE != 3 && PEDGE != 4 && a.in_norm) {     // (stag_agg_bwd_edge / _dp: in_norm 0, checked on the host)
           asm volatile("" ::: "memory");
 #pragma unroll
           for (int q = 0; q < 4; ++q) wsum[q] += w[q];   // edge order; 0/1 draws (Bernoulli + norm): exact
@@ -611,7 +630,8 @@ struct AggTeam {
 // One unit (a whole row or a segment of a long row) on LPE x SLOTS lanes of a wave:
 // c = this lane's chunk (4 channels) of the channel tile, sl = its edge slot.
 template <int KIND, int LPE, bool VEC, int PEDGE, int SLOTS, int MULT, int NOUT = 1, bool MC = false>
-__device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const int c, const int sl) {
+__device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const int c, const int sl,
+                                         float (*dp_out)[4] = nullptr) {
   static_assert(LPE * SLOTS <= 64 && 64 % (LPE * SLOTS) == 0, "a unit's lanes stay inside one wave");
   static_assert(NOUT == 1 || SLOTS == 1, "the derivative outputs take the one-slot loop");
   // edges per block: the RNG kinds are VALU-bound and register-hungry, the others want
@@ -623,7 +643,11 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
 #endif
   // (the three-accumulator backward, NOUT 3, at one edge per block: 84 VGPRs = 5 waves instead of 104 = 4, and
   // no faster: 915-1040 against 869-885 us for the r1 layer step; it keeps the block of its separate passes)
-  constexpr int BLK = PEDGE == 3 ? STAG_BLK_EG : (KIND >= kNormal) ? STAG_BLK_RNG : STAG_BLK_MEM;
+  // (PEDGE 4 at one edge per block as well: agg_dp_kernel 189.5 against 204 us at cfg2)
+#ifndef STAG_BLK_DP
+#define STAG_BLK_DP 1
+#endif
+  constexpr int BLK = PEDGE == 3 ? STAG_BLK_EG : PEDGE == 4 ? STAG_BLK_DP : (KIND >= kNormal) ? STAG_BLK_RNG : STAG_BLK_MEM;
   constexpr int NB = BLK * MULT;
 
   const uint32_t chunk = blockIdx.y * LPE + c;
@@ -669,10 +693,15 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
 #pragma unroll
     for (int o = 0; o < NOUT - 1; ++o) T.KX.k[o] = key_plus(T.key, (uint64_t)(o + 1) * a.mc_stride);
   }
-  if constexpr (PEDGE == 3) {
+  if constexpr (PEDGE == 3 || PEDGE == 4) {
     const int row = slot >= 0 ? a.long_rows[v] : v;
     const float os = a.own_scale ? a.own_scale[row] : 1.0f;
-    load4(a.xown + (int64_t)row * a.ldxo, k0, a.D, VEC, T.XO.v);
+    if (PEDGE == 3 || a.xown) {
+      load4(a.xown + (int64_t)row * a.ldxo, k0, a.D, VEC, T.XO.v);
+    } else {                      // no own row: ones (the in-norm term of the parameter gradients)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) T.XO.v[q] = (k0 + q < a.D) ? 1.0f : 0.0f;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) T.XO.v[q] *= os;
   }
@@ -774,6 +803,12 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
 #ifdef STAG_TRACE
   if (trace) trace[1] = wall_clock64();
 #endif
+  if constexpr (PEDGE == 4) {     // the lane's share of the parameter gradients: complete once the edges are walked
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dp_out[i][q] = T.DP.v[i][q];
+  }
   if (slot < 0) {
     if (sl != 0) return;                // every slot holds the row's sum; slot 0 writes it
     agg_epilogue(a, v, len, k0, VEC, T.acc, T.wsum);
@@ -795,7 +830,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   const uint32_t woff = (uint32_t)slot * ((uint32_t)a.ws_stride * 4u) + (uint32_t)k0 * 4u;
   if (sl == 0) {
     store4_sc1(rws, woff, k0, a.D, VEC, T.acc);
-    if (PEDGE != 3 && a.in_norm) store4_sc1(rws, woff + (uint32_t)a.D * 4u, k0, a.D, VEC, T.wsum);
+    if (PEDGE != 3 && PEDGE != 4 && a.in_norm) store4_sc1(rws, woff + (uint32_t)a.D * 4u, k0, a.D, VEC, T.wsum);
     if constexpr (NOUT > 1) {
 #pragma unroll
       for (int o = 0; o < NOUT - 1; ++o)
@@ -832,7 +867,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   float facc[4], fws[4] = {0.f, 0.f, 0.f, 0.f};
   const int slot0 = lane0 + (c << 2);   // slot 0's lane of my channels
   two_level_sum<NF, VEC, LPE, SLOTS>(a.ws, a.ws_stride, s0, s1, k0, a.D, sl, slot0, facc);
-  if (PEDGE != 3 && a.in_norm) two_level_sum<NF, VEC, LPE, SLOTS>(a.ws + a.D, a.ws_stride, s0, s1, k0, a.D, sl, slot0, fws);
+  if (PEDGE != 3 && PEDGE != 4 && a.in_norm) two_level_sum<NF, VEC, LPE, SLOTS>(a.ws + a.D, a.ws_stride, s0, s1, k0, a.D, sl, slot0, fws);
   if (sl != 0) return;
   agg_epilogue(a, row, deg, k0, VEC, facc, fws);
 #pragma unroll
@@ -901,6 +936,32 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
   agg_unit<KIND, LPE, VEC, PEDGE, 1, NOUT == 1 ? mult_of<KIND, LPE>() : 1, NOUT, MC>(a, unit, c, 0);
 }
 
+// The dx pass that also sums the gradients of scalar / per-channel parameters (PEDGE 4; stag_agg_bwd_dp).  A unit's
+// lanes keep their share of sum_e dw/dp_i * g * x in registers; the block's teams are added through LDS in team
+// order and the block leaves ONE partial [2][LPE * 4]; a second launch adds the blocks in order (api.hip).  No
+// [N, D] aggregate per derivative, no column-dot pass over them.
+template <int KIND, int LPE, bool VEC>
+__global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_dp_kernel(const AggArgs a) {
+  constexpr int TEAMS = STAG_BLOCK_THREADS / LPE;
+  __shared__ float s_dp[TEAMS][2][LPE * 4];
+  const int c = threadIdx.x % LPE, tm = threadIdx.x / LPE;
+  const int unit = blockIdx.x * TEAMS + tm;
+  float dp[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (unit < a.n_units) agg_unit<KIND, LPE, VEC, 4, 1, 1>(a, unit, c, 0, dp);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_dp[tm][i][c * 4 + q] = dp[i][q];
+  __syncthreads();
+  float* part = a.dp_part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * LPE * 4);
+  for (int i = threadIdx.x; i < 2 * LPE * 4; i += STAG_BLOCK_THREADS) {
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < TEAMS; ++j) sum += s_dp[j][i / (LPE * 4)][i % (LPE * 4)];
+    part[i] = sum;
+  }
+}
+
 // Launch one (KIND, PEDGE) family; defined per kind in agg_<kind>.hip so the
 // instantiations compile in parallel.
 template <int KIND>
@@ -918,7 +979,7 @@ inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles
   constexpr int TPB = STAG_BLOCK_THREADS / LPE;
   constexpr int HS = heavy_slots_of<LPE>();
   constexpr int TPBH = STAG_BLOCK_THREADS / (LPE * HS);
-  if (HS == 1 || a.outx[0] || pedge == 3) a.n_heavy = 0;
+  if (HS == 1 || a.outx[0] || pedge == 3 || a.dp_part) a.n_heavy = 0;
   a.n_heavy_blocks = (a.n_heavy + TPBH - 1) / TPBH;
   dim3 grid(a.n_heavy_blocks + (a.n_units - a.n_heavy + TPB - 1) / TPB, tiles);
   if (grid.x == 0) return;
@@ -943,6 +1004,11 @@ inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles
     }
   }
   if constexpr (KIND == kNormal || KIND == kUniform) {
+    if (a.dp_part) {        // scalar / per-channel parameters and their gradients (stag_agg_bwd_dp): no heavy blocks
+      if (vec) hipLaunchKernelGGL((agg_dp_kernel<KIND, LPE, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      else     hipLaunchKernelGGL((agg_dp_kernel<KIND, LPE, false>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      return;
+    }
     if (pedge == 3) {       // [E, 1] parameters and their gradients (stag_agg_bwd_edge)
       if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 3>), grid, block, STAG_AGG_LDS_BYTES, s, a);
       else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 3>), grid, block, STAG_AGG_LDS_BYTES, s, a);

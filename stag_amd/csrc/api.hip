@@ -587,11 +587,12 @@ int stag_normal_tables(float* rad, float* cosv, float* sinv, void* stream) {
 
 // one aggregation launch; nout > 1: extra outputs ride along — the two parameter-derivative
 // aggregates (nout = 3, mc = 0) or Monte-Carlo samples 1.. (nout = 2 | 4, mc = 1)
-struct EdgeGradOut {      // stag_agg_bwd_edge: per-edge parameter gradients out of the same pass
-  const float* xown;      // [n_dst, ldxo]: the rows the units own
+struct EdgeGradOut {      // stag_agg_bwd_edge / stag_agg_bwd_dp: parameter gradients out of the same pass
+  const float* xown;      // [n_dst, ldxo]: the rows the units own (stag_agg_bwd_dp: may be null = ones)
   int64_t ldxo;
-  float* eg0;
+  float* eg0;             // per edge (stag_agg_bwd_edge)
   float* eg1;
+  float* dp_part;         // block partials (stag_agg_bwd_dp)
 };
 static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x, int64_t ldx,
                       int32_t D, const stag_noise_spec* spec, int32_t reduce, const float* src_scale,
@@ -642,7 +643,10 @@ static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x
   a.out = out; a.ldo = ldo; a.norm_scale_out = norm_scale_out;
   for (int o = 0; o + 1 < nout; ++o) a.outx[o] = extra[o];
   a.mc = mc; a.mc_stride = mc_stride;
-  if (eg) { a.xown = eg->xown; a.ldxo = eg->ldxo; a.own_scale = dst_scale; a.eg0 = eg->eg0; a.eg1 = eg->eg1; }
+  if (eg) {
+    a.xown = eg->xown; a.ldxo = eg->ldxo; a.own_scale = dst_scale; a.eg0 = eg->eg0; a.eg1 = eg->eg1;
+    a.dp_part = eg->dp_part;
+  }
 
   const bool use_plan = plan && plan->n_units > 0;
   const bool has_segs = use_plan && plan->n_seg > 0;
@@ -676,7 +680,7 @@ static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x
       spec->param_mode != STAG_PARAM_PER_EDGE1)
     vec = vec && aligned16(spec->p0) && (!spec->p1 || aligned16(spec->p1));
   if (has_segs) vec = vec && aligned16(plan->workspace);
-  if (eg) vec = vec && aligned16(eg->xown) && (eg->ldxo % 4 == 0);
+  if (eg && eg->xown) vec = vec && aligned16(eg->xown) && (eg->ldxo % 4 == 0);
 
   hipStream_t s = (hipStream_t)stream;
   auto launch = [&](const AggArgs& args) -> hipError_t {
@@ -754,9 +758,91 @@ int stag_agg_bwd_edge(const stag_csr* csr_t, const stag_plan* plan_t, const floa
   // the parameters and their gradients live at edge ids, the noise at forward positions
   if (csr_t->n_edges > 0 && (!csr_t->nidx || !csr_t->eid)) return STAG_EINVAL;
   if (D > 256) return STAG_ENOSYS;      // the channel sum of an edge is one team sum: one channel tile
-  const EdgeGradOut eg{x, ldx, dp0_edge, dp1_edge};
+  const EdgeGradOut eg{x, ldx, dp0_edge, dp1_edge, nullptr};
   return agg_common(csr_t, plan_t, g, ldg, D, spec, STAG_REDUCE_SUM, g_scale, row_scale, dx, ldo, nullptr,
                     1, nullptr, 0, 0, stream, &eg);
+}
+
+// ---- stag_agg_bwd_dp: the block partials of agg_dp_kernel -> dp0 [D], dp1 [D], two fixed-order stages ----------
+constexpr int kDpSlabs = 256;
+// stage 1: block (channel group of 64, derivative i, slab s) adds its slab of the gx block partials: 4 slices of
+// the slab side by side, then the slices in order -> part2[s][i][k]
+__global__ __launch_bounds__(256) void dp_stage1_kernel(const float* part, int gx, int lpe4, int D, float* part2) {
+  __shared__ float red[4][64];
+  const int kx = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + kx, i = blockIdx.y, slab = blockIdx.z;
+  const int per = (gx + kDpSlabs - 1) / kDpSlabs;
+  const int b0 = slab * per, b1 = min(gx, b0 + per);
+  float sum = 0.f;
+  if (k < D) {
+    const int tile = k / lpe4, kk = k - tile * lpe4;
+    const float* base = part + ((int64_t)tile * gx) * (2 * lpe4) + (int64_t)i * lpe4 + kk;
+    for (int b = b0 + slice; b < b1; b += 4) sum += base[(int64_t)b * (2 * lpe4)];
+  }
+  red[slice][kx] = sum;
+  __syncthreads();
+  if (slice == 0 && k < D) part2[((int64_t)slab * 2 + i) * D + k] = (red[0][kx] + red[1][kx]) + (red[2][kx] + red[3][kx]);
+}
+// stage 2: a wave per channel: lane s adds slabs s, s + 64, ... in order, then the wave's butterfly
+__global__ __launch_bounds__(256) void dp_stage2_kernel(const float* part2, int D, float* dp0, float* dp1) {
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, i = blockIdx.y;
+  float sum = 0.f;
+  if (k < D)
+    for (int s = lane; s < kDpSlabs; s += 64) sum += part2[((int64_t)s * 2 + i) * D + k];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+  if (lane == 0 && k < D) (i == 0 ? dp0 : dp1)[k] = sum;
+}
+
+static void dp_shape(int32_t D, int64_t n_units, int& lpe, int& tiles, int64_t& gx) {
+  const int nchunk = (D + 3) / 4;
+  lpe = 1;
+  while (lpe < nchunk && lpe < 64) lpe <<= 1;
+  tiles = (nchunk + lpe - 1) / lpe;
+  const int tpb = STAG_BLOCK_THREADS / lpe;
+  gx = (n_units + tpb - 1) / tpb;
+}
+
+size_t stag_agg_bwd_dp_workspace_bytes(int64_t n_units, int32_t D) {
+  if (n_units <= 0 || D <= 0) return 0;
+  int lpe, tiles;
+  int64_t gx;
+  dp_shape(D, n_units, lpe, tiles, gx);
+  return ((size_t)tiles * (size_t)gx * 2u * (size_t)lpe * 4u + (size_t)kDpSlabs * 2u * (size_t)D) * sizeof(float);
+}
+
+int stag_agg_bwd_dp(const stag_csr* csr_t, const stag_plan* plan_t, const float* g, int64_t ldg,
+                    int32_t D, const stag_noise_spec* spec, const float* g_scale, const float* row_scale,
+                    const float* x, int64_t ldx, float* dx, int64_t ldo, float* dp0, float* dp1,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+  if (!spec || !csr_t || !dp0 || !dp1 || D <= 0) return STAG_EINVAL;
+  if (x && ldx < D) return STAG_EINVAL;
+  if (spec->kind != STAG_NOISE_NORMAL && spec->kind != STAG_NOISE_UNIFORM) return STAG_EINVAL;
+  if (spec->param_mode != STAG_PARAM_SCALAR && spec->param_mode != STAG_PARAM_PER_CHANNEL) return STAG_EINVAL;
+  if (spec->in_norm || spec->deriv) return STAG_EINVAL;
+  if (csr_t->n_edges > 0 && !csr_t->nidx) return STAG_EINVAL;      // must redraw the FORWARD's noise
+  hipStream_t s = (hipStream_t)stream;
+  if (csr_t->n_dst == 0 || csr_t->n_edges == 0) {
+    if (hipMemsetAsync(dp0, 0, sizeof(float) * D, s) != hipSuccess) return STAG_EIO;
+    if (hipMemsetAsync(dp1, 0, sizeof(float) * D, s) != hipSuccess) return STAG_EIO;
+    if (dx && csr_t->n_dst > 0 && hipMemset2DAsync(dx, sizeof(float) * ldo, 0, sizeof(float) * D, csr_t->n_dst, s) != hipSuccess)
+      return STAG_EIO;
+    return STAG_OK;
+  }
+  const int64_t n_units = (plan_t && plan_t->n_units > 0) ? plan_t->n_units : csr_t->n_dst;
+  int lpe, tiles;
+  int64_t gx;
+  dp_shape(D, n_units, lpe, tiles, gx);
+  if (!workspace || workspace_bytes < stag_agg_bwd_dp_workspace_bytes(n_units, D)) return STAG_ENOMEM;
+  float* part = static_cast<float*>(workspace);
+  float* part2 = part + (size_t)tiles * (size_t)gx * 2u * (size_t)lpe * 4u;
+  const EdgeGradOut eg{x, ldx, nullptr, nullptr, part};
+  const int rc = agg_common(csr_t, plan_t, g, ldg, D, spec, STAG_REDUCE_SUM, g_scale, row_scale, dx, ldo, nullptr,
+                            1, nullptr, 0, 0, stream, &eg);
+  if (rc) return rc;
+  hipLaunchKernelGGL(dp_stage1_kernel, dim3((D + 63) / 64, 2, kDpSlabs), dim3(256), 0, s, part, (int)gx, lpe * 4, D, part2);
+  hipLaunchKernelGGL(dp_stage2_kernel, dim3((D + 3) / 4, 2), dim3(256), 0, s, part2, D, dp0, dp1);
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }
 
 // plan fields the unit-walking auxiliary kernels need

@@ -204,14 +204,21 @@ class StagLayer(torch.nn.Module):
 
 
     def _kl_normal_fused(self):
-        """KL of an amortised Normal against a Normal prior with one-element parameters: one pass over the
-        [E, out] heads forward, one backward (ops.normal_kl_mean) — torch's closed form is ~25 elementwise
-        passes over them.  None when the pair is anything else."""
-        params = getattr(self.q_a, "new_parameters", None)
-        if not (isinstance(params, dict) and set(params) == {"loc", "log_scale"}
-                and getattr(self.q_a, "base_distribution_class", None) is torch.distributions.Normal):
+        """KL of a Normal q_a that keeps (loc, log_scale) — an amortised one's heads [E, out], or a vi=True
+        ParametrizedDistribution's parameters — against a Normal prior with one-element parameters: one pass
+        forward, one backward (ops.normal_kl_mean); torch's closed form is ~25 elementwise launches (passes over
+        the [E, out] heads, or as many one-element launches: 100 us of a 790 us layer step).  None when the pair is
+        anything else."""
+        q = self.q_a
+        params = getattr(q, "new_parameters", None)
+        if (isinstance(params, dict) and set(params) == {"loc", "log_scale"}
+                and getattr(q, "base_distribution_class", None) is torch.distributions.Normal):
+            loc, ls = params["loc"], params["log_scale"]              # amortised heads, [E, out]
+        elif (isinstance(q, ParametrizedDistribution) and getattr(q, "distribution_type", None) is torch.distributions.Normal
+              and list(q.new_parameter_names) == ["loc", "log_scale"]):
+            loc, ls = q.loc, q.log_scale                              # learned scalars / rows (vi=True): a dozen
+        else:                                                         # one-element launches otherwise
             return None
-        loc, ls = params["loc"], params["log_scale"]
         if not (torch.is_tensor(loc) and loc.is_cuda and loc.shape == ls.shape and loc.numel() > 0):
             return None
         try:

@@ -219,6 +219,32 @@ def _agg_bwd_edge_raw(csrv_t, g, x, D, spec, g_scale, row_scale, seg_len, want_d
     return dx, e0, e1
 
 
+def _agg_bwd_dp_raw(csrv_t, g, x, D, spec, g_scale, row_scale, seg_len, want_dx=True):
+    """One stag_agg_bwd_dp launch on the source-major CSR: dx (if wanted) and the FINISHED gradients of scalar /
+    per-channel parameters, dp0 [D], dp1 [D] (x = None: ones in its place)."""
+    dev = _lib.require_device(g, x, csrv_t.indptr, g_scale, row_scale)
+    dx = torch.empty((csrv_t.n_dst, D), dtype=torch.float32, device=dev) if want_dx else None
+    dp0 = torch.empty(D, dtype=torch.float32, device=dev)
+    dp1 = torch.empty(D, dtype=torch.float32, device=dev)
+    plan_t = csrv_t.plan(seg_len)
+    nbytes = _lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], D, 0) if plan_t is not None else 0
+    plan_c, _keep = _plan_struct(csrv_t, seg_len, (D + 255) // 256, nbytes, dev)
+    n_units = plan_t["n_units"] if plan_t is not None else csrv_t.n_dst
+    wbytes = _lib.lib().stag_agg_bwd_dp_workspace_bytes(n_units, D)
+    ws = torch.empty(max(wbytes // 4, 1), dtype=torch.float32, device=dev)
+    cs = csrv_t.struct()
+    with _lib.on_device(dev):
+        rc = _lib.lib().stag_agg_bwd_dp(
+            C.byref(cs), C.byref(plan_c) if plan_c is not None else None, _lib.ptr(g), g.stride(0), D,
+            C.byref(spec), _lib.ptr(g_scale), _lib.ptr(row_scale), _lib.ptr(x), x.stride(0) if x is not None else 0,
+            _lib.ptr(dx), D, _lib.ptr(dp0), _lib.ptr(dp1), _lib.ptr(ws), wbytes, _lib.stream_of(dev))
+    _lib.check(rc, "stag_agg_bwd_dp")
+    return dx, dp0, dp1
+
+
+_AGG_BWD_DP_ONE_PASS = True     # stag_agg_bwd_dp | stag_agg_bwd + stag_coldot (A/B, and the torch-op argument form)
+
+
 def coldot(x, t0, t1=None):
     """out_i[k] = sum_n x[n,k] * t_i[n,k]  (stag_coldot; no autograd — a backward-pass helper)."""
     dev = _lib.require_device(x, t0, t1)
@@ -649,9 +675,17 @@ class _AggregateVI(torch.autograd.Function):
         dx = dp0 = dp1 = None
         per_edge = noise.param_mode >= _lib.PARAM_PER_EDGE1
         need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-        if not per_edge:
-            # scalar / per-channel parameters: ONE transposed pass yields dx and the two
-            # derivative aggregates T_i[u,k] = ss[u] sum_p dw/dp_i[p,k] g'[v_p,k]; then
+        if not per_edge and need_p and _AGG_BWD_DP_ONE_PASS and not isinstance(spec, tuple):
+            # scalar / per-channel parameters: ONE transposed pass yields dx AND the finished gradients
+            #   dp_i[k] = sum_e dw/dp_i[e,k] dv g'[v,k] s_u x[u,k]   (x[u] is the unit's own row there)
+            dx, c0, c1 = _agg_bwd_dp_raw(graph.csr_t, g, x, D, spec, dvec, src_scale, ctx.seg_len,
+                                         want_dx=ctx.needs_input_grad[0])
+            if q is not None:       # in-norm: minus sum_e dw/dp_i[e,k] q[v,k], the same pass over q without x
+                _, n0, n1 = _agg_bwd_dp_raw(graph.csr_t, q, None, D, spec, None, None, ctx.seg_len, want_dx=False)
+                c0, c1 = c0 - n0, c1 - n1
+            rows = {1: c0, 2: c1}
+        elif not per_edge:
+            # the two-step form: the two derivative aggregates T_i[u,k] = ss[u] sum_p dw/dp_i[p,k] g'[v_p,k], then
             # dp_i[k] = sum_u x[u,k] T_i[u,k]   (sum_e D[e,k] s_u x[u,k] g'[v,k] regrouped by u)
             dx, t0, t1 = _agg_bwd_raw(graph.csr_t, g, D, spec, dvec, src_scale, ctx.seg_len, need_p)
             if not ctx.needs_input_grad[0]:

@@ -42,6 +42,9 @@ def test_torch_ops_equal_ctypes_binding(dev, monkeypatch):
     import stag_amd
     from stag_amd import _lib, _torch_ext, ops
     monkeypatch.setenv("STAG_TORCH_OPS", "1")
+    # the same library calls on both sides: the dispatcher has agg_fwd / agg_bwd, so the ctypes side takes the
+    # two-step parameter gradient too (stag_agg_bwd + stag_coldot), not stag_agg_bwd_dp
+    monkeypatch.setattr(ops, "_AGG_BWD_DP_ONE_PASS", False)
     assert _torch_ext.available(), "the torch front end must be built and loaded on the GPU box"
     g = random_graph(400, 5000, seed=2, hub=900, device=dev)
     E, D = g.number_of_edges(), 48
@@ -690,3 +693,46 @@ def test_agg_bwd_edge_one_pass(dev, oracle, kind, relu, logs, D):
         assert_close(got / sc, ref / sc, what=f"deriv {deriv} vs oracle")
     # wider than one channel tile: no one-pass form
     assert ops._agg_bwd_edge_raw(g.csr_t, gd, xd, 300, spec, gsd, rsd, 32) is None
+
+
+@pytest.mark.parametrize("kind,relu", [("normal", False), ("normal", True), ("uniform", True)])
+@pytest.mark.parametrize("D", [1, 6, 40, 128, 300])
+def test_agg_bwd_dp_one_pass(dev, oracle, kind, relu, D):
+    """stag_agg_bwd_dp: dx and the FINISHED gradients of per-channel parameters from one pass over the source-major
+    CSR, against the oracle's two-step statement (the aggregates T_i of spec.deriv = 1, 2, then sum_u x[u,k]
+    T_i[u,k] in float64) and against stag_agg_bwd + stag_coldot; hub rows (segments), more than one channel tile
+    (D = 300), no own row (x = None: the in-norm term), dx not wanted."""
+    from stag_amd import ops
+    rng = np.random.default_rng(29)
+    n = 150
+    g = random_graph(n, 1500, seed=6, hub=300, device=dev)
+    ogt = oracle_graph(oracle, g, transposed=True)
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    gout = rng.standard_normal((n, D)).astype(np.float32)
+    gs = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    rs = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    p0 = torch.from_numpy(rng.uniform(0.2, 1.0, D).astype(np.float32)).to(dev)
+    p1 = torch.from_numpy(rng.uniform(1.1, 1.8, D).astype(np.float32)).to(dev)
+    xd, gd, gsd, rsd = (torch.from_numpy(a).to(dev) for a in (x, gout, gs, rs))
+    noise = _noise(g, D, kind, p0, p1, relu=relu, seed=3, offset=11)
+    spec = noise.spec()
+    spec = spec if not isinstance(spec, tuple) else ops._targs_to_ctypes(spec)
+    dx, c0, c1 = ops._agg_bwd_dp_raw(g.csr_t, gd, xd, D, spec, gsd, rsd, 32)
+    ref_dx, t0, t1 = ops._agg_bwd_raw(g.csr_t, gd, D, noise.spec(), gsd, rsd, 32, True)
+    assert_close(dx, ref_dx.cpu().numpy(), what="dx")
+    k0, k1 = ops.coldot(xd, t0, t1)
+    nodx, d0, d1 = ops._agg_bwd_dp_raw(g.csr_t, gd, xd, D, spec, gsd, rsd, 32, want_dx=False)
+    assert nodx is None and torch.equal(c0, d0) and torch.equal(c1, d1)
+    for deriv, got, two_step in ((1, c0, k0), (2, c1, k1)):
+        T = oracle.agg_fwd(ogt, gout, _ospec(oracle, g, D, kind, p0, p1, relu=relu, seed=3, offset=11, deriv=deriv),
+                           src_scale=gs, dst_scale=rs)
+        ref = (x.astype(np.float64) * T.astype(np.float64)).sum(0)
+        sc = max(1.0, float(np.abs(ref).max()))
+        assert_close(got / sc, ref / sc, what=f"d p{deriv - 1} vs oracle")
+        assert_close(got / sc, (two_step / sc).cpu().numpy(), what=f"d p{deriv - 1} vs stag_agg_bwd + stag_coldot")
+    # no own row, no scales: the column sums of the aggregates
+    _, n0, n1 = ops._agg_bwd_dp_raw(g.csr_t, gd, None, D, spec, None, None, 32, want_dx=False)
+    _, u0, u1 = ops._agg_bwd_raw(g.csr_t, gd, D, noise.spec(), None, None, 32, True)
+    for got, ref in ((n0, u0.double().sum(0)), (n1, u1.double().sum(0))):
+        sc = max(1.0, float(ref.abs().max()))
+        assert_close(got / sc, (ref / sc).cpu().numpy(), what="x = None")
