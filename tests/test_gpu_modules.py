@@ -1177,8 +1177,9 @@ def test_layers_on_edgeless_and_one_edge_graphs(dev, n, E):
 
 def test_new_backward_paths_are_bit_reproducible(dev):
     """Fixed-order reductions everywhere: the one-pass [E,1] backward, the narrow amortised heads, the KL, GAT's
-    per-head dots and its one-gather backward give the same bits on every run (hub rows, segments, block partials
-    included) — nothing is accumulated with atomics."""
+    per-head dots and its one-gather backward, the parameter gradients finished in the dx pass (stag_agg_bwd_dp,
+    with in-norm) give the same bits on every run (hub rows, segments, block partials included) — nothing is
+    accumulated with atomics."""
     import stag_amd
     from stag_amd.distributions import AmortizedDistribution
     from util import random_graph
@@ -1193,6 +1194,7 @@ def test_new_backward_paths_are_bit_reproducible(dev):
         torch.nn.init.normal_(p, 0.0, 0.3)
     re_layer = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(D, D), q_a=q, vi=True).to(dev)
     gat_layer = stag_amd.layers.StagLayer(stag_amd.zoo.GAT(D, 16, num_heads=4), q_a=N(1.0, 0.5)).to(dev)
+    r1_layer = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(D, D), q_a=N(1.0, 0.5), vi=True, relu=True, norm=True).to(dev)
 
     def run(layer, with_kl):
         stag_amd.manual_seed(11)
@@ -1207,7 +1209,7 @@ def test_new_backward_paths_are_bit_reproducible(dev):
         return [y.detach().clone(), x.grad.clone()] + [o.detach().clone() for o in outs[1:]] + \
                [p.grad.clone() for p in layer.parameters() if p.grad is not None]
 
-    for layer, with_kl in ((re_layer, True), (gat_layer, False)):
+    for layer, with_kl in ((re_layer, True), (gat_layer, False), (r1_layer, True)):
         first = run(layer, with_kl)
         for _ in range(3):
             again = run(layer, with_kl)

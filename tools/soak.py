@@ -31,7 +31,7 @@ x0 = torch.randn(n, D, device=dev)
 gout = torch.randn(n, 256, device=dev)
 N = torch.distributions.Normal
 layers = {
-    "gcn vi relu (stag_agg_fwd, stag_agg_bwd, stag_coldot)":
+    "gcn vi relu (stag_agg_fwd, stag_agg_bwd_dp, normal_kl)":
         stag_amd.layers.StagLayer(stag_amd.zoo.GCN(D, D), q_a=N(1.0, 0.5), vi=True, relu=True),
     "gcn amortised [E,1] + KL (stag_agg_bwd_edge, node_project, edge_mlp, normal_kl)":
         stag_amd.layers.StagLayer(stag_amd.zoo.GCN(D, D), q_a=stag_amd.distributions.AmortizedDistribution(
