@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 14
+#define STAG_ABI_VERSION 15
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -332,7 +332,7 @@ int stag_coldot(const float* x, int64_t ldx, const float* t0, const float* t1, i
                 size_t workspace_bytes, void* stream);
 
 /* ---- amortised per-edge parameters with narrow heads ---------------------------------
- * AmortizedDistribution(in_features, 1) — what every scripts/*_rec/run.py builds (scripts/arxiv_rec/gcn/run.py:85);
+ * AmortizedDistribution(in_features, 1) — what every scripts/<set>_rec/run.py builds (scripts/arxiv_rec/gcn/run.py:85);
  * hidden_features defaults to out_features = 1 (stag/distributions.py:158-159):
  *     h_e   = SiLU(W_e [feat[src_e] || feat[dst_e]] + b_e)        stag/distributions.py:178-183, 225-227
  *     par_c = W_c h_e + b_c   (c = loc, log_scale, ...)            stag/distributions.py:186-191, 229-231
@@ -386,6 +386,17 @@ int stag_normal_kl_bwd(const float* loc, const float* log_scale, int64_t n, cons
                        const float* p_scale, const float* g, float* dloc, float* dlog_scale, float* dp_loc,
                        float* dp_scale, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Attention dropout of a GAT call (stag/zoo/gat.py:122: `attn_drop(edge_softmax(...))`, 0.6 in the reference's GAT
+ * scripts): a[e,h] -> a[e,h] * keep[e,h] / keep_prob after the softmax, keep[e,h] = u < keep_prob with u the uniform
+ * of the mask's OWN Philox stream (seed, offset (+ *epoch)) at (global forward position, head) — regenerated in the
+ * backward, never stored.  NULL or keep_prob >= 1: no dropout.  Workgroup-cooperative kernels only (other shapes:
+ * STAG_ENOSYS).                                                                                              */
+typedef struct stag_gat_drop {
+  float keep_prob;          /* 1 - p, in (0, 1] */
+  uint64_t seed, offset;
+  const uint64_t* epoch;    /* device counter added to offset when the kernel runs, or NULL (as stag_noise_spec) */
+} stag_gat_drop;
+
 /* GAT edge attention with noisy logits + softmax + aggregation, one launch:
  *   e[p,h]  = w[p,h] * leaky_relu(el[u_p,h] + er[v,h])     stag/zoo/gat.py:114-119
  *   a[p,h]  = softmax over the in-edges of v                stag/zoo/gat.py:122
@@ -401,8 +412,8 @@ int stag_normal_kl_bwd(const float* loc, const float* log_scale, int64_t n, cons
 size_t stag_gat_workspace_bytes(int32_t n_seg, int32_t H, int32_t F);
 int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const float* el, const float* er,
                  const float* ft, int32_t H, int32_t F, float neg_slope,
-                 const stag_noise_spec* spec, const float* norm_scale, float* out,
-                 float* stats_out, void* stream);
+                 const stag_noise_spec* spec, const float* norm_scale, const stag_gat_drop* drop,
+                 float* out, float* stats_out, void* stream);
 
 /* The attention values a[eid, h] = exp(e[p,h] - m[v,h]) / l[v,h] (get_attention=True,
  * stag/zoo/gat.py:146-147) from the statistics of stag_gat_fwd; same spec (the noisy logits are
@@ -456,7 +467,9 @@ int stag_halo_exchange(void* comm, const float* send, const int64_t* send_counts
  *      d s[e,h] = a (dot - sdot[v,h]) w ns lrelu'(.), d ft[u,h,:] = sum_out a g[v,h,:], d el[u,h] = sum_out d s;
  *      d s goes to scratch by FORWARD position, dw (may be NULL: [E, H] by edge id) = d s-factor * lrelu * ns;
  *   3. d er[v,h] = sum of d s over the row's positions, which are contiguous there.
- * stag_gat_bwd_two_pass — the form it replaces: an edge pass over csr (gathers ft[u]; a, de to scratch, d er)
+ * With `drop` (attention dropout) the mask is redrawn from its counters: d ft and the dot use a keep / keep_prob,
+ * the softmax correction keeps a (sdot is unchanged: sum_e a_e d a_e = <g, out> with or without the mask).
+ * stag_gat_bwd_two_pass — the form it replaces (no attention dropout: STAG_ENOSYS): an edge pass over csr (gathers ft[u]; a, de to scratch, d er)
  * and a source pass over csr_t (gathers g[v]; d ft, d el): two gathers; needs block plans on both orientations.
  * scratch: stag_gat_bwd_scratch_bytes(n_dst, n_edges, H) bytes, 16-byte aligned.
  * Long rows leave per-segment partials in plan->workspace (>= stag_gat_bwd_workspace_bytes(); the forward
@@ -470,12 +483,14 @@ int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr
                  const stag_plan* plan_t, const float* el, const float* er, const float* ft,
                  const float* stats, const float* g, const float* out, int32_t H, int32_t F,
                  float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
-                 float* d_el, float* d_er, float* d_ft, float* dw, float* scratch, void* stream);
+                 const stag_gat_drop* drop, float* d_el, float* d_er, float* d_ft, float* dw, float* scratch,
+                 void* stream);
 int stag_gat_bwd_two_pass(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
                           const stag_plan* plan_t, const float* el, const float* er, const float* ft,
                           const float* stats, const float* g, const float* out, int32_t H, int32_t F,
                           float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
-                          float* d_el, float* d_er, float* d_ft, float* dw, float* scratch, void* stream);
+                          const stag_gat_drop* drop, float* d_el, float* d_er, float* d_ft, float* dw,
+                          float* scratch, void* stream);
 
 #ifdef __cplusplus
 }

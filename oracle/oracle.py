@@ -73,6 +73,8 @@ def lib():
                                                  C.c_int32, _f32p, C.c_int64]
         _lib.stag_gat_fwd_cpu.argtypes = [C.POINTER(Csr), _f32p, _f32p, _f32p, C.c_int32,
                                           C.c_int32, C.c_float, C.POINTER(NoiseSpec), _f32p, _f32p]
+        _lib.stag_gat_fwd_drop_cpu.argtypes = [C.POINTER(Csr), _f32p, _f32p, _f32p, C.c_int32, C.c_int32, C.c_float,
+                                               C.POINTER(NoiseSpec), _f32p, C.c_float, _f32p, _f32p]
         _lib.stag_philox4x32_10_cpu.argtypes = [_u32p, _u32p, _u32p]
     return _lib
 
@@ -286,15 +288,18 @@ def segment_reduce(x, offsets, reduce=REDUCE_SUM):
     return out
 
 
-def gat_fwd(g, el, er, ft, neg_slope, spec, want_attn=False):
+def gat_fwd(g, el, er, ft, neg_slope, spec, want_attn=False, keep=None, keep_prob=1.0):
+    """keep [E, H] by edge id (0/1) + keep_prob: attention dropout between the softmax and the sum
+    (stag/zoo/gat.py:122); the returned attention is then the dropped one, as the reference's edata is."""
     el, er, ft = _f32(el), _f32(er), _f32(ft)
     H = el.shape[1]
     F = ft.shape[-1] if ft.ndim == 3 else ft.shape[1] // H
     out = np.zeros((g.n_dst, H, F), np.float32)
     attn = np.zeros((g.n_edges, H), np.float32) if want_attn else None
-    _check(lib().stag_gat_fwd_cpu(C.byref(g.c), _p(el, _f32p), _p(er, _f32p), _p(ft, _f32p), H, F,
-                                  float(neg_slope), C.byref(spec), _p(out, _f32p),
-                                  _p(attn, _f32p)), "gat_fwd")
+    keep = None if keep is None else _f32(keep)
+    _check(lib().stag_gat_fwd_drop_cpu(C.byref(g.c), _p(el, _f32p), _p(er, _f32p), _p(ft, _f32p), H, F,
+                                       float(neg_slope), C.byref(spec), _p(keep, _f32p), float(keep_prob),
+                                       _p(out, _f32p), _p(attn, _f32p)), "gat_fwd")
     return (out, attn) if want_attn else out
 
 

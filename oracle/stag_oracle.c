@@ -435,6 +435,17 @@ int stag_segment_reduce_cpu(const float* x, int64_t ldx, int32_t D,
 int stag_gat_fwd_cpu(const stag_csr* csr, const float* el, const float* er,
                      const float* ft, int32_t H, int32_t F, float neg_slope,
                      const stag_noise_spec* spec, float* out, float* attn_out) {
+  return stag_gat_fwd_drop_cpu(csr, el, er, ft, H, F, neg_slope, spec, NULL, 1.0f, out, attn_out);
+}
+
+/* ... with attention dropout between the softmax and the sum (stag/zoo/gat.py:122:
+ * `graph.edata["a"] = self.attn_drop(edge_softmax(graph, e))`): keep [E, H] by edge id is the 0/1 mask
+ * (the caller draws it: a Bernoulli(keep_prob) stream of its own), a -> a * keep / keep_prob; attn_out
+ * receives the dropped attention, as the reference's edata does. */
+int stag_gat_fwd_drop_cpu(const stag_csr* csr, const float* el, const float* er,
+                          const float* ft, int32_t H, int32_t F, float neg_slope,
+                          const stag_noise_spec* spec, const float* keep, float keep_prob,
+                          float* out, float* attn_out) {
   int rc = check_spec(spec);
   if (rc) return rc;
   if (!csr || !el || !er || !ft || !out || H <= 0 || F <= 0) return STAG_EINVAL;
@@ -475,10 +486,9 @@ int stag_gat_fwd_cpu(const stag_csr* csr, const float* el, const float* er,
         for (int32_t p = b; p < e; ++p) {
           int32_t u = csr->indices[p];
           double a = exp((double)logit[(int64_t)(p - b) * H + h] - mx) / den;
-          if (attn_out) {
-            int64_t eid = csr->eid ? csr->eid[p] : p;
-            attn_out[eid * H + h] = (float)a;
-          }
+          int64_t eid = csr->eid ? csr->eid[p] : p;
+          if (keep) a = a * (double)keep[eid * H + h] / (double)keep_prob;
+          if (attn_out) attn_out[eid * H + h] = (float)a;
           const float* fr = ft + ((int64_t)u * H + h) * F;
           for (int32_t f = 0; f < F; ++f) acc[f] += a * (double)fr[f];
         }

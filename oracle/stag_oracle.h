@@ -37,6 +37,10 @@ int stag_segment_reduce_cpu(const float* x, int64_t ldx, int32_t D,
 int stag_gat_fwd_cpu(const stag_csr* csr, const float* el, const float* er,
                      const float* ft, int32_t H, int32_t F, float neg_slope,
                      const stag_noise_spec* spec, float* out, float* attn_out);
+int stag_gat_fwd_drop_cpu(const stag_csr* csr, const float* el, const float* er,
+                          const float* ft, int32_t H, int32_t F, float neg_slope,
+                          const stag_noise_spec* spec, const float* keep, float keep_prob,
+                          float* out, float* attn_out);
 
 #ifdef __cplusplus
 }

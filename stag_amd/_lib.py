@@ -36,6 +36,10 @@ class NoiseSpec(C.Structure):
                 ("chunk_base", C.c_int32), ("p1_log", C.c_int32), ("epoch", C.c_void_p)]
 
 
+class GatDrop(C.Structure):       # stag_gat_drop
+    _fields_ = [("keep_prob", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64), ("epoch", C.c_void_p)]
+
+
 class Plan(C.Structure):
     _fields_ = [("seg_len", C.c_int32), ("n_units", C.c_int32), ("n_long", C.c_int32),
                 ("n_seg", C.c_int32), ("units", _vp), ("long_rows", _vp), ("long_seg_ptr", _vp),
@@ -130,7 +134,7 @@ def lib():
     l.stag_gat_workspace_bytes.restype = C.c_size_t
     l.stag_gat_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     l.stag_gat_fwd.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp, C.c_int32, C.c_int32,
-                               C.c_float, C.POINTER(NoiseSpec), _vp, _vp, _vp, _vp]
+                               C.c_float, C.POINTER(NoiseSpec), _vp, C.POINTER(GatDrop), _vp, _vp, _vp]
     l.stag_gat_attn.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, C.c_int32, C.c_float,
                                 C.POINTER(NoiseSpec), _vp, _vp, _vp, _vp]
     l.stag_gat_bwd_edge.argtypes = [C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp, _vp, _vp, _vp,
@@ -140,7 +144,7 @@ def lib():
     l.stag_gat_bwd_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     l.stag_gat_bwd.argtypes = [C.POINTER(Csr), C.POINTER(Plan), C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp,
                                _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_float, C.POINTER(NoiseSpec), _vp,
-                               _vp, _vp, _vp, _vp, _vp, _vp]
+                               C.POINTER(GatDrop), _vp, _vp, _vp, _vp, _vp, _vp]
     l.stag_gat_bwd_two_pass.argtypes = l.stag_gat_bwd.argtypes
     l.stag_gat_bwd_scratch_bytes.restype = C.c_size_t
     l.stag_gat_bwd_scratch_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32]
@@ -149,7 +153,7 @@ def lib():
     l.stag_comm_destroy.argtypes = [_vp]
     l.stag_halo_allgather.argtypes = [_vp, _vp, C.c_int64, _vp, _vp]
     l.stag_halo_exchange.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
-    if l.stag_abi_version() != 14:
+    if l.stag_abi_version() != 15:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     _lib = l
     return l

@@ -59,7 +59,19 @@ struct GatArgs {
   uint32_t ws_bytes;
   const int32_t* block_ptr;   // [n_blocks+1] unit batches of the workgroup-cooperative kernels
   int32_t hvec;               // el / er / nscale are 16-byte aligned (rows of H % 4 == 0 heads load as dwordx4)
+  // attention dropout (stag/zoo/gat.py:122): a[e,h] -> a[e,h] keep[e,h] / keep_prob, keep from its own Philox stream
+  float drop_keep;            // keep probability; 0: no dropout
+  float drop_scale;           // 1 / keep probability
+  PhiloxKey drop_key;
 };
+
+// bit j = head 4c + j of the edge with noise index n survives the attention dropout
+__device__ __forceinline__ uint32_t drop_keep4(const GatArgs& a, const PhiloxKey& dkey, uint32_t n, uint32_t chunk) {
+  const float q[4] = {a.drop_keep, a.drop_keep, a.drop_keep, a.drop_keep};
+  float k[4];
+  draw4<kBernoulli>(n, chunk | (a.pos_hi << 20), dkey, q, q, 0, k);
+  return (k[0] != 0.f ? 1u : 0u) | (k[1] != 0.f ? 2u : 0u) | (k[2] != 0.f ? 4u : 0u) | (k[3] != 0.f ? 8u : 0u);
+}
 
 // the 4 weights of heads [4c, 4c+4) of the edge with noise index n and edge id ed
 __device__ __forceinline__ void head_w4(const GatArgs& a, const PhiloxKey& key, uint32_t n, int64_t ed,
@@ -412,6 +424,7 @@ __global__ __launch_bounds__(kBlkThreads) STAG_GAT_SGPR_ATTR void gat_fwd_block_
   const int ne = s_start[nu];                          // edges of the batch (<= kBlkEdges by the plan)
 
   // ---- phase 1: thread t <-> edge slot t ---------------------------------------------------------
+  uint32_t kmask = 0;                                  // attention dropout: bit h = head h of my edge survives
   if (t < ne) {
     int lo = 0, hi = nu;                               // unit j with s_start[j] <= t < s_start[j+1]
     while (hi - lo > 1) {
@@ -444,6 +457,7 @@ __global__ __launch_bounds__(kBlkThreads) STAG_GAT_SGPR_ATTR void gat_fwd_block_
         }
       }
       head_w4(a, key, n, ed, (uint32_t)cc, w);
+      if (a.drop_keep > 0.f) kmask |= drop_keep4(a, resolve_epoch(a.drop_key), n, (uint32_t)cc) << (4 * cc);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int h = 4 * cc + j;
@@ -477,6 +491,13 @@ __global__ __launch_bounds__(kBlkThreads) STAG_GAT_SGPR_ATTR void gat_fwd_block_
   GAT_TS(4)
   __syncthreads();
   GAT_TS(5)
+  if (a.drop_keep > 0.f) {       // (uniform) the softmax statistics saw every edge; the weighted sum sees the survivors
+    if (t < ne) {
+      for (int h = 0; h < H; ++h)
+        s_w[t * H + h] = ((kmask >> h) & 1u) ? s_w[t * H + h] * a.drop_scale : 0.f;
+    }
+    __syncthreads();
+  }
 
   // ---- phase 2: a team per unit, weighted gather -------------------------------------------------------
   // lane c owns CPL chunks of 4 channels: [4 (c + LPE j), +4), j < CPL  (H*F <= 256: one; up to 1024: 2 or 4)
@@ -1245,6 +1266,7 @@ __global__ __launch_bounds__(kBlkThreads) void gat_bwd_one_kernel(const GatBwd1A
         }
       }
       head_w4(a, key, n, ed, (uint32_t)cc, w);
+      const uint32_t kbits = a.drop_keep > 0.f ? drop_keep4(a, resolve_epoch(a.drop_key), n, (uint32_t)cc) : 15u;
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int h = 4 * cc + jj;
@@ -1252,7 +1274,9 @@ __global__ __launch_bounds__(kBlkThreads) void gat_bwd_one_kernel(const GatBwd1A
           const float sL = sl4[jj] + sr4[jj];
           const float lr = sL > 0.f ? sL : a.neg_slope * sL;
           const float wn = w[jj] * ns4[jj];
-          s_a[t * H + h] = __expf(wn * lr - m4[jj]) / l4[jj];
+          const float av = __expf(wn * lr - m4[jj]) / l4[jj];
+          // attention dropout: the sign carries the keep bit (a > 0): dropped edges are stored as -a
+          s_a[t * H + h] = (a.drop_keep > 0.f && !((kbits >> jj) & 1u)) ? -av : av;
           s_c1[t * H + h] = wn * (sL > 0.f ? 1.0f : a.neg_slope);
           s_sd[t * H + h] = sd4[jj];
           if (ba.dw) s_c2[t * H + h] = lr * ns4[jj];
@@ -1313,11 +1337,18 @@ __global__ __launch_bounds__(kBlkThreads) void gat_bwd_one_kernel(const GatBwd1A
               dot = (fu[cj][0] * fv[r][cj][0] + fu[cj][1] * fv[r][cj][1]) + (fu[cj][2] * fv[r][cj][2] + fu[cj][3] * fv[r][cj][3]);
             dot = gat_head_sum(dot, lph);
             if (kin[cj]) {
-              const float w = s_a[(e + r) * H + hl[cj]];
+              float w = s_a[(e + r) * H + hl[cj]];
+              float ds;
+              if (a.drop_keep > 0.f) {        // a' = a keep / q feeds d ft and <G, ft>; the correction stays with a
+                const float aa = fabsf(w);
+                w = w > 0.f ? w * a.drop_scale : 0.f;
+                ds = w * dot - aa * s_sd[(e + r) * H + hl[cj]];
+              } else {
+                ds = w * (dot - s_sd[(e + r) * H + hl[cj]]);
+              }
 #pragma unroll
               for (int x = 0; x < 4; ++x) acc[cj][x] = __builtin_fmaf(w, fv[r][cj][x], acc[cj][x]);
               if ((k0[cj] % F) == 0) {
-                const float ds = w * (dot - s_sd[(e + r) * H + hl[cj]]);
                 s_c1[(e + r) * H + hl[cj]] = ds * s_c1[(e + r) * H + hl[cj]];
                 if (ba.dw) s_c2[(e + r) * H + hl[cj]] = ds * s_c2[(e + r) * H + hl[cj]];
               }
@@ -1412,6 +1443,20 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+// attention dropout of a call: 0 = none / set, STAG_EINVAL for a bad probability
+static int fill_drop(GatArgs& a, const stag_gat_drop* drop) {
+  a.drop_keep = 0.f; a.drop_scale = 1.f;
+  if (!drop || drop->keep_prob >= 1.0f) return STAG_OK;
+  if (!(drop->keep_prob > 0.0f)) return STAG_EINVAL;
+  a.drop_keep = drop->keep_prob;
+  a.drop_scale = 1.0f / drop->keep_prob;
+  a.drop_key.k0 = (uint32_t)(drop->seed & 0xFFFFFFFFull); a.drop_key.k1 = (uint32_t)(drop->seed >> 32);
+  a.drop_key.o0 = (uint32_t)(drop->offset & 0xFFFFFFFFull); a.drop_key.o1 = (uint32_t)(drop->offset >> 32);
+  a.drop_key.epoch = drop->epoch;
+  return STAG_OK;
+}
+static bool drop_on(const stag_gat_drop* drop) { return drop && drop->keep_prob < 1.0f; }
+
 extern "C" size_t stag_gat_workspace_bytes(int32_t n_seg, int32_t H, int32_t F) {
   if (n_seg <= 0 || H <= 0 || F <= 0) return 0;
   return (size_t)n_seg * (size_t)((H * F + 2 * H + 3) & ~3) * sizeof(float);   // rows padded to 16 bytes
@@ -1419,8 +1464,8 @@ extern "C" size_t stag_gat_workspace_bytes(int32_t n_seg, int32_t H, int32_t F) 
 
 extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const float* el,
                             const float* er, const float* ft, int32_t H, int32_t F, float neg_slope,
-                            const stag_noise_spec* spec, const float* norm_scale, float* out,
-                            float* stats_out, void* stream) {
+                            const stag_noise_spec* spec, const float* norm_scale, const stag_gat_drop* drop,
+                            float* out, float* stats_out, void* stream) {
   if (!csr || !csr->indptr || csr->n_dst < 0 || csr->n_edges < 0) return STAG_EINVAL;
   if (!spec || spec->kind < STAG_NOISE_NONE || spec->kind > STAG_NOISE_BERNOULLI) return STAG_EINVAL;
   if (!out || H <= 0 || F <= 0) return STAG_EINVAL;
@@ -1457,6 +1502,7 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
   if (spec->kind >= STAG_NOISE_NORMAL && (uint64_t)a.pos_lo + (uint64_t)csr->n_edges > (1ull << 32))
     return STAG_ENOSYS;
   a.out = out; a.stats = stats_out;
+  if (fill_drop(a, drop)) return STAG_EINVAL;
   const uint64_t ftb = (uint64_t)csr->n_src * (uint64_t)HF * 4u;
   a.ft_bytes = (ftb < (1ull << 32) && csr->n_src < (1 << 24)) ? (uint32_t)ftb : 0u;
 
@@ -1489,6 +1535,7 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
   hipStream_t s = (hipStream_t)stream;
   const bool blk_ok = use_plan && plan->block_ptr && plan->n_blocks > 0 && vec && H <= kBlkMaxH && plan->seg_len <= kBlkEdges;
   if (HF > 256 && !blk_ok) return STAG_ENOSYS;
+  if (a.drop_keep > 0.f && !blk_ok) return STAG_ENOSYS;      // attention dropout lives in the cooperative kernels
   if (blk_ok) {
     // workgroup-cooperative form: batches of units (stag_plan_blocks with STAG_BLOCK_EDGES / _UNITS)
     a.block_ptr = plan->block_ptr;
@@ -1625,10 +1672,12 @@ extern "C" size_t stag_gat_bwd_workspace_bytes(int32_t n_seg, int32_t n_seg_t, i
 }
 
 extern "C" int stag_gat_bwd_two_pass(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
-                            const stag_plan* plan_t, const float* el, const float* er, const float* ft,
-                            const float* stats, const float* g, const float* out, int32_t H, int32_t F,
-                            float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
-                            float* d_el, float* d_er, float* d_ft, float* dw, float* ade_ws, void* stream) {
+                                     const stag_plan* plan_t, const float* el, const float* er, const float* ft,
+                                     const float* stats, const float* g, const float* out, int32_t H, int32_t F,
+                                     float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
+                                     const stag_gat_drop* drop, float* d_el, float* d_er, float* d_ft, float* dw,
+                                     float* ade_ws, void* stream) {
+  if (drop_on(drop)) return STAG_ENOSYS;               // attention dropout: stag_gat_bwd
   if (!csr || !csr_t || !csr->indptr || !csr_t->indptr || csr->n_dst < 0 || csr->n_edges < 0) return STAG_EINVAL;
   if (csr_t->n_edges != csr->n_edges || csr_t->n_dst != csr->n_src || csr_t->n_src != csr->n_dst) return STAG_EINVAL;
   if (!spec || spec->kind < STAG_NOISE_NONE || spec->kind > STAG_NOISE_BERNOULLI || spec->deriv) return STAG_EINVAL;
@@ -1729,7 +1778,8 @@ extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const st
                             const stag_plan* plan_t, const float* el, const float* er, const float* ft,
                             const float* stats, const float* g, const float* out, int32_t H, int32_t F,
                             float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
-                            float* d_el, float* d_er, float* d_ft, float* dw, float* scratch, void* stream) {
+                            const stag_gat_drop* drop, float* d_el, float* d_er, float* d_ft, float* dw,
+                            float* scratch, void* stream) {
   if (!csr || !csr_t || !csr->indptr || !csr_t->indptr || csr->n_dst < 0 || csr->n_edges < 0) return STAG_EINVAL;
   if (csr_t->n_edges != csr->n_edges || csr_t->n_dst != csr->n_src || csr_t->n_src != csr->n_dst) return STAG_EINVAL;
   if (!spec || spec->kind < STAG_NOISE_NONE || spec->kind > STAG_NOISE_BERNOULLI || spec->deriv) return STAG_EINVAL;
@@ -1786,6 +1836,7 @@ extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const st
   if (rc) return rc;
   a.ft = ft; a.F = F; a.HF = HF;
   a.block_ptr = plan_t->block_ptr;
+  if (fill_drop(a, drop)) return STAG_EINVAL;
   a.hvec = aligned16(el) && aligned16(pack) && (!a.nscale || aligned16(a.nscale));
   ba.g = g; ba.pack = pack; ba.d_ft = d_ft; ba.d_el = d_el; ba.dsl = dsl; ba.dw = dw;
   ba.ws = plan ? plan->workspace : nullptr;

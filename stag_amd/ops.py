@@ -973,9 +973,28 @@ def _gat_norm_scale(csrv, noise, H, seg_len, dev):
     return torch.where(sums != 0, deg / sums, torch.ones_like(sums)).contiguous()
 
 
+def _gat_drop_struct(attn_drop):
+    """(p, seed, offset[, epoch tensor]) -> stag_gat_drop, or None"""
+    if attn_drop is None:
+        return None
+    d = _lib.GatDrop()
+    d.keep_prob = 1.0 - float(attn_drop[0])
+    d.seed, d.offset = int(attn_drop[1]) & ((1 << 64) - 1), int(attn_drop[2]) & ((1 << 64) - 1)
+    d.epoch = _lib.ptr(attn_drop[3]) if len(attn_drop) > 3 else None
+    return d
+
+
+def attn_drop_fusable(H, F, seg_len, want_attn=False):
+    """Attention dropout rides in the workgroup-cooperative GAT kernels (forward and one-gather backward)."""
+    lph = F // 4
+    return (not want_attn and _GAT_BWD_FUSED and _GAT_BWD_ONE_GATHER and F % 4 == 0 and 0 < lph <= 64
+            and (lph & (lph - 1)) == 0 and H <= 16 and H * F <= 1024 and seg_len is not None
+            and 0 < seg_len <= _lib.BLOCK_EDGES)
+
+
 class _GatAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, el, er, ft, w, graph, noise, neg_slope, want_attn, seg_len):
+    def forward(ctx, el, er, ft, w, graph, noise, neg_slope, want_attn, seg_len, attn_drop=None):
         el, er, ft = _f32c(el), _f32c(er), _f32c(ft)
         H, F = ft.shape[1], ft.shape[2]
         csrv = graph.csr
@@ -999,10 +1018,12 @@ class _GatAggregate(torch.autograd.Function):
         plan_c, _keep = _plan_struct(csrv, seg_len, 1, nbytes, dev)
         cs = csrv.struct()
         attn = None
+        drop = _gat_drop_struct(attn_drop)
         with _lib.on_device(dev):
             rc = _lib.lib().stag_gat_fwd(C.byref(cs), C.byref(plan_c) if plan_c is not None else None,
                                          _lib.ptr(el), _lib.ptr(er), _lib.ptr(ft), H, F,
                                          float(neg_slope), C.byref(spec), _lib.ptr(nscale),
+                                         C.byref(drop) if drop is not None else None,
                                          _lib.ptr(out), _lib.ptr(stats), _lib.stream_of(dev))
             _lib.check(rc, "stag_gat_fwd")
             if want_attn:
@@ -1014,6 +1035,7 @@ class _GatAggregate(torch.autograd.Function):
                 _lib.check(rc, "stag_gat_attn")
         if need_grad:
             ctx.graph, ctx.noise, ctx.neg_slope, ctx.seg_len = _owner(graph), noise, float(neg_slope), seg_len
+            ctx.attn_drop = attn_drop
             ctx.save_for_backward(el, er, ft, w, stats, out, nscale)
         if want_attn:
             ctx.mark_non_differentiable(attn)
@@ -1040,13 +1062,15 @@ class _GatAggregate(torch.autograd.Function):
             return (torch.zeros_like(el) if ctx.needs_input_grad[0] else None,
                     torch.zeros_like(er) if ctx.needs_input_grad[1] else None,
                     torch.zeros_like(ft) if ctx.needs_input_grad[2] else None,
-                    torch.zeros_like(w) if want_dw else None, None, None, None, None, None)
+                    torch.zeros_like(w) if want_dw else None, None, None, None, None, None, None)
         fused = _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, ctx.neg_slope, spec, nscale,
-                               want_dw, ctx.seg_len, dev)
+                               want_dw, ctx.seg_len, dev, ctx.attn_drop)
         if fused is not None:
             d_el, d_er, d_ft, dw = fused
             return (d_el if ctx.needs_input_grad[0] else None, d_er if ctx.needs_input_grad[1] else None,
-                    d_ft if ctx.needs_input_grad[2] else None, dw, None, None, None, None, None)
+                    d_ft if ctx.needs_input_grad[2] else None, dw, None, None, None, None, None, None)
+        if ctx.attn_drop is not None:
+            raise NotImplementedError("attention dropout needs the one-gather GAT backward (stag_gat_bwd)")
         de = torch.empty((csrv.n_edges, H), dtype=torch.float32, device=dev)
         dw = torch.empty((csrv.n_edges, H), dtype=torch.float32, device=dev) if want_dw else None
         # a[E, H], a by-product of the edge pass: the weights of the d ft aggregation
@@ -1075,10 +1099,11 @@ class _GatAggregate(torch.autograd.Function):
             d_ft, _ = _agg_raw(csrt, G.reshape(-1, HF), HF, _explicit_spec(attn, group=F), _lib.REDUCE_SUM, None, None,
                                ctx.seg_len)
             d_ft = d_ft.reshape(-1, H, F)
-        return d_el, d_er, d_ft, dw, None, None, None, None, None
+        return d_el, d_er, d_ft, dw, None, None, None, None, None, None
 
 
-def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec, nscale, want_dw, seg_len, dev):
+def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec, nscale, want_dw, seg_len, dev,
+                   attn_drop=None):
     """stag_gat_bwd: the whole backward on the workgroup-cooperative kernels (one gather of the [H*F] rows; the
     two-gather form stag_gat_bwd_two_pass stays for A/B); None when the shape or the plans are outside what it
     covers (the caller then composes the older kernels)."""
@@ -1097,12 +1122,13 @@ def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec,
     dw = torch.empty((E, H), dtype=torch.float32, device=dev) if want_dw else None
     scratch = torch.empty(_lib.lib().stag_gat_bwd_scratch_bytes(csrv.n_dst, E, H) // 4, dtype=torch.float32, device=dev)
     cs, ct = csrv.struct(), csrt.struct()
-    fn = _lib.lib().stag_gat_bwd if _GAT_BWD_ONE_GATHER else _lib.lib().stag_gat_bwd_two_pass
+    fn = _lib.lib().stag_gat_bwd if (_GAT_BWD_ONE_GATHER or attn_drop is not None) else _lib.lib().stag_gat_bwd_two_pass
+    drop = _gat_drop_struct(attn_drop)
     with _lib.on_device(dev):
         rc = fn(C.byref(cs), C.byref(pf), C.byref(ct), C.byref(pb), _lib.ptr(el), _lib.ptr(er),
                 _lib.ptr(ft), _lib.ptr(stats), _lib.ptr(G), _lib.ptr(out), H, F, neg_slope,
-                C.byref(spec), _lib.ptr(nscale), _lib.ptr(d_el), _lib.ptr(d_er), _lib.ptr(d_ft),
-                _lib.ptr(dw), _lib.ptr(scratch), _lib.stream_of(dev))
+                C.byref(spec), _lib.ptr(nscale), C.byref(drop) if drop is not None else None,
+                _lib.ptr(d_el), _lib.ptr(d_er), _lib.ptr(d_ft), _lib.ptr(dw), _lib.ptr(scratch), _lib.stream_of(dev))
     if rc == -38:
         return None
     _lib.check(rc, "stag_gat_bwd")
@@ -1114,9 +1140,12 @@ _GAT_BWD_ONE_GATHER = True  # stag_gat_bwd (one gather of [H*F] rows) | stag_gat
 
 
 def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False,
-                  seg_len=DEFAULT_SEG_LEN, _gathered=False, attn_fn=None):
+                  seg_len=DEFAULT_SEG_LEN, _gathered=False, attn_fn=None, attn_drop=None):
     """Fused noisy-logit edge softmax + aggregation (stag/zoo/gat.py:114-126).
     el: [N,H], er: [N,H], ft: [N,H,F]; weight: None | [E,H] tensor | EdgeNoise(dn=H).
+    attn_drop: (p, seed, offset[, epoch]) — attention dropout (stag/zoo/gat.py:122) inside the kernels, its mask
+    from its own Philox stream (attn_drop_fusable() says whether the shape has that form); attn_fn: any function of
+    a[E, H] between the softmax and the sum, on the composed path.
     On a node-range shard the inputs are this rank's rows and the call includes the exchange."""
     if getattr(graph, "is_shard", False) and not _gathered:
         return graph.gat_aggregate(el, er, ft, neg_slope, weight, seg_len=seg_len, want_attn=want_attn)
@@ -1139,8 +1168,12 @@ def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False
             or (H * F > 256 and torch.is_grad_enabled() and not _GAT_BWD_FUSED)):
         if getattr(graph, "is_shard", False):
             raise NotImplementedError("the composed GAT path (attention dropout, H > 64 or H*F > 256) is not partitioned")
+        if attn_drop is not None:
+            raise NotImplementedError("attn_drop rides in the fused kernels only: check attn_drop_fusable()")
         return _gat_composed(graph, el, er, ft, neg_slope, noise, w, want_attn, seg_len, attn_fn)
-    return _GatAggregate.apply(el, er, ft, w, graph, noise, neg_slope, want_attn, seg_len)
+    if attn_drop is not None and not attn_drop_fusable(H, F, seg_len, want_attn):
+        raise NotImplementedError("attn_drop rides in the fused kernels only: check attn_drop_fusable()")
+    return _GatAggregate.apply(el, er, ft, w, graph, noise, neg_slope, want_attn, seg_len, attn_drop)
 
 
 def _gat_composed(graph, el, er, ft, neg_slope, noise, w, want_attn, seg_len, attn_fn=None):

@@ -736,3 +736,95 @@ def test_agg_bwd_dp_one_pass(dev, oracle, kind, relu, D):
     for got, ref in ((n0, u0.double().sum(0)), (n1, u1.double().sum(0))):
         sc = max(1.0, float(ref.abs().max()))
         assert_close(got / sc, (ref / sc).cpu().numpy(), what="x = None")
+
+
+@pytest.mark.parametrize("H,F,kind", [(8, 32, "normal"), (4, 16, "explicit"), (2, 256, "none"), (3, 8, "bernoulli"), (16, 64, "uniform")])
+def test_gat_attention_dropout_in_the_kernels(dev, oracle, H, F, kind):
+    """Attention dropout (stag/zoo/gat.py:122; 0.6 in the reference's GAT scripts) inside the fused GAT kernels: the
+    keep mask is a Bernoulli(keep_prob) stream of its own at (forward position, head) — the same words
+    EdgeNoise(..., NOISE_BERNOULLI, keep_prob, seed, offset) materialises.  Forward against the oracle with that
+    mask; backward (mask redrawn, never stored) against autograd through the composed statement with the mask as
+    a tensor; hub rows, segments, explicit-weight gradients; eval-equivalent when nothing is dropped."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    rng = np.random.default_rng(41)
+    n, p_drop, dseed, doff = 400, 0.6, 77, 5
+    g = random_graph(n, 6000, seed=8, hub=900, device=dev)
+    E = g.number_of_edges()
+    og = oracle_graph(oracle, g)
+    el = rng.standard_normal((n, H)).astype(np.float32)
+    er = rng.standard_normal((n, H)).astype(np.float32)
+    ft = rng.standard_normal((n, H, F)).astype(np.float32)
+    if kind == "none":
+        w, spec = None, oracle.make_spec("none")
+    elif kind == "explicit":
+        wt = rng.uniform(0.2, 1.5, (E, H)).astype(np.float32)
+        w, spec = torch.from_numpy(wt).to(dev).requires_grad_(True), oracle.make_spec("explicit", wt)
+    else:
+        p0, p1 = {"normal": (1.0, 0.5), "uniform": (0.2, 1.7), "bernoulli": (0.7, None)}[kind]
+        kw = dict(relu=(kind == "normal"), in_norm=(kind == "bernoulli"), seed=9, offset=3)
+        w, spec = _noise(g, H, kind, p0, p1, **kw), _ospec(oracle, g, H, kind, p0, p1, **kw)
+    keep_prob = float(np.float32(1.0) - np.float32(p_drop))
+    keep = stag_amd.EdgeNoise(g, H, _lib.NOISE_BERNOULLI, keep_prob, seed=dseed, offset=doff).materialize()   # [E, H]
+    frac = float(keep.mean())
+    assert abs(frac - keep_prob) < 0.02
+    t = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (el, er, ft)]
+    out = ops.gat_aggregate(g, *t, 0.2, w, attn_drop=(p_drop, dseed, doff))
+    ref = oracle.gat_fwd(og, el, er, ft, 0.2, spec, keep=keep.cpu().numpy(), keep_prob=keep_prob)
+    assert_close(out, ref, what="forward vs oracle")
+    G = torch.from_numpy(rng.standard_normal((n, H, F)).astype(np.float32)).to(dev)
+    out.backward(G)
+    got_dw = w.grad.clone() if kind == "explicit" else None
+    if kind == "explicit":
+        w.grad = None
+    t2 = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (el, er, ft)]
+    out2 = ops.gat_aggregate(g, *t2, 0.2, w, attn_fn=lambda a_: a_ * keep / keep_prob)          # the composed path
+    assert_close(out2, ref, what="composed forward vs oracle")
+    out2.backward(G)
+    for a_, b_, nm in zip(t, t2, ("d el", "d er", "d ft")):
+        sc = max(1.0, float(b_.grad.abs().max()))
+        assert_close(a_.grad / sc, (b_.grad / sc).cpu().numpy(), what=nm)
+    if kind == "explicit":
+        sc = max(1.0, float(w.grad.abs().max()))
+        assert_close(got_dw / sc, (w.grad / sc).cpu().numpy(), what="dw")
+    # the same call twice: the same bits (mask from counters); another offset: another mask
+    again = ops.gat_aggregate(g, *[x_.detach() for x_ in t], 0.2, w.detach() if torch.is_tensor(w) else w,
+                              attn_drop=(p_drop, dseed, doff))
+    other = ops.gat_aggregate(g, *[x_.detach() for x_ in t], 0.2, w.detach() if torch.is_tensor(w) else w,
+                              attn_drop=(p_drop, dseed, doff + 1))
+    assert torch.equal(again, out.detach()) and not torch.equal(other, out.detach())
+    # shapes without the cooperative form say so
+    assert not ops.attn_drop_fusable(8, 12, 64) and ops.attn_drop_fusable(H, F, 64)
+
+
+def test_gat_layer_trains_with_attention_dropout_on_the_fused_path(dev):
+    """zoo.GAT(attn_drop=0.6) in training mode — the reference's GAT scripts (scripts/citation_mle/gat/run.py:40) —
+    stays on the fused kernels: every call takes one generator offset for its mask, gradients flow, eval mode is
+    the plain kernel, and a fixed generator state replays the step bit for bit."""
+    import stag_amd
+    g = random_graph(300, 4000, seed=3, hub=500, device=dev)
+    x = torch.randn(300, 32, device=dev)
+    torch.manual_seed(1)
+    layer = stag_amd.layers.StagLayer(stag_amd.zoo.GAT(32, 8, num_heads=4, attn_drop=0.6),
+                                      q_a=torch.distributions.Normal(1.0, 0.5)).to(dev)
+    layer.train()
+
+    def run():
+        stag_amd.manual_seed(21)
+        o0 = stag_amd.random.default_generator.offset
+        layer.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        y = layer(g, xg)
+        y.square().mean().backward()
+        used = stag_amd.random.default_generator.offset - o0
+        return y.detach().clone(), xg.grad.clone(), layer.base_layer.attn_l.grad.clone(), used
+    y1, dx1, da1, used = run()
+    y2, dx2, da2, _ = run()
+    assert used == 2                                   # one offset for the edge noise, one for the dropout mask
+    assert torch.equal(y1, y2) and torch.equal(dx1, dx2) and torch.equal(da1, da2)
+    assert torch.isfinite(y1).all() and float(dx1.abs().sum()) > 0 and float(da1.abs().sum()) > 0
+    layer.eval()
+    stag_amd.manual_seed(21)
+    with torch.no_grad():
+        ye = layer(g, x)
+    assert not torch.equal(ye, y1)                     # no mask in eval mode

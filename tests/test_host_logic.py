@@ -20,7 +20,7 @@ def test_abi_exports_every_declared_symbol():
     assert {"stag_agg_fwd", "stag_noise_materialize", "stag_gat_fwd", "stag_plan_fill"} <= names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/stag_hip.h but not exported"
-    assert lib.stag_abi_version() == 14
+    assert lib.stag_abi_version() == 15
     assert lib.stag_strerror(-22) == b"invalid argument"
 
 
@@ -30,7 +30,7 @@ def test_torch_library_front_end_loads_and_traces():
     from stag_amd import _torch_ext
     assert os.path.exists(os.path.join(ROOT, "stag_amd", "_stag_torch.so")), "build with make -C stag_amd/csrc"
     assert _torch_ext.loaded() and not _torch_ext.available()      # eager mode keeps ctypes (it is faster)
-    assert int(torch.ops.stag.abi_version()) == 14
+    assert int(torch.ops.stag.abi_version()) == 15
     ip = torch.zeros(6, dtype=torch.int32, device="meta")
     ix = torch.zeros(9, dtype=torch.int32, device="meta")
     x = torch.zeros(5, 12, device="meta")
@@ -421,15 +421,20 @@ def test_abi_argument_validation_without_gpu():
     a = ok_args(); a[1] = C.byref(plan)
     assert lib.stag_agg_fwd(*a) == EINVAL                                   # plan without units
     # GAT limits
-    g = [C.byref(csr), None, f, f, f, 65, 2, 0.2, C.byref(spec), None, f, None, None]
+    g = [C.byref(csr), None, f, f, f, 65, 2, 0.2, C.byref(spec), None, None, f, None, None]
     assert lib.stag_gat_fwd(*g) == ENOSYS                                   # H > 64
     g[5], g[6] = 8, 64
     assert lib.stag_gat_fwd(*g) == ENOSYS                                   # H*F > 256
     g[5], g[6] = 0, 4
     assert lib.stag_gat_fwd(*g) == EINVAL
     ns = _lib.NoiseSpec(); ns.in_norm = 1
-    g = [C.byref(csr), None, f, f, f, 2, 4, 0.2, C.byref(ns), None, f, None, None]
+    g = [C.byref(csr), None, f, f, f, 2, 4, 0.2, C.byref(ns), None, None, f, None, None]
     assert lib.stag_gat_fwd(*g) == EINVAL                                   # in-norm needs norm_scale
+    drop = _lib.GatDrop(); drop.keep_prob = 0.0
+    g = [C.byref(csr), None, f, f, f, 2, 4, 0.2, C.byref(spec), None, C.byref(drop), f, None, None]
+    assert lib.stag_gat_fwd(*g) == EINVAL                                   # attention dropout that keeps nothing
+    drop.keep_prob = 0.4
+    assert lib.stag_gat_fwd(*g) == ENOSYS                                   # ... needs the cooperative kernel (a block plan)
     # planning on host arrays
     nu, nl, nsg = C.c_int32(), C.c_int32(), C.c_int32()
     assert lib.stag_plan_count(None, 2, 64, C.byref(nu), C.byref(nl), C.byref(nsg), None) == EINVAL

@@ -30,7 +30,7 @@ nz = stag_amd.EdgeNoise(g, H, _lib.NOISE_NORMAL, 1.0, 0.5, seed=1, offset=0)
 spec = nz.spec(); cs = csrv.struct()
 for it in range(3):
     rc = _lib.lib().stag_gat_fwd(C.byref(cs), C.byref(plan_c), _lib.ptr(el), _lib.ptr(er), _lib.ptr(ft), H, F, 0.2,
-                                 C.byref(spec), None, _lib.ptr(out), _lib.ptr(trace), _lib.stream_of(dev))
+                                 C.byref(spec), None, None, _lib.ptr(out), _lib.ptr(trace), _lib.stream_of(dev))
     assert rc == 0
 torch.cuda.synchronize()
 t = trace[:nb * 8].cpu().numpy().reshape(nb, 8).astype(np.float64) * 0.01   # us (100 MHz)

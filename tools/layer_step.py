@@ -26,6 +26,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--mode", default="r1", choices=["r1", "re", "rec", "vi_norm", "fixed", "gat", "sage", "gin"])
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--kl", action="store_true")
+ap.add_argument("--attn-drop", type=float, default=0.0, help="--mode gat: attention dropout (the reference's GAT scripts: 0.6)")
 ap.add_argument("--lib", default=None, help="A/B: a build variant tools/_bin/libstag_<name>.so (tools/ab_bench.py build)")
 args = ap.parse_args()
 if args.lib:
@@ -45,7 +46,7 @@ kw = {"r1": dict(q_a=N(1.0, 0.5), vi=True, relu=True),
       "rec": dict(q_a=stag_amd.distributions.AmortizedDistribution(D, D, init_like=N(1.0, 0.3)), vi=True),
       "vi_norm": dict(q_a=N(1.0, 0.5), vi=True, norm=True),
       "fixed": dict(q_a=N(1.0, 0.5))}.get(args.mode, dict(q_a=N(1.0, 0.5)))
-base = {"gat": lambda: stag_amd.zoo.GAT(D, 32, num_heads=8), "sage": lambda: stag_amd.zoo.GraphSAGE(D, D),
+base = {"gat": lambda: stag_amd.zoo.GAT(D, 32, num_heads=8, attn_drop=args.attn_drop), "sage": lambda: stag_amd.zoo.GraphSAGE(D, D),
         "gin": lambda: stag_amd.zoo.GIN(D, D)}.get(args.mode, lambda: stag_amd.zoo.GCN(D, D))()
 layer = stag_amd.layers.StagLayer(base, **kw).to(dev)
 xg = x.clone().requires_grad_(True)
