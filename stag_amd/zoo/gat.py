@@ -43,21 +43,47 @@ class GAT(torch.nn.Module):
         if isinstance(self.res_fc, torch.nn.Linear):
             torch.nn.init.xavier_uniform_(self.res_fc.weight, gain=gain)
 
+    @staticmethod
+    def _padded_width(H, F):
+        """F if the cooperative kernels take it (F % 4 == 0, F / 4 a power of two) or no padded width fits them
+        (H <= 16, H * Fp <= 1024, Fp <= 256); else the next 4 * 2^k."""
+        lph = F // 4
+        if F % 4 == 0 and lph > 0 and (lph & (lph - 1)) == 0:
+            return F
+        Fp = 4
+        while Fp < F:
+            Fp *= 2
+        return Fp if (H <= 16 and Fp <= 256 and H * Fp <= 1024) else F
+
     def forward(self, graph, feat, get_attention=False, edge_weight=None):
         H, F = self._num_heads, self._out_feats
         h = self.feat_drop(feat)
-        ft = ops.node_linear(h, self.fc.weight.t()).view(-1, H, F)
+        # Head widths the cooperative kernels do not take as they are — F % 4 != 0 or F / 4 not a power of two:
+        # class counts like 7, 40, 121 on the last layer of the reference's GAT scripts
+        # (scripts/arxiv_mle/gat/run.py:50-58) — run with each head zero-padded to Fp = 4 * 2^k: the padding is rows
+        # of zeros in the fc weight and zeros in attn_l / attn_r (parameter-sized ops), so the extra channels of
+        # ft are exactly 0, add nothing to the logits, come out as 0 and are cut off again; the layer keeps the
+        # fused forward, the one-gather backward and in-kernel attention dropout instead of the composed path.
+        Fp = self._padded_width(H, F) if feat.is_cuda else F
+        if Fp != F:
+            pad = torch.nn.functional.pad
+            wp = pad(self.fc.weight.view(H, F, -1), (0, 0, 0, Fp - F)).reshape(H * Fp, -1)
+            attn_l, attn_r = pad(self.attn_l, (0, Fp - F)), pad(self.attn_r, (0, Fp - F))
+            F_out, F = F, Fp
+        else:
+            wp, attn_l, attn_r, F_out = self.fc.weight, self.attn_l, self.attn_r, F
+        ft = ops.node_linear(h, wp.t()).view(-1, H, F)
         # el[n,h] = sum_f ft[n,h,f] attn_l[h,f], er likewise (zoo/gat.py:109-110).  The elementwise-multiply +
         # reduce form costs 2 x 242 us at cfg5 (and as much again in the backward); ops.head_dot is one pass
         # over ft forward and one back.  Head widths it does not take go through ONE [N, HF] x [HF, 2H]
         # product with a block-diagonal right side.
-        lr = ops.head_dot(ft, self.attn_l, self.attn_r)
+        lr = ops.head_dot(ft, attn_l, attn_r)
         if lr is not None:
             el, er = lr
         else:
             eye = torch.eye(H, dtype=ft.dtype, device=ft.device)
-            w_lr = torch.cat([(self.attn_l.reshape(H, F, 1) * eye.reshape(H, 1, H)).reshape(H * F, H),
-                              (self.attn_r.reshape(H, F, 1) * eye.reshape(H, 1, H)).reshape(H * F, H)], 1)
+            w_lr = torch.cat([(attn_l.reshape(H, F, 1) * eye.reshape(H, 1, H)).reshape(H * F, H),
+                              (attn_r.reshape(H, F, 1) * eye.reshape(H, 1, H)).reshape(H * F, H)], 1)
             elr = ops.node_linear(ft.reshape(-1, H * F), w_lr)
             el, er = elr[:, :H], elr[:, H:]
         if edge_weight is not None:
@@ -79,6 +105,8 @@ class GAT(torch.nn.Module):
         res = ops.gat_aggregate(graph, el, er, ft, self._negative_slope, edge_weight,
                                 want_attn=get_attention, attn_fn=drop, attn_drop=fused_drop)
         rst, attn = res if get_attention else (res, None)
+        if F_out != F:
+            rst, F = rst[..., :F_out], F_out
         if self.res_fc is not None:
             rst = rst + self.res_fc(h).view(h.shape[0], -1, F)
         if self.bias is not None:

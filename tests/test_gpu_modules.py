@@ -1214,3 +1214,51 @@ def test_new_backward_paths_are_bit_reproducible(dev):
         for _ in range(3):
             again = run(layer, with_kl)
             assert len(again) == len(first) and all(torch.equal(a, b) for a, b in zip(first, again))
+
+
+@pytest.mark.parametrize("H,F,last", [(3, 7, False), (8, 40, True), (2, 121, False), (4, 6, True), (1, 3, False)])
+def test_gat_odd_head_widths_stay_fused(dev, H, F, last):
+    """Head widths the cooperative kernels do not take as they are (F % 4 != 0, F / 4 not a power of two — the class
+    counts on the last layer of the reference's GAT scripts, scripts/arxiv_mle/gat/run.py:50-58) run zero-padded to
+    4 * 2^k per head inside zoo.GAT: output, d/dx and every parameter gradient equal the layer's own statement
+    on the composed path (torch ops over [E, H] + the aggregation kernel, unpadded), and the layer's autograd graph
+    holds the fused node."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    from util import random_graph
+    n, D = 250, 24
+    g = random_graph(n, 3000, seed=14, hub=400, device=dev)
+    torch.manual_seed(5)
+    gat = stag_amd.zoo.GAT(D, F, num_heads=H, last=last).to(dev)
+    with torch.no_grad():
+        gat.bias.copy_(torch.randn_like(gat.bias) * 0.1)
+    x = torch.randn(n, D, device=dev, requires_grad=True)
+    noise = stag_amd.EdgeNoise(g, H, _lib.NOISE_NORMAL, 1.0, 0.5, seed=6, offset=1)
+    y = gat(g, x, edge_weight=noise)
+    assert y.shape == ((n, F) if last else (n, H * F))
+    names = []
+    node = y.grad_fn
+    stack = [node]
+    while stack and len(names) < 200:
+        nd = stack.pop()
+        if nd is None:
+            continue
+        names.append(type(nd).__name__)
+        stack.extend(f for f, _ in nd.next_functions)
+    assert any("GatAggregate" in nm for nm in names), "the fused GAT node is in the graph"
+    gout = torch.randn_like(y)
+    y.backward(gout)
+    got = {"x": x.grad.clone(), **{k: p.grad.clone() for k, p in gat.named_parameters()}}
+    # the same layer, unpadded, on the composed path
+    x2 = x.detach().clone().requires_grad_(True)
+    gat.zero_grad()
+    ft = (x2 @ gat.fc.weight.t()).view(n, H, F)
+    el, er = (ft * gat.attn_l).sum(-1), (ft * gat.attn_r).sum(-1)
+    rst = ops._gat_composed(g, el, er, ft, 0.2, noise, None, False, 64) + gat.bias.view(1, H, F)
+    ref = rst.mean(-2) if last else rst.flatten(-2, -1)
+    assert_close(y, ref.detach().cpu().numpy(), what="output")
+    ref.backward(gout)
+    want = {"x": x2.grad, **{k: p.grad for k, p in gat.named_parameters()}}
+    for k in got:
+        sc = max(1.0, float(want[k].abs().max()))
+        assert_close(got[k] / sc, (want[k] / sc).cpu().numpy(), what=f"d {k}")
