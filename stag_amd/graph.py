@@ -26,11 +26,16 @@ from . import function as fn
 DEFAULT_SEG_LEN = 64
 
 
+PLAN_AFTER_LAUNCHES = 16     # launches a short-row view runs without a plan before one is built for it
+
+
 class CsrView:
     """Tensors of one CSR plus the ctypes struct the library takes."""
 
     def __init__(self, n_dst, n_src, indptr, indices, eid=None, nidx=None):
         self.n_dst, self.n_src = int(n_dst), int(n_src)
+        self._short = None
+        self._plan_requests = 0
         self.indptr, self.indices, self.eid, self.nidx = indptr, indices, eid, nidx
         self.n_edges = int(indices.shape[0])
         self._plans = {}
@@ -54,11 +59,30 @@ class CsrView:
             self._degrees = (self.indptr[1:] - self.indptr[:-1])
         return self._degrees
 
-    def plan(self, seg_len=DEFAULT_SEG_LEN):
+    def _short_rows(self):
+        """Every row has at most HEAVY_LEN edges (one device reduction and a one-number read-back, kept)."""
+        if self._short is None:
+            self._short = bool(self.indptr.is_cuda and self.n_dst > 0 and self.n_edges > 0 and
+                               int((self.indptr[1:] - self.indptr[:-1]).max()) <= _lib.HEAVY_LEN)
+        return self._short
+
+    def plan(self, seg_len=DEFAULT_SEG_LEN, need=False):
         """Launch plan (stag_plan_count / stag_plan_fill on the host, uploaded once): units
-        sorted by length, long rows cut into segments of seg_len edges."""
+        sorted by length, long rows cut into segments of seg_len edges.
+        None when planning is off (seg_len) — or, unless the caller needs one (need=True: the cooperative GAT
+        kernels want unit batches), when no row has more than HEAVY_LEN edges: no segments, no heavy units, the
+        plan would only restate the row order, and building it (indptr to the host, four uploads: 0.5 ms) is
+        what a freshly batched minibatch graph — molecules, superpixels — would pay on every step
+        (Graph + both CSRs + both plans 1.43 ms -> 0.39 ms for the 4096-molecule batch).  A view that is launched
+        more than PLAN_AFTER_LAUNCHES times gets its plan after all."""
         if seg_len is None or seg_len <= 0:
             return None
+        if seg_len not in self._plans and not need and self._short_rows():
+            # ... but a view that keeps being launched (a static graph) earns its plan: unit records instead of
+            # two dependent indptr loads per row are worth 7 us of a 40 us launch on the molecule batch
+            self._plan_requests += 1
+            if self._plan_requests <= PLAN_AFTER_LAUNCHES:
+                return None
         if seg_len not in self._plans:
             lib = _lib.lib()
             indptr_h = np.ascontiguousarray(self.indptr.detach().cpu().numpy(), dtype=np.int32)
@@ -85,7 +109,7 @@ class CsrView:
         """The plan of `seg_len` restricted to the units keep[i] is True for (a host bool array over
         the plan's units; the segments of a long row must be kept or dropped together).  Order is the
         plan's, so segments still come first and the heavy units stay a prefix."""
-        full = self.plan(seg_len)
+        full = self.plan(seg_len, need=True)
         units = full["units"].cpu().numpy()[:full["n_units"]]
         keep = np.asarray(keep, bool)
         sel = units[keep]

@@ -1013,9 +1013,9 @@ class _GatAggregate(torch.autograd.Function):
         # from them (storing a[E, H] from the forward kernel cost it 250 us at cfg5)
         stats = (torch.empty((csrv.n_dst, 2 * H), dtype=torch.float32, device=dev)
                  if (want_attn or need_grad) else None)
-        plan_t = csrv.plan(seg_len)
+        plan_t = csrv.plan(seg_len, need=True)       # the cooperative kernels want the plan's unit batches
         nbytes = _lib.lib().stag_gat_workspace_bytes(plan_t["n_seg"], H, F) if plan_t is not None else 0
-        plan_c, _keep = _plan_struct(csrv, seg_len, 1, nbytes, dev)
+        plan_c, _keep = _plan_struct(csrv, seg_len, 1, nbytes, dev, plan_t=plan_t)
         cs = csrv.struct()
         attn = None
         drop = _gat_drop_struct(attn_drop)
@@ -1112,10 +1112,10 @@ def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec,
     if not (_GAT_BWD_FUSED and F % 4 == 0 and lph <= 64 and lph & (lph - 1) == 0 and H <= 16 and H * F <= 1024 and E > 0
             and seg_len is not None and 0 < seg_len <= _lib.BLOCK_EDGES):
         return None
-    plan_f, plan_b = csrv.plan(seg_len), csrt.plan(seg_len)
+    plan_f, plan_b = csrv.plan(seg_len, need=True), csrt.plan(seg_len, need=True)
     nbytes = _lib.lib().stag_gat_bwd_workspace_bytes(plan_f["n_seg"], plan_b["n_seg"], H, F)
-    pf, _k1 = _plan_struct(csrv, seg_len, 1, nbytes, dev)
-    pb, _k2 = _plan_struct(csrt, seg_len, 1, 0, dev)
+    pf, _k1 = _plan_struct(csrv, seg_len, 1, nbytes, dev, plan_t=plan_f)
+    pb, _k2 = _plan_struct(csrt, seg_len, 1, 0, dev, plan_t=plan_b)
     d_el = torch.empty((csrt.n_dst, H), dtype=torch.float32, device=dev)
     d_er = torch.empty((csrv.n_dst, H), dtype=torch.float32, device=dev)
     d_ft = torch.empty((csrt.n_dst, H, F), dtype=torch.float32, device=dev)

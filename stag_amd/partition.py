@@ -403,7 +403,7 @@ class GraphShard:
         same kernel: results do not change."""
         o = self._origin
         if seg_len not in o._plan_split:
-            full = self._csr.plan(seg_len)
+            full = self._csr.plan(seg_len, need=True)
             units = full["units"].cpu().numpy()[:full["n_units"]]
             whole = units[:, 3] < 0
             loc = whole & self._row_is_local[np.where(whole, units[:, 0], 0)]

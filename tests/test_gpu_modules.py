@@ -1262,3 +1262,29 @@ def test_gat_odd_head_widths_stay_fused(dev, H, F, last):
     for k in got:
         sc = max(1.0, float(want[k].abs().max()))
         assert_close(got[k] / sc, (want[k] / sc).cpu().numpy(), what=f"d {k}")
+
+
+def test_short_row_graphs_run_without_a_plan_until_they_are_reused(dev):
+    """A batch of molecules (no row longer than HEAVY_LEN edges) is launched plan-less — building a plan costs a
+    host round trip per minibatch graph — with the same bits as the planned launch; a view that keeps being
+    launched gets its plan after PLAN_AFTER_LAUNCHES launches; the GAT kernels get one at once (need=True)."""
+    import stag_amd
+    import importlib
+    from stag_amd import _lib, ops, synthetic
+    G = importlib.import_module("stag_amd.graph")
+    s, d, sizes = synthetic.molecules_like(256)
+    n = int(sizes.sum())
+    g = stag_amd.Graph(torch.from_numpy(s), torch.from_numpy(d), n, device=dev)
+    assert g.csr._short_rows()
+    x = torch.randn(n, 32, device=dev)
+    mk = lambda: stag_amd.EdgeNoise(g, 32, _lib.NOISE_NORMAL, 1.0, 0.5, seed=2, offset=7)
+    assert g.csr.plan(64) is None
+    first = ops.aggregate(g, x, mk())
+    for _ in range(G.PLAN_AFTER_LAUNCHES):
+        ops.aggregate(g, x, mk())
+    assert g.csr.plan(64) is not None                       # the view earned its plan
+    assert torch.equal(ops.aggregate(g, x, mk()), first)    # and the planned launch gives the same bits
+    g2 = stag_amd.Graph(torch.from_numpy(s), torch.from_numpy(d), n, device=dev)
+    assert g2.csr.plan(64, need=True) is not None and g2.csr.plan(64, need=True)["n_blocks"] > 0
+    hub = stag_amd.Graph(torch.zeros(40, dtype=torch.int64), torch.arange(40) % 2, 3, device=dev)   # a 20-edge row
+    assert not hub.csr._short_rows() and hub.csr.plan(64) is not None
