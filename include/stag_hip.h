@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 15
+#define STAG_ABI_VERSION 16
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -191,6 +191,18 @@ size_t stag_plan_workspace_bytes(int32_t n_seg, int32_t D, int32_t in_norm);
 #endif
 int stag_plan_blocks(const stag_unit* units_host, int32_t n_units, int32_t max_edges,
                      int32_t max_units, int32_t* block_ptr_host, int32_t* n_blocks_out);
+
+/* The same plan built ON THE DEVICE from a device indptr (rocPRIM sort + scan + one fill kernel), array for array
+ * what stag_plan_count / stag_plan_fill produce on the host: a freshly batched minibatch graph (scripts/ppi_mle,
+ * scripts/molhiv_mle build one per step) is planned where it was built — no indptr read-back, no host loops, no
+ * uploads, ONE 16-byte read-back of the counts (the call synchronises `stream` for it).
+ * units: device array of >= n_dst + n_edges / seg_len + 1 records; long_rows, long_seg_ptr: device arrays of
+ * >= n_edges / (seg_len + 1) + 1 ints; counts_out_host[4] = n_units, n_long, n_seg, n_heavy;
+ * workspace >= stag_plan_device_workspace_bytes(n_dst).  (stag_plan_blocks still takes host unit records.)   */
+size_t stag_plan_device_workspace_bytes(int32_t n_dst);
+int stag_plan_device(const int32_t* indptr, int32_t n_dst, int64_t n_edges, int32_t seg_len, stag_unit* units,
+                     int64_t units_capacity, int32_t* long_rows, int32_t* long_seg_ptr, int64_t long_capacity,
+                     int32_t* counts_out_host, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- graph preprocessing on the device: COO -> stable destination-major CSR ----------------
  * Position order inside a row = ascending original edge id (the order `graph.edata` frames

@@ -89,6 +89,10 @@ def lib():
     l.stag_plan_blocks.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, ip]
     l.stag_plan_workspace_bytes.restype = C.c_size_t
     l.stag_plan_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    l.stag_plan_device_workspace_bytes.restype = C.c_size_t
+    l.stag_plan_device_workspace_bytes.argtypes = [C.c_int32]
+    l.stag_plan_device.argtypes = [_vp, C.c_int32, C.c_int64, C.c_int32, _vp, C.c_int64, _vp, _vp, C.c_int64,
+                                   C.POINTER(C.c_int32), _vp, C.c_size_t, _vp]
     l.stag_csr_build_workspace_bytes.restype = C.c_size_t
     l.stag_csr_build_workspace_bytes.argtypes = [C.c_int32, C.c_int64]
     l.stag_csr_build.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp, _vp, _vp, _vp,
@@ -153,7 +157,7 @@ def lib():
     l.stag_comm_destroy.argtypes = [_vp]
     l.stag_halo_allgather.argtypes = [_vp, _vp, C.c_int64, _vp, _vp]
     l.stag_halo_exchange.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
-    if l.stag_abi_version() != 15:
+    if l.stag_abi_version() != 16:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     _lib = l
     return l

@@ -85,3 +85,127 @@ extern "C" int stag_csr_build(const int32_t* src, const int32_t* dst, int32_t n_
     return STAG_EIO;
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }
+
+// ---- the launch plan on the device (stag_plan_device) -----------------------------------------------------
+// The same plan stag_plan_count / stag_plan_fill build on the host, array for array: long rows (more than seg_len
+// edges) first, most edges first, cut into balanced segments; then the whole rows, longest first; ties in row order.
+// A minibatch graph is planned where it was built: no indptr read-back, no host loops, no uploads — one 16-byte
+// read-back of the counts at the end.
+//   1. key[r] = long ? (0x7FFFFFFF - deg) : (1 << 31) | (seg_len - deg);  stable radix sort of (key, row)
+//   2. units per sorted row (segments | 1), exclusive scan -> first unit of every sorted row
+//   3. fill: one thread per sorted row writes its unit records, long_rows, long_seg_ptr
+namespace {
+
+__global__ void plan_keys_kernel(const int32_t* indptr, int32_t n, int32_t seg_len, uint32_t* keys, int32_t* rows) {
+  const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int32_t deg = indptr[r + 1] - indptr[r];
+  keys[r] = deg > seg_len ? (0x7FFFFFFFu - (uint32_t)deg) : (0x80000000u | (uint32_t)(seg_len - deg));
+  rows[r] = r;
+}
+
+// nu[i] = units of sorted row i; counts[0..2] += (long rows, segments, whole rows longer than STAG_HEAVY_LEN)
+__global__ void plan_units_kernel(const int32_t* indptr, const int32_t* rows, int32_t n, int32_t seg_len,
+                                  int32_t* nu, int32_t* counts) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  int32_t is_long = 0, nseg = 0, heavy = 0;
+  if (i < n) {
+    const int32_t v = rows[i];
+    const int32_t deg = indptr[v + 1] - indptr[v];
+    if (deg > seg_len) { is_long = 1; nseg = (deg + seg_len - 1) / seg_len; nu[i] = nseg; }
+    else { nu[i] = 1; heavy = deg > STAG_HEAVY_LEN ? 1 : 0; }
+  }
+  // integer sums: any order gives the same counts
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    is_long += __shfl_xor(is_long, d); nseg += __shfl_xor(nseg, d); heavy += __shfl_xor(heavy, d);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (is_long) atomicAdd(counts + 0, is_long);
+    if (nseg) atomicAdd(counts + 1, nseg);
+    if (heavy) atomicAdd(counts + 2, heavy);
+  }
+}
+
+__global__ void plan_fill_kernel(const int32_t* indptr, const int32_t* rows, const int32_t* uoff, int32_t n,
+                                 int32_t seg_len, stag_unit* units, int32_t* long_rows, int32_t* long_seg_ptr,
+                                 const int32_t* counts) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) long_seg_ptr[counts[0]] = counts[1];
+  if (i >= n) return;
+  const int32_t v = rows[i];
+  const int32_t b = indptr[v], deg = indptr[v + 1] - b;
+  const int32_t u0 = uoff[i];
+  if (deg > seg_len) {                       // sorted position = index among the long rows (they come first)
+    const int32_t nseg = (deg + seg_len - 1) / seg_len;
+    const int32_t base = deg / nseg, rem = deg % nseg;      // balanced: lengths differ by at most 1
+    long_rows[i] = v;
+    long_seg_ptr[i] = u0;
+    int32_t p = b;
+    for (int32_t k = 0; k < nseg; ++k) {
+      const int32_t l = base + (k < rem ? 1 : 0);
+      units[u0 + k] = stag_unit{i, p, l, u0 + k};
+      p += l;
+    }
+  } else {
+    units[u0] = stag_unit{v, b, deg, -1};
+  }
+}
+
+}  // namespace
+
+extern "C" size_t stag_plan_device_workspace_bytes(int32_t n_dst) {
+  if (n_dst <= 0) return 256;
+  size_t sort_tmp = 0, scan_tmp = 0;
+  uint32_t* ku = nullptr;
+  int32_t* null = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, ku, ku, null, null, (size_t)n_dst, 0u, 32u);
+  (void)rocprim::exclusive_scan(nullptr, scan_tmp, null, null, 0, (size_t)n_dst, rocprim::plus<int32_t>());
+  // keys in/out, rows in/out, units per row, unit offsets, 4 counters, rocPRIM's temporary storage
+  return align_up((size_t)n_dst * 4) * 6 + 256 + align_up(sort_tmp > scan_tmp ? sort_tmp : scan_tmp);
+}
+
+extern "C" int stag_plan_device(const int32_t* indptr, int32_t n_dst, int64_t n_edges, int32_t seg_len,
+                                stag_unit* units, int64_t units_capacity, int32_t* long_rows, int32_t* long_seg_ptr,
+                                int64_t long_capacity, int32_t* counts_out_host, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  if (!indptr || n_dst < 0 || n_edges < 0 || seg_len <= 0 || seg_len > (1 << 20) || !counts_out_host) return STAG_EINVAL;
+  counts_out_host[0] = counts_out_host[1] = counts_out_host[2] = counts_out_host[3] = 0;
+  if (n_dst == 0) return STAG_OK;
+  // upper bounds the caller sized the arrays with: a long row has more than seg_len edges
+  const int64_t max_long = n_edges / ((int64_t)seg_len + 1);
+  const int64_t max_units = (int64_t)n_dst + n_edges / seg_len + 1;
+  if (!units || !long_rows || !long_seg_ptr || units_capacity < max_units || long_capacity < max_long + 1) return STAG_EINVAL;
+  if (!workspace || workspace_bytes < stag_plan_device_workspace_bytes(n_dst)) return STAG_ENOMEM;
+  hipStream_t s = (hipStream_t)stream;
+  char* w = static_cast<char*>(workspace);
+  const size_t slot = align_up((size_t)n_dst * 4);
+  uint32_t* keys = reinterpret_cast<uint32_t*>(w);
+  uint32_t* keys_s = reinterpret_cast<uint32_t*>(w + slot);
+  int32_t* rows = reinterpret_cast<int32_t*>(w + 2 * slot);
+  int32_t* rows_s = reinterpret_cast<int32_t*>(w + 3 * slot);
+  int32_t* nu = reinterpret_cast<int32_t*>(w + 4 * slot);
+  int32_t* uoff = reinterpret_cast<int32_t*>(w + 5 * slot);
+  int32_t* counts = reinterpret_cast<int32_t*>(w + 6 * slot);
+  void* tmp = w + 6 * slot + 256;
+  size_t tmp_bytes = workspace_bytes - (6 * slot + 256);
+  const dim3 grid((n_dst + 255) / 256), block(256);
+  if (hipMemsetAsync(counts, 0, 16, s) != hipSuccess) return STAG_EIO;
+  hipLaunchKernelGGL(plan_keys_kernel, grid, block, 0, s, indptr, n_dst, seg_len, keys, rows);
+  if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_s, rows, rows_s, (size_t)n_dst, 0u, 32u, s) != hipSuccess)
+    return STAG_EIO;
+  hipLaunchKernelGGL(plan_units_kernel, grid, block, 0, s, indptr, rows_s, n_dst, seg_len, nu, counts);
+  if (rocprim::exclusive_scan(tmp, tmp_bytes, nu, uoff, 0, (size_t)n_dst, rocprim::plus<int32_t>(), s) != hipSuccess)
+    return STAG_EIO;
+  hipLaunchKernelGGL(plan_fill_kernel, grid, block, 0, s, indptr, rows_s, uoff, n_dst, seg_len, units, long_rows,
+                     long_seg_ptr, counts);
+  int32_t c[4] = {0, 0, 0, 0};
+  if (hipMemcpyAsync(c, counts, 16, hipMemcpyDeviceToHost, s) != hipSuccess) return STAG_EIO;
+  if (hipStreamSynchronize(s) != hipSuccess) return STAG_EIO;
+  const int64_t n_long = c[0], n_seg = c[1], n_heavy = (int64_t)c[1] + c[2];
+  const int64_t n_units = (int64_t)n_dst - n_long + n_seg;
+  if (n_units > 0x7FFFFFFFll) return STAG_EINVAL;
+  counts_out_host[0] = (int32_t)n_units; counts_out_host[1] = (int32_t)n_long;
+  counts_out_host[2] = (int32_t)n_seg; counts_out_host[3] = (int32_t)(n_heavy > 0x7FFFFFFFll ? 0x7FFFFFFFll : n_heavy);
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}

@@ -26,6 +26,7 @@ from . import function as fn
 DEFAULT_SEG_LEN = 64
 
 
+DEVICE_PLANNER = True        # plans of device-resident graphs come from stag_plan_device (False: the host planner)
 PLAN_AFTER_LAUNCHES = 16     # launches a short-row view runs without a plan before one is built for it
 
 
@@ -83,6 +84,8 @@ class CsrView:
             self._plan_requests += 1
             if self._plan_requests <= PLAN_AFTER_LAUNCHES:
                 return None
+        if seg_len not in self._plans and self.indptr.is_cuda and DEVICE_PLANNER:
+            self._plans[seg_len] = self._plan_on_device(seg_len)
         if seg_len not in self._plans:
             lib = _lib.lib()
             indptr_h = np.ascontiguousarray(self.indptr.detach().cpu().numpy(), dtype=np.int32)
@@ -103,7 +106,33 @@ class CsrView:
                 long_rows=torch.from_numpy(long_rows).to(dev),
                 long_seg_ptr=torch.from_numpy(long_seg_ptr).to(dev),
                 counters={}, **_block_plan(units, nu, dev))
-        return self._plans[seg_len]
+        plan = self._plans[seg_len]
+        if need and plan.get("block_ptr") is None:
+            # the unit batches of the cooperative GAT kernels: a greedy pass over the unit records on the host
+            units_h = plan["units"][:max(plan["n_units"], 1)].cpu().numpy()
+            plan.update(_block_plan(units_h, plan["n_units"], self.indptr.device))
+            plan.pop("_structs", None)
+            plan.pop("_ints", None)
+        return plan
+
+    def _plan_on_device(self, seg_len):
+        """stag_plan_device: the plan from the device indptr, no host pass (block batches are added on demand)."""
+        lib, dev = _lib.lib(), self.indptr.device
+        n, E = self.n_dst, self.n_edges
+        ucap, lcap = n + E // seg_len + 1, E // (seg_len + 1) + 1
+        units = torch.empty((max(ucap, 1), 4), dtype=torch.int32, device=dev)
+        long_rows = torch.empty(max(lcap, 1), dtype=torch.int32, device=dev)
+        long_seg_ptr = torch.zeros(lcap + 1, dtype=torch.int32, device=dev)
+        nbytes = lib.stag_plan_device_workspace_bytes(n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        counts = (C.c_int32 * 4)()
+        with _lib.on_device(dev):
+            rc = lib.stag_plan_device(_lib.ptr(self.indptr), n, E, seg_len, _lib.ptr(units), ucap, _lib.ptr(long_rows),
+                                      _lib.ptr(long_seg_ptr), lcap + 1, counts, _lib.ptr(ws), nbytes, _lib.stream_of(dev))
+        _lib.check(rc, "stag_plan_device")
+        nu, nl, ns, nh = (int(v) for v in counts)
+        return dict(seg_len=seg_len, n_units=nu, n_long=nl, n_seg=ns, n_heavy=nh, units=units, long_rows=long_rows,
+                    long_seg_ptr=long_seg_ptr, counters={}, n_blocks=0, block_ptr=None)
 
     def subplan(self, seg_len, keep):
         """The plan of `seg_len` restricted to the units keep[i] is True for (a host bool array over

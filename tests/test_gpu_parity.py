@@ -828,3 +828,38 @@ def test_gat_layer_trains_with_attention_dropout_on_the_fused_path(dev):
     with torch.no_grad():
         ye = layer(g, x)
     assert not torch.equal(ye, y1)                     # no mask in eval mode
+
+
+@pytest.mark.parametrize("seg_len", [16, 64, 256])
+def test_device_planner_equals_host_planner(dev, seg_len):
+    """stag_plan_device builds, from the device indptr, the plan stag_plan_count / stag_plan_fill build on the host:
+    the same unit records in the same order (long rows first, most edges first, balanced segments; whole rows
+    longest first; ties by row), long_rows, long_seg_ptr and counts — hubs, empty rows, a one-row graph, a graph
+    without edges; and the block batches added on demand equal the host's."""
+    import importlib
+    import stag_amd
+    G = importlib.import_module("stag_amd.graph")
+    rng = np.random.default_rng(seg_len)
+    cases = [random_graph(300, 5000, seed=1, hub=700, device=dev), random_graph(50, 30, seed=2, device=dev),
+             random_graph(2000, 30000, seed=3, hub=3000, device=dev),
+             stag_amd.Graph(torch.zeros(200, dtype=torch.int64), torch.zeros(200, dtype=torch.int64), 1, device=dev),
+             stag_amd.Graph(torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64), 7, device=dev)]
+    for g in cases:
+        for view_name in ("csr", "csr_t"):
+            view = getattr(g, view_name)
+            assert G.DEVICE_PLANNER
+            dplan = view.plan(seg_len, need=True)
+            view._plans.clear()
+            G.DEVICE_PLANNER = False
+            try:
+                hplan = view.plan(seg_len, need=True)
+            finally:
+                G.DEVICE_PLANNER = True
+            view._plans.clear()
+            for k in ("n_units", "n_long", "n_seg", "n_heavy", "n_blocks"):
+                assert dplan[k] == hplan[k], (k, dplan[k], hplan[k])
+            nu, nl = hplan["n_units"], hplan["n_long"]
+            assert torch.equal(dplan["units"][:nu].cpu(), hplan["units"][:nu].cpu())
+            assert torch.equal(dplan["long_rows"][:nl].cpu(), hplan["long_rows"][:nl].cpu())
+            assert torch.equal(dplan["long_seg_ptr"][:nl + 1].cpu(), hplan["long_seg_ptr"][:nl + 1].cpu())
+            assert torch.equal(dplan["block_ptr"].cpu(), hplan["block_ptr"].cpu())
