@@ -465,8 +465,12 @@ def batch(graphs):
     sizes = [g._n for g in graphs]
     n_edges = [int(g._src.shape[0]) for g in graphs]
     total = int(sum(sizes))
-    node_off = torch.tensor(np.concatenate([[0], np.cumsum(sizes[:-1])]) if graphs else [], dtype=torch.int64)
-    edge_off = torch.repeat_interleave(node_off, torch.tensor(n_edges, dtype=torch.int64)).to(dev)
+    node_off = np.concatenate([[0], np.cumsum(sizes[:-1])]).astype(np.int64) if graphs else np.zeros(0, np.int64)
+    if dev.type == "cuda":      # on the device, output size given: no host pass over the edges, no read-back
+        edge_off = torch.repeat_interleave(torch.from_numpy(node_off).to(dev), torch.tensor(n_edges, dtype=torch.int64, device=dev),
+                                           output_size=int(sum(n_edges)))
+    else:                       # (numpy: torch's CPU repeat_interleave spins up its thread pool: 80 ms stalls seen)
+        edge_off = torch.from_numpy(np.repeat(node_off, n_edges))
     src = torch.cat([g._src for g in graphs]).to(torch.int64) + edge_off
     dst = torch.cat([g._dst for g in graphs]).to(torch.int64) + edge_off
     out = Graph(src, dst, total, batch_num_nodes=torch.tensor(sizes, dtype=torch.int64, device=dev))
