@@ -204,16 +204,26 @@ __device__ __forceinline__ float lanes_sum(float v, int nl) {     // aligned gro
   return v;
 }
 
+// lane L of a team -> (head, chunk of 4 channels): a head takes gl = F / 4 rounded up to a power of two lanes (the
+// head sums are butterflies); lanes past a head's F channels idle (F = 40: 10 of 16).  F / 4 a power of two: k0 = 4 L.
+__device__ __forceinline__ void head_lane(int L, int G, int F, int gl, int& k0, bool& in, int& head) {
+  head = L / gl;
+  const int j = L - head * gl;
+  in = head < G && 4 * j < F;
+  k0 = in ? head * F + 4 * j : 0;
+}
+
 template <int LPE, int CG>
-__global__ __launch_bounds__(256) void head_dot_fwd_kernel(const float* x, int64_t ldx, int n, int K, int F,
+__global__ __launch_bounds__(256) void head_dot_fwd_kernel(const float* x, int64_t ldx, int n, int K, int F, int gl,
                                                            const float* w, float* y) {
   constexpr int R = kFwdRows;
   const int c = threadIdx.x % LPE;
   const int row0 = (blockIdx.x * (256 / LPE) + threadIdx.x / LPE) * R;
-  const int G = K / F, gl = F >> 2;                 // heads; lanes per head
-  for (int kt = 0; kt < K; kt += LPE * 4) {
-    const int k0 = kt + c * 4;
-    const bool in = k0 < K;
+  const int G = K / F;                              // heads; gl lanes per head
+  for (int L0 = 0; L0 < G * gl; L0 += LPE) {
+    int k0, hd;
+    bool in;
+    head_lane(L0 + c, G, F, gl, k0, in, hd);
     float wv[CG][4], xv[R][4];
 #pragma unroll
     for (int cc = 0; cc < CG; ++cc) {
@@ -233,14 +243,14 @@ __global__ __launch_bounds__(256) void head_dot_fwd_kernel(const float* x, int64
 #pragma unroll
         for (int q = 0; q < 4; ++q) d = __builtin_fmaf(xv[r][q], wv[cc][q], d);
         d = lanes_sum(d, gl);
-        if (in && row0 + r < n && (c % gl) == 0) y[((int64_t)cc * n + (row0 + r)) * G + k0 / F] = d;
+        if (in && row0 + r < n && k0 == hd * F) y[((int64_t)cc * n + (row0 + r)) * G + hd] = d;
       }
   }
 }
 
 // dx[n, k] = sum_c gy[c][n][g(k)] w[c][k];  dw[c][k] = sum_n gy[c][n][g(k)] x[n, k]: one pass over x
 template <int LPE, int CG>
-__global__ __launch_bounds__(256) void head_dot_bwd_kernel(const float* x, int64_t ldx, int n, int K, int F,
+__global__ __launch_bounds__(256) void head_dot_bwd_kernel(const float* x, int64_t ldx, int n, int K, int F, int gl,
                                                            const float* w, const float* gy, float* dx, int64_t lddx,
                                                            float* part) {
   constexpr int TEAMS = 256 / LPE;
@@ -250,10 +260,10 @@ __global__ __launch_bounds__(256) void head_dot_bwd_kernel(const float* x, int64
   const int t0 = blockIdx.x * TEAMS + tm;
   const int G = K / F;
   float* mypart = part + (int64_t)blockIdx.x * CG * K;
-  for (int kt = 0; kt < K; kt += LPE * 4) {
-    const int k0 = kt + c * 4;
-    const bool in = k0 < K;
-    const int g = in ? k0 / F : 0;
+  for (int L0 = 0; L0 < G * gl; L0 += LPE) {
+    int k0, g;
+    bool in;
+    head_lane(L0 + c, G, F, gl, k0, in, g);
     float wv[CG][4], dwacc[CG][4];
 #pragma unroll
     for (int cc = 0; cc < CG; ++cc) {
@@ -299,8 +309,11 @@ __global__ __launch_bounds__(256) void head_dot_bwd_kernel(const float* x, int64
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < TEAMS; ++j) s += s_red[j][i];
-      const int cc = i / (LPE * 4), k = kt + i % (LPE * 4);
-      if (k < K) mypart[(int64_t)cc * K + k] = s;
+      const int cc = i / (LPE * 4), lane = (i % (LPE * 4)) >> 2, q = i & 3;
+      int kk, hh;
+      bool kin;
+      head_lane(L0 + lane, G, F, gl, kk, kin, hh);
+      if (kin) mypart[(int64_t)cc * K + kk + q] = s;
     }
     __syncthreads();
   }
@@ -536,19 +549,21 @@ int stag_node_project_bwd(const float* x, int64_t ldx, int64_t n_rows, int32_t K
 
 int stag_head_dot_fwd(const float* x, int64_t ldx, int64_t n_rows, int32_t G, int32_t F, const float* w, int32_t C,
                       float* y, void* stream) {
-  if (n_rows < 0 || G <= 0 || F < 4 || F > 256 || (F & (F - 1)) != 0 || C < 1 || C > 2 || n_rows >= (1ll << 31))
+  if (n_rows < 0 || G <= 0 || F < 4 || F > 256 || F % 4 != 0 || C < 1 || C > 2 || n_rows >= (1ll << 31))
     return STAG_EINVAL;
   if (n_rows == 0) return STAG_OK;
   const int K = G * F;
   if (!x || !w || !y || ldx < K || ldx % 4 != 0 || !aligned16(x) || !aligned16(w)) return STAG_EINVAL;
-  const int lpe = lpe_for(K, 1) < F / 4 ? F / 4 : lpe_for(K, 1);
+  int gl = 1;                                     // lanes per head: F / 4 rounded up to a power of two
+  while (gl * 4 < F) gl <<= 1;
+  const int lpe = lpe_for(G * gl * 4, 1) < gl ? gl : lpe_for(G * gl * 4, 1);
   const int64_t rows_per_block = (int64_t)(256 / lpe) * kFwdRows;
   const dim3 grid((unsigned)((n_rows + rows_per_block - 1) / rows_per_block));
   hipStream_t s = (hipStream_t)stream;
 #define STAG_HD_FWD(L)                                                                                          \
   do {                                                                                                          \
-    if (C == 1) hipLaunchKernelGGL((head_dot_fwd_kernel<L, 1>), grid, dim3(256), 0, s, x, ldx, (int)n_rows, K, F, w, y); \
-    else        hipLaunchKernelGGL((head_dot_fwd_kernel<L, 2>), grid, dim3(256), 0, s, x, ldx, (int)n_rows, K, F, w, y); \
+    if (C == 1) hipLaunchKernelGGL((head_dot_fwd_kernel<L, 1>), grid, dim3(256), 0, s, x, ldx, (int)n_rows, K, F, gl, w, y); \
+    else        hipLaunchKernelGGL((head_dot_fwd_kernel<L, 2>), grid, dim3(256), 0, s, x, ldx, (int)n_rows, K, F, gl, w, y); \
   } while (0)
   switch (lpe) {
     case 8: STAG_HD_FWD(8); break;
@@ -563,7 +578,7 @@ int stag_head_dot_fwd(const float* x, int64_t ldx, int64_t n_rows, int32_t G, in
 int stag_head_dot_bwd(const float* x, int64_t ldx, int64_t n_rows, int32_t G, int32_t F, const float* w, int32_t C,
                       const float* gy, float* dx, int64_t lddx, float* dw, void* workspace, size_t workspace_bytes,
                       void* stream) {
-  if (n_rows < 0 || G <= 0 || F < 4 || F > 256 || (F & (F - 1)) != 0 || C < 1 || C > 2 || n_rows >= (1ll << 31))
+  if (n_rows < 0 || G <= 0 || F < 4 || F > 256 || F % 4 != 0 || C < 1 || C > 2 || n_rows >= (1ll << 31))
     return STAG_EINVAL;
   if (!dx && !dw) return STAG_EINVAL;
   const int K = G * F, nv = C * K;
@@ -574,7 +589,9 @@ int stag_head_dot_bwd(const float* x, int64_t ldx, int64_t n_rows, int32_t G, in
   }
   if (!x || !w || !gy || ldx < K || ldx % 4 != 0 || !aligned16(x) || !aligned16(w)) return STAG_EINVAL;
   if (dx && (lddx < K || lddx % 4 != 0 || !aligned16(dx))) return STAG_EINVAL;
-  const int lpe = lpe_for(K, 1) < F / 4 ? F / 4 : lpe_for(K, 1);
+  int gl = 1;
+  while (gl * 4 < F) gl <<= 1;
+  const int lpe = lpe_for(G * gl * 4, 1) < gl ? gl : lpe_for(G * gl * 4, 1);
   int nb = kRedBlocks;
   while (nb > 16 && (size_t)nb * nv * sizeof(float) > (32u << 20)) nb >>= 1;
   while (nb > 1 && (int64_t)(nb / 2) * (256 / lpe) >= n_rows) nb >>= 1;
@@ -582,8 +599,8 @@ int stag_head_dot_bwd(const float* x, int64_t ldx, int64_t n_rows, int32_t G, in
   float* part = static_cast<float*>(workspace);
 #define STAG_HD_BWD(L)                                                                                          \
   do {                                                                                                          \
-    if (C == 1) hipLaunchKernelGGL((head_dot_bwd_kernel<L, 1>), dim3(nb), dim3(256), 0, s, x, ldx, (int)n_rows, K, F, w, gy, dx, lddx, part); \
-    else        hipLaunchKernelGGL((head_dot_bwd_kernel<L, 2>), dim3(nb), dim3(256), 0, s, x, ldx, (int)n_rows, K, F, w, gy, dx, lddx, part); \
+    if (C == 1) hipLaunchKernelGGL((head_dot_bwd_kernel<L, 1>), dim3(nb), dim3(256), 0, s, x, ldx, (int)n_rows, K, F, gl, w, gy, dx, lddx, part); \
+    else        hipLaunchKernelGGL((head_dot_bwd_kernel<L, 2>), dim3(nb), dim3(256), 0, s, x, ldx, (int)n_rows, K, F, gl, w, gy, dx, lddx, part); \
   } while (0)
   switch (lpe) {
     case 8: STAG_HD_BWD(8); break;

@@ -59,6 +59,7 @@ struct GatArgs {
   uint32_t ws_bytes;
   const int32_t* block_ptr;   // [n_blocks+1] unit batches of the workgroup-cooperative kernels
   int32_t hvec;               // el / er / nscale are 16-byte aligned (rows of H % 4 == 0 heads load as dwordx4)
+  int32_t lphp;               // lanes per head in the cooperative kernels: F / 4 rounded up to a power of two
   // attention dropout (stag/zoo/gat.py:122): a[e,h] -> a[e,h] keep[e,h] / keep_prob, keep from its own Philox stream
   float drop_keep;            // keep probability; 0: no dropout
   float drop_scale;           // 1 / keep probability
@@ -106,6 +107,16 @@ __device__ __forceinline__ void head_w4(const GatArgs& a, const PhiloxKey& key, 
       break;
     default: w[0] = w[1] = w[2] = w[3] = 1.0f;
   }
+}
+
+// Lane L of a team -> its 4 channels.  A head takes lphp lanes (F / 4 rounded up to a power of two: the head sums
+// are DPP butterflies); lanes past a head's F channels idle, so a width like F = 40 (lphp = 16) costs idle lanes but
+// no padded bytes.  F / 4 a power of two: k0 = 4 L, the plain contiguous mapping.
+__device__ __forceinline__ void lane_chunk(int L, int H, int F, int lphp, int& k0, bool& kin, int& hl) {
+  const int head = L / lphp, j = L - head * lphp;
+  kin = head < H && 4 * j < F;
+  k0 = kin ? head * F + 4 * j : 0;
+  hl = kin ? head : 0;
 }
 
 // The row output is written once and not read again by this launch: a non-temporal store keeps it from
@@ -508,9 +519,7 @@ __global__ __launch_bounds__(kBlkThreads) STAG_GAT_SGPR_ATTR void gat_fwd_block_
   bool kin[CPL];
 #pragma unroll
   for (int cj = 0; cj < CPL; ++cj) {
-    k0[cj] = (c + LPE * cj) * 4;
-    kin[cj] = k0[cj] < HF;
-    hl[cj] = kin[cj] ? k0[cj] / F : 0;
+    lane_chunk(c + LPE * cj, H, F, a.lphp, k0[cj], kin[cj], hl[cj]);
   }
   const __amdgpu_buffer_rsrc_t rft =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ft), 0, (int)a.ft_bytes, 0x00020000);
@@ -944,14 +953,12 @@ __global__ __launch_bounds__(kBlkThreads) void gat_bwd_edge_block_kernel(const G
   // ---- phase 2: a team per unit: <G[v,h,:], ft[u,h,:]> per in-edge -> ds -> de ---------------------------
   constexpr int TEAMS = kBlkThreads / LPE, NR = CPL >= 4 ? 2 : STAG_GAT_NR;
   const int team = t / LPE, c = t % LPE;
-  const int lph = F / 4;
+  const int lph = a.lphp;
   int k0[CPL], hl[CPL];
   bool kin[CPL];
 #pragma unroll
   for (int cj = 0; cj < CPL; ++cj) {
-    k0[cj] = (c + LPE * cj) * 4;
-    kin[cj] = k0[cj] < HF;
-    hl[cj] = kin[cj] ? k0[cj] / F : 0;
+    lane_chunk(c + LPE * cj, H, F, a.lphp, k0[cj], kin[cj], hl[cj]);
   }
   const __amdgpu_buffer_rsrc_t rft =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ft), 0, (int)a.ft_bytes, 0x00020000);
@@ -1174,14 +1181,15 @@ constexpr int kRowdotRows = 4;
 // pack[v] = er[H] | m[H] | l[H] | sdot[H]
 template <int LPE>
 __global__ __launch_bounds__(256) void gat_rowdot_kernel(const float* g, const float* out, int n, int H, int F, int HF,
-                                                         const float* er, const float* stats, float* pack) {
+                                                         int lphp, const float* er, const float* stats, float* pack) {
   constexpr int R = kRowdotRows;
   const int c = threadIdx.x % LPE;
   const int row0 = (blockIdx.x * (256 / LPE) + threadIdx.x / LPE) * R;
-  const int lph = F / 4;
-  for (int kt = 0; kt < HF; kt += LPE * 4) {            // every lane makes every trip (the head sums are DPP)
-    const int k0 = kt + c * 4;
-    const bool in = k0 < HF;
+  const int lph = lphp;
+  for (int L0 = 0; L0 < H * lphp; L0 += LPE) {          // every lane makes every trip (the head sums are DPP)
+    int k0, hd;
+    bool in;
+    lane_chunk(L0 + c, H, F, lphp, k0, in, hd);
     float gv[R][4], ov[R][4];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -1289,14 +1297,12 @@ __global__ __launch_bounds__(kBlkThreads) void gat_bwd_one_kernel(const GatBwd1A
   // ---- phase 2: a team per source row: gather G[v]; <G[v,h,:], ft[u,h,:]> -> d s; d ft[u] += a G[v] ----------
   constexpr int TEAMS = kBlkThreads / LPE, NR = CPL >= 4 ? 2 : STAG_GAT_NR;
   const int team = t / LPE, c = t % LPE;
-  const int lph = F / 4;
+  const int lph = a.lphp;
   int k0[CPL], hl[CPL];
   bool kin[CPL];
 #pragma unroll
   for (int cj = 0; cj < CPL; ++cj) {
-    k0[cj] = (c + LPE * cj) * 4;
-    kin[cj] = k0[cj] < HF;
-    hl[cj] = kin[cj] ? k0[cj] / F : 0;
+    lane_chunk(c + LPE * cj, H, F, a.lphp, k0[cj], kin[cj], hl[cj]);
   }
   const __amdgpu_buffer_rsrc_t rg =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ba.g), 0, (int)ba.g_bytes, 0x00020000);
@@ -1443,6 +1449,13 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+// lanes per head of the cooperative kernels: F / 4 rounded up to a power of two (F % 4 == 0)
+static int lanes_per_head(int F) {
+  int l = 1;
+  while (l * 4 < F) l <<= 1;
+  return l;
+}
+
 // attention dropout of a call: 0 = none / set, STAG_EINVAL for a bad probability
 static int fill_drop(GatArgs& a, const stag_gat_drop* drop) {
   a.drop_keep = 0.f; a.drop_scale = 1.f;
@@ -1525,20 +1538,29 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
   bool vec = (F % 4 == 0) && aligned16(ft) && aligned16(out);
   if (a.ws) vec = vec && aligned16(a.ws) && (a.ws_stride % 4 == 0);
 
-  const int nchunk = (HF + 3) / 4;
+  int nchunk = (HF + 3) / 4;
   int lpe = 4;
   while (lpe < nchunk && lpe < 64) lpe <<= 1;
-  const int cpl = nchunk <= 64 ? 1 : (nchunk <= 128 ? 2 : 4);   // chunks of 4 channels per lane
+  int cpl = nchunk <= 64 ? 1 : (nchunk <= 128 ? 2 : 4);   // chunks of 4 channels per lane
   const int tpb = 256 / lpe;
   const dim3 grid((a.n_units + tpb - 1) / tpb);
   const size_t lds_bytes = (size_t)256 * H * sizeof(float);   // [teams][LPE][H]
   hipStream_t s = (hipStream_t)stream;
-  const bool blk_ok = use_plan && plan->block_ptr && plan->n_blocks > 0 && vec && H <= kBlkMaxH && plan->seg_len <= kBlkEdges;
+  // the cooperative kernel gives a head lphp = F / 4 rounded up to a power of two lanes (the backward's head sums are
+  // DPP butterflies, and the forward keeps the backward's mapping): a row takes H * lphp lanes, at most 256
+  const int lphp = (F % 4 == 0) ? lanes_per_head(F) : 0;
+  const bool blk_ok = use_plan && plan->block_ptr && plan->n_blocks > 0 && vec && H <= kBlkMaxH && plan->seg_len <= kBlkEdges &&
+                      lphp > 0 && lphp <= 64 && H * lphp <= 256;
   if (HF > 256 && !blk_ok) return STAG_ENOSYS;
   if (a.drop_keep > 0.f && !blk_ok) return STAG_ENOSYS;      // attention dropout lives in the cooperative kernels
   if (blk_ok) {
     // workgroup-cooperative form: batches of units (stag_plan_blocks with STAG_BLOCK_EDGES / _UNITS)
     a.block_ptr = plan->block_ptr;
+    a.lphp = lphp;
+    nchunk = H * lphp;
+    lpe = 4;
+    while (lpe < nchunk && lpe < 64) lpe <<= 1;
+    cpl = nchunk <= 64 ? 1 : (nchunk <= 128 ? 2 : 4);
     a.hvec = aligned16(el) && aligned16(er) && (!a.nscale || aligned16(a.nscale));
     size_t lds_blk = (size_t)(kBlkEdges * H + 2 * kBlkUnits * H) * sizeof(float) +
                      (size_t)(kBlkEdges + kBlkUnits + 4) * sizeof(int) + (size_t)kBlkUnits * sizeof(int4);
@@ -1705,7 +1727,7 @@ extern "C" int stag_gat_bwd_two_pass(const stag_csr* csr, const stag_plan* plan,
   GatArgs& a = ba.f;
   int rc = fill_edge_args(a, csr, plan, el, er, H, neg_slope, spec, norm_scale, stats);
   if (rc) return rc;
-  a.ft = ft; a.F = F; a.HF = HF;
+  a.ft = ft; a.F = F; a.HF = HF; a.lphp = lph;
   const uint64_t ftb = (uint64_t)csr->n_src * (uint64_t)HF * 4u;
   a.ft_bytes = (ftb < (1ull << 32) && csr->n_src < (1 << 24)) ? (uint32_t)ftb : 0u;
   a.block_ptr = plan->block_ptr;
@@ -1785,8 +1807,10 @@ extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const st
   if (!spec || spec->kind < STAG_NOISE_NONE || spec->kind > STAG_NOISE_BERNOULLI || spec->deriv) return STAG_EINVAL;
   if (!d_el || !d_er || !d_ft || !scratch || H <= 0 || F <= 0) return STAG_EINVAL;
   const int64_t HF64 = (int64_t)H * F;
-  const int lph = F / 4;
-  if (H > kBlkMaxH || HF64 > 1024 || F % 4 != 0 || lph > 64 || (lph & (lph - 1)) != 0) return STAG_ENOSYS;
+  if (H > kBlkMaxH || HF64 > 1024 || F % 4 != 0) return STAG_ENOSYS;
+  const int lphp = lanes_per_head(F);                   // any F % 4 == 0: lanes past a head's channels idle
+  const int lph = lphp;
+  if (lphp > 64 || H * lphp > 256) return STAG_ENOSYS;
   if (spec->chunk_base != 0) return STAG_ENOSYS;
   if (!plan_t || !plan_t->block_ptr || plan_t->n_blocks <= 0 || plan_t->seg_len > kBlkEdges) return STAG_ENOSYS;
   if (spec->in_norm && !norm_scale) return STAG_EINVAL;
@@ -1810,7 +1834,7 @@ extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const st
   float* dsl = scratch;
   float* pack = scratch + (size_t)csr->n_edges * H;        // 16-byte aligned whenever H % 4 == 0 (the vector form)
 
-  const int nchunk = (HF + 3) / 4;
+  const int nchunk = H * lphp;                          // lanes a row takes
   int lpe = 4;
   while (lpe < nchunk && lpe < 64) lpe <<= 1;
   const int cpl = nchunk <= 64 ? 1 : (nchunk <= 128 ? 2 : 4);
@@ -1821,11 +1845,11 @@ extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const st
     const int64_t rpb = (int64_t)(256 / rl) * kRowdotRows;
     const dim3 gr((unsigned)((csr->n_dst + rpb - 1) / rpb));
     switch (rl) {
-      case 64: hipLaunchKernelGGL((gat_rowdot_kernel<64>), gr, dim3(256), 0, s, g, out, csr->n_dst, H, F, HF, er, stats, pack); break;
-      case 32: hipLaunchKernelGGL((gat_rowdot_kernel<32>), gr, dim3(256), 0, s, g, out, csr->n_dst, H, F, HF, er, stats, pack); break;
-      case 16: hipLaunchKernelGGL((gat_rowdot_kernel<16>), gr, dim3(256), 0, s, g, out, csr->n_dst, H, F, HF, er, stats, pack); break;
-      case 8: hipLaunchKernelGGL((gat_rowdot_kernel<8>), gr, dim3(256), 0, s, g, out, csr->n_dst, H, F, HF, er, stats, pack); break;
-      default: hipLaunchKernelGGL((gat_rowdot_kernel<4>), gr, dim3(256), 0, s, g, out, csr->n_dst, H, F, HF, er, stats, pack); break;
+      case 64: hipLaunchKernelGGL((gat_rowdot_kernel<64>), gr, dim3(256), 0, s, g, out, csr->n_dst, H, F, HF, lphp, er, stats, pack); break;
+      case 32: hipLaunchKernelGGL((gat_rowdot_kernel<32>), gr, dim3(256), 0, s, g, out, csr->n_dst, H, F, HF, lphp, er, stats, pack); break;
+      case 16: hipLaunchKernelGGL((gat_rowdot_kernel<16>), gr, dim3(256), 0, s, g, out, csr->n_dst, H, F, HF, lphp, er, stats, pack); break;
+      case 8: hipLaunchKernelGGL((gat_rowdot_kernel<8>), gr, dim3(256), 0, s, g, out, csr->n_dst, H, F, HF, lphp, er, stats, pack); break;
+      default: hipLaunchKernelGGL((gat_rowdot_kernel<4>), gr, dim3(256), 0, s, g, out, csr->n_dst, H, F, HF, lphp, er, stats, pack); break;
     }
   }
 
@@ -1834,7 +1858,7 @@ extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const st
   GatArgs& a = ba.f;
   int rc = fill_edge_args(a, csr_t, plan_t, el, er, H, neg_slope, spec, norm_scale, stats);
   if (rc) return rc;
-  a.ft = ft; a.F = F; a.HF = HF;
+  a.ft = ft; a.F = F; a.HF = HF; a.lphp = lphp;
   a.block_ptr = plan_t->block_ptr;
   if (fill_drop(a, drop)) return STAG_EINVAL;
   a.hvec = aligned16(el) && aligned16(pack) && (!a.nscale || aligned16(a.nscale));

@@ -443,11 +443,11 @@ class _HeadDot(torch.autograd.Function):
 
 def head_dot(ft, attn_l, attn_r):
     """el, er [N, H] = (ft * attn_l).sum(-1), (ft * attn_r).sum(-1) for ft [N, H, F], attn_* [1, H, F] | [H, F].
-    None when the shape has no one-pass form (F not a power of two in [4, 256]): the caller takes the GEMM form."""
+    None when the shape has no one-pass form (F % 4 != 0 or F > 256): the caller takes the GEMM form."""
     if ft.dim() != 3 or not ft.is_cuda or ft.shape[0] == 0:
         return None
     F = ft.shape[2]
-    if F < 4 or F > 256 or (F & (F - 1)) != 0:
+    if F < 4 or F > 256 or F % 4 != 0:
         return None
     return _HeadDot.apply(ft, attn_l, attn_r)
 
@@ -984,12 +984,24 @@ def _gat_drop_struct(attn_drop):
     return d
 
 
+def gat_lanes_per_head(F):
+    """Lanes a head takes in the cooperative GAT kernels: F / 4 rounded up to a power of two (their head sums are
+    butterflies; lanes past a head's channels idle)."""
+    l = 1
+    while l * 4 < F:
+        l *= 2
+    return l
+
+
+def gat_cooperative_shape(H, F, seg_len):
+    """The workgroup-cooperative GAT kernels (forward, one-gather backward, in-kernel dropout) take this shape."""
+    return (F % 4 == 0 and F >= 4 and H <= 16 and H * F <= 1024 and gat_lanes_per_head(F) <= 64
+            and H * gat_lanes_per_head(F) <= 256 and seg_len is not None and 0 < seg_len <= _lib.BLOCK_EDGES)
+
+
 def attn_drop_fusable(H, F, seg_len, want_attn=False):
     """Attention dropout rides in the workgroup-cooperative GAT kernels (forward and one-gather backward)."""
-    lph = F // 4
-    return (not want_attn and _GAT_BWD_FUSED and _GAT_BWD_ONE_GATHER and F % 4 == 0 and 0 < lph <= 64
-            and (lph & (lph - 1)) == 0 and H <= 16 and H * F <= 1024 and seg_len is not None
-            and 0 < seg_len <= _lib.BLOCK_EDGES)
+    return not want_attn and _GAT_BWD_FUSED and _GAT_BWD_ONE_GATHER and gat_cooperative_shape(H, F, seg_len)
 
 
 class _GatAggregate(torch.autograd.Function):
@@ -1109,8 +1121,9 @@ def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec,
     covers (the caller then composes the older kernels)."""
     lph = F // 4
     E = csrv.n_edges
-    if not (_GAT_BWD_FUSED and F % 4 == 0 and lph <= 64 and lph & (lph - 1) == 0 and H <= 16 and H * F <= 1024 and E > 0
-            and seg_len is not None and 0 < seg_len <= _lib.BLOCK_EDGES):
+    one = _GAT_BWD_ONE_GATHER or attn_drop is not None
+    if not (_GAT_BWD_FUSED and E > 0 and gat_cooperative_shape(H, F, seg_len)
+            and (one or (lph & (lph - 1)) == 0)):      # the two-pass form wants F / 4 a power of two
         return None
     plan_f, plan_b = csrv.plan(seg_len, need=True), csrt.plan(seg_len, need=True)
     nbytes = _lib.lib().stag_gat_bwd_workspace_bytes(plan_f["n_seg"], plan_b["n_seg"], H, F)
@@ -1162,10 +1175,11 @@ def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False
     lph = F // 4
     # the fused kernels: H*F <= 256 always; up to 1024 channels on the workgroup-cooperative forms (F % 4 == 0,
     # H <= 16, the default plan); the backward wants F/4 a power of two (<= 64)
-    wide_ok = F % 4 == 0 and H <= 16 and seg_len is not None and 0 < seg_len <= _lib.BLOCK_EDGES
+    wide_ok = gat_cooperative_shape(H, F, seg_len)
+    bwd_ok = wide_ok and _GAT_BWD_FUSED and (_GAT_BWD_ONE_GATHER or (lph & (lph - 1)) == 0)
+    old_bwd_ok = F % 4 == 0 and lph <= 64 and (lph & (lph - 1)) == 0 and H * F <= 256     # stag_gat_bwd_edge + aggregations
     if (attn_fn is not None or H > 64 or H * F > (1024 if wide_ok else 256)
-            or (F % 4 != 0 or lph > 64 or (lph & (lph - 1)) != 0) and torch.is_grad_enabled()
-            or (H * F > 256 and torch.is_grad_enabled() and not _GAT_BWD_FUSED)):
+            or torch.is_grad_enabled() and not (bwd_ok or old_bwd_ok)):
         if getattr(graph, "is_shard", False):
             raise NotImplementedError("the composed GAT path (attention dropout, H > 64 or H*F > 256) is not partitioned")
         if attn_drop is not None:

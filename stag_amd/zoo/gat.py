@@ -45,25 +45,23 @@ class GAT(torch.nn.Module):
 
     @staticmethod
     def _padded_width(H, F):
-        """F if the cooperative kernels take it (F % 4 == 0, F / 4 a power of two) or no padded width fits them
-        (H <= 16, H * Fp <= 1024, Fp <= 256); else the next 4 * 2^k."""
-        lph = F // 4
-        if F % 4 == 0 and lph > 0 and (lph & (lph - 1)) == 0:
+        """F if the cooperative kernels take it (F % 4 == 0: a head gets F / 4 rounded up to a power of two lanes,
+        the extra lanes idle) or no padded width fits them; else the next multiple of 4."""
+        if F % 4 == 0:
             return F
-        Fp = 4
-        while Fp < F:
-            Fp *= 2
-        return Fp if (H <= 16 and Fp <= 256 and H * Fp <= 1024) else F
+        Fp = (F + 3) // 4 * 4
+        return Fp if ops.gat_cooperative_shape(H, Fp, ops.DEFAULT_SEG_LEN) else F
 
     def forward(self, graph, feat, get_attention=False, edge_weight=None):
         H, F = self._num_heads, self._out_feats
         h = self.feat_drop(feat)
-        # Head widths the cooperative kernels do not take as they are — F % 4 != 0 or F / 4 not a power of two:
-        # class counts like 7, 40, 121 on the last layer of the reference's GAT scripts
-        # (scripts/arxiv_mle/gat/run.py:50-58) — run with each head zero-padded to Fp = 4 * 2^k: the padding is rows
-        # of zeros in the fc weight and zeros in attn_l / attn_r (parameter-sized ops), so the extra channels of
-        # ft are exactly 0, add nothing to the logits, come out as 0 and are cut off again; the layer keeps the
-        # fused forward, the one-gather backward and in-kernel attention dropout instead of the composed path.
+        # Head widths that are not a multiple of 4 — class counts like 7, 121 on the last layer of the reference's
+        # GAT scripts — run with each head zero-padded to the next multiple of 4: the padding is rows of zeros in
+        # the fc weight and zeros in attn_l / attn_r (parameter-sized ops), so the extra channels of ft are exactly
+        # 0, add nothing to the logits, come out as 0 and are cut off again; the layer keeps the fused forward, the
+        # one-gather backward and in-kernel attention dropout instead of the composed path.  (F % 4 == 0 with F / 4
+        # not a power of two — 40 classes on arxiv, scripts/arxiv_mle/gat/run.py:50-58 — needs no padding: the
+        # kernels give such a head the next power of two lanes and leave the extra ones idle.)
         Fp = self._padded_width(H, F) if feat.is_cuda else F
         if Fp != F:
             pad = torch.nn.functional.pad

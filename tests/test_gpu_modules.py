@@ -1120,7 +1120,7 @@ def test_narrow_amortized_distribution_equals_dense_dataflow(dev, hidden):
 
 
 @pytest.mark.parametrize("n,H,F", [(1, 1, 4), (1000, 8, 32), (777, 3, 32), (500, 4, 64), (300, 2, 256), (2000, 16, 8),
-                                   (900, 1, 128)])
+                                   (900, 1, 128), (1200, 8, 40), (640, 5, 12), (333, 3, 124), (50, 1, 252)])
 def test_head_dot(dev, n, H, F):
     """stag_head_dot_fwd / _bwd: GAT's el / er = (ft * attn).sum(-1) (stag/zoo/gat.py:109-110) and the gradients
     to ft, attn_l, attn_r against float64 torch."""
@@ -1141,7 +1141,7 @@ def test_head_dot(dev, n, H, F):
     for got, r, nm in ((al.grad, ald.grad, "d attn_l"), (ar.grad, ard.grad, "d attn_r")):
         sc = max(1.0, float(r.abs().max()))
         assert_close(got / sc, (r / sc).cpu().numpy(), what=nm)
-    assert ops.head_dot(torch.zeros(4, 2, 12, device=dev), al, ar) is None      # F = 12: the GEMM form
+    assert ops.head_dot(torch.zeros(4, 2, 10, device=dev), al, ar) is None      # F % 4 != 0: the GEMM form
 
 
 @pytest.mark.parametrize("n,E", [(5, 0), (1, 0), (3, 1)])
@@ -1218,11 +1218,11 @@ def test_new_backward_paths_are_bit_reproducible(dev):
 
 @pytest.mark.parametrize("H,F,last", [(3, 7, False), (8, 40, True), (2, 121, False), (4, 6, True), (1, 3, False)])
 def test_gat_odd_head_widths_stay_fused(dev, H, F, last):
-    """Head widths the cooperative kernels do not take as they are (F % 4 != 0, F / 4 not a power of two — the class
-    counts on the last layer of the reference's GAT scripts, scripts/arxiv_mle/gat/run.py:50-58) run zero-padded to
-    4 * 2^k per head inside zoo.GAT: output, d/dx and every parameter gradient equal the layer's own statement
-    on the composed path (torch ops over [E, H] + the aggregation kernel, unpadded), and the layer's autograd graph
-    holds the fused node."""
+    """Head widths off the kernels' natural grid — the class counts on the last layer of the reference's GAT scripts,
+    scripts/arxiv_mle/gat/run.py:50-58 — stay fused: F % 4 == 0 with F / 4 not a power of two (40) runs as it is, a
+    head taking the next power of two lanes; F % 4 != 0 (7, 121, 6, 3) runs zero-padded to the next multiple of 4
+    inside zoo.GAT.  Output, d/dx and every parameter gradient equal the layer's own statement on the composed
+    path (torch ops over [E, H] + the aggregation kernel, unpadded), and the autograd graph holds the fused node."""
     import stag_amd
     from stag_amd import _lib, ops
     from util import random_graph

@@ -738,7 +738,8 @@ def test_agg_bwd_dp_one_pass(dev, oracle, kind, relu, D):
         assert_close(got / sc, (ref / sc).cpu().numpy(), what="x = None")
 
 
-@pytest.mark.parametrize("H,F,kind", [(8, 32, "normal"), (4, 16, "explicit"), (2, 256, "none"), (3, 8, "bernoulli"), (16, 64, "uniform")])
+@pytest.mark.parametrize("H,F,kind", [(8, 32, "normal"), (4, 16, "explicit"), (2, 256, "none"), (3, 8, "bernoulli"), (16, 64, "uniform"),
+                                      (8, 40, "normal"), (5, 12, "explicit")])
 def test_gat_attention_dropout_in_the_kernels(dev, oracle, H, F, kind):
     """Attention dropout (stag/zoo/gat.py:122; 0.6 in the reference's GAT scripts) inside the fused GAT kernels: the
     keep mask is a Bernoulli(keep_prob) stream of its own at (forward position, head) — the same words
@@ -794,7 +795,7 @@ def test_gat_attention_dropout_in_the_kernels(dev, oracle, H, F, kind):
                               attn_drop=(p_drop, dseed, doff + 1))
     assert torch.equal(again, out.detach()) and not torch.equal(other, out.detach())
     # shapes without the cooperative form say so
-    assert not ops.attn_drop_fusable(8, 12, 64) and ops.attn_drop_fusable(H, F, 64)
+    assert not ops.attn_drop_fusable(8, 10, 64) and ops.attn_drop_fusable(H, F, 64)
 
 
 def test_gat_layer_trains_with_attention_dropout_on_the_fused_path(dev):
