@@ -21,6 +21,8 @@ from stag_amd import synthetic  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--static", action="store_true")
+ap.add_argument("--model", default="sage", choices=["sage", "gat"],
+                help="gat: scripts/ppi_mle/gat/run.py:21-58 — GAT(50, 256, 4 heads) -> GAT(1024, 256, 4) -> GAT(1024, 121, 4, last)")
 args = ap.parse_args()
 torch.distributions.Distribution.set_default_validate_args(False)
 dev = torch.device("cuda:0")
@@ -38,10 +40,17 @@ x = torch.randn(n, 50, device=dev)
 y = (torch.rand(n, 121, device=dev) < 0.3).float()
 N = torch.distributions.Normal
 SL, FO, Z = stag_amd.layers.StagLayer, stag_amd.layers.FeatOnlyLayer, stag_amd.zoo
-layers = torch.nn.ModuleList([
-    SL(Z.GraphSAGE(50, 256, aggregator_type="mean", activation=torch.relu), q_a=N(1.0, 0.3)),
-    SL(Z.GraphSAGE(256, 256, aggregator_type="mean", activation=torch.relu), q_a=N(1.0, 0.3)),
-    SL(Z.GraphSAGE(256, 121, aggregator_type="mean"), q_a=N(1.0, 0.3))]).to(dev)
+if args.model == "gat":
+    elu = torch.nn.functional.elu
+    layers = torch.nn.ModuleList([
+        SL(Z.GAT(50, 256, num_heads=4, activation=elu), q_a=N(1.0, 0.3)),
+        SL(Z.GAT(1024, 256, num_heads=4, activation=elu), q_a=N(1.0, 0.3)),
+        SL(Z.GAT(1024, 121, num_heads=4, last=True), q_a=N(1.0, 0.3))]).to(dev)
+else:
+    layers = torch.nn.ModuleList([
+        SL(Z.GraphSAGE(50, 256, aggregator_type="mean", activation=torch.relu), q_a=N(1.0, 0.3)),
+        SL(Z.GraphSAGE(256, 256, aggregator_type="mean", activation=torch.relu), q_a=N(1.0, 0.3)),
+        SL(Z.GraphSAGE(256, 121, aggregator_type="mean"), q_a=N(1.0, 0.3))]).to(dev)
 opt = torch.optim.Adam(layers.parameters(), 1e-3)
 static_graph = stag_amd.batch(parts)
 
