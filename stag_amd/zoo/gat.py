@@ -108,7 +108,9 @@ class GAT(torch.nn.Module):
         if self.res_fc is not None:
             rst = rst + self.res_fc(h).view(h.shape[0], -1, F)
         if self.bias is not None:
-            rst = rst + self.bias.view(1, H, F)
+            # (the bias gradient of an odd total width goes through ops.column_sum: torch's own column reduction
+            # takes a slow path when the width is not a multiple of 4)
+            rst = ops.add_bias(rst.reshape(rst.shape[0], H * F), self.bias).view(-1, H, F)
         rst = rst.mean(-2) if self.last else rst.flatten(-2, -1)
         if self.activation:
             rst = self.activation(rst)

@@ -56,7 +56,7 @@ class GraphSAGE(torch.nn.Module):
             raise NotImplementedError("'lstm' aggregator is outside the accelerated path")
         rst = h_neigh if self._aggre_type == "gcn" else ops.node_linear(h_self, self.fc_self.weight.t()) + h_neigh
         if self.bias is not None:
-            rst = rst + self.bias
+            rst = ops.add_bias(rst, self.bias)
         if self.activation is not None:
             rst = self.activation(rst)
         if self.norm is not None:
