@@ -1059,6 +1059,8 @@ class _GatAggregate(torch.autograd.Function):
             spec = _targs_or_c(_explicit_spec(w))
         else:
             spec = _targs_or_c(_none_spec())
+        if attn_drop is not None and noise is None:
+            spec.pos_base = int(getattr(graph, "pos_base", 0))    # a shard's dropout mask is the whole graph's
         nscale = _gat_norm_scale(csrv, noise, H, seg_len, dev) if spec.in_norm else None
         need_grad = any(ctx.needs_input_grad[:4])
         out = torch.empty((csrv.n_dst, H, F), dtype=torch.float32, device=dev)
@@ -1111,6 +1113,8 @@ class _GatAggregate(torch.autograd.Function):
         else:
             spec = _targs_or_c(_none_spec())
         want_dw = w is not None and ctx.needs_input_grad[3]
+        if ctx.attn_drop is not None and noise is None:
+            spec.pos_base = int(getattr(graph, "pos_base", 0))
         if csrv.n_edges == 0:        # no edge, no gradient
             return (torch.zeros_like(el) if ctx.needs_input_grad[0] else None,
                     torch.zeros_like(er) if ctx.needs_input_grad[1] else None,
@@ -1202,7 +1206,10 @@ def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False
     a[E, H] between the softmax and the sum, on the composed path.
     On a node-range shard the inputs are this rank's rows and the call includes the exchange."""
     if getattr(graph, "is_shard", False) and not _gathered:
-        return graph.gat_aggregate(el, er, ft, neg_slope, weight, seg_len=seg_len, want_attn=want_attn)
+        if attn_fn is not None:
+            raise NotImplementedError("a function of a[E, H] (attn_fn) is not partitioned: pass attn_drop")
+        return graph.gat_aggregate(el, er, ft, neg_slope, weight, seg_len=seg_len, want_attn=want_attn,
+                                   attn_drop=attn_drop)
     noise = weight if isinstance(weight, EdgeNoise) else None
     w = weight if torch.is_tensor(weight) else None
     if w is not None and w.shape[0] != graph.number_of_edges():

@@ -522,7 +522,7 @@ class GraphShard:
         return out
 
     def gat_aggregate(self, el_local, er_local, ft_local, neg_slope=0.2, weight=None, seg_len=None,
-                      want_attn=False):
+                      want_attn=False, attn_drop=None):
         """Partitioned GAT layer-forward (BASELINE cfg5): ONE exchange carries [ft | el] of the
         referenced source rows (H*F + H columns), then the single-GPU fused kernel runs on this
         rank's rows.  `weight`: None or an EdgeNoise(dn=H) built on this shard."""
@@ -535,8 +535,10 @@ class GraphShard:
         el_full = full[:, H * F:]
         if isinstance(weight, EdgeNoise):
             weight.pos_base = self.pos_base
+        # attn_drop: the mask is keyed by GLOBAL forward position (pos_base), so shards draw the whole graph's mask
         return ops.gat_aggregate(self, el_full, er_local, ft_full, neg_slope, weight, want_attn=want_attn,
-                                 seg_len=DEFAULT_SEG_LEN if seg_len is None else seg_len, _gathered=True)
+                                 seg_len=DEFAULT_SEG_LEN if seg_len is None else seg_len, _gathered=True,
+                                 attn_drop=attn_drop)
 
 
 # ------------------------------------------------------------------------------------- #

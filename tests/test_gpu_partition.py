@@ -77,7 +77,7 @@ def _worker(rank, world, port, tmp):
         assert p_loc["n_units"] > 0 and p_rem["n_units"] > 0
         res["agg"] = a.cpu()
         # ---- whole layers on the shard: forward + backward ---------------------------------------------
-        for name in ("gcn", "sage", "gin", "gat", "gcn_vi"):
+        for name in ("gcn", "sage", "gin", "gat", "gat_drop", "gcn_vi"):
             torch.manual_seed(7)
             if name in ("gcn", "gcn_vi"):
                 base = stag_amd.zoo.GCN(D, 32)
@@ -85,8 +85,8 @@ def _worker(rank, world, port, tmp):
                 base = stag_amd.zoo.GraphSAGE(D, 32, aggregator_type="mean")
             elif name == "gin":
                 base = stag_amd.zoo.GIN(D, 32)
-            else:
-                base = stag_amd.zoo.GAT(D, 8, num_heads=4)
+            else:   # gat_drop: attention dropout inside the kernels, its mask keyed by the GLOBAL forward position
+                base = stag_amd.zoo.GAT(D, 8, num_heads=4, attn_drop=0.5 if name == "gat_drop" else 0.0)
             layer = stag_amd.layers.StagLayer(base, q_a=torch.distributions.Normal(1.0, 0.5), relu=(name == "gcn_vi"),
                                               vi=(name == "gcn_vi")).to(dev)
             stag_amd.manual_seed(99)
@@ -126,7 +126,7 @@ def test_layers_on_two_shards_match_the_whole_graph(dev, tmp_path):
     g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
     whole = ops.aggregate(g, x.to(dev), stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, 1.0, 0.5, seed=4, offset=2))
     assert torch.equal(torch.cat([p["agg"] for p in parts], 0), whole.cpu()), "partitioned aggregation: bit-identical"
-    for name in ("gcn", "sage", "gin", "gat", "gcn_vi"):
+    for name in ("gcn", "sage", "gin", "gat", "gat_drop", "gcn_vi"):
         torch.manual_seed(7)
         if name in ("gcn", "gcn_vi"):
             base = stag_amd.zoo.GCN(D, 32)
@@ -135,7 +135,7 @@ def test_layers_on_two_shards_match_the_whole_graph(dev, tmp_path):
         elif name == "gin":
             base = stag_amd.zoo.GIN(D, 32)
         else:
-            base = stag_amd.zoo.GAT(D, 8, num_heads=4)
+            base = stag_amd.zoo.GAT(D, 8, num_heads=4, attn_drop=0.5 if name == "gat_drop" else 0.0)
         layer = stag_amd.layers.StagLayer(base, q_a=torch.distributions.Normal(1.0, 0.5), relu=(name == "gcn_vi"),
                                           vi=(name == "gcn_vi")).to(dev)
         stag_amd.manual_seed(99)
