@@ -165,6 +165,11 @@ class AmortizedDistribution(Distribution):
         act((feat W_src^T)[src] + (feat W_dst^T)[dst] + b): the Linear runs over the N node rows
         and the E-row work is two gathers — no [E, 2 in] concatenation, no E-row GEMM — and the
         gathers' backward is the aggregation kernel, not a scatter-add."""
+        if getattr(graph, "is_shard", False):
+            # the per-edge MLP reads feat[src] of REMOTE source rows: it needs its own halo exchange of the projected
+            # features, which is not built; fail here rather than index this rank's rows with buffer positions
+            raise NotImplementedError("AmortizedDistribution is not partitioned (node-range shards): condition() "
+                                      "needs the source rows of other ranks")
         lin = self.embedding_mlp[0]
         if feat.is_cuda and feat.dim() == 2 and isinstance(lin, torch.nn.Linear) and self._narrow(graph, lin):
             # narrow heads — AmortizedDistribution(in, 1), hidden_features = 1 by default: what every
