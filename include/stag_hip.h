@@ -373,7 +373,8 @@ size_t stag_amort_workspace_bytes(int32_t n_values);
  *     y[c][n][g] = sum_f x[n, g F + f] * w[c][g F + f]
  * GAT's el / er = (ft * attn_l).sum(-1), (ft * attn_r).sum(-1) (stag/zoo/gat.py:109-110) from ONE pass over ft; the
  * backward (dx [n_rows, G F] = sum_c gy[c][n][g] w[c][k]; dw [C][G F] = sum_n gy[c][n][g] x[n, k]) from one pass too.
- * F a power of two in [4, 256]; rows 16-byte aligned; workspace >= stag_amort_workspace_bytes(C * G * F).       */
+ * F % 4 == 0, 4 <= F <= 256 (a head takes F / 4 rounded up to a power of two lanes: the rest idle); rows 16-byte
+ * aligned; workspace >= stag_amort_workspace_bytes(C * G * F).                                                  */
 int stag_head_dot_fwd(const float* x, int64_t ldx, int64_t n_rows, int32_t G, int32_t F, const float* w, int32_t C,
                       float* y, void* stream);
 int stag_head_dot_bwd(const float* x, int64_t ldx, int64_t n_rows, int32_t G, int32_t F, const float* w, int32_t C,
@@ -468,8 +469,10 @@ int stag_halo_allgather(void* comm, const float* x_local, int64_t n_floats, floa
 int stag_halo_exchange(void* comm, const float* send, const int64_t* send_counts_host, float* recv,
                        const int64_t* recv_counts_host, void* stream);
 
-/* The whole backward of stag_gat_fwd in one call, for shapes with F % 4 == 0, F/4 a power of two,
- * H <= 16, H*F <= 1024 and a block plan (stag_plan.block_ptr) on the source-major orientation.
+/* The whole backward of stag_gat_fwd in one call, for shapes with F % 4 == 0, H <= 16, H*F <= 1024,
+ * H * lanes_per_head <= 256 (lanes_per_head = F / 4 rounded up to a power of two <= 64: the lanes past a head's
+ * channels idle; stag_gat_bwd_two_pass wants F / 4 itself a power of two) and a block plan (stag_plan.block_ptr)
+ * on the source-major orientation.
  *
  * stag_gat_bwd — ONE gather of the [H*F] rows (the forward has one, autograd through DGL's ops has four):
  *   1. sdot[v,h] = <g[v,h,:], out[v,h,:]>, the softmax's correction term, from one streaming pass;
