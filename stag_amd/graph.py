@@ -78,6 +78,13 @@ class CsrView:
         more than PLAN_AFTER_LAUNCHES times gets its plan after all."""
         if seg_len is None or seg_len <= 0:
             return None
+        if seg_len not in self._plans and self.indptr.is_cuda and torch.cuda.is_current_stream_capturing():
+            # building a plan reads counts back from the device: not inside a hipGraph capture.  A view that was
+            # launched before the capture has its plan already (or runs plan-less, which gives the same bits)
+            if need:
+                raise RuntimeError("the launch plan of this graph must exist before a hipGraph capture: run one "
+                                   "eager step first")
+            return None
         if seg_len not in self._plans and not need and self._short_rows():
             # ... but a view that keeps being launched (a static graph) earns its plan: unit records instead of
             # two dependent indptr loads per row are worth 7 us of a 40 us launch on the molecule batch
