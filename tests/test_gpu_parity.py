@@ -864,3 +864,66 @@ def test_device_planner_equals_host_planner(dev, seg_len):
             assert torch.equal(dplan["long_rows"][:nl].cpu(), hplan["long_rows"][:nl].cpu())
             assert torch.equal(dplan["long_seg_ptr"][:nl + 1].cpu(), hplan["long_seg_ptr"][:nl + 1].cpu())
             assert torch.equal(dplan["block_ptr"].cpu(), hplan["block_ptr"].cpu())
+
+
+def test_fuzz_backward_passes_against_oracle(dev, oracle):
+    """Seeded sweep over graphs x widths x plans x kinds for the three backward entry points on the source-major
+    CSR: stag_agg_bwd (dx + derivative aggregates), stag_agg_bwd_dp (dx + finished scalar / per-channel gradients),
+    stag_agg_bwd_edge (dx + [E,1] gradients) — each against the oracle's aggregation with spec.deriv = 0, 1, 2 on
+    the transposed graph (and, for the per-edge sums, its dw/dp rows summed over the channels)."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    rng = np.random.default_rng(20261005)
+    widths = [1, 3, 4, 8, 20, 32, 50, 64, 100, 128, 200, 256, 300, 515]
+    for it in range(30):
+        n = int(rng.integers(1, 400))
+        e = int(rng.integers(0, 5000))
+        hub = int(rng.choice([0, 0, 80, 600])) if n > 4 else 0
+        D = int(widths[it % len(widths)])
+        kind = ["normal", "uniform"][it % 2]
+        relu = bool(rng.random() < 0.4)
+        seg_len = int(rng.choice([64, 64, 16, 256, 0]))
+        g = random_graph(n, e, seed=7000 + it, hub=hub, device=dev)
+        E = g.number_of_edges()
+        ogt, og = oracle_graph(oracle, g, transposed=True), oracle_graph(oracle, g)
+        x = rng.standard_normal((n, D)).astype(np.float32)
+        gout = rng.standard_normal((n, D)).astype(np.float32)
+        gs = rng.uniform(0.5, 1.5, n).astype(np.float32)
+        rs = rng.uniform(0.5, 1.5, n).astype(np.float32)
+        xd, gd, gsd, rsd = (torch.from_numpy(a).to(dev) for a in (x, gout, gs, rs))
+        what = f"bwd fuzz {it}: n={n} E={E} D={D} {kind} relu={relu} seg={seg_len}"
+        seed, off = int(rng.integers(0, 2**40)), int(rng.integers(0, 99))
+        # ---- per-channel parameters: stag_agg_bwd and stag_agg_bwd_dp ------------------------------------
+        p0 = rng.uniform(0.2, 1.0, D).astype(np.float32)
+        p1 = (p0 + rng.uniform(0.6, 1.2, D)).astype(np.float32) if kind == "uniform" else rng.uniform(0.3, 0.9, D).astype(np.float32)
+        noise = _noise(g, D, kind, torch.from_numpy(p0).to(dev), torch.from_numpy(p1).to(dev), relu=relu, seed=seed, offset=off)
+        T = [oracle.agg_fwd(ogt, gout, _ospec(oracle, g, D, kind, p0, p1, relu=relu, seed=seed, offset=off, deriv=dv),
+                            src_scale=gs, dst_scale=rs) for dv in (0, 1, 2)]
+        dx, t0, t1 = ops._agg_bwd_raw(g.csr_t, gd, D, noise.spec(), gsd, rsd, seg_len, True)
+        for got, ref, nm in ((dx, T[0], "dx"), (t0, T[1], "T0"), (t1, T[2], "T1")):
+            assert_close(got, ref, tol=TOL if 0 < seg_len <= 64 else 2 * TOL, what=f"{what} stag_agg_bwd {nm}")
+        spec = noise.spec()
+        spec = spec if not isinstance(spec, tuple) else ops._targs_to_ctypes(spec)
+        dx2, c0, c1 = ops._agg_bwd_dp_raw(g.csr_t, gd, xd, D, spec, gsd, rsd, seg_len)
+        assert_close(dx2, T[0], tol=TOL if 0 < seg_len <= 64 else 2 * TOL, what=f"{what} stag_agg_bwd_dp dx")
+        for got, Ti, nm in ((c0, T[1], "d p0"), (c1, T[2], "d p1")):
+            ref = (x.astype(np.float64) * Ti.astype(np.float64)).sum(0)
+            sc = max(1.0, float(np.abs(ref).max()))
+            assert_close(got / sc, ref / sc, what=f"{what} stag_agg_bwd_dp {nm}")
+        # ---- [E, 1] parameters: stag_agg_bwd_edge (one channel tile) --------------------------------------
+        if D <= 256 and E > 0:
+            q0 = rng.uniform(0.2, 1.0, (E, 1)).astype(np.float32)
+            q1 = (q0 + rng.uniform(0.6, 1.2, (E, 1))).astype(np.float32) if kind == "uniform" else rng.uniform(0.3, 0.9, (E, 1)).astype(np.float32)
+            K = _lib.NOISE_NORMAL if kind == "normal" else _lib.NOISE_UNIFORM
+            nz = stag_amd.EdgeNoise(g, D, K, torch.from_numpy(q0).to(dev), torch.from_numpy(q1).to(dev), relu=relu, seed=seed, offset=off)
+            sp = nz.spec()
+            sp = sp if not isinstance(sp, tuple) else ops._targs_to_ctypes(sp)
+            dx3, e0, e1 = ops._agg_bwd_edge_raw(g.csr_t, gd, xd, D, sp, gsd, rsd, seg_len if seg_len else 64)
+            ref_dx = oracle.agg_fwd(ogt, gout, oracle.make_spec(kind, q0, q1, relu=relu, seed=seed, offset=off, Dn=D, n_edges=E),
+                                    src_scale=gs, dst_scale=rs)
+            assert_close(dx3, ref_dx, what=f"{what} stag_agg_bwd_edge dx")
+            for dv, got in ((1, e0), (2, e1)):
+                osp = oracle.make_spec(kind, q0, q1, relu=relu, seed=seed, offset=off, Dn=D, n_edges=E, deriv=dv)
+                ref = oracle.agg_bwd_w(og, x, gout * gs[:, None], src_scale=rs, spec=osp).astype(np.float64).sum(1, keepdims=True)
+                sc = max(1.0, float(np.abs(ref).max()))
+                assert_close(got / sc, ref / sc, what=f"{what} stag_agg_bwd_edge d p{dv - 1}")
