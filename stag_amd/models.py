@@ -24,6 +24,20 @@ def nll_contrastive(q_a, graph, feat):
     return nll.sum(dim=-1).mean()
 
 
+def _masked_mean(nll, mask):
+    """nll[mask].mean() (stag/models.py:73-76).  A boolean mask over the nodes is applied as a weight: the same
+    value and gradient, without the boolean index (a nonzero + a size read-back: a host synchronisation per
+    Monte-Carlo sample, and not capturable in a hipGraph)."""
+    if mask is None:
+        return nll.mean()
+    if mask.dtype == torch.bool and mask.dim() == 1 and mask.shape[0] == nll.shape[0] and nll.is_cuda:
+        per_row = nll.numel() // max(nll.shape[0], 1)
+        m = mask.view(-1, *([1] * (nll.dim() - 1)))
+        # (where, not a product: an infinite log-probability outside the mask must not turn the sum into NaN)
+        return torch.where(m, nll, torch.zeros((), dtype=nll.dtype, device=nll.device)).sum() / (mask.sum() * per_row)
+    return nll[mask].mean()
+
+
 class StagModel(torch.nn.Module):
     def __init__(self, layers: List[torch.nn.Module], likelihood: Likelihood = None,
                  kl_scaling=1.0):
@@ -94,9 +108,7 @@ class StagModel(torch.nn.Module):
         for _ in range(n_samples):
             out = self._forward(graph, feat)
             nll = -self.likelihood.log_prob(out, y)
-            if mask is not None:
-                nll = nll[mask]
-            total_nll = total_nll + nll.mean()
+            total_nll = total_nll + _masked_mean(nll, mask)
             total_reg = total_reg + self._regulariser()
         return total_nll / n_samples, total_reg / n_samples * kl_scaling
 
@@ -128,8 +140,6 @@ class StagModelContrastive(StagModel):
         for _ in range(n_samples):
             out, contrastive = self._forward(graph, feat)
             nll = -self.likelihood.log_prob(out, y)
-            if mask is not None:
-                nll = nll[mask]
-            total_nll = total_nll + nll.mean()
+            total_nll = total_nll + _masked_mean(nll, mask)
             total_reg = total_reg + contrastive + self._regulariser()
         return total_nll / n_samples, total_reg / n_samples * kl_scaling

@@ -1305,3 +1305,25 @@ def test_column_sum_and_bias_gradient(dev, n, D):
     y.backward(g)
     assert torch.equal(y.detach(), x.detach() + b.detach()) and torch.equal(x.grad, g)
     assert_close(b.grad / sc, (ref / sc).cpu().numpy(), what="d bias")
+
+
+def test_masked_loss_equals_boolean_indexing(dev):
+    """StagModel.loss with a boolean train mask (stag/models.py:73-76: `nll[mask].mean()`) applies the mask as a
+    where(): the same value and gradients as the boolean index, no nonzero / size read-back on the step —
+    Categorical ([N] log-probabilities) and Bernoulli ([N, C]) likelihoods, an infinite value outside the mask."""
+    from stag_amd.models import _masked_mean
+    torch.manual_seed(0)
+    for shape in ((500,), (500, 7)):
+        nll = torch.randn(*shape, device=dev, requires_grad=True)
+        mask = torch.rand(500, device=dev) < 0.4
+        got = _masked_mean(nll, mask)
+        ref_in = nll.detach().clone().requires_grad_(True)
+        ref = ref_in[mask].mean()
+        got.backward(); ref.backward()
+        assert torch.allclose(got, ref, rtol=1e-6, atol=1e-7) and torch.allclose(nll.grad, ref_in.grad, rtol=1e-6, atol=1e-8)
+        poisoned = nll.detach().clone()
+        poisoned[~mask] = float("inf")
+        assert torch.isfinite(_masked_mean(poisoned, mask))
+    idx = torch.tensor([1, 5, 9], device=dev)
+    v = torch.randn(20, device=dev)
+    assert torch.equal(_masked_mean(v, idx), v[idx].mean()) and torch.equal(_masked_mean(v, None), v.mean())
