@@ -5,6 +5,12 @@ import abc
 import torch
 
 
+def _validate(feat):
+    """torch's argument validation reads a reduction of the probabilities back to the host — a synchronisation per
+    Monte-Carlo sample and not capturable in a hipGraph: off for device tensors (None = torch's default elsewhere)."""
+    return False if feat.is_cuda else None
+
+
 class Likelihood(torch.nn.Module, abc.ABC):
     def __init__(self, distribution):
         super().__init__()
@@ -23,7 +29,7 @@ class CategoricalLikelihood(Likelihood):
         super().__init__(torch.distributions.Categorical)
 
     def condition(self, feat):
-        return self.distribution(probs=feat)
+        return self.distribution(probs=feat, validate_args=_validate(feat))
 
 
 class BernoulliLikelihood(Likelihood):
@@ -31,4 +37,4 @@ class BernoulliLikelihood(Likelihood):
         super().__init__(torch.distributions.Bernoulli)
 
     def condition(self, feat):
-        return self.distribution(probs=feat)
+        return self.distribution(probs=feat, validate_args=_validate(feat))

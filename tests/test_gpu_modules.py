@@ -1327,3 +1327,51 @@ def test_masked_loss_equals_boolean_indexing(dev):
     idx = torch.tensor([1, 5, 9], device=dev)
     v = torch.randn(20, device=dev)
     assert torch.equal(_masked_mean(v, idx), v[idx].mean()) and torch.equal(_masked_mean(v, None), v.mean())
+
+
+def test_steady_state_training_steps_do_not_synchronise_the_host(dev):
+    """After the first steps (plans, cached degree vectors), a masked training step of every model family — fixed
+    Bernoulli + in-norm GCN, vi GCN with the KL term, amortised GCN, GAT with feature and attention dropout,
+    GraphSAGE — issues no synchronising torch call (torch's sync debug mode raises on .item(), nonzero, boolean
+    indexing, device->host copies): the stream never waits for the host, and the step is capturable."""
+    import stag_amd
+    from util import random_graph
+    n = 600
+    g = random_graph(n, 9000, seed=5, hub=900, device=dev)
+    x = torch.randn(n, 32, device=dev)
+    y = torch.randint(0, 5, (n,), device=dev)
+    mask = torch.rand(n, device=dev) < 0.5
+    N = torch.distributions.Normal
+    SL, Z = stag_amd.layers.StagLayer, stag_amd.zoo
+    sm = lambda t: torch.softmax(t, -1)
+    families = {
+        "gcn bernoulli norm": [SL(Z.GCN(32, 16), q_a=torch.distributions.Bernoulli(0.9), norm=True),
+                               SL(Z.GCN(16, 5, activation=sm), q_a=torch.distributions.Bernoulli(0.9), norm=True)],
+        "gcn vi": [SL(Z.GCN(32, 16), q_a=N(1.0, 0.3), vi=True, relu=True), SL(Z.GCN(16, 5, activation=sm), q_a=N(1.0, 0.3), vi=True)],
+        "gcn amortised": [SL(Z.GCN(32, 16), q_a=stag_amd.distributions.AmortizedDistribution(32, 1, init_like=N(1.0, 0.3)), vi=True),
+                          SL(Z.GCN(16, 5, activation=sm), q_a=stag_amd.distributions.AmortizedDistribution(16, 1, init_like=N(1.0, 0.3)), vi=True)],
+        "gat dropout": [SL(Z.GAT(32, 8, num_heads=4, feat_drop=0.5, attn_drop=0.5), q_a=N(1.0, 0.3)),
+                        SL(Z.GAT(32, 5, num_heads=4, last=True, attn_drop=0.5, activation=sm), q_a=N(1.0, 0.3))],
+        "sage": [SL(Z.GraphSAGE(32, 16, aggregator_type="mean"), q_a=N(1.0, 0.3)),
+                 SL(Z.GraphSAGE(16, 5, aggregator_type="mean", activation=sm), q_a=N(1.0, 0.3))],
+    }
+    for name, layers in families.items():
+        model = stag_amd.models.StagModel(layers=torch.nn.ModuleList(layers)).to(dev)
+        opt = torch.optim.Adam(model.parameters(), 1e-3)
+
+        def step():
+            opt.zero_grad()
+            loss = model.loss(g, x, y, mask=mask)
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(12):
+            step()
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            for _ in range(3):
+                loss = step()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        assert torch.isfinite(loss), name
