@@ -119,7 +119,18 @@ class ParametrizedDistribution(Distribution):
 
     @property
     def base_distribution(self):
-        return self.base_distribution_class(**self.arguments())
+        """The torch distribution over the stored arguments.  With buffers (vi=False) the object is kept while the
+        buffers are the same tensors at the same version (`.to()`, `load_state_dict`, an in-place update all change
+        one or the other): a launch-bound layer call spends 4 us building it and 15 us re-expanding its device
+        scalars for the kernel (noise.EdgeNoise keeps those rows per parameter tensor)."""
+        if any(isinstance(getattr(self, k), torch.nn.Parameter) for k in self.new_parameter_names):
+            return self.base_distribution_class(**self.arguments())
+        key = tuple((id(getattr(self, k)), getattr(self, k)._version) for k in self.new_parameter_names)
+        cached = self.__dict__.get("_base_cache")
+        if cached is None or cached[0] != key:
+            cached = (key, self.base_distribution_class(**self.arguments()))
+            self.__dict__["_base_cache"] = cached
+        return cached[1]
 
 
 class AmortizedDistribution(Distribution):

@@ -40,6 +40,30 @@ def _param_mode(p, n_edges, dn):
     raise ValueError(f"parameter of shape {tuple(p.shape)} does not broadcast to [{n_edges}, {dn}]")
 
 
+_ROW_CACHE = {}      # id(parameter tensor) -> (weakref to it, its version, {(shape, device): expanded row})
+
+
+def _expanded(p, shape, dev, cache=False, src=None, tag=False):
+    """p broadcast to `shape` as a contiguous device tensor.  For a per-channel row made from a module's buffer
+    (a device scalar that must not be read back) the result is kept per source tensor while that tensor is alive
+    and at the same version: two small launches less per layer call on launch-bound graphs."""
+    if not (cache and torch.is_tensor(src) and not src.requires_grad):
+        return p.detach().to(dev).expand(shape).contiguous()
+    import weakref
+    ent = _ROW_CACHE.get(id(src))
+    if ent is None or ent[0]() is not src or ent[1] != src._version:
+        if len(_ROW_CACHE) > 256:
+            _ROW_CACHE.clear()
+        ent = (weakref.ref(src), src._version, {})
+        _ROW_CACHE[id(src)] = ent
+    key = (tuple(shape), str(dev), bool(tag))        # tag: p = exp(src), not src
+    row = ent[2].get(key)
+    if row is None:
+        row = p.detach().to(dev).expand(shape).contiguous()
+        ent[2][key] = row
+    return row
+
+
 class EdgeNoise:
     def __init__(self, graph, dn, kind, p0, p1=None, relu=False, in_norm=False, seed=0, offset=0,
                  pos_base=0, differentiable=False, chunk_base=0, epoch=None, p1_log=False):
@@ -82,8 +106,10 @@ class EdgeNoise:
                 # hipGraph, so it travels as a per-channel row instead
                 mode = _lib.PARAM_PER_CHANNEL
             self.param_mode = mode
+            exp_applied = False
             if self.p1_log and mode == _lib.PARAM_PER_CHANNEL:      # the library takes log-scales per edge or scalar
                 ps[1] = ps[1].exp()
+                exp_applied = True
                 self.p1_log = False
                 if self.grad_params is not None:
                     raise ValueError("a per-channel log-scale with gradients: exponentiate it yourself (p1_log=False)")
@@ -94,7 +120,9 @@ class EdgeNoise:
             else:
                 shape = {_lib.PARAM_PER_CHANNEL: (dn,), _lib.PARAM_PER_EDGE1: (E, 1),
                          _lib.PARAM_PER_EDGE: (E, dn)}[mode]
-                ex = [p.detach().to(dev).expand(shape).contiguous() for p in ps]
+                srcs = (p0,) if p1 is None else (p0, p1)
+                ex = [_expanded(p, shape, dev, cache=(mode == _lib.PARAM_PER_CHANNEL), src=srcs[i],
+                                tag=(i == 1 and exp_applied)) for i, p in enumerate(ps)]
                 self.p0 = ex[0]
                 self.p1 = ex[1] if p1 is not None else None
 

@@ -1375,3 +1375,34 @@ def test_steady_state_training_steps_do_not_synchronise_the_host(dev):
         finally:
             torch.cuda.set_sync_debug_mode("default")
         assert torch.isfinite(loss), name
+
+
+def test_cached_parameter_rows_follow_their_tensors(dev):
+    """A non-learned distribution's device scalars travel to the kernel as per-channel rows that are kept per
+    buffer tensor (launch-bound graphs: two small launches less per layer call).  The rows must follow the buffers:
+    an in-place update, load_state_dict and .to() all show in the next forward."""
+    import stag_amd
+    from util import random_graph
+    g = random_graph(200, 1500, seed=2, device=dev)
+    x = torch.ones(200, 8, device=dev)
+    layer = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(8, 8, weight=False, bias=False, norm="none"),
+                                      q_a=torch.distributions.Normal(2.0, 1e-6)).to(dev)
+
+    def mean_out():
+        stag_amd.manual_seed(3)
+        with torch.no_grad():
+            y = layer(g, x)
+        deg = g.in_degrees().clamp(min=1).float().unsqueeze(1)
+        return float((y / deg)[g.in_degrees() > 0].mean())
+    assert abs(mean_out() - 2.0) < 1e-3 and abs(mean_out() - 2.0) < 1e-3          # second call: from the kept rows
+    d1 = layer.q_a.base_distribution
+    assert layer.q_a.base_distribution is d1                                        # kept while the buffers stand
+    with torch.no_grad():
+        layer.q_a.loc.fill_(5.0)                                                    # in-place: version bump
+    assert layer.q_a.base_distribution is not d1 and abs(mean_out() - 5.0) < 1e-3
+    sd = layer.state_dict()
+    sd["q_a.loc"] = torch.tensor(7.0)
+    layer.load_state_dict(sd)
+    assert abs(mean_out() - 7.0) < 1e-3
+    layer.q_a.loc = layer.q_a.loc.clone() * 0 + 9.0                                 # a new buffer tensor
+    assert abs(mean_out() - 9.0) < 1e-3
