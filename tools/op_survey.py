@@ -58,7 +58,7 @@ def main():
         "GCN  Bernoulli(.5) + norm (arxiv_mle)    ": dict(q_a=torch.distributions.Bernoulli(0.5), norm=True),
         "GCN  vi Normal, relu   (r1)              ": dict(q_a=N(1.0, 0.5), vi=True, relu=True),
         "GCN  vi Normal per-channel (rc)          ": dict(q_a=N(torch.ones(D), 0.5 * torch.ones(D)), vi=True),
-        "GCN  vi Normal + norm (materialised path)": dict(q_a=N(1.0, 0.5), vi=True, norm=True),
+        "GCN  vi Normal + norm                    ": dict(q_a=N(1.0, 0.5), vi=True, norm=True),
     }
     for name, kw in modes.items():
         layer = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(D, D), **kw).to(dev)
