@@ -471,3 +471,27 @@ def test_hot_kernel_register_budget():
         assert occ >= 7 and v <= 72, f"Normal, LPE {lpe}: {v} VGPRs, {occ} waves/SIMD"
         v, occ = none[f"void stag::agg_kernel<0, {lpe}, true, 0, 1, false>(stag::AggArgs)"]
         assert occ >= 7 and v <= 72, f"no noise, LPE {lpe}: {v} VGPRs, {occ} waves/SIMD"
+
+
+def test_round2_host_helpers_on_cpu():
+    """Host-side pieces added late in round 2, checked without a GPU: the masked mean of the loss (index masks keep
+    torch's indexing, boolean masks on CPU too), the GAT shape rules (lanes per head, which widths get padded,
+    which shapes the cooperative kernels take), column_sum's CPU form, the amortised-parameter oracle's shapes."""
+    import stag_amd
+    from stag_amd import ops
+    from stag_amd.models import _masked_mean
+    v = torch.randn(30, 3)
+    m = torch.rand(30) < 0.5
+    assert torch.allclose(_masked_mean(v, m), v[m].mean()) and torch.allclose(_masked_mean(v, None), v.mean())
+    idx = torch.tensor([0, 4, 9])
+    assert torch.equal(_masked_mean(v, idx), v[idx].mean())
+    assert [ops.gat_lanes_per_head(f) for f in (4, 8, 12, 32, 40, 124, 256)] == [1, 2, 4, 8, 16, 32, 64]
+    assert ops.gat_cooperative_shape(8, 32, 64) and ops.gat_cooperative_shape(8, 40, 64) and ops.gat_cooperative_shape(4, 256, 64)
+    assert not ops.gat_cooperative_shape(8, 10, 64) and not ops.gat_cooperative_shape(32, 8, 64)      # F % 4, H > 16
+    assert not ops.gat_cooperative_shape(8, 256, 64) and not ops.gat_cooperative_shape(8, 32, 0)      # H*F > 1024, no plan
+    GAT = stag_amd.zoo.GAT
+    assert GAT._padded_width(8, 40) == 40 and GAT._padded_width(3, 7) == 8 and GAT._padded_width(4, 121) == 124
+    assert GAT._padded_width(8, 32) == 32 and GAT._padded_width(64, 7) == 7                           # nothing fits: unchanged
+    g = torch.randn(100, 7)
+    assert torch.allclose(ops.column_sum(g), g.sum(0)) and torch.equal(ops.add_bias(g, torch.ones(7)), g + 1)
+    assert ops.attn_drop_fusable(8, 32, 64) and not ops.attn_drop_fusable(8, 32, 64, want_attn=True)
