@@ -325,7 +325,12 @@ class _NodeLinear(torch.autograd.Function):
         x, w = ctx.saved_tensors
         # g @ w^T as an NN product on a transposed copy of w (64 KB): 75 against 92 us for the NT form at
         # N = 169,343, 128 x 128 (tools/gemm_probe.py)
-        dx = g @ w.t().contiguous() if ctx.needs_input_grad[0] else None
+        # (and when the output is wider than the input — GAT's fc, 128 -> 8 x 32 — the NT form on a contiguous w
+        # wins instead: 119 against 158 us; the library's kernel choice is what differs)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (torch.nn.functional.linear(g, w.contiguous()) if g.shape[1] > w.shape[0]
+                  else g @ w.t().contiguous())
         db = column_sum(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         dw = None
         if ctx.needs_input_grad[1]:
