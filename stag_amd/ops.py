@@ -314,10 +314,14 @@ class _NodeLinear(torch.autograd.Function):
     SPLIT = 64
 
     @staticmethod
-    def forward(ctx, x, w, bias=None):
+    def forward(ctx, x, w, bias=None, add=None):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
-        # the bias rides in the GEMM's epilogue (one pass over the [rows, out] result instead of two)
+        ctx.has_add = add is not None
+        # the bias — or a whole addend [rows, out]: GraphSAGE's other branch — rides in the GEMM's epilogue (one
+        # pass over the result instead of two)
+        if add is not None:
+            return torch.addmm(add if bias is None else add + bias, x, w)
         return torch.addmm(bias, x, w) if bias is not None else x @ w
 
     @staticmethod
@@ -344,14 +348,18 @@ class _NodeLinear(torch.autograd.Function):
                     dw = dw + x[n1:].t() @ g[n1:]
             else:
                 dw = x.t() @ g
-        return dx, dw, db
+        return dx, dw, db, (g if (ctx.has_add and ctx.needs_input_grad[3]) else None)
 
 
-def node_linear(x, w, bias=None):
-    """x [N, in] @ w [in, out] (+ bias, in the GEMM's epilogue) with a split-K weight gradient (see _NodeLinear)."""
+def node_linear(x, w, bias=None, add=None):
+    """x [N, in] @ w [in, out] (+ bias, + add [N, out], both in the GEMM's epilogue) with a split-K weight gradient
+    (see _NodeLinear)."""
     if x.dim() != 2 or not x.is_contiguous():
-        return x @ w if bias is None else x @ w + bias
-    return _NodeLinear.apply(x, w, bias)
+        y = x @ w if bias is None else x @ w + bias
+        return y if add is None else y + add
+    if add is not None and (add.shape != (x.shape[0], w.shape[1]) or add.dtype != x.dtype):
+        return _NodeLinear.apply(x, w, bias) + add
+    return _NodeLinear.apply(x, w, bias, add)
 
 
 class _GatherRows(torch.autograd.Function):

@@ -43,9 +43,13 @@ class GraphSAGE(torch.nn.Module):
         if edge_weight is not None:
             check_edge_weight(graph, edge_weight)
         h_self = feat_dst
+        bias_done = False
         if self._aggre_type == "mean":
+            # the shared bias rides in this GEMM's epilogue, the whole neighbour branch in the self branch's (below):
+            # two passes over [N, out] less than `fc_self(h) + fc_neigh(agg) + bias`
             h_neigh = ops.node_linear(ops.aggregate(graph, feat_src, edge_weight, reduce="mean"),
-                                      self.fc_neigh.weight.t())
+                                      self.fc_neigh.weight.t(), self.bias)
+            bias_done = self.bias is not None
         elif self._aggre_type == "gcn":
             neigh = ops.aggregate(graph, feat_src, edge_weight, reduce="sum")
             degs = graph.in_degrees().to(feat_dst)
@@ -54,8 +58,8 @@ class GraphSAGE(torch.nn.Module):
             h_neigh = self.fc_neigh(ops.aggregate_max(graph, torch.relu(self.fc_pool(feat_src)), edge_weight))
         else:
             raise NotImplementedError("'lstm' aggregator is outside the accelerated path")
-        rst = h_neigh if self._aggre_type == "gcn" else ops.node_linear(h_self, self.fc_self.weight.t()) + h_neigh
-        if self.bias is not None:
+        rst = h_neigh if self._aggre_type == "gcn" else ops.node_linear(h_self, self.fc_self.weight.t(), add=h_neigh)
+        if self.bias is not None and not bias_done:
             rst = ops.add_bias(rst, self.bias)
         if self.activation is not None:
             rst = self.activation(rst)
