@@ -98,6 +98,30 @@ def main():
         s32, d32 = torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev)
         from stag_amd.graph import build_csr
         print(f"stag_csr_build (E = {E})             : {ev(lambda: build_csr(s32, d32, n, n), 5):9.1f} us")
+        spec = nz.spec()
+        spec = spec if not isinstance(spec, tuple) else ops._targs_to_ctypes(spec)
+        print(f"agg_bwd_dp (dx + finished dp0, dp1)      : {ev(lambda: ops._agg_bwd_dp_raw(g.csr_t, gout, x, D, spec, None, None, 64)):9.1f} us")
+        loc, ls = torch.rand(E, 1, device=dev) + 0.5, torch.rand(E, 1, device=dev) - 1.5
+        nz1 = stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, loc, ls, seed=1, offset=0, p1_log=True)
+        sp1 = nz1.spec()
+        sp1 = sp1 if not isinstance(sp1, tuple) else ops._targs_to_ctypes(sp1)
+        print(f"aggregate, [E,1] parameters              : {ev(lambda: ops.aggregate(g, x, nz1)):9.1f} us")
+        print(f"agg_bwd_edge (dx + [E,1] gradients)      : {ev(lambda: ops._agg_bwd_edge_raw(g.csr_t, gout, x, D, sp1, None, None, 64)):9.1f} us")
+        w2, b2 = torch.randn(D, 2, device=dev), torch.randn(2, device=dev)
+        print(f"node_project [N,128] -> [N,2]            : {ev(lambda: ops.node_project(x, w2, b2)):9.1f} us")
+        P = ops.node_project(x, w2, b2)
+        wh, bh = torch.randn(1, 2, device=dev), torch.randn(2, device=dev)
+        print(f"edge_mlp (hidden 1, 2 parameters)        : {ev(lambda: ops.edge_mlp(g, P, wh, bh)):9.1f} us")
+        pl, ps = torch.tensor(1.0, device=dev), torch.tensor(0.5, device=dev)
+        print(f"normal_kl_mean over [E,1]                : {ev(lambda: ops.normal_kl_mean(loc, ls, pl, ps)):9.1f} us")
+        ft = torch.randn(n, 8, 32, device=dev)
+        al, ar = torch.randn(1, 8, 32, device=dev), torch.randn(1, 8, 32, device=dev)
+        print(f"head_dot [N,8,32] -> el, er              : {ev(lambda: ops.head_dot(ft, al, ar)):9.1f} us")
+        print(f"column_sum [N,121]                       : {ev(lambda: ops.column_sum(ft.reshape(n, 256)[:, :121].contiguous())):9.1f} us (incl. the slice copy)")
+        g.csr._plans.clear(); g.csr_t._plans.clear()
+        import time as _t
+        torch.cuda.synchronize(); t0 = _t.perf_counter(); g.csr.plan(64); torch.cuda.synchronize()
+        print(f"stag_plan_device (arxiv CSR)             : {(_t.perf_counter() - t0) * 1e6:9.1f} us")
 
 
 if __name__ == "__main__":
