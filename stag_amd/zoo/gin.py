@@ -27,7 +27,7 @@ class GIN(torch.nn.Module):
         if edge_weight is not None:
             check_edge_weight(graph, edge_weight)
         neigh = ops.aggregate(graph, feat, edge_weight, reduce=self._aggregator_type)
-        h = (1 + self.eps) * feat + neigh
+        h = torch.addcmul(neigh, feat, 1 + self.eps)       # (1 + eps) * feat + neigh in ONE pass (stag/zoo/gin.py:9)
         if isinstance(self.apply_func, torch.nn.Linear):      # split-K weight gradient (ops.node_linear)
             rst = ops.node_linear(h, self.apply_func.weight.t(), self.apply_func.bias)
         else:
