@@ -4,13 +4,18 @@ Bit-exact: CSR arrays, raw Philox words, Uniform and Bernoulli draws.
 Within |a-b| <= 1e-5 (1+|b|): Normal draws (hardware log/sin/cos vs libm) and every
 aggregated feature.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from util import TOL, assert_close, oracle_graph, random_graph, scaled_err
+from util import TOL, assert_close, assert_close_cond, oracle_graph, random_graph, scaled_err
 
 pytestmark = pytest.mark.gpu
+# the seeded sweeps run FUZZ_SCALE times their committed number of cases (the first ones are the same cases):
+# STAG_FUZZ_SCALE=10 is the soak run whose result is kept in profiles/r02/fuzz_soak.txt
+FUZZ_SCALE = max(1, int(os.environ.get("STAG_FUZZ_SCALE", "1")))
 
 
 def _noise(g, dn, kind, p0, p1=None, **kw):
@@ -544,7 +549,7 @@ def test_fuzz_agg_against_oracle(dev, oracle):
     from stag_amd import ops
     rng = np.random.default_rng(20261003)
     kinds = ["none", "explicit", "normal", "uniform", "bernoulli"]
-    for it in range(60):
+    for it in range(60 * FUZZ_SCALE):
         n = int(rng.integers(1, 400))
         e = int(rng.integers(0, 3000))
         hub = int(rng.choice([0, 0, 70, 400]))
@@ -593,7 +598,7 @@ def test_fuzz_gat_against_oracle_and_composed_backward(dev, oracle):
     rng = np.random.default_rng(20261004)
     shapes = [(1, 4), (2, 8), (3, 4), (4, 16), (8, 32), (8, 64), (16, 64), (5, 12), (4, 5), (2, 256), (16, 8), (6, 40)]
     kinds = ["none", "explicit", "normal", "uniform", "bernoulli"]
-    for it in range(36):
+    for it in range(36 * FUZZ_SCALE):
         n = int(rng.integers(2, 500))
         e = int(rng.integers(1, 4000))
         hub = int(rng.choice([0, 0, 90, 700]))
@@ -875,55 +880,68 @@ def test_fuzz_backward_passes_against_oracle(dev, oracle):
     from stag_amd import _lib, ops
     rng = np.random.default_rng(20261005)
     widths = [1, 3, 4, 8, 20, 32, 50, 64, 100, 128, 200, 256, 300, 515]
-    for it in range(30):
-        n = int(rng.integers(1, 400))
-        e = int(rng.integers(0, 5000))
-        hub = int(rng.choice([0, 0, 80, 600])) if n > 4 else 0
-        D = int(widths[it % len(widths)])
-        kind = ["normal", "uniform"][it % 2]
-        relu = bool(rng.random() < 0.4)
-        seg_len = int(rng.choice([64, 64, 16, 256, 0]))
-        g = random_graph(n, e, seed=7000 + it, hub=hub, device=dev)
-        E = g.number_of_edges()
-        ogt, og = oracle_graph(oracle, g, transposed=True), oracle_graph(oracle, g)
-        x = rng.standard_normal((n, D)).astype(np.float32)
-        gout = rng.standard_normal((n, D)).astype(np.float32)
-        gs = rng.uniform(0.5, 1.5, n).astype(np.float32)
-        rs = rng.uniform(0.5, 1.5, n).astype(np.float32)
-        xd, gd, gsd, rsd = (torch.from_numpy(a).to(dev) for a in (x, gout, gs, rs))
-        what = f"bwd fuzz {it}: n={n} E={E} D={D} {kind} relu={relu} seg={seg_len}"
-        seed, off = int(rng.integers(0, 2**40)), int(rng.integers(0, 99))
-        # ---- per-channel parameters: stag_agg_bwd and stag_agg_bwd_dp ------------------------------------
-        p0 = rng.uniform(0.2, 1.0, D).astype(np.float32)
-        p1 = (p0 + rng.uniform(0.6, 1.2, D)).astype(np.float32) if kind == "uniform" else rng.uniform(0.3, 0.9, D).astype(np.float32)
-        noise = _noise(g, D, kind, torch.from_numpy(p0).to(dev), torch.from_numpy(p1).to(dev), relu=relu, seed=seed, offset=off)
-        T = [oracle.agg_fwd(ogt, gout, _ospec(oracle, g, D, kind, p0, p1, relu=relu, seed=seed, offset=off, deriv=dv),
-                            src_scale=gs, dst_scale=rs) for dv in (0, 1, 2)]
-        dx, t0, t1 = ops._agg_bwd_raw(g.csr_t, gd, D, noise.spec(), gsd, rsd, seg_len, True)
-        for got, ref, nm in ((dx, T[0], "dx"), (t0, T[1], "T0"), (t1, T[2], "T1")):
-            assert_close(got, ref, tol=TOL if 0 < seg_len <= 64 else 2 * TOL, what=f"{what} stag_agg_bwd {nm}")
-        spec = noise.spec()
-        spec = spec if not isinstance(spec, tuple) else ops._targs_to_ctypes(spec)
-        dx2, c0, c1 = ops._agg_bwd_dp_raw(g.csr_t, gd, xd, D, spec, gsd, rsd, seg_len)
-        assert_close(dx2, T[0], tol=TOL if 0 < seg_len <= 64 else 2 * TOL, what=f"{what} stag_agg_bwd_dp dx")
-        for got, Ti, nm in ((c0, T[1], "d p0"), (c1, T[2], "d p1")):
-            ref = (x.astype(np.float64) * Ti.astype(np.float64)).sum(0)
-            sc = max(1.0, float(np.abs(ref).max()))
-            assert_close(got / sc, ref / sc, what=f"{what} stag_agg_bwd_dp {nm}")
-        # ---- [E, 1] parameters: stag_agg_bwd_edge (one channel tile) --------------------------------------
-        if D <= 256 and E > 0:
-            q0 = rng.uniform(0.2, 1.0, (E, 1)).astype(np.float32)
-            q1 = (q0 + rng.uniform(0.6, 1.2, (E, 1))).astype(np.float32) if kind == "uniform" else rng.uniform(0.3, 0.9, (E, 1)).astype(np.float32)
-            K = _lib.NOISE_NORMAL if kind == "normal" else _lib.NOISE_UNIFORM
-            nz = stag_amd.EdgeNoise(g, D, K, torch.from_numpy(q0).to(dev), torch.from_numpy(q1).to(dev), relu=relu, seed=seed, offset=off)
-            sp = nz.spec()
-            sp = sp if not isinstance(sp, tuple) else ops._targs_to_ctypes(sp)
-            dx3, e0, e1 = ops._agg_bwd_edge_raw(g.csr_t, gd, xd, D, sp, gsd, rsd, seg_len if seg_len else 64)
-            ref_dx = oracle.agg_fwd(ogt, gout, oracle.make_spec(kind, q0, q1, relu=relu, seed=seed, offset=off, Dn=D, n_edges=E),
-                                    src_scale=gs, dst_scale=rs)
-            assert_close(dx3, ref_dx, what=f"{what} stag_agg_bwd_edge dx")
-            for dv, got in ((1, e0), (2, e1)):
-                osp = oracle.make_spec(kind, q0, q1, relu=relu, seed=seed, offset=off, Dn=D, n_edges=E, deriv=dv)
-                ref = oracle.agg_bwd_w(og, x, gout * gs[:, None], src_scale=rs, spec=osp).astype(np.float64).sum(1, keepdims=True)
+    # relu's derivative is a step: a weight within an ulp of 0 (case 944 of the soak: -2.5e-8 from libm, +1.9e-8 from the
+    # hardware functions) puts a whole term x g on one side or the other.  The oracle therefore draws from the device's
+    # tables here (util.hw_normals: identical weights, bit for bit; the tables are pinned against libm exhaustively).
+    from util import hw_normals
+    with hw_normals(oracle, dev):
+        for it in range(30 * FUZZ_SCALE):
+            n = int(rng.integers(1, 400))
+            e = int(rng.integers(0, 5000))
+            hub = int(rng.choice([0, 0, 80, 600])) if n > 4 else 0
+            D = int(widths[it % len(widths)])
+            kind = ["normal", "uniform"][it % 2]
+            relu = bool(rng.random() < 0.4)
+            seg_len = int(rng.choice([64, 64, 16, 256, 0]))
+            g = random_graph(n, e, seed=7000 + it, hub=hub, device=dev)
+            E = g.number_of_edges()
+            ogt, og = oracle_graph(oracle, g, transposed=True), oracle_graph(oracle, g)
+            x = rng.standard_normal((n, D)).astype(np.float32)
+            gout = rng.standard_normal((n, D)).astype(np.float32)
+            gs = rng.uniform(0.5, 1.5, n).astype(np.float32)
+            rs = rng.uniform(0.5, 1.5, n).astype(np.float32)
+            xd, gd, gsd, rsd = (torch.from_numpy(a).to(dev) for a in (x, gout, gs, rs))
+            what = f"bwd fuzz {it}: n={n} E={E} D={D} {kind} relu={relu} seg={seg_len}"
+            seed, off = int(rng.integers(0, 2**40)), int(rng.integers(0, 99))
+            # ---- per-channel parameters: stag_agg_bwd and stag_agg_bwd_dp ------------------------------------
+            p0 = rng.uniform(0.2, 1.0, D).astype(np.float32)
+            p1 = (p0 + rng.uniform(0.6, 1.2, D)).astype(np.float32) if kind == "uniform" else rng.uniform(0.3, 0.9, D).astype(np.float32)
+            noise = _noise(g, D, kind, torch.from_numpy(p0).to(dev), torch.from_numpy(p1).to(dev), relu=relu, seed=seed, offset=off)
+            T = [oracle.agg_fwd(ogt, gout, _ospec(oracle, g, D, kind, p0, p1, relu=relu, seed=seed, offset=off, deriv=dv),
+                                src_scale=gs, dst_scale=rs) for dv in (0, 1, 2)]
+            # sum |terms| of each of the three sums (the weights, or their derivatives, by edge id; util.assert_close_cond)
+            A = [oracle.agg_fwd(ogt, np.abs(gout), oracle.make_spec("explicit", np.abs(oracle.noise_materialize(
+                     ogt, _ospec(oracle, g, D, kind, p0, p1, relu=relu, seed=seed, offset=off, deriv=dv), D))),
+                     src_scale=gs, dst_scale=rs) for dv in (0, 1, 2)]
+            dx, t0, t1 = ops._agg_bwd_raw(g.csr_t, gd, D, noise.spec(), gsd, rsd, seg_len, True)
+            for got, ref, ab, nm in ((dx, T[0], A[0], "dx"), (t0, T[1], A[1], "T0"), (t1, T[2], A[2], "T1")):
+                assert_close_cond(got, ref, ab, tol=TOL if 0 < seg_len <= 64 else 2 * TOL, what=f"{what} stag_agg_bwd {nm}")
+            spec = noise.spec()
+            spec = spec if not isinstance(spec, tuple) else ops._targs_to_ctypes(spec)
+            dx2, c0, c1 = ops._agg_bwd_dp_raw(g.csr_t, gd, xd, D, spec, gsd, rsd, seg_len)
+            assert_close_cond(dx2, T[0], A[0], tol=TOL if 0 < seg_len <= 64 else 2 * TOL, what=f"{what} stag_agg_bwd_dp dx")
+            for got, Ti, nm in ((c0, T[1], "d p0"), (c1, T[2], "d p1")):
+                ref = (x.astype(np.float64) * Ti.astype(np.float64)).sum(0)
                 sc = max(1.0, float(np.abs(ref).max()))
-                assert_close(got / sc, ref / sc, what=f"{what} stag_agg_bwd_edge d p{dv - 1}")
+                # (the sums over a row's edges inside are T0 / T1 above: the same allowance off the default segment length)
+                assert_close(got / sc, ref / sc, tol=TOL if 0 < seg_len <= 64 else 2 * TOL, what=f"{what} stag_agg_bwd_dp {nm}")
+            # ---- [E, 1] parameters: stag_agg_bwd_edge (one channel tile) --------------------------------------
+            if D <= 256 and E > 0:
+                q0 = rng.uniform(0.2, 1.0, (E, 1)).astype(np.float32)
+                q1 = (q0 + rng.uniform(0.6, 1.2, (E, 1))).astype(np.float32) if kind == "uniform" else rng.uniform(0.3, 0.9, (E, 1)).astype(np.float32)
+                K = _lib.NOISE_NORMAL if kind == "normal" else _lib.NOISE_UNIFORM
+                nz = stag_amd.EdgeNoise(g, D, K, torch.from_numpy(q0).to(dev), torch.from_numpy(q1).to(dev), relu=relu, seed=seed, offset=off)
+                sp = nz.spec()
+                sp = sp if not isinstance(sp, tuple) else ops._targs_to_ctypes(sp)
+                dx3, e0, e1 = ops._agg_bwd_edge_raw(g.csr_t, gd, xd, D, sp, gsd, rsd, seg_len if seg_len else 64)
+                ref_dx = oracle.agg_fwd(ogt, gout, oracle.make_spec(kind, q0, q1, relu=relu, seed=seed, offset=off, Dn=D, n_edges=E),
+                                        src_scale=gs, dst_scale=rs)
+                ab = oracle.agg_fwd(ogt, np.abs(gout), oracle.make_spec("explicit", np.abs(oracle.noise_materialize(
+                    ogt, oracle.make_spec(kind, q0, q1, relu=relu, seed=seed, offset=off, Dn=D, n_edges=E), D))),
+                    src_scale=gs, dst_scale=rs)
+                assert_close_cond(dx3, ref_dx, ab, what=f"{what} stag_agg_bwd_edge dx")
+                for dv, got in ((1, e0), (2, e1)):
+                    osp = oracle.make_spec(kind, q0, q1, relu=relu, seed=seed, offset=off, Dn=D, n_edges=E, deriv=dv)
+                    ref = oracle.agg_bwd_w(og, x, gout * gs[:, None], src_scale=rs, spec=osp).astype(np.float64).sum(1, keepdims=True)
+                    sc = max(1.0, float(np.abs(ref).max()))
+                    assert_close(got / sc, ref / sc, what=f"{what} stag_agg_bwd_edge d p{dv - 1}")
