@@ -803,6 +803,64 @@ def test_gat_attention_dropout_in_the_kernels(dev, oracle, H, F, kind):
     assert not ops.attn_drop_fusable(8, 10, 64) and ops.attn_drop_fusable(H, F, 64)
 
 
+def test_fuzz_gat_attention_dropout(dev, oracle):
+    """Seeded sweep over graphs x head shapes x weight kinds x drop rates for attention dropout inside the GAT
+    kernels (stag/zoo/gat.py:122): forward against the oracle given the mask the same counters materialise, the
+    one-gather backward (mask redrawn from the counters, its bit carried in the sign of a; the only form that takes
+    dropout) against autograd through the composed statement with the mask as a tensor."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    rng = np.random.default_rng(20261006)
+    shapes = [(1, 4), (2, 8), (3, 4), (4, 16), (8, 32), (8, 64), (16, 64), (5, 12), (2, 256), (16, 8), (6, 40), (8, 8)]
+    kinds = ["none", "explicit", "normal", "uniform", "bernoulli"]
+    for it in range(24 * FUZZ_SCALE):
+        n = int(rng.integers(2, 500))
+        e = int(rng.integers(1, 4000))
+        hub = int(rng.choice([0, 0, 90, 700]))
+        H, F = shapes[it % len(shapes)]
+        kind = kinds[it % 5]
+        p_drop = float(rng.choice([0.1, 0.5, 0.6, 0.9]))
+        dseed, doff = int(rng.integers(0, 2**40)), int(rng.integers(0, 99))
+        g = random_graph(n, e, seed=9000 + it, hub=hub if n > 4 else 0, device=dev)
+        E = g.number_of_edges()
+        og = oracle_graph(oracle, g)
+        assert ops.attn_drop_fusable(H, F, 64)
+        el = rng.standard_normal((n, H)).astype(np.float32)
+        er = rng.standard_normal((n, H)).astype(np.float32)
+        ft = rng.standard_normal((n, H, F)).astype(np.float32)
+        if kind == "none":
+            w, spec = None, oracle.make_spec("none")
+        elif kind == "explicit":
+            wt = rng.uniform(0.2, 1.5, (E, H)).astype(np.float32)
+            w, spec = torch.from_numpy(wt).to(dev).requires_grad_(True), oracle.make_spec("explicit", wt)
+        else:
+            p0, p1 = {"normal": (1.0, 0.5), "uniform": (0.2, 1.7), "bernoulli": (0.7, None)}[kind]
+            kw = dict(relu=bool(rng.random() < 0.3), in_norm=(kind == "bernoulli" and bool(rng.random() < 0.5)),
+                      seed=int(rng.integers(0, 2**40)), offset=int(rng.integers(0, 99)))
+            w, spec = _noise(g, H, kind, p0, p1, **kw), _ospec(oracle, g, H, kind, p0, p1, **kw)
+        what = f"gat drop fuzz {it}: n={n} E={E} H={H} F={F} {kind} p={p_drop}"
+        keep_prob = float(np.float32(1.0) - np.float32(p_drop))
+        keep = stag_amd.EdgeNoise(g, H, _lib.NOISE_BERNOULLI, keep_prob, seed=dseed, offset=doff).materialize()   # [E, H]
+        t = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (el, er, ft)]
+        out = ops.gat_aggregate(g, *t, 0.2, w, attn_drop=(p_drop, dseed, doff))
+        ref = oracle.gat_fwd(og, el, er, ft, 0.2, spec, keep=keep.cpu().numpy(), keep_prob=keep_prob)
+        assert_close(out, ref, what=what + " out")
+        G = torch.from_numpy(rng.standard_normal((n, H, F)).astype(np.float32)).to(dev)
+        out.backward(G)
+        got_dw = None
+        if kind == "explicit":
+            got_dw, w.grad = w.grad.clone(), None
+        t2 = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (el, er, ft)]
+        ops.gat_aggregate(g, *t2, 0.2, w, attn_fn=lambda a_: a_ * keep / keep_prob).backward(G)      # the composed path
+        for a_, b_, nm in zip(t, t2, ("d el", "d er", "d ft")):
+            sc = max(1.0, float(b_.grad.abs().max()))
+            assert_close(a_.grad / sc, (b_.grad / sc).cpu().numpy(), what=what + " " + nm)
+        if kind == "explicit":
+            sc = max(1.0, float(w.grad.abs().max()))
+            assert_close(got_dw / sc, (w.grad / sc).cpu().numpy(), what=what + " dw")
+            w.grad = None
+
+
 def test_gat_layer_trains_with_attention_dropout_on_the_fused_path(dev):
     """zoo.GAT(attn_drop=0.6) in training mode — the reference's GAT scripts (scripts/citation_mle/gat/run.py:40) —
     stays on the fused kernels: every call takes one generator offset for its mask, gradients flow, eval mode is
