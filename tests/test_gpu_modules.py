@@ -1144,6 +1144,95 @@ def test_head_dot(dev, n, H, F):
     assert ops.head_dot(torch.zeros(4, 2, 10, device=dev), al, ar) is None      # F % 4 != 0: the GEMM form
 
 
+def test_fuzz_amortized_head_kernels(dev):
+    """Seeded sweep over shapes for the narrow-head kernels of csrc/amort.hip — stag_node_project, stag_edge_mlp,
+    stag_head_dot, stag_normal_kl, forward and backward — against float64 torch: row counts around the kernels' row
+    and block granularities, odd widths, hub rows on both sides of the edge MLP.  STAG_FUZZ_SCALE multiplies the
+    number of cases (profiles/r02/fuzz_soak.txt)."""
+    import os
+    from stag_amd import ops
+    from util import random_graph
+    rng = np.random.default_rng(20261007)
+    scale = max(1, int(os.environ.get("STAG_FUZZ_SCALE", "1")))
+    T = lambda a, grad=True: torch.tensor(np.asarray(a, np.float32), device=dev, requires_grad=grad)
+
+    def rel(got, ref, what):
+        sc = max(1.0, float(ref.abs().max()))
+        assert_close(got / sc, (ref / sc).cpu().numpy(), what=what)
+
+    for it in range(16 * scale):
+        # ---- node_project: y = x w + b ---------------------------------------------------------------------
+        n = int(rng.choice([1, 3, 4, 5, 63, 64, 255, 257, 1000, 2049, int(rng.integers(1, 6000))]))
+        K = int(rng.choice([1, 3, 4, 8, 9, 50, 127, 128, 200, 256, 515, 1433]))
+        C = int(rng.integers(1, 9))
+        what = f"amort fuzz {it}: n={n} K={K} C={C}"
+        x, w, b = T(rng.standard_normal((n, K))), T(rng.standard_normal((K, C)) / np.sqrt(K)), T(rng.standard_normal(C))
+        gy = T(rng.standard_normal((n, C)), False)
+        y = ops._NodeProject.apply(x, w, b)
+        y.backward(gy)
+        xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+        ref = xd @ wd + bd
+        ref.backward(gy.double())
+        assert_close(y, ref.detach().cpu().numpy(), what=what + " node_project y")
+        assert_close(x.grad, xd.grad.cpu().numpy(), what=what + " node_project dx")
+        rel(w.grad, wd.grad, what + " node_project dw")
+        rel(b.grad, bd.grad, what + " node_project db")
+        # ---- edge_mlp: SiLU(P_src[src] + P_dst[dst]) -> heads ---------------------------------------------------
+        hidden, n_par = int(rng.choice([1, 1, 2, 3, 4, 8])), int(rng.integers(1, 5))
+        nn = int(rng.integers(2, 500))
+        g = random_graph(nn, int(rng.integers(1, 5000)), seed=9500 + it, hub=int(rng.choice([0, 0, 300, 900])) if nn > 4 else 0,
+                         device=dev)
+        src, dst = g.edges()
+        E = g.number_of_edges()
+        what = f"amort fuzz {it}: n={nn} E={E} hidden={hidden} n_par={n_par}"
+        P, wh, bh = T(rng.standard_normal((nn, 2 * hidden))), T(rng.standard_normal((hidden, n_par))), T(rng.standard_normal(n_par))
+        gs = [T(rng.standard_normal((E, 1)), False) for _ in range(n_par)]
+        outs = ops.edge_mlp(g, P, wh, bh)
+        torch.autograd.backward(outs, gs)
+        Pd, whd, bhd = (t.detach().double().requires_grad_(True) for t in (P, wh, bh))
+        ref = torch.nn.functional.silu(Pd[src, :hidden] + Pd[dst, hidden:]) @ whd + bhd
+        ref.backward(torch.cat(gs, 1).double())
+        for c in range(n_par):
+            assert_close(outs[c], ref[:, c:c + 1].detach().cpu().numpy(), what=what + f" edge_mlp head {c}")
+        rel(P.grad, Pd.grad, what + " edge_mlp dP")
+        rel(wh.grad, whd.grad, what + " edge_mlp dwh")
+        rel(bh.grad, bhd.grad, what + " edge_mlp dbh")
+        # ---- head_dot: el / er = (ft * attn).sum(-1) -----------------------------------------------------------
+        H = int(rng.choice([1, 2, 3, 4, 5, 8, 16]))
+        F = int(rng.choice([f for f in (4, 8, 12, 16, 32, 40, 64, 124, 128, 252, 256) if H * f <= 2048]))
+        what = f"amort fuzz {it}: n={n} H={H} F={F}"
+        ft, al, ar = T(rng.standard_normal((n, H, F))), T(rng.standard_normal((1, H, F))), T(rng.standard_normal((1, H, F)))
+        gl, gr = T(rng.standard_normal((n, H)), False), T(rng.standard_normal((n, H)), False)
+        lr = ops.head_dot(ft, al, ar)
+        if lr is not None:
+            torch.autograd.backward(list(lr), [gl, gr])
+            ftd, ald, ard = (t.detach().double().requires_grad_(True) for t in (ft, al, ar))
+            rl, rr = (ftd * ald).sum(-1), (ftd * ard).sum(-1)
+            torch.autograd.backward([rl, rr], [gl.double(), gr.double()])
+            assert_close(lr[0], rl.detach().cpu().numpy(), what=what + " head_dot el")
+            assert_close(lr[1], rr.detach().cpu().numpy(), what=what + " head_dot er")
+            assert_close(ft.grad, ftd.grad.cpu().numpy(), what=what + " head_dot d ft")
+            rel(al.grad, ald.grad, what + " head_dot d attn_l")
+            rel(ar.grad, ard.grad, what + " head_dot d attn_r")
+        # ---- normal_kl_mean ------------------------------------------------------------------------------------
+        shape = (int(rng.choice([1, 7, 256, 513, 5000, 70000])), int(rng.choice([1, 1, 3, 16])))
+        what = f"amort fuzz {it}: kl {shape}"
+        loc, ls = T(rng.normal(1.0, 0.4, shape)), T(rng.normal(-1.0, 0.5, shape))
+        pl, pls = T(rng.normal(0.8, 0.2)), T(rng.normal(-0.4, 0.2))
+        kl = ops.normal_kl_mean(loc, ls, pl, pls.exp())
+        kl.backward()
+        Nm = torch.distributions.Normal
+        locd, lsd, pld, plsd = (t.detach().double().requires_grad_(True) for t in (loc, ls, pl, pls))
+        ref = torch.distributions.kl_divergence(Nm(locd, lsd.exp()), Nm(pld, plsd.exp())).mean()
+        ref.backward()
+        m = loc.numel()
+        assert_close(kl, ref.detach().cpu().numpy(), what=what + " kl")
+        assert_close(loc.grad * m, (locd.grad * m).cpu().numpy(), what=what + " d loc")
+        assert_close(ls.grad * m, (lsd.grad * m).cpu().numpy(), what=what + " d log_scale")
+        assert_close(pl.grad, pld.grad.cpu().numpy(), what=what + " d prior loc")
+        assert_close(pls.grad, plsd.grad.cpu().numpy(), what=what + " d prior log_scale")
+
+
 @pytest.mark.parametrize("n,E", [(5, 0), (1, 0), (3, 1)])
 def test_layers_on_edgeless_and_one_edge_graphs(dev, n, E):
     """Degenerate graphs through whole layers, forward and backward: no edges at all (per-edge arrays without an
