@@ -929,6 +929,38 @@ def test_device_planner_equals_host_planner(dev, seg_len):
             assert torch.equal(dplan["block_ptr"].cpu(), hplan["block_ptr"].cpu())
 
 
+def test_fuzz_device_planner_equals_host_planner(dev):
+    """Seeded sweep of test_device_planner_equals_host_planner: random multigraphs (1 ... 3000 nodes, 0 ... 40,000
+    edges, with and without hubs, a few nodes with thousands of parallel edges) x segment lengths, both CSR views,
+    element for element."""
+    import importlib
+    G = importlib.import_module("stag_amd.graph")
+    rng = np.random.default_rng(20261008)
+    keys = ("units", "long_rows", "long_seg_ptr", "block_ptr")
+    for it in range(20 * FUZZ_SCALE):
+        n = int(rng.choice([1, 2, 3, 17, int(rng.integers(1, 3000))]))
+        e = int(rng.choice([0, 1, int(rng.integers(0, 40000))]))
+        hub = int(rng.choice([0, 0, 65, 1000, 5000])) if n > 4 else 0
+        seg_len = int(rng.choice([8, 16, 64, 64, 100, 256]))
+        g = random_graph(n, e, seed=11000 + it, hub=hub, device=dev)
+        for view_name in ("csr", "csr_t"):
+            view = getattr(g, view_name)
+            dplan = view.plan(seg_len, need=True)
+            view._plans.clear()
+            G.DEVICE_PLANNER = False
+            try:
+                hplan = view.plan(seg_len, need=True)
+            finally:
+                G.DEVICE_PLANNER = True
+            view._plans.clear()
+            what = f"plan fuzz {it}: n={n} E={g.number_of_edges()} seg={seg_len} {view_name}"
+            for k in ("n_units", "n_long", "n_seg", "n_heavy", "n_blocks"):
+                assert dplan[k] == hplan[k], (what, k, dplan[k], hplan[k])
+            nu, nl = hplan["n_units"], hplan["n_long"]
+            for k, m in zip(keys, (nu, nl, nl + 1, None)):
+                assert torch.equal(dplan[k][:m].cpu(), hplan[k][:m].cpu()), (what, k)
+
+
 def test_fuzz_backward_passes_against_oracle(dev, oracle):
     """Seeded sweep over graphs x widths x plans x kinds for the three backward entry points on the source-major
     CSR: stag_agg_bwd (dx + derivative aggregates), stag_agg_bwd_dp (dx + finished scalar / per-channel gradients),
