@@ -103,7 +103,7 @@ def test_gat_past_the_narrow_address_forms(dev):
         sc = max(1.0, float(b_.grad[rows].abs().max()))
         assert_close(a_.grad[rows] / sc, (b_.grad[rows] / sc).cpu().numpy(), tol=5 * TOL, what=nm)
     del t2, out2
-    keep_prob = float(np.float32(1.0) - np.float32(0.6))
+    keep_prob = float(np.float32(1.0 - 0.6))      # as ops._gat_drop_struct hands it over: 1 - p in double, then fp32
     keep = stag_amd.EdgeNoise(g, H, _lib.NOISE_BERNOULLI, keep_prob, seed=21, offset=3).materialize()
     with torch.no_grad():
         fused = ops.gat_aggregate(g, el, er, ft, 0.2, noise(), attn_drop=(0.6, 21, 3))

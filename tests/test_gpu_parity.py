@@ -583,10 +583,15 @@ def test_fuzz_agg_against_oracle(dev, oracle):
             spec = _ospec(oracle, g, D, kind, p0, p1, **kw)
         t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
         got = ops.aggregate(g, t(x), w, reduce=reduce, src_scale=t(ss), dst_scale=t(ds), seg_len=seg_len)
-        ref = oracle.agg_fwd(og, x, spec, reduce=oracle.REDUCE_MEAN if reduce == "mean" else oracle.REDUCE_SUM,
-                             src_scale=ss, dst_scale=ds)
-        assert_close(got, ref,
-                     what=f"fuzz {it}: n={n} E={E} D={D} {kind} seg={seg_len} {reduce} relu={relu}")
+        red = oracle.REDUCE_MEAN if reduce == "mean" else oracle.REDUCE_SUM
+        ref = oracle.agg_fwd(og, x, spec, reduce=red, src_scale=ss, dst_scale=ds)
+        # sum |terms| of every output (util.assert_close_cond: graphs of a few nodes and hundreds of edges add the same
+        # few rows over and over, and the one fp32 rounding of x[u] s[u] is shared by all of a row's repeats: soak
+        # case 9410, n=4 E=494 without noise, 1.05e-5)
+        absspec = oracle.make_spec("none") if kind == "none" else oracle.make_spec(
+            "explicit", np.abs(wt if kind == "explicit" else oracle.noise_materialize(og, spec, D)))
+        ab = oracle.agg_fwd(og, np.abs(x), absspec, reduce=red, src_scale=ss, dst_scale=ds)
+        assert_close_cond(got, ref, ab, what=f"fuzz {it}: n={n} E={E} D={D} {kind} seg={seg_len} {reduce} relu={relu}")
 
 
 def test_fuzz_gat_against_oracle_and_composed_backward(dev, oracle):
@@ -770,7 +775,9 @@ def test_gat_attention_dropout_in_the_kernels(dev, oracle, H, F, kind):
         p0, p1 = {"normal": (1.0, 0.5), "uniform": (0.2, 1.7), "bernoulli": (0.7, None)}[kind]
         kw = dict(relu=(kind == "normal"), in_norm=(kind == "bernoulli"), seed=9, offset=3)
         w, spec = _noise(g, H, kind, p0, p1, **kw), _ospec(oracle, g, H, kind, p0, p1, **kw)
-    keep_prob = float(np.float32(1.0) - np.float32(p_drop))
+    # the kernels' threshold is fp32(1 - p) with the difference taken in double (ops._gat_drop_struct); fp32(1) - fp32(p)
+    # is one ulp below it at p = 0.6, and a uniform on the grid point between them flips an edge (soak case 617)
+    keep_prob = float(np.float32(1.0 - p_drop))
     keep = stag_amd.EdgeNoise(g, H, _lib.NOISE_BERNOULLI, keep_prob, seed=dseed, offset=doff).materialize()   # [E, H]
     frac = float(keep.mean())
     assert abs(frac - keep_prob) < 0.02
@@ -839,7 +846,7 @@ def test_fuzz_gat_attention_dropout(dev, oracle):
                       seed=int(rng.integers(0, 2**40)), offset=int(rng.integers(0, 99)))
             w, spec = _noise(g, H, kind, p0, p1, **kw), _ospec(oracle, g, H, kind, p0, p1, **kw)
         what = f"gat drop fuzz {it}: n={n} E={E} H={H} F={F} {kind} p={p_drop}"
-        keep_prob = float(np.float32(1.0) - np.float32(p_drop))
+        keep_prob = float(np.float32(1.0 - p_drop))           # the kernels' threshold: ops._gat_drop_struct
         keep = stag_amd.EdgeNoise(g, H, _lib.NOISE_BERNOULLI, keep_prob, seed=dseed, offset=doff).materialize()   # [E, H]
         t = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (el, er, ft)]
         out = ops.gat_aggregate(g, *t, 0.2, w, attn_drop=(p_drop, dseed, doff))
@@ -852,8 +859,17 @@ def test_fuzz_gat_attention_dropout(dev, oracle):
             got_dw, w.grad = w.grad.clone(), None
         t2 = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (el, er, ft)]
         ops.gat_aggregate(g, *t2, 0.2, w, attn_fn=lambda a_: a_ * keep / keep_prob).backward(G)      # the composed path
+        # d el / d er are sums of d s[e,h] = a' <G[v,h], ft[u,h]> - a <G[v,h], out[v,h]>: two F-term fp32 dot products
+        # that cancel — exactly, when v has one in-edge and it is kept (a' = 1 / keep_prob, out = a' ft[u]).  Soak case
+        # 1138: 20 edges, every destination of in-degree 1, p = 0.9: the true gradient is 0 everywhere, autograd's
+        # softmax backward returns an exact 0, the kernels 36.6145 - 36.6145 = 1.7e-5.  So these two are measured
+        # against the largest TERM of the sums as well as the largest result.
+        with torch.no_grad():
+            _, attn = ops.gat_aggregate(g, *[x_.detach() for x_ in t], 0.2, w.detach() if torch.is_tensor(w) else w, want_attn=True)
+            src_, dst_ = g.edges()
+            term = float((attn * keep / keep_prob * (G[dst_] * t[2].detach()[src_]).sum(-1)).abs().max()) if E else 0.0
         for a_, b_, nm in zip(t, t2, ("d el", "d er", "d ft")):
-            sc = max(1.0, float(b_.grad.abs().max()))
+            sc = max(1.0, float(b_.grad.abs().max()), term if nm != "d ft" else 0.0)
             assert_close(a_.grad / sc, (b_.grad / sc).cpu().numpy(), what=what + " " + nm)
         if kind == "explicit":
             sc = max(1.0, float(w.grad.abs().max()))
