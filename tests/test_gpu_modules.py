@@ -154,6 +154,54 @@ def test_fused_layer_equals_materialised_layer(dev, oracle):
             assert not torch.equal(layer(g, x), out), "next forward draws fresh noise"
 
 
+def test_fuzz_layers_equal_their_materialised_form(dev):
+    """Seeded sweep of test_fused_layer_equals_materialised_layer over graphs x widths x base layers (GCN, GraphSAGE,
+    GIN, GAT) x q_a (Normal, Normal + relu, Bernoulli + in-norm, Uniform) x vi: the layer's fused forward, d x and
+    the base layer's parameter gradients equal the base layer called with the weights the layer reports in
+    `_edge_weight_sample` (stag/layers.py:107-113) — the explicit-weight kernels, a different code path end to end."""
+    import os
+    import stag_amd
+    from util import random_graph
+    rng = np.random.default_rng(20261009)
+    N, B, U = torch.distributions.Normal, torch.distributions.Bernoulli, torch.distributions.Uniform
+    qs = [lambda: dict(q_a=N(1.0, 0.5)), lambda: dict(q_a=N(0.2, 1.0), relu=True),
+          lambda: dict(q_a=B(probs=0.7), norm=True), lambda: dict(q_a=U(0.5, 1.5))]
+    for it in range(16 * max(1, int(os.environ.get("STAG_FUZZ_SCALE", "1")))):
+        n = int(rng.integers(20, 500))
+        g = random_graph(n, int(rng.integers(1, 5000)), seed=12000 + it, hub=int(rng.choice([0, 0, 100, 800])), device=dev)
+        din, dout = int(rng.choice([1, 3, 8, 32, 50, 128, 200])), int(rng.choice([1, 7, 16, 40]))
+        which, qi = it % 4, int(rng.integers(0, 4))
+        vi = bool(rng.random() < 0.4) and qi != 2                  # (Bernoulli has no rsample)
+        torch.manual_seed(it)
+        H = int(rng.choice([1, 2, 4, 8]))
+        base = [lambda: stag_amd.zoo.GCN(din, dout, allow_zero_in_degree=True), lambda: stag_amd.zoo.GraphSAGE(din, dout),
+                lambda: stag_amd.zoo.GIN(din, dout),
+                lambda: stag_amd.zoo.GAT(din, dout, num_heads=H, allow_zero_in_degree=True)][which]()
+        kw = qs[qi]()
+        layer = stag_amd.layers.StagLayer(base, vi=vi, **kw).to(dev)
+        what = f"layer fuzz {it}: n={n} E={g.number_of_edges()} {type(base).__name__} {din}->{dout} q={qi} vi={vi}" + (f" H={H}" if which == 3 else "")
+        x = torch.tensor(rng.standard_normal((n, din)).astype(np.float32), device=dev, requires_grad=True)
+        stag_amd.manual_seed(1000 + it)
+        out = layer(g, x)
+        gout = torch.tensor(rng.standard_normal(tuple(out.shape)).astype(np.float32), device=dev)
+        out.backward(gout)
+        w = layer._edge_weight_sample.detach()
+        assert w.shape == (g.number_of_edges(), H if which == 3 else din), what
+        grads = {k: p.grad.clone() for k, p in base.named_parameters() if p.grad is not None}
+        base.zero_grad(set_to_none=True)
+        x2 = x.detach().clone().requires_grad_(True)
+        out2 = base(g, x2, edge_weight=w)
+        out2.backward(gout)
+        assert_close(out, out2.detach().cpu().numpy(), what=what + " out")
+        sc = max(1.0, float(x2.grad.abs().max()))
+        assert_close(x.grad / sc, (x2.grad / sc).cpu().numpy(), what=what + " dx")
+        for k, p in base.named_parameters():
+            if p.grad is None:
+                continue
+            sc = max(1.0, float(p.grad.abs().max()))
+            assert_close(grads[k] / sc, (p.grad / sc).cpu().numpy(), what=what + f" d {k}")
+
+
 def test_training_step_reduces_loss(dev):
     """End to end: 3-layer GCN stack of scripts/arxiv_mle/gcn/run.py shape, Adam steps."""
     import stag_amd
