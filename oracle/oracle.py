@@ -76,6 +76,8 @@ def lib():
         _lib.stag_gat_fwd_drop_cpu.argtypes = [C.POINTER(Csr), _f32p, _f32p, _f32p, C.c_int32, C.c_int32, C.c_float,
                                                C.POINTER(NoiseSpec), _f32p, C.c_float, _f32p, _f32p]
         _lib.stag_philox4x32_10_cpu.argtypes = [_u32p, _u32p, _u32p]
+        _lib.stag_gat_bwd_cpu.argtypes = [C.POINTER(Csr), _f32p, _f32p, _f32p, _f32p, C.c_int32, C.c_int32, C.c_float,
+                                          C.POINTER(NoiseSpec), _f32p, C.c_float, _f32p, _f32p, _f32p, _f32p]
     return _lib
 
 
@@ -301,6 +303,24 @@ def gat_fwd(g, el, er, ft, neg_slope, spec, want_attn=False, keep=None, keep_pro
                                        float(neg_slope), C.byref(spec), _p(keep, _f32p), float(keep_prob),
                                        _p(out, _f32p), _p(attn, _f32p)), "gat_fwd")
     return (out, attn) if want_attn else out
+
+
+def gat_bwd(g, el, er, ft, gout, neg_slope, spec, keep=None, keep_prob=1.0, want_dw=False):
+    """CPU twin of stag_gat_bwd: (d_el [n_src, H], d_er [n_dst, H], d_ft [n_src, H, F], dw [E, H] | None) — the
+    gradients autograd returns for stag/zoo/gat.py:109-126 given d out = gout, in float64 rounded once; keep /
+    keep_prob: the attention-dropout mask of the forward (by edge id)."""
+    el, er, ft, gout = _f32(el), _f32(er), _f32(ft), _f32(gout)
+    H = el.shape[1]
+    F = ft.shape[-1] if ft.ndim == 3 else ft.shape[1] // H
+    d_el = np.zeros((g.n_src, H), np.float32)
+    d_er = np.zeros((g.n_dst, H), np.float32)
+    d_ft = np.zeros((g.n_src, H, F), np.float32)
+    dw = np.zeros((g.n_edges, H), np.float32) if want_dw else None
+    keep = None if keep is None else _f32(keep)
+    _check(lib().stag_gat_bwd_cpu(C.byref(g.c), _p(el, _f32p), _p(er, _f32p), _p(ft, _f32p), _p(gout, _f32p), H, F,
+                                  float(neg_slope), C.byref(spec), _p(keep, _f32p), float(keep_prob),
+                                  _p(d_el, _f32p), _p(d_er, _f32p), _p(d_ft, _f32p), _p(dw, _f32p)), "gat_bwd")
+    return d_el, d_er, d_ft, dw
 
 
 def coldot(x, t0, t1=None):

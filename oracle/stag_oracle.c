@@ -502,3 +502,122 @@ int stag_gat_fwd_drop_cpu(const stag_csr* csr, const float* el, const float* er,
   }
   return STAG_OK;
 }
+
+/* ------------------------------------------------------------------------- */
+/* GAT backward: what autograd returns for stag/zoo/gat.py:109-126 given d out = G.
+ *   s = el[u] + er[v];  lr = leaky_relu(s);  e = wt * lr  (wt = relu?(w) * in-norm factor, a constant of the
+ *   backward unless the weights are EXPLICIT and dw is asked for);  a = edge_softmax(e);  a' = a * keep / q
+ *   (attn_drop, :122);  out[v,h,:] = sum_e a'_e ft[u_e,h,:]  (:125-126).
+ *   d ft[u,h,:] += a'_e G[v,h,:];   dot_e = <G[v,h,:], ft[u_e,h,:]>;   d a_e = dot_e keep_e / q;
+ *   d e_e = a_e (d a_e - sum_e' a_e' d a_e')   [softmax];   d s_e = d e_e wt_e lrelu'(s_e);
+ *   d el[u_e,h] += d s_e;  d er[v,h] += d s_e;   d w_e = d e_e lr_e (1[w_e > 0] under relu; in-norm must be off).
+ * Everything in double, rounded once; edge data by edge id.  d_el [n_src, H], d_ft [n_src, H, F], d_er [n_dst, H],
+ * dw [E, H] (EXPLICIT weights only) — each may be NULL. */
+int stag_gat_bwd_cpu(const stag_csr* csr, const float* el, const float* er, const float* ft,
+                     const float* gout, int32_t H, int32_t F, float neg_slope,
+                     const stag_noise_spec* spec, const float* keep, float keep_prob,
+                     float* d_el, float* d_er, float* d_ft, float* dw) {
+  int rc = check_spec(spec);
+  if (rc) return rc;
+  if (!csr || !el || !er || !ft || !gout || H <= 0 || F <= 0) return STAG_EINVAL;
+  if (dw && (spec->kind != STAG_NOISE_EXPLICIT || spec->in_norm)) return STAG_EINVAL;
+  const int64_t E = csr->n_edges;
+  const int32_t nchunk = (H + 3) / 4;
+  /* pass 1 (rows in parallel): a' and d s of every (position, head) */
+  double* ap = (double*)malloc(sizeof(double) * (size_t)(E > 0 ? E : 1) * H);
+  double* ds = (double*)malloc(sizeof(double) * (size_t)(E > 0 ? E : 1) * H);
+  if (!ap || !ds) { free(ap); free(ds); return STAG_EINVAL; }
+#pragma omp parallel
+  {
+    float* scale = (float*)malloc(sizeof(float) * (size_t)H);
+#pragma omp for schedule(dynamic, 64)
+    for (int32_t v = 0; v < csr->n_dst; ++v) {
+      const int32_t b = csr->indptr[v], e = csr->indptr[v + 1];
+      const int32_t deg = e - b;
+      if (deg == 0) { if (d_er) for (int32_t h = 0; h < H; ++h) d_er[(int64_t)v * H + h] = 0.0f; continue; }
+      for (int32_t h = 0; h < H; ++h) scale[h] = 1.0f;
+      if (spec->in_norm) row_norm_scale(csr, spec, v, H, scale);
+      double* logit = (double*)malloc(sizeof(double) * (size_t)deg * H);
+      double* wt = (double*)malloc(sizeof(double) * (size_t)deg * H);
+      double* lr = (double*)malloc(sizeof(double) * (size_t)deg * H);
+      double* sl = (double*)malloc(sizeof(double) * (size_t)deg * H);   /* lrelu'(s) */
+      for (int32_t p = b; p < e; ++p) {
+        const int32_t u = csr->indices[p];
+        for (int32_t c = 0; c < nchunk; ++c) {
+          float w[4];
+          edge_weights4(csr, spec, p, c, H, w);
+          for (int j = 0; j < 4; ++j) {
+            const int32_t h = 4 * c + j;
+            if (h >= H) break;
+            const float s = el[(int64_t)u * H + h] + er[(int64_t)v * H + h];
+            const int64_t i = (int64_t)(p - b) * H + h;
+            lr[i] = s > 0.0f ? (double)s : (double)neg_slope * (double)s;
+            sl[i] = s > 0.0f ? 1.0 : (double)neg_slope;
+            wt[i] = (double)(w[j] * scale[h]);
+            /* the forward's logit is the fp32 product (stag_gat_fwd_cpu); the softmax is taken of that */
+            logit[i] = (double)((w[j] * scale[h]) * (s > 0.0f ? s : neg_slope * s));
+          }
+        }
+      }
+      for (int32_t h = 0; h < H; ++h) {
+        double mx = -INFINITY, den = 0.0, corr = 0.0;
+        for (int32_t q = 0; q < deg; ++q) if (logit[(int64_t)q * H + h] > mx) mx = logit[(int64_t)q * H + h];
+        for (int32_t q = 0; q < deg; ++q) den += exp(logit[(int64_t)q * H + h] - mx);
+        const float* gr = gout + ((int64_t)v * H + h) * F;
+        /* first sweep: a, d a, the softmax correction sum_e a_e d a_e */
+        for (int32_t q = 0; q < deg; ++q) {
+          const int64_t p = b + q, i = (int64_t)q * H + h;
+          const int64_t eid = csr->eid ? csr->eid[p] : p;
+          const double a = exp(logit[i] - mx) / den;
+          const double kq = keep ? (double)keep[eid * H + h] / (double)keep_prob : 1.0;
+          const float* fr = ft + ((int64_t)csr->indices[p] * H + h) * F;
+          double dot = 0.0;
+          for (int32_t f = 0; f < F; ++f) dot += (double)gr[f] * (double)fr[f];
+          ap[p * H + h] = a * kq;
+          ds[p * H + h] = dot * kq;          /* d a for now */
+          logit[i] = a;                      /* reuse: a */
+          corr += a * dot * kq;
+        }
+        double der = 0.0;
+        for (int32_t q = 0; q < deg; ++q) {
+          const int64_t p = b + q, i = (int64_t)q * H + h;
+          const double de = logit[i] * (ds[p * H + h] - corr);
+          if (dw) {
+            const int64_t eid = csr->eid ? csr->eid[p] : p;
+            double m = 1.0;
+            if (spec->relu && !(spec->p0[eid * H + h] > 0.0f)) m = 0.0;
+            dw[eid * H + h] = (float)(de * lr[i] * m);
+          }
+          ds[p * H + h] = de * wt[i] * sl[i];
+          der += ds[p * H + h];
+        }
+        if (d_er) d_er[(int64_t)v * H + h] = (float)der;
+      }
+      free(logit); free(wt); free(lr); free(sl);
+    }
+    free(scale);
+  }
+  /* pass 2: scatter by source, in position order, double accumulators */
+  if (d_el || d_ft) {
+    const int64_t ns = csr->n_src;
+    double* ael = d_el ? (double*)calloc((size_t)(ns > 0 ? ns : 1) * H, sizeof(double)) : NULL;
+    double* aft = d_ft ? (double*)calloc((size_t)(ns > 0 ? ns : 1) * H * F, sizeof(double)) : NULL;
+    for (int32_t v = 0; v < csr->n_dst; ++v)
+      for (int32_t p = csr->indptr[v]; p < csr->indptr[v + 1]; ++p) {
+        const int64_t u = csr->indices[p];
+        for (int32_t h = 0; h < H; ++h) {
+          if (ael) ael[u * H + h] += ds[(int64_t)p * H + h];
+          if (aft) {
+            const double a = ap[(int64_t)p * H + h];
+            const float* gr = gout + ((int64_t)v * H + h) * F;
+            double* o = aft + (u * H + h) * F;
+            for (int32_t f = 0; f < F; ++f) o[f] += a * (double)gr[f];
+          }
+        }
+      }
+    if (ael) { for (int64_t i = 0; i < ns * H; ++i) d_el[i] = (float)ael[i]; free(ael); }
+    if (aft) { for (int64_t i = 0; i < ns * H * F; ++i) d_ft[i] = (float)aft[i]; free(aft); }
+  }
+  free(ap); free(ds);
+  return STAG_OK;
+}

@@ -42,6 +42,13 @@ int stag_gat_fwd_drop_cpu(const stag_csr* csr, const float* el, const float* er,
                           const stag_noise_spec* spec, const float* keep, float keep_prob,
                           float* out, float* attn_out);
 
+/* twin of stag_gat_bwd (and of stag_gat_bwd_two_pass): d el, d er, d ft and, for EXPLICIT weights, dw [E, H] —
+ * what autograd returns for stag/zoo/gat.py:109-126; keep / keep_prob as in stag_gat_fwd_drop_cpu (NULL: no dropout) */
+int stag_gat_bwd_cpu(const stag_csr* csr, const float* el, const float* er, const float* ft,
+                     const float* gout, int32_t H, int32_t F, float neg_slope,
+                     const stag_noise_spec* spec, const float* keep, float keep_prob,
+                     float* d_el, float* d_er, float* d_ft, float* dw);
+
 #ifdef __cplusplus
 }
 #endif

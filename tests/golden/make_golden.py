@@ -429,6 +429,40 @@ def main():
     fx["model_l0_qa_loc_grad"] = l1.q_a.loc.grad.numpy()
     fx["model_l0_qa_log_scale_grad"] = l1.q_a.log_scale.grad.numpy()
 
+    # ---- (e) autograd gradients of the zoo layers with explicit weights (round 3) ---------------
+    #      loss = <gout, layer(g, x, edge_weight=w)>: d x, d w and every parameter gradient, by the reference's own
+    #      forward under torch autograd (stag/zoo/gcn.py:58-116, graph_sage.py:44-119, gat.py:74-149).  Placed after
+    #      every earlier draw so the older fixtures keep their values; the layers are rebuilt from the stored
+    #      state dicts.
+    torch.manual_seed(31)
+    g = G("hub40")
+    x0, w0 = torch.from_numpy(fx["zoo_x"]), torch.from_numpy(fx["zoo_w"])
+
+    def grads_of(tag, layer, w_init, out_shape):
+        x = x0.clone().requires_grad_(True)
+        w = w_init.clone().requires_grad_(True)
+        gout = torch.randn(*out_shape)
+        out = layer(g, x, edge_weight=w)
+        assert tuple(out.shape) == tuple(out_shape), (tag, out.shape)
+        (out * gout).sum().backward()
+        fx[f"{tag}_gout"] = gout.numpy()
+        fx[f"{tag}_grad_x"], fx[f"{tag}_grad_w"] = x.grad.numpy().copy(), w.grad.numpy().copy()
+        for k, prm in layer.named_parameters():
+            fx[f"{tag}_grad_{k}"] = prm.grad.numpy().copy()
+
+    gcn2 = zoo.GCN(16, 8)
+    gcn2.load_state_dict({"weight": torch.from_numpy(fx["gcn_weight"]), "bias": torch.from_numpy(fx["gcn_bias"])})
+    grads_of("gcn", gcn2, w0, (40, 8))
+    sage2 = zoo.GraphSAGE(16, 8, activation=torch.relu)
+    sage2.load_state_dict({k[len("sage_sd_"):]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("sage_sd_")})
+    grads_of("sage", sage2, w0, (40, 8))
+    for last in (False, True):
+        tag = "gat_last" if last else "gat"
+        gat2 = zoo.GAT(16, 4, num_heads=3, last=last)
+        gat2.load_state_dict({k[len(tag + "_sd_"):]: torch.from_numpy(v) for k, v in fx.items()
+                              if k.startswith(tag + "_sd_")})
+        grads_of(tag, gat2, torch.from_numpy(fx[f"{tag}_w"]), (40, 4) if last else (40, 12))
+
     path = os.path.join(OUT, "stag_reference.npz")
     np.savez_compressed(path, **fx)
     print(f"wrote {path}: {len(fx)} arrays, {os.path.getsize(path)} bytes; torch {torch.__version__}")

@@ -86,6 +86,35 @@ def test_gcn_sage_gat_modules_golden(dev, golden):
         assert_close(attn, golden[tag + "_attn"], what=tag + " attention")
 
 
+def test_gcn_sage_gat_module_gradients_golden(dev, golden):
+    """The reference's own autograd gradients (tests/golden/make_golden.py (e): loss = <gout, layer(g, x, edge_weight=w)>
+    through stag/zoo/gcn.py:58-116, graph_sage.py:44-119, gat.py:74-149) against the HIP backward paths: d x, d w and
+    every parameter gradient of zoo.GCN, zoo.GraphSAGE and zoo.GAT (both `last` modes)."""
+    import stag_amd
+    g = _graph(golden, "hub40", dev)
+
+    def check(tag, layer, w_key):
+        x = torch.from_numpy(golden["zoo_x"]).to(dev).requires_grad_(True)
+        w = torch.from_numpy(golden[w_key]).to(dev).requires_grad_(True)
+        out = layer(g, x, edge_weight=w)
+        (out * torch.from_numpy(golden[f"{tag}_gout"]).to(dev)).sum().backward()
+        for name, got in [("x", x.grad), ("w", w.grad)] + [(k, p.grad) for k, p in layer.named_parameters()]:
+            ref = golden[f"{tag}_grad_{name}"]
+            sc = max(1.0, float(np.abs(ref).max()))
+            assert_close(got.reshape(ref.shape) / sc, ref / sc, what=f"{tag} d {name}")
+
+    gcn = stag_amd.zoo.GCN(16, 8).to(dev)
+    gcn.load_state_dict({"weight": torch.from_numpy(golden["gcn_weight"]), "bias": torch.from_numpy(golden["gcn_bias"])})
+    check("gcn", gcn, "zoo_w")
+    sage = stag_amd.zoo.GraphSAGE(16, 8, activation=torch.relu).to(dev)
+    sage.load_state_dict(_sd(golden, "sage_sd_", dev))
+    check("sage", sage, "zoo_w")
+    for tag, last in (("gat", False), ("gat_last", True)):
+        gat = stag_amd.zoo.GAT(16, 4, num_heads=3, last=last).to(dev)
+        gat.load_state_dict(_sd(golden, tag + "_sd_", dev))
+        check(tag, gat, tag + "_w")
+
+
 def test_gated_gcn_module_golden(dev, golden):
     """zoo.GatedGCN against the reference's own forward (stag/zoo/gated_gcn.py:25-55)."""
     import stag_amd
@@ -692,7 +721,10 @@ def _gat_torch_reference(src, dst, n, el, er, ft, w, neg_slope):
 
 @pytest.mark.parametrize("H,F", [(8, 32), (3, 4), (2, 16)])
 @pytest.mark.parametrize("mode", ["none", "explicit", "noise", "noise_norm"])
-def test_gat_backward(dev, H, F, mode):
+def test_gat_backward(dev, oracle, H, F, mode):
+    """stag_gat_bwd against its CPU twin (oracle.gat_bwd = stag_gat_bwd_cpu, float64; pinned by the reference's own
+    autograd gradients in tests/test_oracle_golden.py::test_gat_gradients_golden); the torch statement on the device
+    stays as a second opinion."""
     import stag_amd
     from stag_amd import _lib, ops
     from util import random_graph
@@ -721,6 +753,30 @@ def test_gat_backward(dev, H, F, mode):
     el2, er2, ft2 = (t.clone().requires_grad_(True) for t in (el0, er0, ft0))
     ref = _gat_torch_reference(src, dst, n, el2, er2, ft2, w_ref, 0.2)
     ref.backward(G)
+    from util import assert_gat_grads_vs_oracle
+    og = oracle_graph(oracle, g)
+    if mode == "noise":
+        spec = oracle.make_spec("normal", 1.0, 0.3, seed=3, offset=1, Dn=H, n_edges=E)
+    elif mode == "noise_norm":
+        spec = oracle.make_spec("bernoulli", 0.7, None, in_norm=True, seed=3, offset=1, Dn=H, n_edges=E)
+    elif mode == "explicit":
+        spec = oracle.make_spec("explicit", w0.cpu().numpy())
+    else:
+        spec = oracle.make_spec("none")
+    assert_gat_grads_vs_oracle(oracle, og, el0.cpu().numpy(), er0.cpu().numpy(), ft0.cpu().numpy(), G.cpu().numpy(), spec,
+                               [el.grad, er.grad, ft.grad], got_dw=weight.grad if mode == "explicit" else None,
+                               what=f"gat bwd {mode} H={H} F={F}", dev=dev)
+    # the two-gather form of the same backward
+    ops._GAT_BWD_ONE_GATHER = False
+    try:
+        t3 = [t.clone().requires_grad_(True) for t in (el0, er0, ft0)]
+        w3 = w0.clone().requires_grad_(True) if mode == "explicit" else weight
+        ops.gat_aggregate(g, *t3, 0.2, w3, seg_len=32).backward(G)
+    finally:
+        ops._GAT_BWD_ONE_GATHER = True
+    assert_gat_grads_vs_oracle(oracle, og, el0.cpu().numpy(), er0.cpu().numpy(), ft0.cpu().numpy(), G.cpu().numpy(), spec,
+                               [a_.grad for a_ in t3], got_dw=w3.grad if mode == "explicit" else None,
+                               what=f"gat bwd two-pass {mode} H={H} F={F}", dev=dev)
     assert_close(out, ref.detach().cpu().numpy(), what="gat forward")
     assert_close(ft.grad, ft2.grad.cpu().numpy(), what="d ft")
     assert_close(el.grad, el2.grad.cpu().numpy(), what="d el")

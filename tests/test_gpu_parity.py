@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import TOL, assert_close, assert_close_cond, oracle_graph, random_graph, scaled_err
+from util import TOL, assert_close, assert_close_cond, assert_gat_grads_vs_oracle, hw_normals, oracle_graph, random_graph, scaled_err
 
 pytestmark = pytest.mark.gpu
 # the seeded sweeps run FUZZ_SCALE times their committed number of cases (the first ones are the same cases):
@@ -637,6 +637,12 @@ def test_fuzz_gat_against_oracle_and_composed_backward(dev, oracle):
         assert_close(attn, ref_attn, tol=tol, what=what + " attn")
         G = torch.from_numpy(rng.standard_normal((n, H, F)).astype(np.float32)).to(dev)
         out.backward(G)
+        # primary: the CPU twin of the backward (oracle.gat_bwd, float64); the composed statement under autograd below
+        # is the second opinion
+        with hw_normals(oracle, dev):
+            ref_hw = oracle.gat_fwd(og, el, er, ft, 0.2, spec)
+        assert_close(out, ref_hw, tol=tol, what=what + " out (device tables)")
+        assert_gat_grads_vs_oracle(oracle, og, el, er, ft, G.cpu().numpy(), spec, [a_.grad for a_ in t], what=what, dev=dev, tol=tol)
         t2 = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (el, er, ft)]
         out2 = ops.gat_aggregate(g, *t2, 0.2, w, seg_len=seg_len if seg_len else 64, attn_fn=lambda a_: a_)   # the composed path
         out2.backward(G)
@@ -653,6 +659,8 @@ def test_fuzz_gat_against_oracle_and_composed_backward(dev, oracle):
         for a_, b_, nm in zip(t3, t2, ("d el", "d er", "d ft")):
             sc = max(1.0, float(b_.grad.abs().max()))
             assert_close(a_.grad / sc, (b_.grad / sc).cpu().numpy(), what=what + " two-pass " + nm)
+        assert_gat_grads_vs_oracle(oracle, og, el, er, ft, G.cpu().numpy(), spec, [a_.grad for a_ in t3],
+                                   what=what + " two-pass", dev=dev, tol=tol)
 
 
 @pytest.mark.parametrize("kind,relu,logs", [("normal", False, False), ("normal", True, True), ("uniform", True, False)])
@@ -794,6 +802,8 @@ def test_gat_attention_dropout_in_the_kernels(dev, oracle, H, F, kind):
     out2 = ops.gat_aggregate(g, *t2, 0.2, w, attn_fn=lambda a_: a_ * keep / keep_prob)          # the composed path
     assert_close(out2, ref, what="composed forward vs oracle")
     out2.backward(G)
+    assert_gat_grads_vs_oracle(oracle, og, el, er, ft, G.cpu().numpy(), spec, [a_.grad for a_ in t],
+                               keep=keep.cpu().numpy(), keep_prob=keep_prob, got_dw=got_dw, what="dropout", dev=dev)
     for a_, b_, nm in zip(t, t2, ("d el", "d er", "d ft")):
         sc = max(1.0, float(b_.grad.abs().max()))
         assert_close(a_.grad / sc, (b_.grad / sc).cpu().numpy(), what=nm)
@@ -868,6 +878,8 @@ def test_fuzz_gat_attention_dropout(dev, oracle):
             _, attn = ops.gat_aggregate(g, *[x_.detach() for x_ in t], 0.2, w.detach() if torch.is_tensor(w) else w, want_attn=True)
             src_, dst_ = g.edges()
             term = float((attn * keep / keep_prob * (G[dst_] * t[2].detach()[src_]).sum(-1)).abs().max()) if E else 0.0
+        assert_gat_grads_vs_oracle(oracle, og, el, er, ft, G.cpu().numpy(), spec, [a_.grad for a_ in t],
+                                   keep=keep.cpu().numpy(), keep_prob=keep_prob, got_dw=got_dw, what=what, dev=dev)
         for a_, b_, nm in zip(t, t2, ("d el", "d er", "d ft")):
             sc = max(1.0, float(b_.grad.abs().max()), term if nm != "d ft" else 0.0)
             assert_close(a_.grad / sc, (b_.grad / sc).cpu().numpy(), what=what + " " + nm)

@@ -228,3 +228,116 @@ def test_segment_reduce_oracle(oracle):
     offs = np.array([0, 3, 3, 8], np.int32)
     assert np.allclose(oracle.segment_reduce(x, offs), [x[:3].sum(0), np.zeros(3), x[3:].sum(0)])
     assert np.allclose(oracle.segment_reduce(x, offs, oracle.REDUCE_MEAN), [x[:3].mean(0), np.zeros(3), x[3:].mean(0)])
+
+
+# ---- gradients: the oracle's backward twins against the reference's autograd (round 3) -----------------------
+# tests/golden/make_golden.py (e): loss = <gout, layer(g, x, edge_weight=w)> through the reference's own forward;
+# the fixtures hold d x, d w and every parameter gradient.
+def _relerr(got, ref):
+    """gradients are compared relative to their own scale (a weight gradient sums 40 rows)"""
+    ref = np.asarray(ref, np.float64)
+    sc = max(1.0, float(np.abs(ref).max()))
+    return np.asarray(got, np.float64) / sc, ref / sc
+
+
+def test_gcn_gradients_golden(oracle, golden):
+    """d/dx = the transposed aggregation, d/dw = agg_bwd_w, around GCN's dense transform (stag/zoo/gcn.py:67-108)."""
+    g, src, dst, n, ind, outd = _g(oracle, golden, "hub40")
+    x, w, gout = golden["zoo_x"], golden["zoo_w"], golden["gcn_gout"].astype(np.float64)
+    W = golden["gcn_weight"].astype(np.float64)
+    ss = np.maximum(outd, 1).astype(np.float32) ** -0.5
+    ds = np.maximum(ind, 1).astype(np.float32) ** -0.5
+    spec = oracle.make_spec("explicit", w)
+    agg = oracle.agg_fwd(g, x, spec, src_scale=ss, dst_scale=ds).astype(np.float64)
+    assert_close(*_relerr(agg.T @ gout, golden["gcn_grad_weight"]), what="gcn d weight")
+    assert_close(*_relerr(gout.sum(0), golden["gcn_grad_bias"]), what="gcn d bias")
+    g_agg = (gout @ W.T).astype(np.float32)                     # d L / d agg
+    dx = oracle.agg_fwd(g.transpose(), g_agg, spec, src_scale=ds, dst_scale=ss)
+    assert_close(*_relerr(dx, golden["gcn_grad_x"]), what="gcn d x")
+    dw = oracle.agg_bwd_w(g, x, g_agg * ds[:, None], src_scale=ss)
+    assert_close(*_relerr(dw, golden["gcn_grad_w"]), what="gcn d w")
+
+
+def test_sage_gradients_golden(oracle, golden):
+    """GraphSAGE mean path under autograd (stag/zoo/graph_sage.py:70-75, 107-118), relu activation."""
+    g, src, dst, n, ind, outd = _g(oracle, golden, "hub40")
+    x, w = golden["zoo_x"], golden["zoo_w"]
+    Ws, Wn = golden["sage_sd_fc_self.weight"].astype(np.float64), golden["sage_sd_fc_neigh.weight"].astype(np.float64)
+    spec = oracle.make_spec("explicit", w)
+    neigh = oracle.agg_fwd(g, x, spec, reduce=oracle.REDUCE_MEAN).astype(np.float64)
+    pre = x @ Ws.T + neigh @ Wn.T + golden["sage_sd_bias"]
+    gp = golden["sage_gout"].astype(np.float64) * (pre > 0)
+    assert_close(*_relerr(gp.sum(0), golden["sage_grad_bias"]), what="sage d bias")
+    assert_close(*_relerr(gp.T @ x, golden["sage_grad_fc_self.weight"]), what="sage d fc_self")
+    assert_close(*_relerr(gp.T @ neigh, golden["sage_grad_fc_neigh.weight"]), what="sage d fc_neigh")
+    g_neigh = (gp @ Wn).astype(np.float32)
+    inv = (1.0 / np.maximum(ind, 1)).astype(np.float32)
+    dx = oracle.agg_fwd(g.transpose(), g_neigh, spec, src_scale=inv).astype(np.float64) + gp @ Ws
+    assert_close(*_relerr(dx, golden["sage_grad_x"]), what="sage d x")
+    dw = oracle.agg_bwd_w(g, x, g_neigh * inv[:, None])
+    assert_close(*_relerr(dw, golden["sage_grad_w"]), what="sage d w")
+
+
+@pytest.mark.parametrize("tag", ["gat", "gat_last"])
+def test_gat_gradients_golden(oracle, golden, tag):
+    """oracle.gat_bwd (stag_gat_bwd_cpu) inside the layer's chain rule against the reference's autograd through
+    stag/zoo/gat.py:93-141: d x, d edge_weight, d fc.weight, d attn_l, d attn_r, d bias."""
+    g, *_ = _g(oracle, golden, "hub40")
+    x, wh = golden["zoo_x"].astype(np.float64), golden[f"{tag}_w"]
+    H, F = 3, 4
+    Wfc = golden[f"{tag}_sd_fc.weight"].astype(np.float64)
+    al, ar = golden[f"{tag}_sd_attn_l"].astype(np.float64).reshape(1, H, F), golden[f"{tag}_sd_attn_r"].astype(np.float64).reshape(1, H, F)
+    ft = (x @ Wfc.T).reshape(-1, H, F)
+    el, er = (ft * al).sum(-1), (ft * ar).sum(-1)
+    gout = golden[f"{tag}_gout"].astype(np.float64)
+    # rst + bias, then mean over the heads (last) or flatten (stag/zoo/gat.py:133-141)
+    G = np.repeat(gout[:, None, :], H, 1) / H if tag == "gat_last" else gout.reshape(-1, H, F)
+    d_el, d_er, d_ft, dw = oracle.gat_bwd(g, el, er, ft, G, 0.2, oracle.make_spec("explicit", wh), want_dw=True)
+    assert_close(*_relerr(G.sum(0).reshape(-1), golden[f"{tag}_grad_bias"]), what=tag + " d bias")
+    assert_close(*_relerr(dw, golden[f"{tag}_grad_w"]), what=tag + " d w")
+    assert_close(*_relerr((d_el[:, :, None] * ft).sum(0), golden[f"{tag}_grad_attn_l"].reshape(H, F)), what=tag + " d attn_l")
+    assert_close(*_relerr((d_er[:, :, None] * ft).sum(0), golden[f"{tag}_grad_attn_r"].reshape(H, F)), what=tag + " d attn_r")
+    d_ft_all = (d_ft.astype(np.float64) + d_el[:, :, None] * al + d_er[:, :, None] * ar).reshape(-1, H * F)
+    assert_close(*_relerr(d_ft_all.T @ x, golden[f"{tag}_grad_fc.weight"]), what=tag + " d fc.weight")
+    assert_close(*_relerr(d_ft_all @ Wfc, golden[f"{tag}_grad_x"]), what=tag + " d x")
+
+
+def test_gat_bwd_oracle_equals_float64_autograd(oracle):
+    """stag_gat_bwd_cpu with every option the device kernels take — drawn weights, relu, in-norm, the attention-dropout
+    mask — against torch autograd in float64 through the plain statement of stag/zoo/gat.py:114-126."""
+    import torch
+    rng = np.random.default_rng(11)
+    n, E, H, F = 50, 600, 4, 8
+    src = rng.integers(0, n, E)
+    dst = np.concatenate([rng.integers(0, n - 1, E - 150), np.full(150, 3)])
+    indptr, indices, eid, *_ = oracle.csr_build(src, dst, n, n)
+    g = oracle.CsrGraph(indptr, indices, eid, n_src=n)
+    el, er = rng.standard_normal((n, H)).astype(np.float32), rng.standard_normal((n, H)).astype(np.float32)
+    ft, G = rng.standard_normal((n, H, F)).astype(np.float32), rng.standard_normal((n, H, F)).astype(np.float32)
+    keep = (rng.random((E, H)) < 0.6).astype(np.float32)
+    wx = rng.uniform(-0.5, 1.5, (E, H)).astype(np.float32)
+    cases = [("none", oracle.make_spec("none"), None, False),
+             ("explicit+relu", oracle.make_spec("explicit", wx, relu=True), None, True),
+             ("normal", oracle.make_spec("normal", 1.0, 0.4, seed=5, offset=2, Dn=H, n_edges=E), keep, False),
+             ("bernoulli+norm", oracle.make_spec("bernoulli", 0.7, None, in_norm=True, seed=5, offset=3, Dn=H, n_edges=E), keep, False)]
+    S, Dt = torch.from_numpy(src).long(), torch.from_numpy(dst).long()
+    for name, spec, kp, want_dw in cases:
+        w_eff = oracle.noise_materialize(g, spec, H) if spec.kind != oracle.NOISE_NONE else np.ones((E, H), np.float32)
+        tl, tr, tf = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (el, er, ft))
+        tw = torch.tensor(wx if want_dw else w_eff, dtype=torch.float64, requires_grad=want_dw)
+        e = (tw.relu() if want_dw else tw) * torch.nn.functional.leaky_relu(tl[S] + tr[Dt], 0.2)
+        mx = torch.full((n, H), -float("inf"), dtype=torch.float64).scatter_reduce(0, Dt[:, None].expand(-1, H), e.detach(), "amax")
+        ex = torch.exp(e - mx[Dt])
+        a = ex / torch.zeros((n, H), dtype=torch.float64).index_add_(0, Dt, ex)[Dt]
+        if kp is not None:
+            a = a * torch.tensor(kp, dtype=torch.float64) / 0.6
+        out = torch.zeros((n, H, F), dtype=torch.float64).index_add_(0, Dt, a[:, :, None] * tf[S])
+        out.backward(torch.tensor(G, dtype=torch.float64))
+        fwd = oracle.gat_fwd(g, el, er, ft, 0.2, spec, keep=kp, keep_prob=0.6)
+        assert_close(fwd, out.detach().numpy(), what=name + " forward")
+        d_el, d_er, d_ft, dw = oracle.gat_bwd(g, el, er, ft, G, 0.2, spec, keep=kp, keep_prob=0.6, want_dw=want_dw)
+        assert_close(d_el, tl.grad.numpy(), what=name + " d el")
+        assert_close(d_er, tr.grad.numpy(), what=name + " d er")
+        assert_close(d_ft, tf.grad.numpy(), what=name + " d ft")
+        if want_dw:
+            assert_close(dw, tw.grad.numpy(), what=name + " d w")

@@ -86,3 +86,35 @@ class hw_normals:
     def __exit__(self, *exc):
         self.oracle.set_normal_tables(None)
         return False
+
+
+def assert_gat_grads_vs_oracle(oracle, og, el, er, ft, G, spec, got, keep=None, keep_prob=1.0, got_dw=None,
+                               what="", dev=None, tol=TOL):
+    """The GAT backward (stag_gat_bwd / stag_gat_bwd_two_pass / the composed calls) against its CPU twin
+    oracle.gat_bwd (stag_gat_bwd_cpu: float64, what autograd returns for stag/zoo/gat.py:109-126).
+    got = (d el, d er, d ft) device tensors; got_dw: d w [E, H] for explicit weights.  Gradients are compared
+    relative to their own scale; d el / d er — sums of d s[e,h] = a' <G, ft[u]> - a <G, out[v]>, two dot products
+    that can cancel exactly (a row with one kept in-edge) — also relative to the largest term a' <G, ft[u]>."""
+    el, er, ft, G = (np.asarray(a, np.float32) for a in (el, er, ft, G))
+    ctx = hw_normals(oracle, dev) if dev is not None else None
+    if ctx is not None:
+        ctx.__enter__()
+    try:
+        d_el, d_er, d_ft, dw = oracle.gat_bwd(og, el, er, ft, G, 0.2, spec, keep=keep, keep_prob=keep_prob,
+                                              want_dw=got_dw is not None)
+        _, attn = oracle.gat_fwd(og, el, er, ft, 0.2, spec, want_attn=True, keep=keep, keep_prob=keep_prob)
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+    term = 0.0
+    if og.n_edges:
+        eid = og.eid if og.eid is not None else np.arange(og.n_edges)
+        u, v = og.indices, og.dst_of_pos
+        dots = np.einsum("phf,phf->ph", G[v].astype(np.float64), ft[u].astype(np.float64))
+        term = float(np.abs(attn[eid].astype(np.float64) * dots).max())
+    for g_, r_, nm in zip(got, (d_el, d_er, d_ft), ("d el", "d er", "d ft")):
+        sc = max(1.0, float(np.abs(r_).max()) if r_.size else 0.0, term if nm != "d ft" else 0.0)
+        assert_close(g_.detach().cpu().numpy() / sc, r_.astype(np.float64) / sc, tol=tol, what=f"{what} {nm} vs oracle")
+    if got_dw is not None:
+        sc = max(1.0, float(np.abs(dw).max()) if dw.size else 0.0)
+        assert_close(got_dw.detach().cpu().numpy() / sc, dw.astype(np.float64) / sc, tol=tol, what=f"{what} d w vs oracle")
