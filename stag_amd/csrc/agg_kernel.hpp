@@ -212,8 +212,14 @@ __device__ __forceinline__ void two_level_sum(const float* ws, int ws_stride, in
 }
 
 // epilogue shared by whole-row units and the last-arriver combine
+__device__ __forceinline__ void agg_epilogue_to(const AggArgs& a, float* out, float* norm_scale_out, int v, int deg,
+                                                int k0, bool vec, float (&acc)[4], const float (&wsum)[4]);
 __device__ __forceinline__ void agg_epilogue(const AggArgs& a, int v, int deg, int k0, bool vec,
                                              float (&acc)[4], const float (&wsum)[4]) {
+  agg_epilogue_to(a, a.out, a.norm_scale_out, v, deg, k0, vec, acc, wsum);
+}
+__device__ __forceinline__ void agg_epilogue_to(const AggArgs& a, float* out, float* norm_scale_out, int v, int deg,
+                                                int k0, bool vec, float (&acc)[4], const float (&wsum)[4]) {
   float dv = a.dst_scale ? a.dst_scale[v] : 1.0f;
   if (a.mean) dv *= __builtin_amdgcn_rcpf((float)(deg > 1 ? deg : 1));
   if (a.in_norm) {
@@ -224,12 +230,12 @@ __device__ __forceinline__ void agg_epilogue(const AggArgs& a, int v, int deg, i
       s[j] = (wsum[j] != 0.0f) ? (float)deg / wsum[j] : 1.0f;
       acc[j] *= s[j];
     }
-    if (a.norm_scale_out) store4(a.norm_scale_out + (int64_t)v * a.D, k0, a.D, vec, s);
+    if (norm_scale_out) store4(norm_scale_out + (int64_t)v * a.D, k0, a.D, vec, s);
   }
-  if (!a.out) return;      // only the in-norm factor was asked for
+  if (!out) return;      // only the in-norm factor was asked for
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] *= dv;
-  store4(a.out + (int64_t)v * a.ldo, k0, a.D, vec, acc);
+  store4(out + (int64_t)v * a.ldo, k0, a.D, vec, acc);
 }
 
 __device__ __forceinline__ void agg_epilogue_extra(const AggArgs& a, float* out, int v, int deg, int k0,
@@ -391,6 +397,12 @@ struct ExtraAcc {
 template <>
 struct ExtraAcc<0> {};
 template <int N>
+struct ExtraW {           // MC + in-norm: the weight sums of samples 1..N (stag/layers.py:12-15, per sample)
+  float w[N][4] = {};
+};
+template <>
+struct ExtraW<0> {};
+template <int N>
 struct ExtraKeys {        // MC: the Philox keys of samples 1..N (SGPRs)
   PhiloxKey k[N];
 };
@@ -400,8 +412,10 @@ struct ExtraKeys<0> {};
 // NOUT outputs from one pass over the gathered rows.  MC = false: 1, or 3 = the weight and its two
 // parameter derivatives (stag_agg_bwd).  MC = true: NOUT Monte-Carlo samples, sample s drawn at
 // offset + s * stride (stag_agg_fwd_mc; the n_samples loop of stag/models.py:45-55 on layer 1).
-template <int KIND, int LPE, bool VEC, int PEDGE, int BLK, int MULT = 1, int NOUT = 1, bool MC = false>
+// WN (MC only): every sample keeps its own in-norm weight sums (registers: two samples per pass, not four)
+template <int KIND, int LPE, bool VEC, int PEDGE, int BLK, int MULT = 1, int NOUT = 1, bool MC = false, bool WN = false>
 struct AggTeam {
+  static_assert(!WN || MC, "per-sample weight sums belong to the Monte-Carlo form");
   static constexpr int NB = BLK * MULT;
   static constexpr int NX = NOUT - 1;              // extra outputs
   static_assert(NOUT == 1 || PEDGE == 0, "extra outputs: scalar / per-channel parameters");
@@ -421,6 +435,7 @@ struct AggTeam {
   const bool kahan;
   [[no_unique_address]] ExtraAcc<NX> X;
   [[no_unique_address]] ExtraKeys<MC ? NX : 0> KX;
+  [[no_unique_address]] ExtraW<WN ? NX : 0> XW;
   [[no_unique_address]] OwnRow<PEDGE == 3 || PEDGE == 4> XO;     // the unit's own row of a.xown (times own_scale)
   [[no_unique_address]] DpAcc<PEDGE == 4> DP;      // this lane's share of the two parameter gradients
   static constexpr bool P1 = PEDGE == 1 || PEDGE == 3;
@@ -486,6 +501,12 @@ struct AggTeam {
           draw4<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w);
 #pragma unroll
           for (int o = 0; o < NX; ++o) draw4<KIND>(I.nn[j], c1, KX.k[o], pa, pb, a.relu, dd.acc[o]);
+          if constexpr (WN) {
+#pragma unroll
+            for (int o = 0; o < NX; ++o)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) XW.w[o][q] += dd.acc[o][q];
+          }
         }
         if (a.src_scale) {
           asm volatile("" ::: "memory");   // keep this a branch: as selects it costs 6 VALU ops per edge
@@ -629,7 +650,7 @@ struct AggTeam {
 
 // One unit (a whole row or a segment of a long row) on LPE x SLOTS lanes of a wave:
 // c = this lane's chunk (4 channels) of the channel tile, sl = its edge slot.
-template <int KIND, int LPE, bool VEC, int PEDGE, int SLOTS, int MULT, int NOUT = 1, bool MC = false>
+template <int KIND, int LPE, bool VEC, int PEDGE, int SLOTS, int MULT, int NOUT = 1, bool MC = false, bool WN = false>
 __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const int c, const int sl,
                                          float (*dp_out)[4] = nullptr) {
   static_assert(LPE * SLOTS <= 64 && 64 % (LPE * SLOTS) == 0, "a unit's lanes stay inside one wave");
@@ -676,7 +697,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   if (trace) { trace[0] = wall_clock64(); trace[1] = trace[2] = trace[3] = 0; }
 #endif
 
-  AggTeam<KIND, LPE, VEC, PEDGE, BLK, MULT, NOUT, MC> T{
+  AggTeam<KIND, LPE, VEC, PEDGE, BLK, MULT, NOUT, MC, WN> T{
       a, (KIND >= kNormal) ? resolve_epoch(a.key) : a.key, k0, (uint32_t)k0 * 4u,
       (chunk + a.chunk_base) | (a.pos_hi << 20),   // Philox counter word 1: a per-lane constant
       b + len,
@@ -814,7 +835,10 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
     agg_epilogue(a, v, len, k0, VEC, T.acc, T.wsum);
     if constexpr (NOUT > 1) {
 #pragma unroll
-      for (int o = 0; o < NOUT - 1; ++o) agg_epilogue_extra(a, a.outx[o], v, len, k0, VEC, T.X.acc[o]);
+      for (int o = 0; o < NOUT - 1; ++o) {
+        if constexpr (WN) agg_epilogue_to(a, a.outx[o], nullptr, v, len, k0, VEC, T.X.acc[o], T.XW.w[o]);
+        else agg_epilogue_extra(a, a.outx[o], v, len, k0, VEC, T.X.acc[o]);
+      }
     }
 #ifdef STAG_TRACE
     if (trace) trace[3] = wall_clock64();
@@ -830,11 +854,14 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   const uint32_t woff = (uint32_t)slot * ((uint32_t)a.ws_stride * 4u) + (uint32_t)k0 * 4u;
   if (sl == 0) {
     store4_sc1(rws, woff, k0, a.D, VEC, T.acc);
-    if (PEDGE != 3 && PEDGE != 4 && a.in_norm) store4_sc1(rws, woff + (uint32_t)a.D * 4u, k0, a.D, VEC, T.wsum);
+    // a segment's row of the workspace: the partial sums of output o at o * D, its weight sums (in-norm) at (NOUT + o) * D
+    if (PEDGE != 3 && PEDGE != 4 && a.in_norm) store4_sc1(rws, woff + (uint32_t)(NOUT * a.D) * 4u, k0, a.D, VEC, T.wsum);
     if constexpr (NOUT > 1) {
 #pragma unroll
-      for (int o = 0; o < NOUT - 1; ++o)
+      for (int o = 0; o < NOUT - 1; ++o) {
         store4_sc1(rws, woff + (uint32_t)(o + 1) * (uint32_t)a.D * 4u, k0, a.D, VEC, T.X.acc[o]);
+        if constexpr (WN) store4_sc1(rws, woff + (uint32_t)(NOUT + o + 1) * (uint32_t)a.D * 4u, k0, a.D, VEC, T.XW.w[o]);
+      }
     }
   }
   const int s0 = a.long_seg_ptr[r], s1 = a.long_seg_ptr[r + 1];
@@ -867,13 +894,18 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   float facc[4], fws[4] = {0.f, 0.f, 0.f, 0.f};
   const int slot0 = lane0 + (c << 2);   // slot 0's lane of my channels
   two_level_sum<NF, VEC, LPE, SLOTS>(a.ws, a.ws_stride, s0, s1, k0, a.D, sl, slot0, facc);
-  if (PEDGE != 3 && PEDGE != 4 && a.in_norm) two_level_sum<NF, VEC, LPE, SLOTS>(a.ws + a.D, a.ws_stride, s0, s1, k0, a.D, sl, slot0, fws);
+  if (PEDGE != 3 && PEDGE != 4 && a.in_norm) two_level_sum<NF, VEC, LPE, SLOTS>(a.ws + NOUT * a.D, a.ws_stride, s0, s1, k0, a.D, sl, slot0, fws);
   if (sl != 0) return;
   agg_epilogue(a, row, deg, k0, VEC, facc, fws);
 #pragma unroll
   for (int o = 0; o < NOUT - 1; ++o) {
     two_level_sum<NF, VEC, LPE, SLOTS>(a.ws + (o + 1) * a.D, a.ws_stride, s0, s1, k0, a.D, sl, slot0, facc);
-    agg_epilogue_extra(a, a.outx[o], row, deg, k0, VEC, facc);
+    if constexpr (WN) {
+      two_level_sum<NF, VEC, LPE, SLOTS>(a.ws + (NOUT + o + 1) * a.D, a.ws_stride, s0, s1, k0, a.D, sl, slot0, fws);
+      agg_epilogue_to(a, a.outx[o], nullptr, row, deg, k0, VEC, facc, fws);
+    } else {
+      agg_epilogue_extra(a, a.outx[o], row, deg, k0, VEC, facc);
+    }
   }
 #ifdef STAG_TRACE
   if (trace) trace[3] = wall_clock64();
@@ -916,7 +948,7 @@ constexpr int heavy_slots_of() {
          : LPE == 16 ? STAG_HSLOTS_LPE16 : LPE == 32 ? STAG_HSLOTS_LPE32 : 1;
 }
 
-template <int KIND, int LPE, bool VEC, int PEDGE, int NOUT = 1, bool MC = false>
+template <int KIND, int LPE, bool VEC, int PEDGE, int NOUT = 1, bool MC = false, bool WN = false>
 __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_kernel(const AggArgs a) {
   constexpr int HS = (NOUT == 1 && PEDGE != 3) ? heavy_slots_of<LPE>() : 1;
   const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
@@ -933,7 +965,7 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
   }
   const int unit = first + blk * (STAG_BLOCK_THREADS / LPE) + threadIdx.x / LPE;
   if (unit >= a.n_units) return;
-  agg_unit<KIND, LPE, VEC, PEDGE, 1, NOUT == 1 ? mult_of<KIND, LPE>() : 1, NOUT, MC>(a, unit, c, 0);
+  agg_unit<KIND, LPE, VEC, PEDGE, 1, NOUT == 1 ? mult_of<KIND, LPE>() : 1, NOUT, MC, WN>(a, unit, c, 0);
 }
 
 // The dx pass that also sums the gradients of scalar / per-channel parameters (PEDGE 4; stag_agg_bwd_dp).  A unit's
@@ -988,6 +1020,11 @@ inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles
     if (a.mc && a.outx[2]) {   // four Monte-Carlo samples per gathered row (validated on the host: !pedge)
       if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 4, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
       else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 4, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      return;
+    }
+    if (a.mc && a.outx[0] && a.in_norm) {   // two, each with its own in-norm weight sums
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 2, true, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 2, true, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
       return;
     }
     if (a.mc && a.outx[0]) {   // two

@@ -662,12 +662,11 @@ static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x
     if (!plan->long_rows || !plan->long_seg_ptr || !plan->workspace || !plan->seg_counters)
       return STAG_EINVAL;
     // partial rows: [D sums | D weight sums if in-norm], or [nout x D] with extra outputs
-    const size_t need = nout > 1 ? stag_plan_workspace_bytes(plan->n_seg, nout * D, 0)
-                                 : stag_plan_workspace_bytes(plan->n_seg, D, spec->in_norm);
+    const size_t need = stag_plan_workspace_bytes(plan->n_seg, nout * D, spec->in_norm);
     if (plan->workspace_bytes < need) return STAG_ENOMEM;
     a.long_rows = plan->long_rows; a.long_seg_ptr = plan->long_seg_ptr;
     if (need >= (1ull << 32)) return STAG_ENOSYS;   // partials go through a 32-bit buffer descriptor
-    a.ws = plan->workspace; a.ws_stride = D * (nout > 1 ? nout : (spec->in_norm ? 2 : 1)); a.ws_bytes = (uint32_t)need;
+    a.ws = plan->workspace; a.ws_stride = D * nout * (spec->in_norm ? 2 : 1); a.ws_bytes = (uint32_t)need;
     a.n_long = plan->n_long; a.seg_counters = plan->seg_counters; a.n_seg = plan->n_seg;
   }
 
@@ -709,14 +708,16 @@ int stag_agg_fwd_mc(const stag_csr* csr, const stag_plan* plan, const float* x, 
                     int32_t reduce, const float* src_scale, const float* dst_scale, float* out,
                     int64_t ldo, int64_t sample_stride, void* stream) {
   if (!spec || n_samples < 1 || offset_stride < 0 || !out) return STAG_EINVAL;
-  if (spec->kind < STAG_NOISE_NORMAL || spec->in_norm || spec->deriv) return STAG_EINVAL;
+  if (spec->kind < STAG_NOISE_NORMAL || spec->deriv) return STAG_EINVAL;
   if (spec->param_mode != STAG_PARAM_SCALAR && spec->param_mode != STAG_PARAM_PER_CHANNEL) return STAG_EINVAL;
   if (n_samples > 1 && sample_stride < (int64_t)(csr ? csr->n_dst : 0) * ldo) return STAG_EINVAL;
   // 4 (then 2, then 1) samples per pass over the gathered rows; every launch starts its own
-  // samples at the right offset, so the result is that of n_samples separate stag_agg_fwd calls
+  // samples at the right offset, so the result is that of n_samples separate stag_agg_fwd calls.
+  // With in-norm (stag/layers.py:8-36) every sample carries its own weight sums: 2 per pass (registers).
   stag_noise_spec sp = *spec;
+  const int kmax = spec->in_norm ? 2 : 4;
   for (int32_t s0 = 0; s0 < n_samples;) {
-    const int k = (n_samples - s0 >= 4) ? 4 : (n_samples - s0 >= 2) ? 2 : 1;
+    const int k = (n_samples - s0 >= 4 && kmax >= 4) ? 4 : (n_samples - s0 >= 2) ? 2 : 1;
     sp.offset = spec->offset + (uint64_t)s0 * (uint64_t)offset_stride;
     float* extra[3] = {nullptr, nullptr, nullptr};
     for (int o = 1; o < k; ++o) extra[o - 1] = out + (int64_t)(s0 + o) * sample_stride;

@@ -1,0 +1,166 @@
+"""BASELINE configs[4] as written, at FULL size, emulated on one GPU: the cfg5 GAT graph
+(N = 169,343, E = 1,166,243, H = 8, F = 32) cut into 8 node-range shards, and the cfg2 aggregation cut the same way.
+
+Every shard is the object the 8-GPU job builds (`partition.GraphShard`, both exchange layouts); only the collective is
+replaced by the indexing it amounts to — `buffer = table[global id of every buffer row]` — whose autograd backward IS
+the transposed exchange (a scatter-add of the buffer's gradient rows into the owners' rows).  Checked:
+  * forward: the 8 shards' outputs, concatenated, are BIT-IDENTICAL to the whole-graph kernel launch — Philox
+    positions in the millions (`pos_base`), the 13k-edge hub inside one shard's plan, `n_buf` remapping at 58 % halo,
+    the `[ft | el]` packing at H*F = 256, in-kernel attention dropout keyed by global position;
+  * forward against the CPU oracle at 1e-5;
+  * backward: per-shard `stag_gat_bwd` / transposed aggregation + the transposed exchange, summed over the shards,
+    against the whole graph's `d ft / d el / d er` (`d x`) — a shard sums a source row's out-edges per shard and the
+    exchange adds 8 partial sums, so this is 1e-5 relative, not bitwise.
+The reference has no multi-GPU code (scripts/arxiv_mle/gcn/run.py:140-142: one process, `cuda:0`); the contract is
+BASELINE.json north_star + SURVEY.md section 8e.
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import TOL, assert_close, hw_normals, oracle_graph
+
+pytestmark = pytest.mark.gpu
+WORLD = 8
+
+
+@pytest.fixture(scope="module")
+def arxiv(dev):
+    import stag_amd
+    from stag_amd import synthetic
+    src, dst = synthetic.arxiv_like(seed=1)
+    n = synthetic.ARXIV_NODES
+    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
+    return src, dst, n, g
+
+
+@pytest.fixture(scope="module")
+def shards(arxiv, dev):
+    """The 8 shards of both exchange layouts + the global id behind every buffer row (-1: padding)."""
+    from stag_amd.partition import GraphShard
+    src, dst, n, _ = arxiv
+    out = {}
+    for exchange in ("halo", "allgather"):
+        lst = []
+        for r in range(WORLD):
+            sh = GraphShard(src, dst, n, r, WORLD, device=dev, exchange=exchange)
+            if exchange == "halo":
+                gid = torch.cat([torch.arange(sh.row_lo, sh.row_hi), torch.from_numpy(sh.recv_ids)])
+            else:
+                gid = torch.full((sh.n_buf,), -1, dtype=torch.int64)
+                for q in range(WORLD):
+                    a, b = int(sh.bounds[q]), int(sh.bounds[q + 1])
+                    gid[q * sh.max_rows:q * sh.max_rows + (b - a)] = torch.arange(a, b)
+            assert gid.shape[0] == sh.n_buf
+            lst.append((sh, gid.to(dev)))
+        out[exchange] = lst
+    return out
+
+
+def _exchange(table, gid):
+    """What the collective delivers to a shard: the table's row behind every buffer row (padding rows: zeros).
+    Differentiable: its backward scatter-adds the buffer's gradient into the owners' rows = the transposed exchange."""
+    rows = table[gid.clamp(min=0)]
+    return rows * (gid >= 0).to(rows.dtype).unsqueeze(1) if bool((gid < 0).any()) else rows
+
+
+def _rel(got, ref):
+    sc = max(1.0, float(ref.abs().max()))
+    return got / sc, (ref / sc).cpu().numpy()
+
+
+def test_shards_cover_the_graph(arxiv, shards):
+    src, dst, n, g = arxiv
+    for exchange, lst in shards.items():
+        assert [int(sh.bounds[r]) for r, (sh, _) in enumerate(lst)] == sorted(int(sh.bounds[r]) for r, (sh, _) in enumerate(lst))
+        assert sum(sh.n_rows for sh, _ in lst) == n
+        assert sum(sh.number_of_edges() for sh, _ in lst) == g.number_of_edges()
+        # edge-balanced: no shard holds more than the hub row above E/8
+        emax = max(sh.number_of_edges() for sh, _ in lst)
+        assert emax <= g.number_of_edges() / WORLD + 14_000
+        assert lst[-1][0].pos_base > 1_000_000          # positions in the millions reach the kernels
+        if exchange == "halo":
+            frac = np.mean([sum(sh.out_splits) / max(n - sh.n_rows, 1) for sh, _ in lst])
+            assert 0.4 < frac < 0.75                     # ~58 % of the remote rows at P = 8 on this graph
+
+
+@pytest.mark.parametrize("exchange", ["halo", "allgather"])
+def test_cfg5_gat_eight_shards_forward_and_backward(dev, oracle, arxiv, shards, exchange):
+    import stag_amd
+    from stag_amd import _lib, ops
+    src, dst, n, g = arxiv
+    H, F = 8, 32
+    gen = torch.Generator().manual_seed(55)
+    el0 = torch.randn(n, H, generator=gen).to(dev)
+    er0 = torch.randn(n, H, generator=gen).to(dev)
+    ft0 = torch.randn(n, H, F, generator=gen).to(dev)
+    G = torch.randn(n, H, F, generator=gen).to(dev)
+    mk = lambda graph: stag_amd.EdgeNoise(graph, H, _lib.NOISE_NORMAL, 1.0, 0.5, seed=0x5747A6, offset=7)
+    drop = (0.6, 1234, 5)
+    for attn_drop in (None, drop):
+        el, er, ft = (t.clone().requires_grad_(True) for t in (el0, er0, ft0))
+        whole = ops.gat_aggregate(g, el, er, ft, 0.2, mk(g), attn_drop=attn_drop)
+        whole.backward(G)
+        els, ers, fts = (t.clone().requires_grad_(True) for t in (el0, er0, ft0))
+        packed = torch.cat([fts.reshape(n, H * F), els], 1)           # what travels: [ft | el], 264 columns
+        parts = []
+        for sh, gid in shards[exchange]:
+            sh = sh.local_var()
+            sh.halo_gather = lambda t, gid=gid: _exchange(packed, gid)
+            lo, hi = sh.row_lo, sh.row_hi
+            parts.append(sh.gat_aggregate(els[lo:hi], ers[lo:hi], fts[lo:hi], 0.2, mk(sh), attn_drop=attn_drop))
+        got = torch.cat(parts, 0)
+        assert torch.equal(got, whole), f"{exchange}, attn_drop={attn_drop}: 8 shards != whole graph"
+        got.backward(G)
+        for a, b, nm in ((fts, ft, "d ft"), (els, el, "d el"), (ers, er, "d er")):
+            assert_close(*_rel(a.grad, b.grad), what=f"cfg5 8 x {exchange} shards, attn_drop={attn_drop}: {nm}")
+        if attn_drop is None and exchange == "halo":
+            og = oracle_graph(oracle, g)
+            with hw_normals(oracle, dev):
+                ref = oracle.gat_fwd(og, el0.cpu().numpy(), er0.cpu().numpy(), ft0.cpu().numpy(), 0.2,
+                                     oracle.make_spec("normal", 1.0, 0.5, seed=0x5747A6, offset=7, Dn=H,
+                                                      n_edges=g.number_of_edges()))
+            assert_close(got.reshape(n, -1), ref.reshape(n, -1), what="cfg5 8 shards vs oracle")
+
+
+@pytest.mark.parametrize("exchange", ["halo", "allgather"])
+@pytest.mark.parametrize("kind", ["normal", "bernoulli_norm"])
+def test_cfg2_aggregation_eight_shards_forward_and_backward(dev, oracle, arxiv, shards, exchange, kind):
+    """cfg2 (D = 128) on the same 8 shards, with GCN's 'both' degree scalings (stag/zoo/gcn.py:67-75, 100-108): the
+    source scale indexes buffer rows (`out_degrees()` of a shard = the GLOBAL out-degree behind each of them)."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    src, dst, n, g = arxiv
+    D = 128
+    gen = torch.Generator().manual_seed(56)
+    x0 = torch.randn(n, D, generator=gen).to(dev)
+    G = torch.randn(n, D, generator=gen).to(dev)
+    if kind == "normal":
+        mk = lambda graph: stag_amd.EdgeNoise(graph, D, _lib.NOISE_NORMAL, 1.0, 0.5, seed=0x5747A6, offset=0)
+        ospec = lambda: oracle.make_spec("normal", 1.0, 0.5, seed=0x5747A6, offset=0, Dn=D, n_edges=g.number_of_edges())
+    else:       # scripts/arxiv_mle/gcn/run.py:70-74: Bernoulli + norm=True
+        mk = lambda graph: stag_amd.EdgeNoise(graph, D, _lib.NOISE_BERNOULLI, 0.9, seed=0x5747A6, offset=0, in_norm=True)
+        ospec = lambda: oracle.make_spec("bernoulli", 0.9, None, in_norm=True, seed=0x5747A6, offset=0, Dn=D,
+                                         n_edges=g.number_of_edges())
+    ss = g.out_degrees().clamp(min=1).float() ** -0.5
+    ds = g.in_degrees().clamp(min=1).float() ** -0.5
+    x = x0.clone().requires_grad_(True)
+    whole = ops.aggregate(g, x, mk(g), src_scale=ss, dst_scale=ds)
+    whole.backward(G)
+    xs = x0.clone().requires_grad_(True)
+    parts = []
+    for sh, gid in shards[exchange]:
+        noise = mk(sh)
+        noise.pos_base = sh.pos_base
+        ss_buf = sh.out_degrees().clamp(min=1).float() ** -0.5
+        ds_loc = sh.in_degrees().clamp(min=1).float() ** -0.5
+        parts.append(ops.aggregate(sh, _exchange(xs, gid), noise, src_scale=ss_buf, dst_scale=ds_loc, _gathered=True))
+    got = torch.cat(parts, 0)
+    assert torch.equal(got, whole), f"{exchange} {kind}: 8 shards != whole graph"
+    got.backward(G)
+    assert_close(*_rel(xs.grad, x.grad), what=f"cfg2 8 x {exchange} shards {kind}: d x")
+    if exchange == "halo":
+        og = oracle_graph(oracle, g)
+        with hw_normals(oracle, dev):
+            ref = oracle.agg_fwd(og, x0.cpu().numpy(), ospec(), src_scale=ss.cpu().numpy(), dst_scale=ds.cpu().numpy())
+        assert_close(got, ref, what=f"cfg2 8 shards {kind} vs oracle")
