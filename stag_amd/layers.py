@@ -97,6 +97,8 @@ class StagLayer(torch.nn.Module):
             if self.norm:
                 w = _in_norm(graph, w)
         self._edge_weight_handle = w
+        if hasattr(self.base_layer, "noise_generator"):      # a base layer that draws itself (GAT's attention dropout)
+            self.base_layer.noise_generator = self._generator()
         return self.base_layer.forward(graph=graph, feat=feat, edge_weight=w)
 
     @property
@@ -107,12 +109,22 @@ class StagLayer(torch.nn.Module):
         except Exception:      # an AmortizedDistribution that was never conditioned
             return False
 
+    def offsets_per_forward(self):
+        """Offsets of the generator one forward pass consumes: one per fused draw, plus what the base layer draws
+        itself (GAT's in-kernel attention dropout)."""
+        extra = getattr(self.base_layer, "extra_offsets_per_forward", None)
+        return (1 if self.consumes_offset else 0) + (extra() if callable(extra) else 0)
+
     def forward_mc(self, graph, feat, n_samples, offset_stride=1):
         """n_samples forward passes on the SAME input from one pass over the gathered rows:
         [n_samples, N, out], sample s drawn at this call's offset + s * offset_stride (what the
         sequential Monte-Carlo loop of stag/models.py:45-55 would use when every pass consumes
         offset_stride offsets).  None when the layer cannot batch (the caller then loops)."""
-        if torch.is_grad_enabled() or self.norm or not getattr(self.base_layer, "supports_edge_noise_mc", False):
+        if not getattr(self.base_layer, "supports_edge_noise_mc", False):
+            return None
+        if torch.is_grad_enabled() and (self.vi or feat.requires_grad):
+            # the batched aggregation has no backward of its own: under autograd it serves the case that needs none —
+            # fixed noise on an input that is data (the first layer of every `*_mle` script)
             return None
         graph = graph.local_var()
         self.q_a.condition(graph, feat)
@@ -121,8 +133,8 @@ class StagLayer(torch.nn.Module):
             return None
         dn = self._sample_dimension(feat)
         gen = self._generator()
-        w = EdgeNoise.from_distribution(graph, dn, dist, relu=self.relu, seed=gen.seed, offset=gen.offset,
-                                        epoch=gen.device_epoch)
+        w = EdgeNoise.from_distribution(graph, dn, dist, relu=self.relu, in_norm=self.norm, seed=gen.seed,
+                                        offset=gen.offset, epoch=gen.device_epoch)
         if w.param_mode > _lib.PARAM_PER_CHANNEL:
             return None
         gen.next_offset()

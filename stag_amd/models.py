@@ -30,6 +30,8 @@ def _masked_mean(nll, mask):
     Monte-Carlo sample, and not capturable in a hipGraph)."""
     if mask is None:
         return nll.mean()
+    if mask.device != nll.device:           # nll[mask] takes a host mask for a device tensor; so does this
+        mask = mask.to(nll.device)
     if mask.dtype == torch.bool and mask.dim() == 1 and mask.shape[0] == nll.shape[0] and nll.is_cuda:
         per_row = nll.numel() // max(nll.shape[0], 1)
         m = mask.view(-1, *([1] * (nll.dim() - 1)))
@@ -53,39 +55,68 @@ class StagModel(torch.nn.Module):
         return feat
 
     def _mc_mean(self, graph, feat, n_samples):
-        batched = self._mc_first_layer_batched(graph, feat, n_samples)
-        if batched is not None:
-            return batched
-        return torch.stack([self._forward(graph, feat) for _ in range(n_samples)], 0).mean(0)
+        return torch.stack(list(self._mc_outputs(graph, feat, n_samples)), 0).mean(0)
 
-    def _mc_first_layer_batched(self, graph, feat, n_samples):
-        """The Monte-Carlo loop with the FIRST layer's samples drawn from one pass over the
-        gathered rows (its input is the same for every sample; StagLayer.forward_mc), the other
-        layers per sample.  Every sample sees exactly the noise the sequential loop would give it
-        (sample s, layer l draws at offset base + s * L + l), so the result is unchanged."""
+    def _mc_outputs(self, graph, feat, n_samples):
+        """The outputs of the Monte-Carlo loop `for _ in range(n_samples): self._forward(graph, feat)`
+        (stag/models.py:45-55 at inference, :67-68 in training), one at a time — a generator, so a caller can read
+        per-sample layer state (the KL terms of `loss_terms`) right after each sample, as the loop would.
+
+        Where it can, the FIRST layer's samples come from one pass over the gathered rows (its input is the same
+        for every sample; `StagLayer.forward_mc` -> stag_agg_fwd_mc) and only the other layers run per sample.
+        Every sample sees exactly the noise the sequential loop would give it: with L offsets consumed per sample
+        (one per fused draw, one more per in-kernel attention-dropout mask) sample s draws its first layer at
+        base + s * L and its other layers from base + s * L + 1 on.  Under autograd this needs the first layer's
+        input to be data and its noise fixed (every `*_mle` script): the batched aggregation then needs no
+        backward, the dense transform differentiates through the S outputs."""
+        plan = self._mc_plan(graph, feat, n_samples)
+        if plan is None:
+            for _ in range(n_samples):
+                yield self._forward(graph, feat)
+            return
+        gen, L, base, first_used, h1, g = plan
+        for s in range(n_samples):
+            gen.offset = base + s * L + first_used
+            h = h1[s]
+            for layer in self.layers[1:]:
+                h = layer(g, h)
+            if gen.offset != base + (s + 1) * L:
+                if s == 0:
+                    # a layer consumed offsets it does not report (offsets_per_forward): the batched first layer
+                    # drew the later samples at the wrong offsets — discard it and run the plain loop, now and
+                    # from here on
+                    self._mc_batching_off = True
+                    gen.offset = base
+                    for _ in range(n_samples):
+                        yield self._forward(graph, feat)
+                    return
+                raise RuntimeError("a layer consumed a different number of noise offsets from one Monte-Carlo "
+                                   "sample to the next")
+            yield h
+        gen.offset = base + n_samples * L
+
+    def _mc_plan(self, graph, feat, n_samples):
+        """(generator, offsets per sample, base offset, offsets of the first layer, [S, N, out] of the first layer,
+        graph) when the first layer's samples can be batched, else None."""
         first = self.layers[0] if len(self.layers) else None
-        if n_samples < 2 or torch.is_grad_enabled() or not hasattr(first, "forward_mc"):
+        if n_samples < 2 or not hasattr(first, "forward_mc") or getattr(self, "_mc_batching_off", False):
             return None
         stoch = [l for l in self.layers if hasattr(l, "forward_mc")]
         gens = {id(l._generator()) for l in stoch}
         if len(gens) != 1 or not all(l.consumes_offset for l in stoch):
             return None
-        gen, L = first._generator(), len(stoch)
+        gen = first._generator()
+        L = sum(l.offsets_per_forward() for l in stoch)
+        first_used = first.offsets_per_forward()
+        if first_used != 1:          # (a first layer that draws more than its noise field is not batched)
+            return None
         base = gen.offset
         graph = graph.local_var()
         h1 = first.forward_mc(graph, feat, n_samples, offset_stride=L)
         if h1 is None:
             gen.offset = base
             return None
-        outs = []
-        for s in range(n_samples):
-            gen.offset = base + s * L + 1
-            h = h1[s]
-            for layer in self.layers[1:]:
-                h = layer(graph, h)
-            outs.append(h)
-        gen.offset = base + n_samples * L
-        return torch.stack(outs, 0).mean(0)
+        return gen, L, base, first_used, h1, graph
 
     def forward(self, graph, feat, n_samples=1, return_parameters=False):
         """Monte-Carlo average over `n_samples` noisy passes; noise stays on at eval time
@@ -105,8 +136,7 @@ class StagModel(torch.nn.Module):
     def loss_terms(self, graph, feat, y, mask=None, n_samples=1, kl_scaling=None):
         kl_scaling = self.kl_scaling if kl_scaling is None else kl_scaling
         total_nll = total_reg = 0.0
-        for _ in range(n_samples):
-            out = self._forward(graph, feat)
+        for out in self._mc_outputs(graph, feat, n_samples):
             nll = -self.likelihood.log_prob(out, y)
             total_nll = total_nll + _masked_mean(nll, mask)
             total_reg = total_reg + self._regulariser()

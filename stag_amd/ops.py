@@ -354,6 +354,11 @@ class _NodeLinear(torch.autograd.Function):
 def node_linear(x, w, bias=None, add=None):
     """x [N, in] @ w [in, out] (+ bias, + add [N, out], both in the GEMM's epilogue) with a split-K weight gradient
     (see _NodeLinear)."""
+    if x.dim() == 3 and x.is_contiguous() and add is None:
+        # [S, N, in]: the Monte-Carlo samples of one layer (aggregate_mc) — ONE product over S*N rows, so the weight
+        # gradient keeps its split-K form instead of a K = S*N single-tile-column reduction
+        S, n = x.shape[0], x.shape[1]
+        return _NodeLinear.apply(x.view(S * n, x.shape[2]), w, bias).view(S, n, w.shape[1])
     if x.dim() != 2 or not x.is_contiguous():
         y = x @ w if bias is None else x @ w + bias
         return y if add is None else y + add
@@ -879,9 +884,13 @@ def aggregate_max(graph, x, weight=None):
 def aggregate_mc(graph, x, noise, n_samples, offset_stride=1, reduce="sum", src_scale=None,
                  dst_scale=None, seg_len=DEFAULT_SEG_LEN, _gathered=False):
     """[n_samples, N, D]: sample s == aggregate(graph, x, noise at offset + s * offset_stride), bit for
-    bit, from one pass over the gathered rows per 4 samples (stag_agg_fwd_mc).  Inference path of the
-    reference's Monte-Carlo loop (stag/models.py:45-55); no autograd — with gradients enabled, or
-    for noise the fused sampler does not cover, it is the stack of n_samples ordinary calls."""
+    bit, from one pass over the gathered rows per 4 samples (2 with in-norm: every sample carries its own weight
+    sums) (stag_agg_fwd_mc).  The reference's Monte-Carlo loops — inference, stag/models.py:45-55, and training,
+    stag/models.py:67-68 with `--n_samples_training` > 1 — on a layer whose input is the same for every sample.
+    It needs no backward of its own when neither x nor the noise parameters carry a gradient (every `*_mle` script:
+    the first layer's input is the data, the noise is fixed): the dense transform that follows differentiates
+    through the S outputs.  When something here does need a gradient, or for noise the fused sampler does not
+    cover, it is the stack of n_samples ordinary calls."""
     def one(s):
         import copy
         nz = copy.copy(noise)
@@ -890,7 +899,7 @@ def aggregate_mc(graph, x, noise, n_samples, offset_stride=1, reduce="sum", src_
                          _gathered=_gathered)
     if getattr(graph, "is_shard", False) and not _gathered:
         return torch.stack([one(s) for s in range(n_samples)], 0)
-    fusable_mc = (isinstance(noise, EdgeNoise) and noise.kind >= _lib.NOISE_NORMAL and not noise.in_norm
+    fusable_mc = (isinstance(noise, EdgeNoise) and noise.kind >= _lib.NOISE_NORMAL
                   and noise.param_mode <= _lib.PARAM_PER_CHANNEL)
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or (noise is not None and noise.grad_params is not None
                                                                   and any(torch.is_tensor(p) and p.requires_grad

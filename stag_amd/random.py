@@ -11,6 +11,9 @@ import threading
 import torch
 
 _MASK64 = (1 << 64) - 1
+# xor-ed into the seed of streams that are not edge noise (GAT's attention-dropout mask): same generator, same
+# offset counter, a different key — the two can never draw from one (seed, offset) pair
+ATTN_DROP_DOMAIN = 0xA77D209D0F5EED55
 
 
 class NoiseGenerator:

@@ -31,6 +31,9 @@ class GAT(torch.nn.Module):
         self.activation = activation
         self.last = last
         self.sample_dimension = num_heads
+        # the generator the in-kernel attention dropout draws from: a StagLayer hands over its own before every
+        # forward, so saving / restoring the layer's generator replays the masks too; None: the default generator
+        self.noise_generator = None
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -42,6 +45,12 @@ class GAT(torch.nn.Module):
             torch.nn.init.constant_(self.bias, 0)
         if isinstance(self.res_fc, torch.nn.Linear):
             torch.nn.init.xavier_uniform_(self.res_fc.weight, gain=gain)
+
+    def extra_offsets_per_forward(self):
+        """Generator offsets a forward takes besides the edge noise: one for the in-kernel attention-dropout mask."""
+        H, F = self._num_heads, self._out_feats
+        Fp = self._padded_width(H, F)
+        return int(self.training and self.attn_drop.p > 0.0 and ops.attn_drop_fusable(H, Fp, ops.DEFAULT_SEG_LEN))
 
     @staticmethod
     def _padded_width(H, F):
@@ -95,8 +104,11 @@ class GAT(torch.nn.Module):
             # the mask comes from its own Philox stream (one offset of the generator per call) inside the kernels
             # and is redrawn in the backward: the step stays on the fused path (6.1 -> 1.4 ms per layer step at cfg5)
             from .. import random as _random
-            gen = _random.default_generator
-            fused_drop, drop = (float(self.attn_drop.p), gen.seed, gen.next_offset(), gen.device_epoch), None
+            gen = self.noise_generator if self.noise_generator is not None else _random.default_generator
+            # the mask's stream is keyed apart from the edge-noise stream: a generator seeded like the one that
+            # draws the layer's noise must not hand the mask the (seed, offset) of a noise field
+            fused_drop, drop = (float(self.attn_drop.p), gen.seed ^ _random.ATTN_DROP_DOMAIN, gen.next_offset(),
+                                gen.device_epoch), None
             if fused_drop[3] is None:
                 fused_drop = fused_drop[:3]
         res = ops.gat_aggregate(graph, el, er, ft, self._negative_slope, edge_weight,

@@ -9,6 +9,7 @@ from ._common import check_edge_weight
 class GIN(torch.nn.Module):
     supports_edge_noise = True
     supports_edge_noise_grad = True   # vi=True stays fused (ops._AggregateVI)
+    supports_edge_noise_mc = True     # an EdgeNoise with n_samples > 1 yields [S, N, out]
 
     def __init__(self, in_features, out_features, aggregator_type="sum", init_eps=0.0,
                  learn_eps=False, activation=None):

@@ -12,6 +12,14 @@ class GraphSAGE(torch.nn.Module):
     supports_edge_noise = True
     supports_edge_noise_grad = True   # vi=True stays fused (ops._AggregateVI)
 
+    @property
+    def supports_edge_noise_mc(self):
+        """An EdgeNoise with n_samples > 1 yields [S, N, out] (the Monte-Carlo loop batched on this layer) — for the
+        fused aggregators, when no per-sample state hides in the layer: the sequential loop would draw a fresh
+        feature-dropout mask per sample, and a `norm` module sees one sample at a time."""
+        return (self._aggre_type in ("mean", "gcn") and self.norm is None
+                and not (self.training and self.feat_drop.p > 0.0))
+
     def __init__(self, in_features, out_features, activation=None, aggregator_type="mean",
                  feat_drop=0.0, bias=True, norm=None):
         super().__init__()
@@ -53,7 +61,7 @@ class GraphSAGE(torch.nn.Module):
         elif self._aggre_type == "gcn":
             neigh = ops.aggregate(graph, feat_src, edge_weight, reduce="sum")
             degs = graph.in_degrees().to(feat_dst)
-            h_neigh = self.fc_neigh((neigh + feat_dst) / (degs.unsqueeze(-1) + 1))
+            h_neigh = ops.node_linear((neigh + feat_dst) / (degs.unsqueeze(-1) + 1), self.fc_neigh.weight.t())
         elif self._aggre_type == "pool":     # max reducer: composed, not fused (ops.aggregate_max)
             h_neigh = self.fc_neigh(ops.aggregate_max(graph, torch.relu(self.fc_pool(feat_src)), edge_weight))
         else:

@@ -923,7 +923,8 @@ def test_model_monte_carlo_first_layer_batched(dev):
     g = random_graph(n, 4000, seed=3, hub=300, device=dev)
     x = torch.randn(n, D, device=dev)
     N = torch.distributions.Normal
-    for first_kw in (dict(q_a=N(1.0, 0.5)), dict(q_a=torch.distributions.Bernoulli(0.7)), dict(q_a=N(1.0, 0.5), relu=True, vi=True)):
+    for first_kw in (dict(q_a=N(1.0, 0.5)), dict(q_a=torch.distributions.Bernoulli(0.7)), dict(q_a=N(1.0, 0.5), relu=True, vi=True),
+                     dict(q_a=torch.distributions.Bernoulli(0.7), norm=True)):     # scripts/arxiv_mle/gcn/run.py:70-74
         gen = NoiseGenerator(seed=5)
         layers = [stag_amd.layers.StagLayer(stag_amd.zoo.GCN(D, 16, activation=torch.relu), generator=gen, **first_kw),
                   stag_amd.layers.StagLayer(stag_amd.zoo.GraphSAGE(16, 16, activation=torch.relu), generator=gen,
@@ -944,10 +945,71 @@ def test_model_monte_carlo_first_layer_batched(dev):
             assert gen.offset == end == 15
         assert calls, "the batched first layer was not used"
         assert torch.equal(got, ref)
-    # with gradients enabled the loop is the reference's
+    # an input that carries a gradient: the loop is the reference's
     gen.manual_seed(5)
     model(g, x.requires_grad_(True), n_samples=2, return_parameters=True).sum().backward()
     assert x.grad is not None
+
+
+@pytest.mark.parametrize("first", ["gcn_normal", "gcn_bernoulli_norm", "sage_normal", "gin_uniform"])
+def test_training_monte_carlo_loop_batched_on_the_first_layer(dev, first):
+    """`model.loss(..., n_samples=4)` — the training loop of stag/models.py:67-68 as the sweeps run it
+    (`--n_samples_training 4`, scripts/arxiv_mle/graph_sage/meta_run.sh:29) — draws the first layer's 4 samples from
+    one pass over the gathered rows when its input is data and its noise fixed: loss, KL term and EVERY parameter
+    gradient equal the sequential loop's, the generator ends where the loop leaves it.  The model has a vi=True
+    layer further up (its KL is read per sample) and a GAT layer with in-kernel attention dropout (two offsets per
+    forward)."""
+    import stag_amd
+    from stag_amd.random import NoiseGenerator
+    from util import random_graph
+    n, D = 400, 24
+    g = random_graph(n, 4000, seed=3, hub=300, device=dev)
+    x = torch.randn(n, D, device=dev)
+    y = torch.randint(0, 5, (n,), device=dev)
+    mask = torch.rand(n, device=dev) < 0.6
+    N, B, U = torch.distributions.Normal, torch.distributions.Bernoulli, torch.distributions.Uniform
+    L, Z = stag_amd.layers, stag_amd.zoo
+    gen = NoiseGenerator(seed=5)
+    torch.manual_seed(1)
+    l0 = {"gcn_normal": lambda: L.StagLayer(Z.GCN(D, 16, activation=torch.relu), generator=gen, q_a=N(1.0, 0.5), relu=True),
+          "gcn_bernoulli_norm": lambda: L.StagLayer(Z.GCN(D, 16, activation=torch.relu), generator=gen, q_a=B(0.7), norm=True),
+          "sage_normal": lambda: L.StagLayer(Z.GraphSAGE(D, 16, activation=torch.relu), generator=gen, q_a=N(1.0, 0.5)),
+          "gin_uniform": lambda: L.StagLayer(Z.GIN(D, 16, activation=torch.relu), generator=gen, q_a=U(0.5, 1.5))}[first]()
+    layers = torch.nn.ModuleList([
+        l0,
+        L.StagLayer(Z.GAT(16, 4, num_heads=4, attn_drop=0.5, activation=torch.nn.functional.elu), generator=gen, q_a=N(1.0, 0.3)),
+        L.StagLayer(Z.GCN(16, 5, activation=lambda t: torch.softmax(t, -1)), generator=gen, q_a=N(1.0, 0.3), vi=True)])
+    model = stag_amd.models.StagModel(layers, kl_scaling=0.3).to(dev)
+    model.train()
+    assert [l.offsets_per_forward() for l in layers] == [1, 2, 1]
+    calls = []
+    orig = l0.forward_mc
+    l0.forward_mc = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+
+    def run(batched):
+        model.zero_grad(set_to_none=True)
+        model._mc_batching_off = not batched
+        gen.manual_seed(5)
+        nll, reg = model.loss_terms(g, x, y, mask=mask, n_samples=4)
+        (nll + reg).backward()
+        return nll.detach(), reg.detach(), gen.offset, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    nll_b, reg_b, end_b, gr_b = run(True)
+    assert calls, "the batched first layer was not used"
+    nll_s, reg_s, end_s, gr_s = run(False)
+    assert end_b == end_s == 16
+    assert_close(torch.stack([nll_b, reg_b]), torch.stack([nll_s, reg_s]).cpu().numpy(), what=f"{first}: nll, kl")
+    assert gr_b.keys() == gr_s.keys() and len(gr_b) >= 8
+    for k in gr_s:
+        sc = max(1.0, float(gr_s[k].abs().max()))
+        assert_close(gr_b[k] / sc, (gr_s[k] / sc).cpu().numpy(), what=f"{first}: d {k}")
+    # a layer that consumes offsets it does not report: the first sample notices, the loop falls back for good
+    layers[1].offsets_per_forward = lambda: 1
+    model._mc_batching_off = False
+    gen.manual_seed(5)
+    nll_f, reg_f = model.loss_terms(g, x, y, mask=mask, n_samples=4)
+    assert model._mc_batching_off and gen.offset == 16
+    assert_close(torch.stack([nll_f, reg_f]), torch.stack([nll_s, reg_s]).cpu().numpy(), what="fallback loop")
 
 
 def test_bench_contract_and_smoke(dev):

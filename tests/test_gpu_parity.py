@@ -410,6 +410,38 @@ def test_node_linear_gradients(dev):
 
 
 @pytest.mark.parametrize("kind", ["normal", "uniform", "bernoulli"])
+@pytest.mark.parametrize("D", [6, 32, 128, 300])
+def test_monte_carlo_samples_with_in_norm(dev, oracle, kind, D):
+    """stag_agg_fwd_mc with in-norm (stag/layers.py:8-36; `norm=True`, scripts/arxiv_mle/gcn/run.py:70-74): every
+    sample carries its own per-destination weight sums (two samples per pass), a hub row's segments included —
+    bit-equal to separate launches, and against the oracle."""
+    import copy
+    from stag_amd import ops
+    rng = np.random.default_rng(29)
+    n = 200
+    g = random_graph(n, 2000, seed=9, hub=500, device=dev)
+    x = torch.randn(n, D, device=dev)
+    ds = torch.rand(n, device=dev) + 0.5
+    p0 = torch.from_numpy(rng.uniform(0.3, 0.9, D).astype(np.float32)).to(dev)
+    p1 = None if kind == "bernoulli" else torch.from_numpy(rng.uniform(1.0, 1.6, D).astype(np.float32)).to(dev)
+    noise = _noise(g, D, kind, p0, p1, relu=(kind == "normal"), in_norm=True, seed=4, offset=100)
+    for S, stride in ((2, 1), (3, 5), (4, 3), (5, 2)):
+        got = ops.aggregate_mc(g, x, noise, S, offset_stride=stride, dst_scale=ds, seg_len=32)
+        assert got.shape == (S, n, D)
+        for s in range(S):
+            nz = copy.copy(noise)
+            nz.offset = 100 + s * stride
+            assert torch.equal(got[s], ops.aggregate(g, x, nz, dst_scale=ds, seg_len=32)), (S, s)
+    og = oracle_graph(oracle, g)
+    with hw_normals(oracle, dev):
+        ref = oracle.agg_fwd_mc(og, x.cpu().numpy(), _ospec(oracle, g, D, kind, p0, p1, relu=(kind == "normal"), in_norm=True,
+                                                             seed=4, offset=100), 4, offset_stride=3, dst_scale=ds.cpu().numpy())
+    got = ops.aggregate_mc(g, x, noise, 4, offset_stride=3, dst_scale=ds)
+    for s in range(4):
+        assert_close(got[s], ref[s], what=f"mc + in-norm sample {s} vs oracle twin")
+
+
+@pytest.mark.parametrize("kind", ["normal", "uniform", "bernoulli"])
 @pytest.mark.parametrize("D", [6, 128, 300])
 def test_monte_carlo_samples_one_pass(dev, oracle, kind, D):
     """stag_agg_fwd_mc: S samples from one pass over the gathered rows == S separate launches at

@@ -4,7 +4,10 @@ scripts/arxiv_mle/gcn/run.py (hidden 128, 40 classes, BatchNorm + ReLU + Dropout
 softmax head, Adam) on the arxiv-shaped synthetic graph after the script's preprocessing (self loops
 removed and re-added, reverse edges added: E = 2,671,172).
 
-    python tools/arxiv_epoch.py [--distribution Bernoulli|Normal|Uniform] [--graph-capture]
+    python tools/arxiv_epoch.py [--distribution Bernoulli|Normal|Uniform] [--n-samples-training S] [--model GCN|GraphSAGE]
+
+With S > 1 (the sweeps run `--n_samples_training 4`: scripts/arxiv_mle/graph_sage/meta_run.sh:29) the epoch is timed
+twice: the Monte-Carlo loop with the first layer's S samples batched (stag_agg_fwd_mc) and the sequential loop.
 """
 import argparse
 import math
@@ -21,7 +24,7 @@ import stag_amd  # noqa: E402
 from stag_amd import synthetic  # noqa: E402
 
 
-def build(dev, distribution, std=0.3, hidden=128, depth=3):
+def build(dev, distribution, std=0.3, hidden=128, depth=3, model="GCN"):
     if distribution == "Normal":
         q_a, norm = torch.distributions.Normal(1.0, std, validate_args=False), False
     elif distribution == "Uniform":
@@ -31,10 +34,11 @@ def build(dev, distribution, std=0.3, hidden=128, depth=3):
         q_a, norm = torch.distributions.Bernoulli(probs=0.5 * (1.0 + math.sqrt(1 - 4.0 * std ** 2))), True
     SL, FO, Z = stag_amd.layers.StagLayer, stag_amd.layers.FeatOnlyLayer, stag_amd.zoo
     mid = lambda: FO(torch.nn.Sequential(torch.nn.BatchNorm1d(hidden), torch.nn.ReLU(), torch.nn.Dropout(0.5)))
-    layers = torch.nn.ModuleList([SL(Z.GCN(128, hidden), q_a=q_a, norm=norm), mid()])
+    conv = Z.GCN if model == "GCN" else Z.GraphSAGE       # scripts/arxiv_mle/gcn/run.py:60-66: --model
+    layers = torch.nn.ModuleList([SL(conv(128, hidden), q_a=q_a, norm=norm), mid()])
     for _ in range(depth - 2):
-        layers += [SL(Z.GCN(hidden, hidden), q_a=q_a, norm=norm), mid()]
-    layers.append(SL(Z.GCN(hidden, 40, activation=lambda t: torch.nn.functional.softmax(t, dim=-1)), q_a=q_a, norm=norm))
+        layers += [SL(conv(hidden, hidden), q_a=q_a, norm=norm), mid()]
+    layers.append(SL(conv(hidden, 40, activation=lambda t: torch.nn.functional.softmax(t, dim=-1)), q_a=q_a, norm=norm))
     return stag_amd.models.StagModel(layers=layers).to(dev)
 
 
@@ -42,6 +46,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--distribution", default="Bernoulli")
     ap.add_argument("--epochs", type=int, default=30)
+    ap.add_argument("--n-samples-training", type=int, default=1)
+    ap.add_argument("--model", default="GCN", choices=["GCN", "GraphSAGE"])
     args = ap.parse_args()
     torch.distributions.Distribution.set_default_validate_args(False)
     dev = torch.device("cuda:0")
@@ -52,30 +58,42 @@ def main():
     x = torch.randn(n, 128, device=dev)
     y = torch.randint(0, 40, (n,), device=dev)
     mask = torch.rand(n, device=dev) < 0.54
-    model = build(dev, args.distribution)
+    model = build(dev, args.distribution, model=args.model)
     opt = torch.optim.Adam(model.parameters(), 1e-2)
+
+    S = args.n_samples_training
 
     def epoch():
         model.train()
         opt.zero_grad()
-        loss = model.loss(g, x, y, mask=mask)
+        loss = model.loss(g, x, y, mask=mask, n_samples=S)
         loss.backward()
         opt.step()
         return loss
-    for _ in range(5):
-        epoch()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.epochs):
-        loss = epoch()
-    e1.record()
-    torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) / args.epochs
-    print(f"{args.distribution}: E = {g.number_of_edges()}, epoch {wall * 1e3:.2f} ms wall, "
-          f"{e0.elapsed_time(e1) / args.epochs:.2f} ms device, loss {loss.item():.4f}; "
-          f"{3 * g.number_of_edges() / wall / 1e9:.2f} G edge-aggregations/s forward (3 layers)")
+
+    def timed(tag):
+        for _ in range(5):
+            epoch()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(args.epochs):
+            loss = epoch()
+        e1.record()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / args.epochs
+        print(f"{args.model} {args.distribution} n_samples_training={S} [{tag}]: E = {g.number_of_edges()}, epoch {wall * 1e3:.2f} ms wall, "
+              f"{e0.elapsed_time(e1) / args.epochs:.2f} ms device, loss {loss.item():.4f}; "
+              f"{3 * S * g.number_of_edges() / wall / 1e9:.2f} G edge-aggregations/s forward (3 layers x {S} samples)")
+
+    if S > 1:
+        model._mc_batching_off = True
+        timed("sequential loop")
+        model._mc_batching_off = False
+        timed("first layer batched")
+    else:
+        timed("one sample")
 
 
 if __name__ == "__main__":
