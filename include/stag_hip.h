@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 16
+#define STAG_ABI_VERSION 17
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -468,6 +468,17 @@ int stag_comm_destroy(void* comm);
 int stag_halo_allgather(void* comm, const float* x_local, int64_t n_floats, float* x_full, void* stream);
 int stag_halo_exchange(void* comm, const float* send, const int64_t* send_counts_host, float* recv,
                        const int64_t* recv_counts_host, void* stream);
+/* (v17) The same exchange for SEVERAL row tables at once — GAT's ft [n, H*F] and el [n, H] travel to the same peers
+ * (stag/zoo/gat.py:109-114 reads both at the source of every edge) — in ONE RCCL group: no packed [ft | el] copy on
+ * either side.  send[t] / recv[t]: table t's rows, widths[t] floats each; send_rows / recv_rows: ROWS per peer, host
+ * arrays of length world, the same for every table. */
+int stag_halo_exchange_multi(void* comm, int32_t n_tables, const float* const* send, float* const* recv,
+                             const int32_t* widths, const int64_t* send_rows_host,
+                             const int64_t* recv_rows_host, void* stream);
+/* (v17) out[i, :] = x[idx[i], :] for i < n: the rows a rank sends to its peers, written straight into the
+ * persistent send buffer of the exchange (no per-step index_select allocation).  idx: int32 device array. */
+int stag_gather_rows(const float* x, int64_t ldx, const int32_t* idx, int64_t n, int32_t width,
+                     float* out, int64_t ldo, void* stream);
 
 /* The whole backward of stag_gat_fwd in one call, for shapes with F % 4 == 0, H <= 16, H*F <= 1024,
  * H * lanes_per_head <= 256 (lanes_per_head = F / 4 rounded up to a power of two <= 64: the lanes past a head's

@@ -157,7 +157,9 @@ def lib():
     l.stag_comm_destroy.argtypes = [_vp]
     l.stag_halo_allgather.argtypes = [_vp, _vp, C.c_int64, _vp, _vp]
     l.stag_halo_exchange.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
-    if l.stag_abi_version() != 16:
+    l.stag_halo_exchange_multi.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]
+    l.stag_gather_rows.argtypes = [_vp, C.c_int64, _vp, C.c_int64, C.c_int32, _vp, C.c_int64, _vp]
+    if l.stag_abi_version() != 17:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     _lib = l
     return l

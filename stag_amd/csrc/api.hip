@@ -457,6 +457,26 @@ __global__ __launch_bounds__(256) void coldot_final_kernel(const float* part, in
 }  // namespace
 
 // ------------------------------------------------------------------------- //
+// out[i, :] = x[idx[i], :]: a thread per 4 floats of a row (dwordx4 when the rows allow it)
+template <bool VEC>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, int64_t ldx,
+                                                          const int32_t* __restrict__ idx, int64_t n, int32_t width,
+                                                          int32_t nchunk, float* __restrict__ out, int64_t ldo) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = t / nchunk;
+  const int k0 = (int)(t - i * nchunk) * 4;
+  if (i >= n) return;
+  const float* src = x + (int64_t)idx[i] * ldx;
+  float* dst = out + i * ldo;
+  if (VEC) {
+    *reinterpret_cast<float4*>(dst + k0) = *reinterpret_cast<const float4*>(src + k0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k0 + j < width) dst[k0 + j] = src[k0 + j];
+  }
+}
+
 extern "C" {
 
 int stag_abi_version(void) { return STAG_ABI_VERSION; }
@@ -989,6 +1009,21 @@ int stag_segment_reduce(const float* x, int64_t ldx, int32_t D, const int32_t* o
     default: STAG_SEG_LAUNCH(1); break;
   }
 #undef STAG_SEG_LAUNCH
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}
+
+int stag_gather_rows(const float* x, int64_t ldx, const int32_t* idx, int64_t n, int32_t width,
+                     float* out, int64_t ldo, void* stream) {
+  if (n < 0 || width <= 0 || ldx < width || ldo < width) return STAG_EINVAL;
+  if (n == 0) return STAG_OK;
+  if (!x || !idx || !out) return STAG_EINVAL;
+  const int nchunk = (width + 3) / 4;
+  const int64_t threads = n * nchunk;
+  if ((threads + 255) / 256 >= (1ll << 31)) return STAG_ENOSYS;
+  const bool vec = (width % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned16(x) && aligned16(out);
+  const dim3 grid((unsigned)((threads + 255) / 256));
+  if (vec) hipLaunchKernelGGL((gather_rows_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, idx, n, width, nchunk, out, ldo);
+  else     hipLaunchKernelGGL((gather_rows_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, idx, n, width, nchunk, out, ldo);
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }
 

@@ -135,4 +135,37 @@ int stag_halo_exchange(void* comm, const float* send, const int64_t* send_counts
   return STAG_OK;
 }
 
+int stag_halo_exchange_multi(void* comm, int32_t n_tables, const float* const* send, float* const* recv,
+                             const int32_t* widths, const int64_t* send_rows_host,
+                             const int64_t* recv_rows_host, void* stream) {
+  if (!comm || n_tables < 1 || !send || !recv || !widths || !send_rows_host || !recv_rows_host) return STAG_EINVAL;
+  StagComm* c = static_cast<StagComm*>(comm);
+  Rccl& r = rccl();
+  int64_t so = 0, ro = 0;
+  for (int p = 0; p < c->world; ++p) {
+    if (send_rows_host[p] < 0 || recv_rows_host[p] < 0) return STAG_EINVAL;
+    if (p == c->rank && (send_rows_host[p] || recv_rows_host[p])) return STAG_EINVAL;
+    so += send_rows_host[p]; ro += recv_rows_host[p];
+  }
+  for (int t = 0; t < n_tables; ++t) {
+    if (widths[t] <= 0) return STAG_EINVAL;
+    if ((so > 0 && !send[t]) || (ro > 0 && !recv[t])) return STAG_EINVAL;
+  }
+  if (r.GroupStart() != ncclSuccess) return STAG_EIO;
+  int bad = 0;
+  for (int t = 0; t < n_tables; ++t) {
+    const int64_t w = widths[t];
+    so = ro = 0;
+    for (int p = 0; p < c->world; ++p) {
+      if (send_rows_host[p] > 0)
+        bad |= r.Send(send[t] + so * w, (size_t)(send_rows_host[p] * w), ncclFloat32, p, c->comm, (hipStream_t)stream) != ncclSuccess;
+      if (recv_rows_host[p] > 0)
+        bad |= r.Recv(recv[t] + ro * w, (size_t)(recv_rows_host[p] * w), ncclFloat32, p, c->comm, (hipStream_t)stream) != ncclSuccess;
+      so += send_rows_host[p]; ro += recv_rows_host[p];
+    }
+  }
+  if (r.GroupEnd() != ncclSuccess || bad) return STAG_EIO;
+  return STAG_OK;
+}
+
 }  // extern "C"

@@ -176,12 +176,11 @@ class AmortizedDistribution(Distribution):
         act((feat W_src^T)[src] + (feat W_dst^T)[dst] + b): the Linear runs over the N node rows
         and the E-row work is two gathers — no [E, 2 in] concatenation, no E-row GEMM — and the
         gathers' backward is the aggregation kernel, not a scatter-add."""
-        if getattr(graph, "is_shard", False):
-            # the per-edge MLP reads feat[src] of REMOTE source rows: it needs its own halo exchange of the projected
-            # features, which is not built; fail here rather than index this rank's rows with buffer positions
-            raise NotImplementedError("AmortizedDistribution is not partitioned (node-range shards): condition() "
-                                      "needs the source rows of other ranks")
         lin = self.embedding_mlp[0]
+        shard = getattr(graph, "is_shard", False)
+        if shard and not (feat.is_cuda and feat.dim() == 2 and isinstance(lin, torch.nn.Linear)):
+            raise NotImplementedError("AmortizedDistribution on a node-range shard: device features [n_rows, in] and a "
+                                      "Linear embedding")
         if feat.is_cuda and feat.dim() == 2 and isinstance(lin, torch.nn.Linear) and self._narrow(graph, lin):
             # narrow heads — AmortizedDistribution(in, 1), hidden_features = 1 by default: what every
             # scripts/*_rec/run.py builds — as three kernels: both projections of feat in ONE pass over it
@@ -196,7 +195,13 @@ class AmortizedDistribution(Distribution):
             bs = [hd.bias for hd in heads]
             bh = (None if all(t is None for t in bs) else
                   torch.cat([t if t is not None else torch.zeros(1, device=feat.device) for t in bs]))
-            outs = ops.edge_mlp(graph, ops.node_project(feat, w, b), wh, bh)
+            P = ops.node_project(feat, w, b)
+            if shard:
+                # node-range shard: the per-edge MLP reads the projected row of every edge's SOURCE, local or not — the
+                # exchange carries the projected rows ([N, 2 hidden]: 8 bytes per node at hidden = 1, not the features)
+                # with the halo lists of the aggregation; the edges then index the buffer (GraphShard.edge_endpoints)
+                P = graph.halo_gather(P)
+            outs = ops.edge_mlp(graph, P, wh, bh)
             self.new_parameters = dict(zip(self.new_parameter_names, outs))
             self._base = None
             return self
@@ -204,7 +209,10 @@ class AmortizedDistribution(Distribution):
             from . import ops
             k = feat.shape[1]
             # the Linear's bias joins the destination half on the N node rows, not the E edge rows
-            h = (ops.gather_rows(graph, ops.node_linear(feat, lin.weight[:, :k].t()), "src")
+            p_src = ops.node_linear(feat, lin.weight[:, :k].t())
+            if shard:       # the source half travels: [n_rows, hidden] -> [n_buf, hidden]
+                p_src = graph.halo_gather(p_src)
+            h = (ops.gather_rows(graph, p_src, "src")
                  + ops.gather_rows(graph, ops.node_linear(feat, lin.weight[:, k:].t(), lin.bias), "dst"))
             for mod in list(self.embedding_mlp)[1:]:
                 h = mod(h)
@@ -227,14 +235,14 @@ class AmortizedDistribution(Distribution):
 
     def _narrow(self, graph, lin):
         """The three-kernel form applies: Sequential(Linear, SiLU), hidden <= 4, every head one column wide,
-        at most 4 heads, a whole graph (a node-range shard keeps the dense form)."""
+        at most 4 heads."""
         from . import ops
         mods = list(self.embedding_mlp)
         heads = [self.parameters_mlp[n] for n in self.new_parameter_names]
         return (len(mods) == 2 and type(mods[1]) is torch.nn.SiLU and lin.out_features <= ops.NARROW_MAX_HIDDEN
                 and len(heads) <= ops.NARROW_MAX_PAR
                 and all(isinstance(hd, torch.nn.Linear) and hd.out_features == 1 for hd in heads)
-                and hasattr(graph, "_src") and not getattr(graph, "is_shard", False))
+                and hasattr(graph, "_src"))
 
     def arguments(self):
         if self.new_parameters is None:

@@ -88,6 +88,9 @@ class StagLayer(torch.nn.Module):
 
     def forward(self, graph, feat):
         graph = graph.local_var()
+        # on a node-range shard the KL term is this rank's SHARE (kl_divergence)
+        self._kl_share = ((graph.number_of_edges() / max(graph.n_edges_global, 1), 1.0 / graph.world)
+                          if getattr(graph, "is_shard", False) else None)
         self.q_a.condition(graph, feat)
         dn = self._sample_dimension(feat)
         w = self.rsample_noise(graph, dn)
@@ -203,6 +206,21 @@ class StagLayer(torch.nn.Module):
         torch has no closed form for the pair (stag/layers.py:132-145)."""
         if not self.vi:
             return 0.0
+        return self._kl_unweighted() * self._kl_weight()
+
+    def _kl_weight(self):
+        """1 on a whole graph.  On a node-range shard every rank returns its SHARE, so that the ranks' values (and
+        gradients) SUM to the whole graph's: per-edge parameters (an AmortizedDistribution's heads, [E_local, .]) —
+        and the sample-based estimate, a mean over this rank's edges — count E_local / E_global, replicated
+        parameters 1 / world."""
+        share = getattr(self, "_kl_share", None)
+        if share is None:
+            return 1.0
+        per_edge = isinstance(getattr(self.q_a, "new_parameters", None), dict)
+        return share[0] if (per_edge or getattr(self, "_kl_sampled", False)) else share[1]
+
+    def _kl_unweighted(self):
+        self._kl_sampled = False
         fused = self._kl_normal_fused()
         if fused is not None:
             return fused
@@ -210,6 +228,7 @@ class StagLayer(torch.nn.Module):
             return torch.distributions.kl_divergence(
                 self.q_a.base_distribution, self.p_a.base_distribution).mean()
         except Exception:   # the reference falls back on ANY failure (stag/layers.py:141)
+            self._kl_sampled = True
             w = self._edge_weight_sample
             return (self.q_a.log_prob(w).sum(dim=-1).mean()
                     - self.p_a.log_prob(w).sum(dim=-1).mean())

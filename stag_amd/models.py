@@ -75,6 +75,7 @@ class StagModel(torch.nn.Module):
                 yield self._forward(graph, feat)
             return
         gen, L, base, first_used, h1, g = plan
+        h1 = h1.unbind(0)       # ONE autograd node for the S slices (S separate selects would each zero-fill [S, N, out])
         for s in range(n_samples):
             gen.offset = base + s * L + first_used
             h = h1[s]

@@ -131,9 +131,10 @@ def _agg_fwd_torch(csrv, x, noise_args, reduce, src_scale, dst_scale, seg_len, w
 
 
 def _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len, want_norm_scale=False,
-             broadcast_x=False, out=None, plan_t=None):
+             broadcast_x=False, out=None, plan_t=None, ns_out=None):
     """One stag_agg_fwd launch on csrv (a CsrView). x: [n_src, D] fp32 contiguous.
-    out / plan_t: write the rows of a sub-plan's units into an existing [n_dst, D] tensor."""
+    out / plan_t: write the rows of a sub-plan's units into an existing [n_dst, D] tensor (ns_out: and their
+    in-norm factors into an existing one)."""
     if isinstance(spec, tuple):
         if out is None and plan_t is None:
             return _agg_fwd_torch(csrv, x, spec, reduce, src_scale, dst_scale, seg_len, want_norm_scale, broadcast_x)
@@ -141,7 +142,8 @@ def _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len, want_norm_
     dev = _lib.require_device(x, csrv.indptr, src_scale, dst_scale)
     if out is None:
         out = torch.empty((csrv.n_dst, D), dtype=torch.float32, device=dev)
-    ns = torch.empty((csrv.n_dst, D), dtype=torch.float32, device=dev) if want_norm_scale else None
+    ns = ns_out if ns_out is not None else (
+        torch.empty((csrv.n_dst, D), dtype=torch.float32, device=dev) if want_norm_scale else None)
     if plan_t is None:
         plan_t = csrv.plan(seg_len)
     nbytes = (_lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], D, int(spec.in_norm))
@@ -185,7 +187,7 @@ def _agg_bwd_raw(csrv_t, g, D, spec, g_scale, row_scale, seg_len, want_dp):
     plan_t = csrv_t.plan(seg_len)
     nbytes = (_lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], (3 if want_dp else 1) * D, 0)
               if plan_t is not None else 0)
-    plan_c, _keep = _plan_struct(csrv_t, seg_len, (D + 255) // 256, nbytes, dev)
+    plan_c, _keep = _plan_struct(csrv_t, seg_len, (D + 255) // 256, nbytes, dev, plan_t=plan_t)
     cs = csrv_t.struct()
     with _lib.on_device(dev):
         rc = _lib.lib().stag_agg_bwd(
@@ -208,7 +210,7 @@ def _agg_bwd_edge_raw(csrv_t, g, x, D, spec, g_scale, row_scale, seg_len, want_d
     e1 = torch.empty_like(e0)
     plan_t = csrv_t.plan(seg_len)
     nbytes = _lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], D, 0) if plan_t is not None else 0
-    plan_c, _keep = _plan_struct(csrv_t, seg_len, 1, nbytes, dev)
+    plan_c, _keep = _plan_struct(csrv_t, seg_len, 1, nbytes, dev, plan_t=plan_t)
     cs = csrv_t.struct()
     with _lib.on_device(dev):
         rc = _lib.lib().stag_agg_bwd_edge(
@@ -228,7 +230,7 @@ def _agg_bwd_dp_raw(csrv_t, g, x, D, spec, g_scale, row_scale, seg_len, want_dx=
     dp1 = torch.empty(D, dtype=torch.float32, device=dev)
     plan_t = csrv_t.plan(seg_len)
     nbytes = _lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], D, 0) if plan_t is not None else 0
-    plan_c, _keep = _plan_struct(csrv_t, seg_len, (D + 255) // 256, nbytes, dev)
+    plan_c, _keep = _plan_struct(csrv_t, seg_len, (D + 255) // 256, nbytes, dev, plan_t=plan_t)
     n_units = plan_t["n_units"] if plan_t is not None else csrv_t.n_dst
     wbytes = _lib.lib().stag_agg_bwd_dp_workspace_bytes(n_units, D)
     ws = torch.empty(max(wbytes // 4, 1), dtype=torch.float32, device=dev)
@@ -375,7 +377,12 @@ class _GatherRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, graph, which):
-        src, dst = graph.edges()
+        if getattr(graph, "is_shard", False):     # sources are buffer rows, destinations this rank's rows
+            src, dst = graph.edge_endpoints()
+            if which == "dst":
+                dst = dst - graph.loc_off
+        else:
+            src, dst = graph.edges()
         ctx.graph, ctx.which = _owner(graph), which
         return x.index_select(0, (src if which == "src" else dst).long())
 
@@ -393,7 +400,7 @@ class _GatherRows(torch.autograd.Function):
 
 def gather_rows(graph, x, which):
     """x[u] (which="src") or x[v] (which="dst") for every edge u -> v, rows by edge id."""
-    if x.dim() != 2 or not x.is_cuda:
+    if (x.dim() != 2 or not x.is_cuda) and not getattr(graph, "is_shard", False):
         src, dst = graph.edges()
         return x[(src if which == "src" else dst).long()]
     return _GatherRows.apply(x, graph, which)
@@ -561,6 +568,10 @@ class _EdgeMlp(torch.autograd.Function):
             spec = _explicit_spec(dpre)
             d_src, _ = _agg_raw(g.csr_t, ones, hidden, spec, _lib.REDUCE_SUM, None, None, DEFAULT_SEG_LEN, broadcast_x=True)
             d_dst, _ = _agg_raw(g.csr, ones, hidden, spec, _lib.REDUCE_SUM, None, None, DEFAULT_SEG_LEN, broadcast_x=True)
+            if getattr(g, "is_shard", False):      # P is the exchanged buffer: destinations are this rank's rows of it
+                full = torch.zeros_like(d_src)
+                full[g.loc_off:g.loc_off + g.n_rows] = d_dst
+                d_dst = full
             dP = torch.cat([d_src, d_dst], 1)
         return None, dP, dwh, dbh
 
@@ -819,7 +830,8 @@ def aggregate(graph, x, weight=None, reduce="sum", src_scale=None, dst_scale=Non
     if x.dim() != 2:
         raise ValueError("aggregate expects x of shape [N, D]")
     if getattr(graph, "is_shard", False) and not _gathered and not _broadcast_x:
-        return graph.aggregate(x, weight, reduce=reduce, src_scale_local=src_scale,
+        # (a source-side scale indexes COLUMNS: on a shard, the rows of the exchanged buffer — shard.out_degrees())
+        return graph.aggregate(x, weight, reduce=reduce, src_scale_buf=src_scale,
                                dst_scale_local=dst_scale, seg_len=seg_len)
     noise = weight if isinstance(weight, EdgeNoise) else None
     w = weight if torch.is_tensor(weight) else None

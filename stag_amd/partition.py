@@ -61,48 +61,118 @@ def edge_balanced_bounds(indptr, world):
     return np.maximum.accumulate(bounds)
 
 
-class _HaloAllToAll(torch.autograd.Function):
-    """Send each peer the local rows it references; backward = the transposed all-to-all,
-    scatter-added into the local rows."""
+class _HaloExchange(torch.autograd.Function):
+    """The halo exchange of one or several row tables as ONE autograd node:
+        forward  x_t [n_rows, W_t] on every rank  ->  the exchanged buffer [n_buf, W_t] of every table
+                 (`GraphShard.halo_start_multi`: local rows in place, no concatenation);
+        backward the TRANSPOSED exchange of the buffers' gradient rows, added to the owners' rows in a FIXED order —
+                 a row's own contribution first, then the peers' in rank order (`GraphShard._segsum_back`: a
+                 segmented sum over a CSR of the send list on the aggregation kernel, no atomics) — so the
+                 gradients of a partitioned step are the same bits on every run."""
 
     @staticmethod
-    def forward(ctx, x_local, send_idx, in_splits, out_splits, group):
-        ctx.group, ctx.in_splits, ctx.out_splits, ctx.n_local = group, in_splits, out_splits, x_local.shape[0]
-        ctx.save_for_backward(send_idx)
-        send = x_local.index_select(0, send_idx)
-        recv = torch.empty((sum(out_splits),) + tuple(x_local.shape[1:]), dtype=x_local.dtype,
-                           device=x_local.device)
-        dist.all_to_all_single(recv, send, out_splits, in_splits, group=group)
-        return recv
+    def forward(ctx, shard, *xs):
+        ctx.shard = shard._origin
+        bufs, work = shard.halo_start_multi(list(xs), persistent=False)
+        if work is not None:
+            work.wait()
+        return tuple(bufs)
 
     @staticmethod
-    def backward(ctx, g):
-        (send_idx,) = ctx.saved_tensors
-        back = torch.empty((sum(ctx.in_splits),) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
-        dist.all_to_all_single(back, g.contiguous(), ctx.in_splits, ctx.out_splits, group=ctx.group)
-        dx = torch.zeros((ctx.n_local,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
-        dx.index_add_(0, send_idx, back)
-        return dx, None, None, None, None
+    def backward(ctx, *gs):
+        return (None,) + tuple(ctx.shard.halo_transpose_multi([g.contiguous() for g in gs]))
 
 
-class _HaloGather(torch.autograd.Function):
-    """all-gather of padded row shards; backward = reduce-scatter (sum) of the gradient."""
+def _wait_all(works):
+    class _W:
+        def wait(self_inner):
+            for w in works:
+                if w is not None:
+                    w.wait()
+    return _W() if any(w is not None for w in works) else None
+
+
+class _ShardAggregate(torch.autograd.Function):
+    """One partitioned layer-forward AND its backward with the collective overlapped on both sides.
+
+    forward : start the exchange; launch the units whose sources are all local rows; wait; launch the rest.
+    backward: launch the transposed aggregation of the REMOTE buffer rows (their gradient has to travel), start
+              the transposed exchange on them, launch the local rows while it is in flight, wait, then ONE launch
+              adds every local row's own gradient and the rows its peers sent, own first, peers in rank order
+              (`GraphShard._combined_csr`): fixed order, no atomics — the same bits on every run.
+    Covers weight = None | an EdgeNoise without parameter gradients (everything `vi=False` runs); the others take
+    halo_gather + ops.aggregate."""
 
     @staticmethod
-    def forward(ctx, x_pad, group):
-        ctx.group = group
-        world = dist.get_world_size(group)
-        out = torch.empty((world * x_pad.shape[0],) + tuple(x_pad.shape[1:]), dtype=x_pad.dtype,
-                          device=x_pad.device)
-        dist.all_gather_into_tensor(out, x_pad.contiguous(), group=group)
+    def forward(ctx, x_local, shard, weight, reduce, src_scale, dst_scale, seg_len, overlap):
+        from . import ops
+        o = shard._origin
+        x_local = ops._f32c(x_local)
+        D = x_local.shape[1]
+        buf, work = shard.halo_start(x_local, persistent=True)
+        spec = ops._targs_or_c(ops._noise_spec(weight)) if weight is not None else ops._targs_or_c(ops._none_spec())
+        need_dx = ctx.needs_input_grad[0]
+        ns = (torch.empty((shard.n_rows, D), dtype=torch.float32, device=x_local.device)
+              if (need_dx and spec.in_norm) else None)
+        out = torch.empty((shard.n_rows, D), dtype=torch.float32, device=x_local.device)
+        p_loc, p_rem = shard.plan_split(seg_len)
+        red = ops._REDUCE[reduce]
+        if overlap and work is not None and p_loc["n_units"]:
+            ops._agg_raw(shard._csr, buf, D, spec, red, src_scale, dst_scale, seg_len, out=out, plan_t=p_loc, ns_out=ns)
+            if work is not None:
+                work.wait()
+            if p_rem["n_units"]:
+                ops._agg_raw(shard._csr, buf, D, spec, red, src_scale, dst_scale, seg_len, out=out, plan_t=p_rem, ns_out=ns)
+        else:
+            if work is not None:
+                work.wait()
+            ops._agg_raw(shard._csr, buf, D, spec, red, src_scale, dst_scale, seg_len, out=out,
+                         plan_t=shard._csr.plan(seg_len, need=True), ns_out=ns)
+        ctx.shard, ctx.weight, ctx.reduce, ctx.seg_len, ctx.D, ctx.overlap = o, weight, red, seg_len, D, overlap
+        ctx.save_for_backward(src_scale, dst_scale, ns)
         return out
 
     @staticmethod
-    def backward(ctx, g):
-        world = dist.get_world_size(ctx.group)
-        out = torch.empty((g.shape[0] // world,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
-        dist.reduce_scatter_tensor(out, g.contiguous(), op=dist.ReduceOp.SUM, group=ctx.group)
-        return out, None
+    def backward(ctx, grad_out):
+        from . import _lib, ops
+        if not ctx.needs_input_grad[0]:
+            return (None,) * 8
+        src_scale, dst_scale, ns = ctx.saved_tensors
+        sh, weight, D, seg_len = ctx.shard, ctx.weight, ctx.D, ctx.seg_len
+        g = ops._f32c(grad_out)
+        if ns is not None:
+            g = g * ns
+        dvec = dst_scale
+        if ctx.reduce == _lib.REDUCE_MEAN:
+            inv = 1.0 / sh._csr.degrees.clamp(min=1).to(torch.float32)
+            dvec = inv if dvec is None else dvec * inv
+        spec = (ops._targs_or_c(ops._noise_spec(weight, in_norm=0)) if weight is not None
+                else ops._targs_or_c(ops._none_spec()))
+        csr_t = sh.csr_t
+        n_send = int(sh.send_idx.shape[0])
+        halo = sh.exchange == "halo" and sh.world > 1
+        # T = [gradient of every buffer row | rows received from the peers]: one allocation, so ONE launch can add a
+        # local row's own gradient and what its peers sent
+        T = torch.empty((sh.n_buf + (n_send if halo else 0), D), dtype=torch.float32, device=g.device)
+        dx_buf = T[:sh.n_buf]
+        p_first, p_second = sh.plan_split_t(seg_len)
+        run = lambda plan: ops._agg_raw(csr_t, g, D, spec, _lib.REDUCE_SUM, dvec, src_scale, seg_len, out=dx_buf, plan_t=plan)
+        if not halo:
+            run(csr_t.plan(seg_len, need=True))
+            if sh.world == 1:
+                return (dx_buf[:sh.n_rows].clone(),) + (None,) * 7
+            return (sh.halo_transpose(dx_buf),) + (None,) * 7
+        if ctx.overlap and p_first["n_units"] and p_second["n_units"]:
+            run(p_first)
+            work = sh._transpose_start(dx_buf[sh.n_rows:], T[sh.n_buf:])
+            run(p_second)
+        else:
+            run(csr_t.plan(seg_len, need=True))
+            work = sh._transpose_start(dx_buf[sh.n_rows:], T[sh.n_buf:])
+        if work is not None:
+            work.wait()
+        dx, _ = ops._agg_raw(sh._combined_csr(), T, D, ops._targs_or_c(ops._none_spec()), _lib.REDUCE_SUM, None, None, seg_len)
+        return (dx,) + (None,) * 7
 
 
 class NativeComm:
@@ -133,7 +203,8 @@ class NativeComm:
             self._handle = None
 
     def allgather(self, x_pad, out=None):
-        """[rows, D] on every rank -> [world * rows, D] (stag_halo_allgather, on the current stream)."""
+        """[rows, D] on every rank -> [world * rows, D] (stag_halo_allgather, on the current stream).  x_pad may BE
+        this rank's slot of `out` (RCCL's in-place all-gather: no staging copy)."""
         from . import _lib
         x_pad = x_pad.contiguous()
         if out is None:
@@ -146,19 +217,26 @@ class NativeComm:
     def exchange_async(self, send, in_rows, recv, out_rows, width):
         """All-to-all-v of rows on a side stream (stag_halo_exchange): -> an object whose wait() orders the
         current stream behind it, so kernels launched in between overlap the transfer."""
+        return self.exchange_multi_async([send], in_rows, [recv], out_rows, [width])
+
+    def exchange_multi_async(self, sends, in_rows, recvs, out_rows, widths):
+        """The same for several row tables bound for the same peers (GAT: ft and el), ONE RCCL group
+        (stag_halo_exchange_multi)."""
         import ctypes as C
         from . import _lib
         cur = torch.cuda.current_stream(self.device)
         self._side.wait_stream(cur)                       # the send rows are produced on the current stream
-        sc = (C.c_int64 * self.world)(*[int(r) * width for r in in_rows])
-        rc_ = (C.c_int64 * self.world)(*[int(r) * width for r in out_rows])
+        n = len(sends)
+        sr = (C.c_int64 * self.world)(*[int(r) for r in in_rows])
+        rr = (C.c_int64 * self.world)(*[int(r) for r in out_rows])
+        sp = (C.c_void_p * n)(*[t.data_ptr() if t.numel() else None for t in sends])
+        rp = (C.c_void_p * n)(*[t.data_ptr() if t.numel() else None for t in recvs])
+        wd = (C.c_int32 * n)(*[int(w) for w in widths])
         with torch.cuda.stream(self._side):
-            rc = _lib.lib().stag_halo_exchange(self._handle, send.data_ptr() if send.numel() else None, sc,
-                                               recv.data_ptr() if recv.numel() else None, rc_,
-                                               self._side.cuda_stream)
-        _lib.check(rc, "stag_halo_exchange")
-        send.record_stream(self._side)
-        recv.record_stream(self._side)
+            rc = _lib.lib().stag_halo_exchange_multi(self._handle, n, sp, rp, wd, sr, rr, self._side.cuda_stream)
+        _lib.check(rc, "stag_halo_exchange_multi")
+        for t in list(sends) + list(recvs):
+            t.record_stream(self._side)
         side = self._side
 
         class _Work:
@@ -293,6 +371,7 @@ class GraphShard:
         if self.exchange == "allgather":
             buf_row = owner * self.max_rows + (g_src - bt[owner])
             self.n_buf = world * self.max_rows
+            self.loc_off = rank * self.max_rows          # this rank's rows sit at [loc_off, loc_off + n_rows)
             gid = torch.full((self.n_buf,), -1, dtype=torch.int64, device=g_src.device)
             for q in range(world):
                 a, b = int(self.bounds[q]), int(self.bounds[q + 1])
@@ -319,12 +398,15 @@ class GraphShard:
             buf_row = torch.where(owner == rank, g_src - lo,
                                   (hi - lo) + torch.searchsorted(need, g_src))
             self.n_buf = (hi - lo) + int(need.shape[0])
+            self.loc_off = 0
             gid = torch.cat([torch.arange(lo, hi, device=g_src.device), need])
         if self.n_buf >= 2 ** 31 or g_src.shape[0] >= 2 ** 31:
             raise ValueError("a shard holds at most 2^31-1 edges / buffer rows: use more ranks")
         self.local_indptr = indptr_rel.to(torch.int32).to(dev)
         self.local_indices = buf_row.to(torch.int32).to(dev)
         self.local_eid_global = eid_g.to(dev)
+        self.send_idx32 = self.send_idx.to(torch.int32)
+        self._bufs, self._sendbufs = {}, {}
         self._csr = CsrView(self.n_rows, self.n_buf, self.local_indptr, self.local_indices, None)
         self._in_deg = in_deg_local.to(torch.int64).to(dev)
         # global out-degree of the node behind every buffer row (GCN's source scaling indexes columns)
@@ -336,7 +418,8 @@ class GraphShard:
             rows = torch.repeat_interleave(torch.arange(self.n_rows, device=g_src.device),
                                            (indptr_rel[1:] - indptr_rel[:-1]))
             remote = torch.zeros(self.n_rows, dtype=torch.int64, device=g_src.device)
-            remote.index_add_(0, rows, (buf_row >= self.n_rows).to(torch.int64))
+            remote.index_add_(0, rows, (owner != rank).to(torch.int64))      # (not "buf_row >= n_rows": the all-gather
+                                                                             # layout keeps rank 0's rows at the front)
             self._row_is_local = (remote == 0).cpu().numpy()
         else:
             self._row_is_local = np.ones(self.n_rows, bool)
@@ -344,6 +427,9 @@ class GraphShard:
     # ---- Graph-like surface used by the layers / ops / EdgeNoise -----------------------------
     device = property(lambda self: self._device)
     csr = property(lambda self: self._csr)
+    # endpoints of this rank's edges as rows of the exchanged buffer, by local edge id (ops.edge_mlp reads them)
+    _src = property(lambda self: self.edge_endpoints()[0])
+    _dst = property(lambda self: self.edge_endpoints()[1])
     srcdata = property(lambda self: self.ndata)
     dstdata = property(lambda self: self.ndata)
 
@@ -378,8 +464,8 @@ class GraphShard:
         return self._origin
 
     def edges(self):
-        raise NotImplementedError("a shard keeps its edges in CSR form over the exchanged buffer; per-edge "
-                                  "endpoint gathers (AmortizedDistribution) are not partitioned")
+        raise NotImplementedError("a shard keeps its edges in CSR form over the exchanged buffer: "
+                                  "edge_endpoints() gives their endpoints as buffer rows")
 
     @property
     def csr_t(self):
@@ -410,6 +496,23 @@ class GraphShard:
             o._plan_split[seg_len] = (self._csr.subplan(seg_len, loc), self._csr.subplan(seg_len, ~loc))
         return o._plan_split[seg_len]
 
+    def plan_split_t(self, seg_len=DEFAULT_SEG_LEN):
+        """(first, second) for the BACKWARD: the plan of the source-major twin `csr_t` (its rows = buffer rows) cut
+        into the rows whose gradient has to travel — the remote buffer rows; all segments of long rows ride with
+        them, a sub-plan takes them together — and this rank's own rows, launched while the transposed exchange
+        is in flight."""
+        o = self._origin
+        key = ("t", seg_len)
+        if key not in o._plan_split:
+            csr_t = self.csr_t
+            full = csr_t.plan(seg_len, need=True)
+            units = full["units"].cpu().numpy()[:full["n_units"]]
+            whole = units[:, 3] < 0
+            row = np.where(whole, units[:, 0], 0)
+            local = whole & (row >= self.loc_off) & (row < self.loc_off + self.n_rows)
+            o._plan_split[key] = (csr_t.subplan(seg_len, ~local), csr_t.subplan(seg_len, local))
+        return o._plan_split[key]
+
     # ---- the exchange step ---------------------------------------------------------
     def pad_rows(self, x_local):
         if x_local.shape[0] != self.n_rows:
@@ -428,117 +531,278 @@ class GraphShard:
             return sum(self.out_splits) * D * itemsize, sum(self.in_splits) * D * itemsize
         return (self.world - 1) * self.max_rows * D * itemsize, (self.world - 1) * self.max_rows * D * itemsize
 
-    def halo_start(self, x_local):
-        """Begin the exchange: -> (buffer [n_buf, D] whose local rows are filled, work | None).  The
+    def exchange_buffer(self, tail, dtype=torch.float32, device=None):
+        """The PERSISTENT exchange buffer [n_buf, *tail] of this shard for rows of that shape (one per shape and
+        dtype, zero-filled once: padding rows of the all-gather layout stay zero).  `local_rows(tail)` is the view
+        a producer writes this rank's rows into — a layer output that already lives there is not copied again."""
+        o = self._origin
+        tail = (tail,) if isinstance(tail, int) else tuple(tail)
+        device = self._device if device is None else torch.device(device)
+        key = (tail, dtype, str(device))
+        buf = o._bufs.get(key)
+        if buf is None:
+            buf = o._bufs[key] = torch.zeros((self.n_buf,) + tail, dtype=dtype, device=device)
+        return buf
+
+    def local_rows(self, tail, dtype=torch.float32, device=None):
+        """This rank's rows INSIDE the persistent exchange buffer: fill them (e.g. as the `out=` of the op that
+        produces the layer's input) and hand them to `aggregate` / `halo_start`: no copy into the buffer."""
+        return self.exchange_buffer(tail, dtype, device)[self.loc_off:self.loc_off + self.n_rows]
+
+    def _send_buffer(self, tail, dtype, device):
+        o = self._origin
+        key = (tuple(tail), dtype, str(device))
+        sb = o._sendbufs.get(key)
+        if sb is None:
+            sb = o._sendbufs[key] = torch.empty((int(self.send_idx.shape[0]),) + tuple(tail), dtype=dtype, device=device)
+        return sb
+
+    def _fill_send(self, x_local, send):
+        """send[j] = x_local[send_idx[j]]: into an existing buffer (stag_gather_rows on the device)."""
+        if send.shape[0] == 0:
+            return send
+        if x_local.is_cuda and x_local.dtype == torch.float32 and x_local.is_contiguous():
+            from . import _lib
+            W = int(np.prod(x_local.shape[1:])) if x_local.dim() > 1 else 1
+            with _lib.on_device(x_local.device):
+                rc = _lib.lib().stag_gather_rows(_lib.ptr(x_local), W, _lib.ptr(self.send_idx32), send.shape[0], W,
+                                                 _lib.ptr(send), W, _lib.stream_of(x_local.device))
+            _lib.check(rc, "stag_gather_rows")
+        else:
+            torch.index_select(x_local, 0, self.send_idx, out=send)
+        return send
+
+    def halo_start(self, x_local, persistent=False):
+        """Begin the exchange: -> (buffer [n_buf, ...] whose local rows are filled, work | None).  The
         remote rows are valid after `work.wait()`, which orders the CURRENT stream behind the
-        collective (RCCL runs it on its own stream): kernels launched in between overlap it."""
-        if x_local.shape[0] != self.n_rows:
-            raise ValueError(f"rank {self.rank} owns {self.n_rows} rows, got {x_local.shape[0]}")
-        tail = tuple(x_local.shape[1:])
-        native = self.native_comm if (x_local.is_cuda and x_local.dtype == torch.float32) else None
-        if self.exchange == "halo":
-            buf = torch.empty((self.n_buf,) + tail, dtype=x_local.dtype, device=x_local.device)
-            buf[:self.n_rows].copy_(x_local)
-            send = x_local.index_select(0, self.send_idx)
-            if native is not None:                      # RCCL through the C ABI, on a side stream
-                width = int(np.prod(tail)) if tail else 1
-                return buf, native.exchange_async(send, self.in_splits, buf[self.n_rows:], self.out_splits, width)
-            work = dist.all_to_all_single(buf[self.n_rows:], send, self.out_splits, self.in_splits,
-                                          group=self.group, async_op=True)
-            return buf, work
-        x_pad = self.pad_rows(x_local).contiguous()
-        if self.world == 1 and native is None:
-            return x_pad, None
+        collective (RCCL runs it on its own stream): kernels launched in between overlap it.
+        persistent=True: the shard's own buffer of this row shape (overwritten by the next exchange of that shape —
+        for callers that keep nothing of it); else a fresh tensor."""
+        bufs, work = self.halo_start_multi([x_local], persistent)
+        return bufs[0], work
+
+    def halo_start_multi(self, xs, persistent=False):
+        """halo_start for several row tables bound for the same peers (GAT: ft [n, H, F] and el [n, H]): each gets
+        its own buffer — no packed copy on either side — and, through the native communicator, they travel in ONE
+        RCCL group; through torch.distributed it is one collective per table, back to back."""
+        bufs, works, sends = [], [], []
+        for x in xs:
+            if x.shape[0] != self.n_rows:
+                raise ValueError(f"rank {self.rank} owns {self.n_rows} rows, got {x.shape[0]}")
+        native = self.native_comm if all(x.is_cuda and x.dtype == torch.float32 for x in xs) else None
+        for x in xs:
+            tail = tuple(x.shape[1:])
+            buf = (self.exchange_buffer(tail, x.dtype, x.device) if persistent
+                   else torch.empty((self.n_buf,) + tail, dtype=x.dtype, device=x.device))
+            loc = buf[self.loc_off:self.loc_off + self.n_rows]
+            if loc.data_ptr() != x.data_ptr() or not x.is_contiguous():
+                loc.copy_(x)
+            bufs.append(buf)
+            if self.world == 1:
+                if not persistent and self.n_buf > self.n_rows:
+                    buf[self.n_rows:].zero_()
+                continue
+            if self.exchange == "halo":
+                send = (self._send_buffer(tail, x.dtype, x.device) if persistent
+                        else torch.empty((int(self.send_idx.shape[0]),) + tail, dtype=x.dtype, device=x.device))
+                sends.append(self._fill_send(x.contiguous(), send))
+                if native is None:
+                    works.append(dist.all_to_all_single(buf[self.n_rows:], send, self.out_splits, self.in_splits,
+                                                        group=self.group, async_op=True))
+            else:
+                slot = buf[self.rank * self.max_rows:(self.rank + 1) * self.max_rows]
+                if not persistent and self.n_rows < self.max_rows:
+                    slot[self.n_rows:].zero_()
+                if native is not None:
+                    native.allgather(slot, out=buf)          # in place: the slot IS this rank's part of buf
+                else:
+                    # (gloo stages through the output: hand it a copy of the slot; RCCL takes the slot in place)
+                    src = slot if x.is_cuda else slot.clone()
+                    works.append(dist.all_gather_into_tensor(buf, src, group=self.group, async_op=True))
+        if self.world > 1 and self.exchange == "halo" and native is not None:
+            widths = [int(np.prod(x.shape[1:])) if x.dim() > 1 else 1 for x in xs]
+            works.append(native.exchange_multi_async(sends, self.in_splits, [b[self.n_rows:] for b in bufs],
+                                                     self.out_splits, widths))
+        return bufs, _wait_all(works)
+
+    # ---- the transposed exchange (backward) ----------------------------------------------------------------
+    def _transpose_start(self, g_remote, back):
+        """Start sending the gradient rows of the remote buffer rows [n_buf - n_rows, W] back to their owners; `back`
+        [n_send, W] receives what the peers computed for MY rows, in send-list order.  -> work | None."""
+        if self.world == 1 or self.exchange != "halo":
+            return None
+        native = self.native_comm if (g_remote.is_cuda and g_remote.dtype == torch.float32) else None
         if native is not None:
-            return native.allgather(x_pad), None
-        buf = torch.empty((self.world * self.max_rows,) + tail, dtype=x_local.dtype, device=x_local.device)
-        return buf, dist.all_gather_into_tensor(buf, x_pad, group=self.group, async_op=True)
+            W = int(np.prod(g_remote.shape[1:])) if g_remote.dim() > 1 else 1
+            return native.exchange_async(g_remote, self.out_splits, back, self.in_splits, W)
+        return dist.all_to_all_single(back, g_remote, self.in_splits, self.out_splits, group=self.group, async_op=True)
+
+    def _send_csr(self):
+        """CSR over the send list: row i of this rank -> the positions j with send_idx[j] == i, ascending (peers in
+        rank order).  A segmented sum over it on the aggregation kernel is the deterministic scatter-add."""
+        o = self._origin
+        if getattr(o, "_send_csr_view", None) is None:
+            idx = self.send_idx
+            order = torch.sort(idx, stable=True).indices
+            cnt = torch.bincount(idx, minlength=self.n_rows)
+            indptr = torch.zeros(self.n_rows + 1, dtype=torch.int64, device=idx.device)
+            indptr[1:] = torch.cumsum(cnt, 0)
+            o._send_csr_view = CsrView(self.n_rows, int(idx.shape[0]), indptr.to(torch.int32),
+                                       order.to(torch.int32).contiguous(), None)
+        return o._send_csr_view
+
+    def _combined_csr(self):
+        """CSR over T = [buffer rows | rows received back]: row i -> its own buffer row first, then the rows its
+        peers sent for it, in rank order.  One launch finishes the backward of a partitioned aggregation."""
+        o = self._origin
+        if getattr(o, "_combined_csr_view", None) is None:
+            idx = self.send_idx
+            n, n_send, dev = self.n_rows, int(idx.shape[0]), idx.device
+            order = torch.sort(idx, stable=True).indices
+            cnt = torch.bincount(idx, minlength=n)
+            indptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+            indptr[1:] = torch.cumsum(cnt + 1, 0)
+            indices = torch.empty(n + n_send, dtype=torch.int64, device=dev)
+            indices[indptr[:-1]] = self.loc_off + torch.arange(n, device=dev)
+            if n_send:
+                rows = idx[order]
+                first = (torch.cumsum(cnt, 0) - cnt)[rows]                 # first sorted position of the row's group
+                indices[indptr[rows] + 1 + (torch.arange(n_send, device=dev) - first)] = self.n_buf + order
+            o._combined_csr_view = CsrView(n, self.n_buf + n_send, indptr.to(torch.int32),
+                                           indices.to(torch.int32).contiguous(), None)
+        return o._combined_csr_view
+
+    def _segsum_back(self, back):
+        """dx[i] = sum over j with send_idx[j] == i of back[j], j ascending — fixed order.  Device: the aggregation
+        kernel over `_send_csr` (each row summed by one team, in order); CPU tensors (the gloo tests): index_add_,
+        which is sequential there."""
+        tail = tuple(back.shape[1:])
+        if back.is_cuda and back.dtype == torch.float32:
+            from . import _lib, ops
+            W = int(np.prod(tail)) if tail else 1
+            out, _ = ops._agg_raw(self._send_csr(), back.reshape(back.shape[0], W).contiguous(), W,
+                                  ops._targs_or_c(ops._none_spec()), _lib.REDUCE_SUM, None, None, DEFAULT_SEG_LEN)
+            return out.reshape((self.n_rows,) + tail)
+        dx = torch.zeros((self.n_rows,) + tail, dtype=back.dtype, device=back.device)
+        return dx.index_add_(0, self.send_idx, back)
+
+    def halo_transpose(self, g_buf):
+        return self.halo_transpose_multi([g_buf])[0]
+
+    def halo_transpose_multi(self, gs):
+        """The adjoint of the exchange: gradient of the buffers [n_buf, ...] -> gradient of this rank's rows
+        [n_rows, ...]: own rows + (halo) what the peers computed for them, added in a fixed order, or (all-gather) the
+        reduce-scatter of the padded shards."""
+        outs = []
+        if self.world == 1:
+            return [g[self.loc_off:self.loc_off + self.n_rows].clone() for g in gs]
+        if self.exchange == "halo":
+            backs, works = [], []
+            for g in gs:
+                back = torch.empty((int(self.send_idx.shape[0]),) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+                works.append(self._transpose_start(g[self.n_rows:], back))
+                backs.append(back)
+            for w in works:
+                if w is not None:
+                    w.wait()
+            for g, back in zip(gs, backs):
+                outs.append(g[:self.n_rows] + self._segsum_back(back))
+            return outs
+        for g in gs:
+            out = torch.empty((self.max_rows,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+            dist.reduce_scatter_tensor(out, g.contiguous(), op=dist.ReduceOp.SUM, group=self.group)
+            outs.append(out[:self.n_rows])
+        return outs
 
     def halo_gather(self, x_local):
-        """[n_rows, D] on every rank -> [n_buf, D] source features this rank's CSR indexes
-        (one collective: RCCL over xGMI on GPUs, gloo in the CPU tests).  Differentiable."""
+        """[n_rows, ...] on every rank -> [n_buf, ...] source rows this rank's CSR indexes
+        (one collective: RCCL over xGMI on GPUs, gloo in the CPU tests).  Differentiable (`_HaloExchange`)."""
         if not (torch.is_grad_enabled() and x_local.requires_grad):
             buf, work = self.halo_start(x_local)
             if work is not None:
                 work.wait()
             return buf
-        if self.exchange == "halo":
-            if x_local.shape[0] != self.n_rows:
-                raise ValueError(f"rank {self.rank} owns {self.n_rows} rows, got {x_local.shape[0]}")
-            recv = _HaloAllToAll.apply(x_local, self.send_idx, self.in_splits, self.out_splits, self.group)
-            return torch.cat([x_local, recv], 0)
-        x_pad = self.pad_rows(x_local)
-        if self.world == 1:
-            return x_pad
-        return _HaloGather.apply(x_pad, self.group)
+        return _HaloExchange.apply(self, x_local)[0]
+
+    def halo_gather_multi(self, xs):
+        """halo_gather for several row tables bound for the same peers, one autograd node (GAT: ft and el)."""
+        if not (torch.is_grad_enabled() and any(x.requires_grad for x in xs)):
+            bufs, work = self.halo_start_multi(list(xs))
+            if work is not None:
+                work.wait()
+            return bufs
+        return list(_HaloExchange.apply(self, *xs))
 
     def scatter_rows(self, x_global):
         """This rank's rows of a replicated [N, D] tensor (test / setup helper)."""
         return x_global[self.row_lo:self.row_hi]
 
-    def _buffer_scale(self, s):
-        """A source-side scale as a vector over buffer rows: [n_buf] is taken as is; [n_rows] (a value
-        per local node) is exchanged once and cached."""
-        if s is None or s.shape[0] == self.n_buf:     # (n_buf == n_rows: nothing is received, same thing)
-            return s
-        cache = self._origin.__dict__.setdefault("_scale_cache", {})
-        key = (s.data_ptr(), s._version)
-        if key not in cache:
-            cache.clear()
-            with torch.no_grad():
-                cache[key] = (s, self.halo_gather(s.detach().reshape(-1, 1)).reshape(-1).contiguous())
-        return cache[key][1]
+    def buffer_scale(self, s_local):
+        """A value per LOCAL node [n_rows] -> the value behind every buffer row [n_buf]: one exchange (every rank
+        enters it, whatever it receives itself).  Keep the result: source-side scales are constants of a graph."""
+        if s_local.shape[0] != self.n_rows:
+            raise ValueError(f"rank {self.rank} owns {self.n_rows} rows, got {s_local.shape[0]}")
+        with torch.no_grad():
+            return self.halo_gather(s_local.detach().reshape(-1, 1)).reshape(-1).contiguous()
 
     def aggregate(self, x_local, weight=None, reduce="sum", src_scale_local=None,
-                  dst_scale_local=None, seg_len=None, overlap=True):
+                  dst_scale_local=None, seg_len=None, overlap=True, src_scale_buf=None):
         """One partitioned layer-forward: halo exchange + the single-GPU fused kernel on this rank's
         rows.  `weight`: None or an EdgeNoise built on this shard (its pos_base is forced to the
-        shard's global offset).  src_scale_local: [n_rows] (exchanged) or [n_buf] (`out_degrees()`-
-        derived, used as is).  Without gradients the rows whose sources are all local are launched
-        while the collective is in flight (`overlap`)."""
+        shard's global offset).  Source-side scale: `src_scale_buf` [n_buf] indexes buffer rows (`out_degrees()`-
+        derived; what ops.aggregate hands over), `src_scale_local` [n_rows] is exchanged first (`buffer_scale`: a
+        collective — every rank must pass it).  The rows whose sources are all local are launched while the
+        collective is in flight (`overlap`), forward and — under autograd — backward (`_ShardAggregate`)."""
         from . import ops
         from .noise import EdgeNoise
         seg_len = DEFAULT_SEG_LEN if seg_len is None else seg_len
         if isinstance(weight, EdgeNoise):
             weight.pos_base = self.pos_base
-        src_scale = self._buffer_scale(src_scale_local)
-        needs_grad = torch.is_grad_enabled() and (
-            x_local.requires_grad or (torch.is_tensor(weight) and weight.requires_grad) or
-            (isinstance(weight, EdgeNoise) and weight.grad_params is not None))
-        fusable = weight is None or (isinstance(weight, EdgeNoise) and weight.n_samples == 1)
-        if needs_grad or not overlap or not fusable or self.world == 1 or not x_local.is_cuda or seg_len <= 0:
-            x_full = self.halo_gather(x_local)
-            return ops.aggregate(self, x_full, weight, reduce=reduce, src_scale=src_scale,
-                                 dst_scale=dst_scale_local, seg_len=seg_len, _gathered=True)
-        buf, work = self.halo_start(x_local)
-        p_loc, p_rem = self.plan_split(seg_len)
-        out = torch.empty((self.n_rows, x_local.shape[1]), dtype=torch.float32, device=x_local.device)
-        if p_loc["n_units"]:
-            ops.aggregate_into(self._csr, buf, out, weight, reduce, src_scale, dst_scale_local, p_loc)
-        if work is not None:
-            work.wait()
-        if p_rem["n_units"]:
-            ops.aggregate_into(self._csr, buf, out, weight, reduce, src_scale, dst_scale_local, p_rem)
-        return out
+        if src_scale_local is not None:
+            if src_scale_buf is not None:
+                raise ValueError("one of src_scale_local / src_scale_buf")
+            src_scale_buf = self.buffer_scale(src_scale_local)
+        if src_scale_buf is not None and src_scale_buf.shape[0] != self.n_buf:
+            raise ValueError(f"src_scale_buf indexes the {self.n_buf} rows of the exchanged buffer, got {src_scale_buf.shape[0]}")
+        live_params = (isinstance(weight, EdgeNoise) and weight.grad_params is not None and torch.is_grad_enabled()
+                       and any(torch.is_tensor(p_) and p_.requires_grad for p_ in weight.grad_params))
+        fusable = (weight is None or (isinstance(weight, EdgeNoise) and weight.n_samples == 1 and not live_params))
+        if fusable and x_local.is_cuda and seg_len > 0 and x_local.dim() == 2:
+            if isinstance(weight, EdgeNoise) and weight.dn != x_local.shape[1]:
+                raise ValueError(f"noise width {weight.dn} != feature width {x_local.shape[1]}")
+            return _ShardAggregate.apply(x_local, self, weight, reduce, ops._f32c(src_scale_buf),
+                                         ops._f32c(dst_scale_local), seg_len, bool(overlap))
+        x_full = self.halo_gather(x_local)
+        return ops.aggregate(self, x_full, weight, reduce=reduce, src_scale=src_scale_buf,
+                             dst_scale=dst_scale_local, seg_len=seg_len, _gathered=True)
 
     def gat_aggregate(self, el_local, er_local, ft_local, neg_slope=0.2, weight=None, seg_len=None,
                       want_attn=False, attn_drop=None):
-        """Partitioned GAT layer-forward (BASELINE cfg5): ONE exchange carries [ft | el] of the
-        referenced source rows (H*F + H columns), then the single-GPU fused kernel runs on this
+        """Partitioned GAT layer-forward (BASELINE cfg5): ft [n, H, F] and el [n, H] of the referenced source rows
+        travel as two tables of ONE exchange step (one RCCL group through the native communicator) — no packed
+        [ft | el] copy before, no column slices after —, then the single-GPU fused kernel runs on this
         rank's rows.  `weight`: None or an EdgeNoise(dn=H) built on this shard."""
         from . import ops
         from .noise import EdgeNoise
-        n, H, F = ft_local.shape
-        packed = torch.cat([ft_local.reshape(n, H * F), el_local], 1)
-        full = self.halo_gather(packed)
-        ft_full = full[:, :H * F].reshape(-1, H, F)
-        el_full = full[:, H * F:]
+        ft_full, el_full = self.halo_gather_multi([ft_local, el_local])
         if isinstance(weight, EdgeNoise):
             weight.pos_base = self.pos_base
         # attn_drop: the mask is keyed by GLOBAL forward position (pos_base), so shards draw the whole graph's mask
         return ops.gat_aggregate(self, el_full, er_local, ft_full, neg_slope, weight, want_attn=want_attn,
                                  seg_len=DEFAULT_SEG_LEN if seg_len is None else seg_len, _gathered=True,
                                  attn_drop=attn_drop)
+
+    # ---- per-edge endpoints over the buffer (AmortizedDistribution on a shard) ---------------------------------
+    def edge_endpoints(self):
+        """(src_buf, dst_buf) int32 [E_local], by LOCAL edge id (= forward CSR position): the buffer row of each
+        edge's source and of its destination.  The per-edge MLP of an AmortizedDistribution
+        (stag/distributions.py:221-233) reads its two projected node rows through these."""
+        o = self._origin
+        if getattr(o, "_edge_endpoints", None) is None:
+            rows = torch.repeat_interleave(torch.arange(self.n_rows, dtype=torch.int32, device=self._device),
+                                           (self.local_indptr[1:] - self.local_indptr[:-1]).long())
+            o._edge_endpoints = (self.local_indices, (rows + self.loc_off).contiguous())
+        return o._edge_endpoints
 
 
 # ------------------------------------------------------------------------------------- #

@@ -48,6 +48,38 @@ def test_subplans_reproduce_the_whole_plan(dev):
             assert torch.equal(out, whole)
 
 
+LAYERS = ("gcn", "sage", "gin", "gat", "gat_drop", "gcn_vi", "gcn_bern_norm", "gcn_re", "gcn_rec")
+
+
+def _make_layer(name, D, dev):
+    """The same layer on every rank and in the single process (seeded)."""
+    import stag_amd
+    torch.manual_seed(7)
+    N = torch.distributions.Normal
+    if name == "sage":
+        base = stag_amd.zoo.GraphSAGE(D, 32, aggregator_type="mean")
+    elif name == "gin":
+        base = stag_amd.zoo.GIN(D, 32)
+    elif name in ("gat", "gat_drop"):   # gat_drop: attention dropout inside the kernels, its mask keyed by the GLOBAL forward position
+        base = stag_amd.zoo.GAT(D, 8, num_heads=4, attn_drop=0.5 if name == "gat_drop" else 0.0)
+    else:
+        base = stag_amd.zoo.GCN(D, 32)
+    if name == "gcn_bern_norm":         # scripts/arxiv_mle/gcn/run.py:70-74
+        kw = dict(q_a=torch.distributions.Bernoulli(probs=0.7), norm=True)
+    elif name == "gcn_re":              # scripts/arxiv_rec/gcn/run.py:85: per-edge parameters from narrow heads, KL in the loss
+        q = stag_amd.distributions.AmortizedDistribution(D, 1, init_like=N(1.0, 0.3))
+        with torch.no_grad():
+            for prm in q.parameters():
+                prm.copy_(torch.randn_like(prm) * 0.3)
+        kw = dict(q_a=q, p_a=N(0.8, 0.6), vi=True)
+    elif name == "gcn_rec":             # scripts/citation_rec/gcn/run.py:59,81: [E, D] parameters from wide heads
+        q = stag_amd.distributions.AmortizedDistribution(D, D, hidden_features=8, init_like=N(1.0, 0.3))
+        kw = dict(q_a=q, p_a=N(0.8, 0.6), vi=True)
+    else:
+        kw = dict(q_a=N(1.0, 0.5), relu=(name == "gcn_vi"), vi=(name == "gcn_vi"))
+    return stag_amd.layers.StagLayer(base, **kw).to(dev)
+
+
 def _worker(rank, world, port, tmp):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -76,24 +108,56 @@ def _worker(rank, world, port, tmp):
         p_loc, p_rem = sh.plan_split(64)
         assert p_loc["n_units"] > 0 and p_rem["n_units"] > 0
         res["agg"] = a.cpu()
+        # ---- the same step under autograd: overlapped forward AND backward (the transposed exchange in flight while
+        #      the local rows are reduced), gradients added in a fixed order: identical bits with and without the
+        #      overlap and from run to run
+        gl = gout[lo:hi, :1].to(dev).expand(-1, D).contiguous()
+        runs = []
+        for ov in (True, False, True):
+            xg = x[lo:hi].to(dev).requires_grad_(True)
+            o = sh.aggregate(xg, mk(), overlap=ov)
+            o.backward(gl)
+            runs.append((o.detach(), xg.grad))
+        assert torch.equal(runs[0][0], a)
+        for o, gx in runs[1:]:
+            assert torch.equal(o, runs[0][0]) and torch.equal(gx, runs[0][1]), "partitioned backward must be deterministic"
+        p_first, p_second = sh.plan_split_t(64)
+        assert p_first["n_units"] > 0 and p_second["n_units"] > 0
+        res["agg_dx"] = runs[0][1].cpu()
+        # Bernoulli + in-norm (scripts/arxiv_mle/gcn/run.py:70-74): the factor is saved by both sub-launches
+        mkb = lambda: stag_amd.EdgeNoise(sh, D, _lib.NOISE_BERNOULLI, 0.7, seed=4, offset=3, in_norm=True)
+        xg = x[lo:hi].to(dev).requires_grad_(True)
+        o = sh.aggregate(xg, mkb())
+        o.backward(gl)
+        res["bern"] = (o.detach().cpu(), xg.grad.cpu())
+        # ---- exchange="allgather": this rank's rows sit at rank * max_rows of the buffer, not at its head; the
+        #      overlapped step must know (round-2 ADVICE: it read rows the collective had not delivered yet)
+        sa = GraphShard(src, dst, n, rank, world, device=dev, exchange="allgather")
+        assert sa.loc_off == rank * sa.max_rows
+        mka = lambda: stag_amd.EdgeNoise(sa, D, _lib.NOISE_NORMAL, 1.0, 0.5, seed=4, offset=2)
+        with torch.no_grad():
+            res["agg_allgather"] = sa.aggregate(xl, mka(), overlap=True).cpu()
+        xg = x[lo:hi].to(dev).requires_grad_(True)
+        sa.aggregate(xg, mka()).backward(gl)
+        res["agg_allgather_dx"] = xg.grad.cpu()
+        # the persistent exchange buffer: rows produced in place are not copied again, and the result is the same
+        inplace = sh.local_rows(D)
+        inplace.copy_(xl)
+        with torch.no_grad():
+            assert torch.equal(sh.aggregate(inplace, mk()), a)
+        # a source-side scale per LOCAL node is exchanged explicitly (every rank enters the collective)
+        sc = torch.arange(lo, hi, dtype=torch.float32, device=dev) * 0.01 + 0.5
+        with torch.no_grad():
+            res["scaled"] = sh.aggregate(xl, mk(), src_scale_local=sc).cpu()
         # ---- whole layers on the shard: forward + backward ---------------------------------------------
-        for name in ("gcn", "sage", "gin", "gat", "gat_drop", "gcn_vi"):
-            torch.manual_seed(7)
-            if name in ("gcn", "gcn_vi"):
-                base = stag_amd.zoo.GCN(D, 32)
-            elif name == "sage":
-                base = stag_amd.zoo.GraphSAGE(D, 32, aggregator_type="mean")
-            elif name == "gin":
-                base = stag_amd.zoo.GIN(D, 32)
-            else:   # gat_drop: attention dropout inside the kernels, its mask keyed by the GLOBAL forward position
-                base = stag_amd.zoo.GAT(D, 8, num_heads=4, attn_drop=0.5 if name == "gat_drop" else 0.0)
-            layer = stag_amd.layers.StagLayer(base, q_a=torch.distributions.Normal(1.0, 0.5), relu=(name == "gcn_vi"),
-                                              vi=(name == "gcn_vi")).to(dev)
+        for name in LAYERS:
+            layer = _make_layer(name, D, dev)
             stag_amd.manual_seed(99)
             xg = x[lo:hi].to(dev).requires_grad_(True)
             out = layer(sh, xg)
             assert out.shape[0] == hi - lo
-            (out.reshape(hi - lo, -1) * gout[lo:hi].to(dev)).sum().backward()
+            # a vi layer's KL term rides in the loss: on a shard it is this rank's SHARE, the shares sum to the whole
+            ((out.reshape(hi - lo, -1) * gout[lo:hi].to(dev)).sum() + layer.kl_divergence()).backward()
             grads = {}
             for k, p in layer.named_parameters():      # replicated parameters: sum the ranks' partial gradients
                 if p.grad is None:                     # p_a's parameters only see the KL term
@@ -101,7 +165,10 @@ def _worker(rank, world, port, tmp):
                 gsum = p.grad.detach().clone()
                 dist.all_reduce(gsum)
                 grads[k] = gsum.cpu()
-            res[name] = {"out": out.detach().cpu(), "dx": xg.grad.cpu(), "grads": grads}
+            kl = layer.kl_divergence()
+            kl = kl.detach().clone() if torch.is_tensor(kl) else torch.tensor(float(kl), device=dev)
+            dist.all_reduce(kl)
+            res[name] = {"out": out.detach().cpu(), "dx": xg.grad.cpu(), "grads": grads, "kl": float(kl)}
         torch.save(res, os.path.join(tmp, f"rank{rank}.pt"))
         dist.barrier()
     finally:
@@ -124,24 +191,31 @@ def test_layers_on_two_shards_match_the_whole_graph(dev, tmp_path):
     x = torch.randn(n, D, generator=gen)
     gout = torch.randn(n, 32, generator=gen)
     g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
-    whole = ops.aggregate(g, x.to(dev), stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, 1.0, 0.5, seed=4, offset=2))
-    assert torch.equal(torch.cat([p["agg"] for p in parts], 0), whole.cpu()), "partitioned aggregation: bit-identical"
-    for name in ("gcn", "sage", "gin", "gat", "gat_drop", "gcn_vi"):
-        torch.manual_seed(7)
-        if name in ("gcn", "gcn_vi"):
-            base = stag_amd.zoo.GCN(D, 32)
-        elif name == "sage":
-            base = stag_amd.zoo.GraphSAGE(D, 32, aggregator_type="mean")
-        elif name == "gin":
-            base = stag_amd.zoo.GIN(D, 32)
-        else:
-            base = stag_amd.zoo.GAT(D, 8, num_heads=4, attn_drop=0.5 if name == "gat_drop" else 0.0)
-        layer = stag_amd.layers.StagLayer(base, q_a=torch.distributions.Normal(1.0, 0.5), relu=(name == "gcn_vi"),
-                                          vi=(name == "gcn_vi")).to(dev)
+    xw = x.to(dev).requires_grad_(True)
+    whole = ops.aggregate(g, xw, stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, 1.0, 0.5, seed=4, offset=2))
+    gl = gout[:, :1].to(dev).expand(-1, D).contiguous()
+    whole.backward(gl)
+    assert torch.equal(torch.cat([p["agg"] for p in parts], 0), whole.detach().cpu()), "partitioned aggregation: bit-identical"
+    assert torch.equal(torch.cat([p["agg_allgather"] for p in parts], 0), whole.detach().cpu()), "all-gather layout, overlapped"
+    for key in ("agg_dx", "agg_allgather_dx"):
+        assert_close(torch.cat([p[key] for p in parts], 0), xw.grad.cpu().numpy(), TOL, key)
+    xb = x.to(dev).requires_grad_(True)
+    wb = ops.aggregate(g, xb, stag_amd.EdgeNoise(g, D, _lib.NOISE_BERNOULLI, 0.7, seed=4, offset=3, in_norm=True))
+    wb.backward(gl)
+    assert torch.equal(torch.cat([p["bern"][0] for p in parts], 0), wb.detach().cpu()), "Bernoulli + in-norm on shards"
+    assert_close(torch.cat([p["bern"][1] for p in parts], 0), xb.grad.cpu().numpy(), TOL, "Bernoulli + in-norm: d/dx")
+    sc = torch.arange(0, n, dtype=torch.float32, device=dev) * 0.01 + 0.5
+    with torch.no_grad():
+        ws = ops.aggregate(g, x.to(dev), stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, 1.0, 0.5, seed=4, offset=2), src_scale=sc)
+    assert torch.equal(torch.cat([p["scaled"] for p in parts], 0), ws.cpu()), "a local source scale, exchanged"
+    for name in LAYERS:
+        layer = _make_layer(name, D, dev)
         stag_amd.manual_seed(99)
         xg = x.to(dev).requires_grad_(True)
         out = layer(g, xg)
-        (out.reshape(n, -1) * gout.to(dev)).sum().backward()
+        kl = layer.kl_divergence()
+        ((out.reshape(n, -1) * gout.to(dev)).sum() + kl).backward()
+        assert abs(parts[0][name]["kl"] - float(kl)) <= 1e-5 * (1 + abs(float(kl))), f"{name}: the ranks' KL shares sum to the whole"
         got_out = torch.cat([p[name]["out"] for p in parts], 0)
         got_dx = torch.cat([p[name]["dx"] for p in parts], 0)
         assert_close(got_out, out.detach().cpu().numpy(), TOL, f"{name}: layer output on shards")

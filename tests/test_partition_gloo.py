@@ -61,6 +61,33 @@ def _worker(rank, world, port, tmp):
                 cnt[ids - hs.row_lo] += r + 1
         assert np.allclose(xl.grad.numpy(), np.broadcast_to(cnt[:, None], xl.shape))
 
+        # ---- the transposed exchange adds in a FIXED order: a row's own gradient, then its peers' in rank order ----
+        rr = np.random.default_rng(100 + rank)
+        gb = torch.from_numpy(rr.standard_normal((hs.n_buf, x.shape[1])).astype(np.float32) * 3.0)
+        grads = []
+        for _ in range(2):
+            xr = torch.from_numpy(x[hs.row_lo:hs.row_hi]).requires_grad_(True)
+            hs.halo_gather(xr).backward(gb)
+            grads.append(xr.grad.clone())
+        assert torch.equal(grads[0], grads[1]), "run to run"
+        np.savez(os.path.join(tmp, f"tr{rank}.npz"), gb=gb.numpy(), dx=grads[0].numpy(), recv_ids=hs.recv_ids,
+                 lo=hs.row_lo, hi=hs.row_hi)
+        # several row tables in one exchange step (GAT: ft and el) == one exchange each
+        y = torch.from_numpy(np.arange(hs.n_rows * 3, dtype=np.float32).reshape(hs.n_rows, 3) + 1000 * rank)
+        xr = torch.from_numpy(x[hs.row_lo:hs.row_hi]).requires_grad_(True)
+        yr = y.clone().requires_grad_(True)
+        bx, by = hs.halo_gather_multi([xr, yr])
+        assert torch.equal(bx.detach(), xf.detach()) and torch.equal(by.detach(), hs.halo_gather(y))
+        (bx * gb).sum().backward()
+        assert torch.equal(xr.grad, grads[0]) and yr.grad is None or torch.equal(yr.grad, torch.zeros_like(yr))
+        # the persistent exchange buffer: rows written in place are not copied, the result is the same buffer
+        loc = hs.local_rows(x.shape[1])
+        loc.copy_(torch.from_numpy(x[hs.row_lo:hs.row_hi]))
+        pb, work = hs.halo_start(loc, persistent=True)
+        if work is not None:
+            work.wait()
+        assert pb.data_ptr() == hs.exchange_buffer(x.shape[1]).data_ptr() and torch.equal(pb, xf.detach())
+
         # ---- distributed construction: every rank starts from E/world edges ---------------------------
         cuts = [len(src) * r // world for r in range(world + 1)]
         ds = GraphShard.from_edge_slices(src[cuts[rank]:cuts[rank + 1]], dst[cuts[rank]:cuts[rank + 1]],
@@ -81,7 +108,7 @@ def _worker(rank, world, port, tmp):
         assert np.array_equal(hs._row_is_local, want_local)
         # a source-side scale given per LOCAL node is exchanged once into buffer order
         sc = torch.arange(hs.row_lo, hs.row_hi, dtype=torch.float32)
-        assert np.array_equal(hs._buffer_scale(sc).numpy(), gid.astype(np.float32))
+        assert np.array_equal(hs.buffer_scale(sc).numpy(), gid.astype(np.float32))
 
         # ---- exchange="allgather" ----------------------------------------------------------------------
         sh = GraphShard(src, dst, n, rank, world, exchange="allgather")
@@ -89,7 +116,11 @@ def _worker(rank, world, port, tmp):
         assert sh.bounds[0] == 0 and sh.bounds[-1] == n and (np.diff(sh.bounds) >= 0).all()
         x_local = torch.from_numpy(x[sh.row_lo:sh.row_hi]).requires_grad_(True)
         x_full = sh.halo_gather(x_local)                        # all_gather_into_tensor (gloo here)
-        assert x_full.shape == (world * sh.max_rows, x.shape[1])
+        assert x_full.shape == (world * sh.max_rows, x.shape[1]) and sh.loc_off == rank * sh.max_rows
+        # rows whose sources are all local: by OWNER, not by buffer position (rank 0's rows sit at the buffer's head)
+        ipa, ixa = sh.local_indptr.numpy(), sh.local_indices.numpy()
+        own = (ixa >= sh.loc_off) & (ixa < sh.loc_off + sh.n_rows)
+        assert np.array_equal(sh._row_is_local, np.array([own[ipa[v]:ipa[v + 1]].all() for v in range(sh.n_rows)]))
         for r in range(world):                                   # padded shards, in rank order
             lo, hi = int(sh.bounds[r]), int(sh.bounds[r + 1])
             assert torch.equal(x_full[r * sh.max_rows:r * sh.max_rows + hi - lo].detach(), torch.from_numpy(x[lo:hi]))
@@ -148,6 +179,21 @@ def test_partition_two_ranks_matches_single(world, tmp_path, oracle):
         got = np.concatenate([np.load(tmp_path / f"{tag}{r}.npy") for r in range(world)], 0)
         assert got.shape == ref.shape
         assert np.array_equal(got, ref), f"{tag}: partitioned result must be bit-identical to the unpartitioned one"
+    # the partitioned backward's adds, replayed in one process in the documented order, give the same BITS:
+    #   dx[i] = g_own[i] + ((0 + g_q1[.]) + g_q2[.] + ...)   over the peers q that hold row i, ascending
+    tr = [np.load(tmp_path / f"tr{r}.npz") for r in range(world)]
+    for r in range(world):
+        lo, hi = int(tr[r]["lo"]), int(tr[r]["hi"])
+        acc = np.zeros((hi - lo, x.shape[1]), np.float32)
+        for q in range(world):
+            if q == r:
+                continue
+            ids = tr[q]["recv_ids"]
+            nq = int(tr[q]["hi"]) - int(tr[q]["lo"])
+            sel = np.nonzero((ids >= lo) & (ids < hi))[0]
+            acc[ids[sel] - lo] = acc[ids[sel] - lo] + tr[q]["gb"][nq + sel]
+        want = tr[r]["gb"][:hi - lo] + acc
+        assert np.array_equal(tr[r]["dx"], want), f"rank {r}: transposed exchange must add in the fixed order"
     chan = np.concatenate([np.load(tmp_path / f"chan{r}.npy") for r in range(world)], 1)
     assert np.array_equal(chan, ref), "channel shards: global Philox channel => bit-identical columns"
     rows = np.concatenate([np.load(tmp_path / f"rows{r}.npy") for r in range(world)], 0)
