@@ -511,6 +511,21 @@ int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr
                  float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
                  const stag_gat_drop* drop, float* d_el, float* d_er, float* d_ft, float* dw, float* scratch,
                  void* stream);
+/* (v17) stag_gat_bwd for a REPARAMETERISED draw whose parameters carry gradients (`vi=True`: `rsample`,
+ * stag/layers.py:123-124, through the logits of stag/zoo/gat.py:117-119): the same pass also returns the FINISHED
+ *   dp_i[h] = sum_e dL/dw[e,h] * dw/dp_i[e,h]      (p0 = loc | low, p1 = scale | high; d/dlog under spec.p1_log;
+ *                                                   times 1[w > 0] under relu)
+ * for SCALAR / PER_CHANNEL parameters of a NORMAL / UNIFORM spec without in-norm: the source pass has dL/dw of its
+ * batch in LDS and redoes the draw with its derivatives; every batch leaves one [2][H] partial, two small launches
+ * add them in a fixed order.  No [E, H] tensor — weights, their gradient — exists at any point.
+ * workspace: stag_gat_bwd_dp_workspace_bytes(plan_t->n_blocks, H).  dp0, dp1: [H] (scalar parameters: sum them). */
+size_t stag_gat_bwd_dp_workspace_bytes(int32_t n_blocks_t, int32_t H);
+int stag_gat_bwd_dp(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
+                    const stag_plan* plan_t, const float* el, const float* er, const float* ft,
+                    const float* stats, const float* g, const float* out, int32_t H, int32_t F,
+                    float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
+                    const stag_gat_drop* drop, float* d_el, float* d_er, float* d_ft, float* dp0, float* dp1,
+                    float* scratch, void* workspace, size_t workspace_bytes, void* stream);
 int stag_gat_bwd_two_pass(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
                           const stag_plan* plan_t, const float* el, const float* er, const float* ft,
                           const float* stats, const float* g, const float* out, int32_t H, int32_t F,

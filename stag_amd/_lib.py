@@ -157,6 +157,11 @@ def lib():
     l.stag_comm_destroy.argtypes = [_vp]
     l.stag_halo_allgather.argtypes = [_vp, _vp, C.c_int64, _vp, _vp]
     l.stag_halo_exchange.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
+    l.stag_gat_bwd_dp_workspace_bytes.restype = C.c_size_t
+    l.stag_gat_bwd_dp_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+    l.stag_gat_bwd_dp.argtypes = [C.POINTER(Csr), C.POINTER(Plan), C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp, _vp, _vp,
+                                  _vp, C.c_int32, C.c_int32, C.c_float, C.POINTER(NoiseSpec), _vp, C.POINTER(GatDrop),
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]
     l.stag_halo_exchange_multi.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]
     l.stag_gather_rows.argtypes = [_vp, C.c_int64, _vp, C.c_int64, C.c_int32, _vp, C.c_int64, _vp]
     if l.stag_abi_version() != 17:

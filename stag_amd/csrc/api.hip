@@ -815,6 +815,18 @@ __global__ __launch_bounds__(256) void dp_stage2_kernel(const float* part2, int 
   if (lane == 0 && k < D) (i == 0 ? dp0 : dp1)[k] = sum;
 }
 
+}  // extern "C" (reopened below)
+namespace stag {
+// per-block partials [gx][2][D] (one channel tile) -> dp0 [D], dp1 [D]; part2: [kDpSlabs][2][D] scratch.  Shared with
+// the GAT backward (gat.hip: stag_gat_bwd_dp), whose batches leave [2][H] partials.
+int dp_reduce_partials(const float* part, int64_t gx, int32_t D, float* part2, float* dp0, float* dp1, hipStream_t s) {
+  hipLaunchKernelGGL(dp_stage1_kernel, dim3((D + 63) / 64, 2, kDpSlabs), dim3(256), 0, s, part, (int)gx, D, D, part2);
+  hipLaunchKernelGGL(dp_stage2_kernel, dim3((D + 3) / 4, 2), dim3(256), 0, s, part2, D, dp0, dp1);
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}
+}  // namespace stag
+extern "C" {
+
 static void dp_shape(int32_t D, int64_t n_units, int& lpe, int& tiles, int64_t& gx) {
   const int nchunk = (D + 3) / 4;
   lpe = 1;

@@ -1173,6 +1173,8 @@ struct GatBwd1Args {
   float* dw;             // [E, H] by edge id, or null
   float* ws;             // segment partials: [n_seg_t][HF + H]
   int32_t eid_is_pos;    // the forward CSR has no eid: edge id = forward position
+  float* dp_part;        // [n_blocks][2][H] or null: this batch's share of the gradients of scalar / per-head noise
+                         // parameters, sum_e dw[e,h] * dw/dp_i[e,h] (stag_gat_bwd_dp; vi=True, stag/layers.py:123-124)
 };
 
 constexpr int kRowdotRows = 4;
@@ -1225,7 +1227,8 @@ __global__ __launch_bounds__(kBlkThreads) void gat_bwd_one_kernel(const GatBwd1A
   float* s_c1 = s_a + kBlkEdges * H;                  // [kBlkEdges][H] w ns lrelu'(s), then d s
   float* s_sd = s_c1 + kBlkEdges * H;                 // [kBlkEdges][H] sdot of the edge's destination
   float* s_c2 = s_sd + kBlkEdges * H;                 // [kBlkEdges][H] lrelu(s) ns, then dw (only when wanted)
-  int* s_v = reinterpret_cast<int*>(s_c2 + (ba.dw ? kBlkEdges * H : 0));
+  const bool want_dw = ba.dw != nullptr || ba.dp_part != nullptr;
+  int* s_v = reinterpret_cast<int*>(s_c2 + (want_dw ? kBlkEdges * H : 0));
   int* s_start = s_v + kBlkEdges;
   int4* s_unit = reinterpret_cast<int4*>(s_start + kBlkUnits + 4);
   const int t = threadIdx.x;
@@ -1287,7 +1290,7 @@ __global__ __launch_bounds__(kBlkThreads) void gat_bwd_one_kernel(const GatBwd1A
           s_a[t * H + h] = (a.drop_keep > 0.f && !((kbits >> jj) & 1u)) ? -av : av;
           s_c1[t * H + h] = wn * (sL > 0.f ? 1.0f : a.neg_slope);
           s_sd[t * H + h] = sd4[jj];
-          if (ba.dw) s_c2[t * H + h] = lr * ns4[jj];
+          if (want_dw) s_c2[t * H + h] = lr * ns4[jj];
         }
       }
     }
@@ -1356,7 +1359,7 @@ __global__ __launch_bounds__(kBlkThreads) void gat_bwd_one_kernel(const GatBwd1A
               for (int x = 0; x < 4; ++x) acc[cj][x] = __builtin_fmaf(w, fv[r][cj][x], acc[cj][x]);
               if ((k0[cj] % F) == 0) {
                 s_c1[(e + r) * H + hl[cj]] = ds * s_c1[(e + r) * H + hl[cj]];
-                if (ba.dw) s_c2[(e + r) * H + hl[cj]] = ds * s_c2[(e + r) * H + hl[cj]];
+                if (want_dw) s_c2[(e + r) * H + hl[cj]] = ds * s_c2[(e + r) * H + hl[cj]];
               }
             }
           }
@@ -1371,6 +1374,47 @@ __global__ __launch_bounds__(kBlkThreads) void gat_bwd_one_kernel(const GatBwd1A
     }
   }
   __syncthreads();
+
+  // ---- gradients of scalar / per-head noise parameters (vi=True): dw[e,h] is in LDS, the draw is redone with its
+  //      derivatives (same counters), the products go where a and sdot were (both consumed), and 2H threads add the
+  //      batch's edges in order: one [2][H] partial per batch, summed by two fixed-order launches (dp_stage*)
+  if (ba.dp_part) {
+    if (t < ne) {
+      const uint32_t n = a.pos_lo + (uint32_t)my_fp;
+      const PhiloxKey key = resolve_epoch(a.key);
+      const uint32_t c1hi = a.pos_hi << 20;
+      for (int cc = 0; cc < (H + 3) / 4; ++cc) {
+        float pa[4], pb[4], w[4], d0[4], d1[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int h = 4 * cc + jj;
+          const bool in = h < H;
+          float q0 = a.p0s, q1 = a.p1s;
+          if (a.pmode == STAG_PARAM_PER_CHANNEL) { q0 = in ? a.p0[h] : 0.f; q1 = (in && a.p1) ? a.p1[h] : 0.f; }
+          if (a.pmode != STAG_PARAM_SCALAR && (a.relu & kFlagLogScale)) q1 = exp_scale(q1);
+          pa[jj] = q0; pb[jj] = q1;
+        }
+        if (a.kind == kNormal) draw4_grad<kNormal>(n, (uint32_t)cc | c1hi, key, pa, pb, a.relu, w, d0, d1);
+        else draw4_grad<kUniform>(n, (uint32_t)cc | c1hi, key, pa, pb, a.relu, w, d0, d1);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int h = 4 * cc + jj;
+          if (h < H) {
+            s_a[t * H + h] = s_c2[t * H + h] * d0[jj];
+            s_sd[t * H + h] = s_c2[t * H + h] * d1[jj];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (t < 2 * H) {
+      const float* src = t < H ? s_a : s_sd;
+      const int h = t < H ? t : t - H;
+      float sum = 0.f;
+      for (int e = 0; e < ne; ++e) sum += src[e * H + h];
+      ba.dp_part[(int64_t)blockIdx.x * 2 * H + t] = sum;
+    }
+  }
 
   // ---- phase 3: d s by forward position, dw by edge id; d el per unit ---------------------------------------
   if (t < ne) {
@@ -1796,12 +1840,58 @@ extern "C" size_t stag_gat_bwd_scratch_bytes(int64_t n_dst, int64_t n_edges, int
   return ((size_t)2 * (size_t)n_edges + (size_t)4 * (size_t)n_dst) * (size_t)H * sizeof(float);
 }
 
+// the fixed-order reduction of per-block partials [gx][2][D] -> dp0 [D], dp1 [D] (api.hip: stag_agg_bwd_dp's stages)
+namespace stag { int dp_reduce_partials(const float* part, int64_t gx, int32_t D, float* part2, float* dp0, float* dp1, hipStream_t s); }
+
+static int gat_bwd_impl(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
+                        const stag_plan* plan_t, const float* el, const float* er, const float* ft,
+                        const float* stats, const float* g, const float* out, int32_t H, int32_t F,
+                        float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
+                        const stag_gat_drop* drop, float* d_el, float* d_er, float* d_ft, float* dw,
+                        float* scratch, void* stream, float* dp0, float* dp1, float* dp_ws);
+
 extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
                             const stag_plan* plan_t, const float* el, const float* er, const float* ft,
                             const float* stats, const float* g, const float* out, int32_t H, int32_t F,
                             float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
                             const stag_gat_drop* drop, float* d_el, float* d_er, float* d_ft, float* dw,
                             float* scratch, void* stream) {
+  return gat_bwd_impl(csr, plan, csr_t, plan_t, el, er, ft, stats, g, out, H, F, neg_slope, spec, norm_scale, drop,
+                      d_el, d_er, d_ft, dw, scratch, stream, nullptr, nullptr, nullptr);
+}
+
+extern "C" size_t stag_gat_bwd_dp_workspace_bytes(int32_t n_blocks_t, int32_t H) {
+  if (n_blocks_t <= 0 || H <= 0) return 0;
+  return ((size_t)n_blocks_t * 2u * (size_t)H + (size_t)256 * 2u * (size_t)H) * sizeof(float);
+}
+
+extern "C" int stag_gat_bwd_dp(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
+                               const stag_plan* plan_t, const float* el, const float* er, const float* ft,
+                               const float* stats, const float* g, const float* out, int32_t H, int32_t F,
+                               float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
+                               const stag_gat_drop* drop, float* d_el, float* d_er, float* d_ft,
+                               float* dp0, float* dp1, float* scratch, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  if (!spec || !dp0 || !dp1 || !plan_t) return STAG_EINVAL;
+  if (spec->kind != STAG_NOISE_NORMAL && spec->kind != STAG_NOISE_UNIFORM) return STAG_EINVAL;
+  if (spec->param_mode != STAG_PARAM_SCALAR && spec->param_mode != STAG_PARAM_PER_CHANNEL) return STAG_EINVAL;
+  if (spec->in_norm) return STAG_EINVAL;          // the in-norm factor is not differentiated here
+  if (csr && (csr->n_dst == 0 || csr->n_edges == 0)) {
+    if (hipMemsetAsync(dp0, 0, sizeof(float) * H, (hipStream_t)stream) != hipSuccess) return STAG_EIO;
+    if (hipMemsetAsync(dp1, 0, sizeof(float) * H, (hipStream_t)stream) != hipSuccess) return STAG_EIO;
+    return STAG_OK;
+  }
+  if (!workspace || workspace_bytes < stag_gat_bwd_dp_workspace_bytes(plan_t->n_blocks, H)) return STAG_ENOMEM;
+  return gat_bwd_impl(csr, plan, csr_t, plan_t, el, er, ft, stats, g, out, H, F, neg_slope, spec, norm_scale, drop,
+                      d_el, d_er, d_ft, nullptr, scratch, stream, dp0, dp1, static_cast<float*>(workspace));
+}
+
+static int gat_bwd_impl(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
+                        const stag_plan* plan_t, const float* el, const float* er, const float* ft,
+                        const float* stats, const float* g, const float* out, int32_t H, int32_t F,
+                        float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
+                        const stag_gat_drop* drop, float* d_el, float* d_er, float* d_ft, float* dw,
+                        float* scratch, void* stream, float* dp0, float* dp1, float* dp_ws) {
   if (!csr || !csr_t || !csr->indptr || !csr_t->indptr || csr->n_dst < 0 || csr->n_edges < 0) return STAG_EINVAL;
   if (csr_t->n_edges != csr->n_edges || csr_t->n_dst != csr->n_src || csr_t->n_src != csr->n_dst) return STAG_EINVAL;
   if (!spec || spec->kind < STAG_NOISE_NONE || spec->kind > STAG_NOISE_BERNOULLI || spec->deriv) return STAG_EINVAL;
@@ -1863,11 +1953,12 @@ extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const st
   if (fill_drop(a, drop)) return STAG_EINVAL;
   a.hvec = aligned16(el) && aligned16(pack) && (!a.nscale || aligned16(a.nscale));
   ba.g = g; ba.pack = pack; ba.d_ft = d_ft; ba.d_el = d_el; ba.dsl = dsl; ba.dw = dw;
+  ba.dp_part = dp_ws;
   ba.ws = plan ? plan->workspace : nullptr;
   ba.eid_is_pos = csr->eid ? 0 : 1;
   const uint64_t gb = (uint64_t)csr->n_dst * (uint64_t)HF * 4u;
   ba.g_bytes = (gb < (1ull << 32) && csr->n_dst < (1 << 24)) ? (uint32_t)gb : 0u;
-  size_t lds_s = (size_t)kBlkEdges * H * (dw ? 4 : 3) * sizeof(float) + (size_t)(kBlkEdges + kBlkUnits + 4) * sizeof(int) +
+  size_t lds_s = (size_t)kBlkEdges * H * ((dw || dp_ws) ? 4 : 3) * sizeof(float) + (size_t)(kBlkEdges + kBlkUnits + 4) * sizeof(int) +
                  (size_t)kBlkUnits * sizeof(int4);
   if (lds_s < STAG_GAT_LDS_MIN_ONE) lds_s = STAG_GAT_LDS_MIN_ONE;
   const dim3 gs(plan_t->n_blocks);
@@ -1898,5 +1989,9 @@ extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const st
   if (fplan && plan->n_long > 0)
     hipLaunchKernelGGL(gat_seg_finish_kernel, dim3(plan->n_long, (H + 15) / 16), dim3(256), 0, s,
                        plan->workspace, H, 0, H, plan->long_rows, plan->long_seg_ptr, d_er, H);
+  if (dp_ws) {
+    const int rc2 = stag::dp_reduce_partials(dp_ws, plan_t->n_blocks, H, dp_ws + (size_t)plan_t->n_blocks * 2u * (size_t)H, dp0, dp1, s);
+    if (rc2) return rc2;
+  }
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }

@@ -1080,9 +1080,13 @@ def attn_drop_fusable(H, F, seg_len, want_attn=False):
 
 
 class _GatAggregate(torch.autograd.Function):
+    """p0, p1 (optional): the live parameter tensors of a reparameterised `noise` (vi=True): the draw stays in the
+    kernels, forward and backward, and the backward returns their finished gradients (stag_gat_bwd_dp)."""
+
     @staticmethod
-    def forward(ctx, el, er, ft, w, graph, noise, neg_slope, want_attn, seg_len, attn_drop=None):
+    def forward(ctx, el, er, ft, w, graph, noise, neg_slope, want_attn, seg_len, attn_drop=None, p0=None, p1=None):
         el, er, ft = _f32c(el), _f32c(er), _f32c(ft)
+        ctx.pshapes = None if p0 is None else (p0.shape, p1.shape)
         H, F = ft.shape[1], ft.shape[2]
         csrv = graph.csr
         dev = _lib.require_device(el, er, ft, csrv.indptr)
@@ -1096,7 +1100,7 @@ class _GatAggregate(torch.autograd.Function):
         if attn_drop is not None and noise is None:
             spec.pos_base = int(getattr(graph, "pos_base", 0))    # a shard's dropout mask is the whole graph's
         nscale = _gat_norm_scale(csrv, noise, H, seg_len, dev) if spec.in_norm else None
-        need_grad = any(ctx.needs_input_grad[:4])
+        need_grad = any(ctx.needs_input_grad[:4]) or any(ctx.needs_input_grad[10:12])
         out = torch.empty((csrv.n_dst, H, F), dtype=torch.float32, device=dev)
         # softmax statistics per row [N, 2H]: the backward and the attention values are computed
         # from them (storing a[E, H] from the forward kernel cost it 250 us at cfg5)
@@ -1149,17 +1153,28 @@ class _GatAggregate(torch.autograd.Function):
         want_dw = w is not None and ctx.needs_input_grad[3]
         if ctx.attn_drop is not None and noise is None:
             spec.pos_base = int(getattr(graph, "pos_base", 0))
+        want_dp = ctx.pshapes is not None and any(ctx.needs_input_grad[10:12])
         if csrv.n_edges == 0:        # no edge, no gradient
+            zp = lambda i: (torch.zeros(ctx.pshapes[i], dtype=torch.float32, device=dev)
+                            if (want_dp and ctx.needs_input_grad[10 + i]) else None)
             return (torch.zeros_like(el) if ctx.needs_input_grad[0] else None,
                     torch.zeros_like(er) if ctx.needs_input_grad[1] else None,
                     torch.zeros_like(ft) if ctx.needs_input_grad[2] else None,
-                    torch.zeros_like(w) if want_dw else None, None, None, None, None, None, None)
+                    torch.zeros_like(w) if want_dw else None, None, None, None, None, None, None, zp(0), zp(1))
         fused = _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, ctx.neg_slope, spec, nscale,
-                               want_dw, ctx.seg_len, dev, ctx.attn_drop)
+                               want_dw, ctx.seg_len, dev, ctx.attn_drop, want_dp=want_dp)
         if fused is not None:
-            d_el, d_er, d_ft, dw = fused
+            d_el, d_er, d_ft, dw = fused[:4]
+            dps = [None, None]
+            if want_dp:
+                for i in range(2):
+                    if ctx.needs_input_grad[10 + i]:
+                        d, shape = fused[4 + i], ctx.pshapes[i]
+                        dps[i] = d.sum().reshape(shape) if len(shape) == 0 or d.numel() != int(torch.Size(shape).numel()) else d.reshape(shape)
             return (d_el if ctx.needs_input_grad[0] else None, d_er if ctx.needs_input_grad[1] else None,
-                    d_ft if ctx.needs_input_grad[2] else None, dw, None, None, None, None, None, None)
+                    d_ft if ctx.needs_input_grad[2] else None, dw, None, None, None, None, None, None, dps[0], dps[1])
+        if want_dp:
+            raise NotImplementedError("vi=True GAT parameter gradients need the one-gather backward (stag_gat_bwd_dp)")
         if ctx.attn_drop is not None:
             raise NotImplementedError("attention dropout needs the one-gather GAT backward (stag_gat_bwd)")
         de = torch.empty((csrv.n_edges, H), dtype=torch.float32, device=dev)
@@ -1190,17 +1205,17 @@ class _GatAggregate(torch.autograd.Function):
             d_ft, _ = _agg_raw(csrt, G.reshape(-1, HF), HF, _explicit_spec(attn, group=F), _lib.REDUCE_SUM, None, None,
                                ctx.seg_len)
             d_ft = d_ft.reshape(-1, H, F)
-        return d_el, d_er, d_ft, dw, None, None, None, None, None, None
+        return d_el, d_er, d_ft, dw, None, None, None, None, None, None, None, None
 
 
 def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec, nscale, want_dw, seg_len, dev,
-                   attn_drop=None):
+                   attn_drop=None, want_dp=False):
     """stag_gat_bwd: the whole backward on the workgroup-cooperative kernels (one gather of the [H*F] rows; the
     two-gather form stag_gat_bwd_two_pass stays for A/B); None when the shape or the plans are outside what it
     covers (the caller then composes the older kernels)."""
     lph = F // 4
     E = csrv.n_edges
-    one = _GAT_BWD_ONE_GATHER or attn_drop is not None
+    one = _GAT_BWD_ONE_GATHER or attn_drop is not None or want_dp
     if not (_GAT_BWD_FUSED and E > 0 and gat_cooperative_shape(H, F, seg_len)
             and (one or (lph & (lph - 1)) == 0)):      # the two-pass form wants F / 4 a power of two
         return None
@@ -1214,8 +1229,23 @@ def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec,
     dw = torch.empty((E, H), dtype=torch.float32, device=dev) if want_dw else None
     scratch = torch.empty(_lib.lib().stag_gat_bwd_scratch_bytes(csrv.n_dst, E, H) // 4, dtype=torch.float32, device=dev)
     cs, ct = csrv.struct(), csrt.struct()
-    fn = _lib.lib().stag_gat_bwd if (_GAT_BWD_ONE_GATHER or attn_drop is not None) else _lib.lib().stag_gat_bwd_two_pass
     drop = _gat_drop_struct(attn_drop)
+    if want_dp:        # the one-gather backward that also finishes the gradients of scalar / per-head noise parameters
+        dp0 = torch.empty(H, dtype=torch.float32, device=dev)
+        dp1 = torch.empty(H, dtype=torch.float32, device=dev)
+        wbytes = _lib.lib().stag_gat_bwd_dp_workspace_bytes(plan_b["n_blocks"], H)
+        ws = torch.empty(max(wbytes // 4, 1), dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            rc = _lib.lib().stag_gat_bwd_dp(C.byref(cs), C.byref(pf), C.byref(ct), C.byref(pb), _lib.ptr(el), _lib.ptr(er),
+                                            _lib.ptr(ft), _lib.ptr(stats), _lib.ptr(G), _lib.ptr(out), H, F, neg_slope,
+                                            C.byref(spec), _lib.ptr(nscale), C.byref(drop) if drop is not None else None,
+                                            _lib.ptr(d_el), _lib.ptr(d_er), _lib.ptr(d_ft), _lib.ptr(dp0), _lib.ptr(dp1),
+                                            _lib.ptr(scratch), _lib.ptr(ws), wbytes, _lib.stream_of(dev))
+        if rc == -38:
+            return None
+        _lib.check(rc, "stag_gat_bwd_dp")
+        return d_el, d_er, d_ft, None, dp0, dp1
+    fn = _lib.lib().stag_gat_bwd if (_GAT_BWD_ONE_GATHER or attn_drop is not None) else _lib.lib().stag_gat_bwd_two_pass
     with _lib.on_device(dev):
         rc = fn(C.byref(cs), C.byref(pf), C.byref(ct), C.byref(pb), _lib.ptr(el), _lib.ptr(er),
                 _lib.ptr(ft), _lib.ptr(stats), _lib.ptr(G), _lib.ptr(out), H, F, neg_slope,
@@ -1227,6 +1257,7 @@ def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec,
     return d_el, d_er, d_ft, dw
 
 
+_GAT_VI_FUSED = True       # vi=True parameter gradients inside the GAT kernels (stag_gat_bwd_dp) | materialised [E, H] weights
 _GAT_BWD_FUSED = True      # tools/bench_configs.py --gat-old-bwd flips it for A/B runs
 _GAT_BWD_ONE_GATHER = True  # stag_gat_bwd (one gather of [H*F] rows) | stag_gat_bwd_two_pass; --gat-two-pass for A/B
 
@@ -1248,12 +1279,20 @@ def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False
     w = weight if torch.is_tensor(weight) else None
     if w is not None and w.shape[0] != graph.number_of_edges():
         raise AssertionError("edge_weight.shape[0] != number_of_edges")
+    H, F = ft.shape[1], ft.shape[2]
+    live = None
     if (noise is not None and noise.grad_params is not None and torch.is_grad_enabled()
             and any(torch.is_tensor(p) and p.requires_grad for p in noise.grad_params)):
-        # vi=True: the H-wide weights are formed from the kernel's standard draw and the live parameters
-        # ([E, H]: 37 MB at cfg5); they enter as explicit weights and the edge pass returns dw[E, H]
-        w, noise = noise.materialize(), None
-    H, F = ft.shape[1], ft.shape[2]
+        # vi=True (stag/layers.py:123-124 through stag/zoo/gat.py:117-119).  Scalar / per-head parameters without
+        # in-norm stay in the kernels: the forward draws from the descriptor, the one-gather backward redoes the draw
+        # with its derivatives and returns the finished parameter gradients (stag_gat_bwd_dp) — no [E, H] tensor.
+        # Otherwise the H-wide weights are formed from the kernel's standard draw and the live parameters ([E, H]:
+        # 37 MB at cfg5), enter as explicit weights, the edge pass returns dw[E, H] and autograd does the affine map.
+        if (_GAT_VI_FUSED and not noise.in_norm and noise.param_mode <= _lib.PARAM_PER_CHANNEL and ft.is_cuda
+                and gat_cooperative_shape(H, F, seg_len) and _GAT_BWD_FUSED and not want_attn):
+            live = tuple(torch.as_tensor(p, dtype=torch.float32, device=ft.device) for p in noise.grad_params)
+        else:
+            w, noise = noise.materialize(), None
     lph = F // 4
     # the fused kernels: H*F <= 256 always; up to 1024 channels on the workgroup-cooperative forms (F % 4 == 0,
     # H <= 16, the default plan); the backward wants F/4 a power of two (<= 64)
@@ -1269,6 +1308,8 @@ def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False
         return _gat_composed(graph, el, er, ft, neg_slope, noise, w, want_attn, seg_len, attn_fn)
     if attn_drop is not None and not attn_drop_fusable(H, F, seg_len, want_attn):
         raise NotImplementedError("attn_drop rides in the fused kernels only: check attn_drop_fusable()")
+    if live is not None:
+        return _GatAggregate.apply(el, er, ft, None, graph, noise, neg_slope, want_attn, seg_len, attn_drop, *live)
     return _GatAggregate.apply(el, er, ft, w, graph, noise, neg_slope, want_attn, seg_len, attn_drop)
 
 

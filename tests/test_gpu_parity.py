@@ -1098,3 +1098,81 @@ def test_fuzz_backward_passes_against_oracle(dev, oracle):
                     ref = oracle.agg_bwd_w(og, x, gout * gs[:, None], src_scale=rs, spec=osp).astype(np.float64).sum(1, keepdims=True)
                     sc = max(1.0, float(np.abs(ref).max()))
                     assert_close(got / sc, ref / sc, what=f"{what} stag_agg_bwd_edge d p{dv - 1}")
+
+
+@pytest.mark.parametrize("H,F", [(8, 32), (3, 4), (4, 40)])
+@pytest.mark.parametrize("kind,pmode,relu,drop", [("normal", "scalar", False, False), ("normal", "channel", True, True),
+                                                  ("uniform", "channel", True, False), ("normal", "logscale", True, False)])
+def test_gat_vi_parameter_gradients_in_the_kernels(dev, oracle, monkeypatch, H, F, kind, pmode, relu, drop):
+    """vi=True through GAT (`rsample` weights scale the logits, stag/layers.py:123-124 + stag/zoo/gat.py:117-119): the
+    draw stays in the kernels and the one-gather backward returns the FINISHED gradients of loc / scale (low / high)
+    — stag_gat_bwd_dp — without an [E, H] tensor on either pass.  Against the oracle: its GAT backward with the
+    materialised weights as explicit weights gives dL/dw [E, H]; dp_i[h] = sum_e dL/dw * dw/dp_i with z from the
+    oracle's own standard draw.  Also d el / d er / d ft of the same call."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    rng = np.random.default_rng(H * 13 + F)
+    n = 300
+    g = random_graph(n, 3000, seed=H + F, hub=500, device=dev)
+    E = g.number_of_edges()
+    og = oracle_graph(oracle, g)
+    el, er = rng.standard_normal((n, H)).astype(np.float32), rng.standard_normal((n, H)).astype(np.float32)
+    ft, G = rng.standard_normal((n, H, F)).astype(np.float32), rng.standard_normal((n, H, F)).astype(np.float32)
+    if pmode == "scalar":
+        p0h, p1h = np.float32(0.9), np.float32(0.6)
+        p0 = torch.tensor(0.9, device=dev, requires_grad=True)
+        p1 = torch.tensor(0.6, device=dev, requires_grad=True)
+    else:
+        p0h = rng.uniform(0.2, 0.9, H).astype(np.float32)
+        p1h = rng.uniform(1.0, 1.8, H).astype(np.float32) if kind == "uniform" else rng.uniform(0.3, 0.8, H).astype(np.float32)
+        p0 = torch.tensor(p0h, device=dev, requires_grad=True)
+        p1 = torch.tensor(np.log(p1h) if pmode == "logscale" else p1h, device=dev, requires_grad=True)
+    K = _lib.NOISE_NORMAL if kind == "normal" else _lib.NOISE_UNIFORM
+    # (a per-channel log-scale is exponentiated by the caller: the descriptor keeps the live exp() node)
+    noise = stag_amd.EdgeNoise(g, H, K, p0, p1.exp() if pmode == "logscale" else p1, relu=relu, seed=31, offset=4,
+                               differentiable=True)
+    monkeypatch.setattr(stag_amd.EdgeNoise, "materialize", lambda self: (_ for _ in ()).throw(AssertionError("an [E, H] tensor was materialised")))
+    attn_drop = (0.4, 77, 2) if drop else None
+    t = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (el, er, ft)]
+    out = ops.gat_aggregate(g, *t, 0.2, noise, attn_drop=attn_drop)
+    out.backward(torch.from_numpy(G).to(dev))
+    monkeypatch.undo()
+    # ---- the oracle's statement --------------------------------------------------------------------------------
+    with hw_normals(oracle, dev):
+        std = oracle.noise_materialize(og, oracle.make_spec(kind, 0.0, 1.0, seed=31, offset=4, Dn=H, n_edges=E), H).astype(np.float64)
+    raw = (p0h + p1h * std) if kind == "normal" else (p0h + (p1h - p0h) * std)             # [E, H] by edge id
+    keep, keep_prob = None, 1.0
+    if drop:
+        keep_prob = float(np.float32(1.0 - 0.4))
+        keep = stag_amd.EdgeNoise(g, H, _lib.NOISE_BERNOULLI, keep_prob, seed=77, offset=2)
+        keep = ops.materialize_noise(g, keep).cpu().numpy()
+    spec = oracle.make_spec("explicit", raw.astype(np.float32), relu=relu)
+    ref_out = oracle.gat_fwd(og, el, er, ft, 0.2, spec, keep=keep, keep_prob=keep_prob)
+    assert_close(out, ref_out, what="forward (weights drawn in the kernel) vs oracle with the materialised weights")
+    d_el, d_er, d_ft, dw = oracle.gat_bwd(og, el, er, ft, G, 0.2, spec, keep=keep, keep_prob=keep_prob, want_dw=True)
+    dw = dw.astype(np.float64)
+    d0 = dw.sum(0) if kind == "normal" else (dw * (1.0 - std)).sum(0)
+    d1 = (dw * std).sum(0)
+    if pmode == "logscale":
+        d1 = d1 * p1h                                  # d / d log(scale)
+    if pmode == "scalar":
+        d0, d1 = d0.sum(), d1.sum()
+    for got, ref, nm in ((p0.grad, d0, "d p0"), (p1.grad, d1, "d p1")):
+        ref = np.asarray(ref, np.float64)
+        sc = max(1.0, float(np.abs(ref).max()), float(np.abs(dw).max()))
+        assert_close(got.cpu().numpy().reshape(ref.shape) / sc, ref / sc, what=f"{nm} ({kind}, {pmode}, relu={relu}, drop={drop})")
+    for got, ref, nm in ((t[0].grad, d_el, "d el"), (t[1].grad, d_er, "d er"), (t[2].grad, d_ft, "d ft")):
+        sc = max(1.0, float(np.abs(ref).max()))
+        assert_close(got / sc, ref.astype(np.float64) / sc, what=nm)
+    # the materialised form (A/B switch) gives the same gradients
+    ops._GAT_VI_FUSED = False
+    try:
+        q0, q1 = p0.detach().clone().requires_grad_(True), p1.detach().clone().requires_grad_(True)
+        nz = stag_amd.EdgeNoise(g, H, K, q0, q1.exp() if pmode == "logscale" else q1, relu=relu, seed=31, offset=4, differentiable=True)
+        t2 = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (el, er, ft)]
+        ops.gat_aggregate(g, *t2, 0.2, nz, attn_drop=attn_drop).backward(torch.from_numpy(G).to(dev))
+    finally:
+        ops._GAT_VI_FUSED = True
+    for got, ref, nm in ((p0.grad, q0.grad, "d p0"), (p1.grad, q1.grad, "d p1")):
+        sc = max(1.0, float(ref.abs().max()), float(np.abs(dw).max()))
+        assert_close(got / sc, (ref / sc).cpu().numpy(), what=nm + " fused vs materialised")

@@ -6,7 +6,7 @@ replaced by the indexing it amounts to — `buffer = table[global id of every bu
 the transposed exchange (a scatter-add of the buffer's gradient rows into the owners' rows).  Checked:
   * forward: the 8 shards' outputs, concatenated, are BIT-IDENTICAL to the whole-graph kernel launch — Philox
     positions in the millions (`pos_base`), the 13k-edge hub inside one shard's plan, `n_buf` remapping at 58 % halo,
-    the `[ft | el]` packing at H*F = 256, in-kernel attention dropout keyed by global position;
+    the two-table exchange (ft at H*F = 256, el), in-kernel attention dropout keyed by global position;
   * forward against the CPU oracle at 1e-5;
   * backward: per-shard `stag_gat_bwd` / transposed aggregation + the transposed exchange, summed over the shards,
     against the whole graph's `d ft / d el / d er` (`d x`) — a shard sums a source row's out-edges per shard and the
@@ -102,11 +102,12 @@ def test_cfg5_gat_eight_shards_forward_and_backward(dev, oracle, arxiv, shards, 
         whole = ops.gat_aggregate(g, el, er, ft, 0.2, mk(g), attn_drop=attn_drop)
         whole.backward(G)
         els, ers, fts = (t.clone().requires_grad_(True) for t in (el0, er0, ft0))
-        packed = torch.cat([fts.reshape(n, H * F), els], 1)           # what travels: [ft | el], 264 columns
         parts = []
         for sh, gid in shards[exchange]:
             sh = sh.local_var()
-            sh.halo_gather = lambda t, gid=gid: _exchange(packed, gid)
+            # the two tables of the exchange step (ft, el), each delivered as the collective would deliver it
+            sh.halo_gather_multi = lambda ts, gid=gid: [_exchange(fts.reshape(n, H * F), gid).reshape(-1, H, F),
+                                                        _exchange(els, gid)]
             lo, hi = sh.row_lo, sh.row_hi
             parts.append(sh.gat_aggregate(els[lo:hi], ers[lo:hi], fts[lo:hi], 0.2, mk(sh), attn_drop=attn_drop))
         got = torch.cat(parts, 0)
