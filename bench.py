@@ -68,6 +68,9 @@ def parse(argv=None):
                     help="N>1, nodes: the exchange through the library's own RCCL communicator "
                          "(stag_halo_exchange, include/stag_hip.h) instead of torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="N=1: skip the short loops over the other workload variants (`variants` in the line: the "
+                         "script's preprocessed graph arxiv_sym, Bernoulli + in-norm, no noise) and the cold reading")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--settle-ms", type=float, default=300.0,
                     help="untimed launches of the same step before the W warm-up steps, until this much wall time "
@@ -351,8 +354,46 @@ def main():
 
     partition = args.partition
     step, parallelism, parts = make_step(partition)
+    cold = None
+    if world == 1 and not rehearse and not args.no_variants:
+        # the same K steps BEFORE the settle phase: what a short run reads while the card is still raising its
+        # clocks — reported beside the headline number, never as it
+        cw, cd = timed(step, args.steps, args.warmup)
+        cold = {"ms_per_step": cw / args.steps * 1e3, "device_ms_per_step": cd, "steps": args.steps,
+                "warmup": args.warmup, "note": "timed before the settle phase (clocks still rising); the headline "
+                                               "loop below runs after it"}
     settle_steps = settle(step)
     wall, dev_ms = timed(step, args.steps, args.warmup)
+
+    def variant_loops():
+        """Short timed loops over the other workload variants of BASELINE configs[1]: the graph after
+        the script's own preprocessing (scripts/arxiv_mle/gcn/run.py:53-55: E = 2,671,154), the script's
+        Bernoulli + in-norm noise (:70-74), and no noise (the plain gather); each with its own device time and
+        fraction of the HBM roofline on its own algorithmic bytes."""
+        out = {}
+        ks, kw = 200, 20
+        graphs = {"arxiv": (src, dst)}
+        for gname, noise in (("arxiv", "bernoulli"), ("arxiv", "none"), ("arxiv_sym", "normal"), ("arxiv_sym", "bernoulli")):
+            if gname == args.graph and noise == args.noise:
+                continue
+            if gname not in graphs:
+                graphs[gname] = synthetic.with_self_loops_and_reverse(*synthetic.arxiv_like(seed=1), n)
+            s_, d_ = graphs[gname]
+            gkey = "_g_" + gname
+            if gkey not in graphs:
+                graphs[gkey] = stag_amd.Graph(torch.from_numpy(s_), torch.from_numpy(d_), n, device=dev)
+                graphs[gkey].csr.plan(args.seg_len)
+            gr, xv, Ev = graphs[gkey], x_host.to(dev), len(s_)
+            st = lambda i, gr=gr, xv=xv, noise=noise: ops.aggregate(gr, xv, make_noise(stag_amd, gr, D, noise, i), seg_len=args.seg_len)
+            w_, d_ms = timed(st, ks, kw)
+            balg = 4 * (n + 1) + 4 * Ev + 8 * n * D
+            out[f"{gname}/{noise}"] = {"graph": gname, "noise": noise + ("+in_norm" if noise == "bernoulli" else ""),
+                                       "E": Ev, "steps": ks, "ms_per_step": w_ / ks * 1e3, "device_ms_per_step": d_ms,
+                                       "edges_per_s": Ev / (w_ / ks), "algorithmic_bytes_per_step": balg,
+                                       "frac": balg / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        return out
+
+    variants = variant_loops() if (world == 1 and not rehearse and not args.no_variants) else None
 
     exchange = None
     if world > 1 and parts is not None:
@@ -373,7 +414,7 @@ def main():
                              "exchange_GBs_max_rank": float(mx[0]) / (ex_ms * 1e-3) / 1e9 if ex_ms > 0 else None,
                              "local_units": parts["local_units"], "remote_units": parts["remote_units"],
                              "note": "separate short loops after the headline loop: the collective alone "
-                                     "(index_select of the send rows + all-to-all) and the local kernels alone "
+                                     "(the send rows gathered into the persistent send buffer + all-to-all) and the local kernels alone "
                                      "on an already exchanged buffer; device time, max over ranks"})
 
     alt = None
@@ -444,6 +485,10 @@ def main():
             line["cpu_baseline"] = cpu_baseline(src, dst, n, x_host.numpy(), args.noise, args.cpu_budget_s)
         else:
             line["cpu_baseline"] = None
+        if cold is not None:
+            line["cold"] = cold
+        if variants is not None:
+            line["variants"] = variants
         if exchange is not None:
             line["exchange"] = exchange
         if alt is not None:

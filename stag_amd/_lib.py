@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libstag_hip.so")
+# STAG_HIP_SO: A/B tooling only (tools/ab_bench.py, tools/profile_bench.py --lib: a build variant of the same sources)
+_SO = os.environ.get("STAG_HIP_SO") or os.path.join(_HERE, "libstag_hip.so")
 
 NOISE_NONE, NOISE_EXPLICIT, NOISE_NORMAL, NOISE_UNIFORM, NOISE_BERNOULLI = range(5)
 PARAM_SCALAR, PARAM_PER_CHANNEL, PARAM_PER_EDGE1, PARAM_PER_EDGE = range(4)

@@ -21,6 +21,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = None      # --lib: a build variant (tools/_bin/libstag_<name>.so) instead of stag_amd/libstag_hip.so
 SQ = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU",
       "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"]
 
@@ -30,7 +31,7 @@ def run_prof(tag, prof_args, bench_args, scratch):
     cmd = ["rocprofv3", *prof_args, "-d", out, "-o", tag, "--output-format", "csv", "--",
            "python3", "bench.py", *bench_args]
     print("+", " ".join(cmd), flush=True)
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", **({"STAG_HIP_SO": LIB} if LIB else {}))
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout[-2000:] + r.stderr[-4000:])
@@ -71,9 +72,12 @@ def main():
     ap.add_argument("--graph", default="arxiv")
     ap.add_argument("--seg-len", type=int, default=64)
     ap.add_argument("--tag", default="n1", help="file-name tag: bench_<tag>.json, bench_<tag>_kernel_stats.csv, ...")
+    ap.add_argument("--lib", default=None, help="profile a build variant: path of its libstag_*.so")
     ap.add_argument("--summarize-only", action="store_true",
                     help="rebuild the summaries from the CSVs already under gpurun_out/prof/ (no GPU needed)")
     args = ap.parse_args()
+    global LIB
+    LIB = os.path.abspath(args.lib) if args.lib else None
     if args.summarize_only:
         global run_prof
         run_prof = lambda tag, prof_args, bench_args, scratch: (os.path.join(scratch, tag), None)
