@@ -206,7 +206,9 @@ class StagLayer(torch.nn.Module):
         torch has no closed form for the pair (stag/layers.py:132-145)."""
         if not self.vi:
             return 0.0
-        return self._kl_unweighted() * self._kl_weight()
+        kl = self._kl_unweighted()
+        w = self._kl_weight()
+        return kl if w == 1.0 else kl * w
 
     def _kl_weight(self):
         """1 on a whole graph.  On a node-range shard every rank returns its SHARE, so that the ranks' values (and

@@ -31,6 +31,8 @@ class GraphSAGE(torch.nn.Module):
         self.feat_drop = torch.nn.Dropout(feat_drop)
         if aggregator_type == "pool":
             self.fc_pool = torch.nn.Linear(in_features, in_features)
+        if aggregator_type == "lstm":      # DGL SAGEConv: nn.LSTM(in, in, batch_first=True) over a node's mailbox
+            self.lstm = torch.nn.LSTM(in_features, in_features, batch_first=True)
         if aggregator_type != "gcn":
             self.fc_self = torch.nn.Linear(in_features, out_features, bias=False)
         self.fc_neigh = torch.nn.Linear(in_features, out_features, bias=False)
@@ -42,6 +44,38 @@ class GraphSAGE(torch.nn.Module):
         for name in ("fc_pool", "fc_self", "fc_neigh"):
             if hasattr(self, name):
                 torch.nn.init.xavier_uniform_(getattr(self, name).weight, gain=gain)
+        if hasattr(self, "lstm"):
+            self.lstm.reset_parameters()
+
+    def _lstm_reduce(self, graph, feat_src, edge_weight):
+        """DGL's `_lstm_reducer` over `u_mul_e` messages [DGL, from memory: SAGEConv._lstm_reducer runs
+        nn.LSTM(batch_first=True) from a zero state over each destination's mailbox and keeps the last hidden state;
+        mailboxes are formed by degree bucketing, messages in edge-id order; a node without in-edges keeps zeros].
+        The messages are materialised ([E, D]: a kernel-backed row gather, the noise as a tensor), the destinations
+        of equal in-degree are batched through the LSTM.  Cost grows with the number of distinct in-degrees."""
+        from ..noise import EdgeNoise
+        m = ops.gather_rows(graph, feat_src, "src")                     # [E, D] by edge id
+        if isinstance(edge_weight, EdgeNoise):
+            edge_weight = edge_weight.materialize()
+        if edge_weight is not None:
+            m = m * (edge_weight if edge_weight.dim() == 2 else edge_weight.unsqueeze(1))
+        csr = graph.csr                                                  # destination-major, stable in edge id
+        n = csr.n_dst
+        out = m.new_zeros((n, feat_src.shape[1]))
+        if csr.n_edges == 0:
+            return out
+        deg = csr.degrees.long()
+        start = csr.indptr[:-1].long()
+        eid = csr.eid.long() if csr.eid is not None else torch.arange(csr.n_edges, device=m.device)
+        for d in torch.unique(deg).tolist():
+            if d == 0:
+                continue
+            rows = torch.nonzero(deg == d).flatten()
+            pos = start[rows].unsqueeze(1) + torch.arange(d, device=m.device).unsqueeze(0)      # [B, d] CSR positions
+            box = m[eid[pos]]                                                                   # [B, d, D]
+            _, (h, _) = self.lstm(box)
+            out = out.index_copy(0, rows, h.squeeze(0))
+        return out
 
     def forward(self, graph, feat, edge_weight=None):
         if isinstance(feat, tuple):
@@ -64,8 +98,8 @@ class GraphSAGE(torch.nn.Module):
             h_neigh = ops.node_linear((neigh + feat_dst) / (degs.unsqueeze(-1) + 1), self.fc_neigh.weight.t())
         elif self._aggre_type == "pool":     # max reducer: composed, not fused (ops.aggregate_max)
             h_neigh = self.fc_neigh(ops.aggregate_max(graph, torch.relu(self.fc_pool(feat_src)), edge_weight))
-        else:
-            raise NotImplementedError("'lstm' aggregator is outside the accelerated path")
+        else:   # 'lstm' (stag/zoo/graph_sage.py:97-99): composed, not fused — no BASELINE config or script uses it
+            h_neigh = self.fc_neigh(self._lstm_reduce(graph, feat_src, edge_weight))
         rst = h_neigh if self._aggre_type == "gcn" else ops.node_linear(h_self, self.fc_self.weight.t(), add=h_neigh)
         if self.bias is not None and not bias_done:
             rst = ops.add_bias(rst, self.bias)

@@ -495,3 +495,35 @@ def test_round2_host_helpers_on_cpu():
     g = torch.randn(100, 7)
     assert torch.allclose(ops.column_sum(g), g.sum(0)) and torch.equal(ops.add_bias(g, torch.ones(7)), g + 1)
     assert ops.attn_drop_fusable(8, 32, 64) and not ops.attn_drop_fusable(8, 32, 64, want_attn=True)
+
+
+def test_sage_lstm_aggregator_composed():
+    """aggregator_type='lstm' (stag/zoo/graph_sage.py:97-99): DGL's degree-bucketed LSTM reducer over u_mul_e messages,
+    composed from torch ops (no BASELINE config uses it; it must not raise).  Checked against a per-node loop with the
+    same LSTM: mailbox in edge-id order, zero initial state, last hidden state, zeros for nodes without in-edges."""
+    import stag_amd
+    torch.manual_seed(3)
+    n, D = 12, 5
+    src = torch.tensor([0, 1, 2, 3, 4, 5, 6, 1, 2, 7, 8, 9, 3, 3])
+    dst = torch.tensor([1, 1, 1, 2, 2, 4, 4, 4, 4, 5, 0, 0, 9, 1])       # node 3, 6, 7, 8, 10, 11: no in-edges
+    g = stag_amd.Graph(src, dst, n)
+    layer = stag_amd.zoo.GraphSAGE(D, 4, aggregator_type="lstm")
+    assert {"lstm.weight_ih_l0", "fc_self.weight", "fc_neigh.weight", "bias"} <= set(layer.state_dict())
+    x = torch.randn(n, D, requires_grad=True)
+    w = torch.rand(len(src), D) + 0.5
+    out = layer(g, x, edge_weight=w)
+    neigh = torch.zeros(n, D)
+    rows = []
+    for v in range(n):
+        ids = torch.nonzero(dst == v).flatten()
+        if len(ids) == 0:
+            rows.append(torch.zeros(D))
+            continue
+        box = (x[src[ids]] * w[ids]).unsqueeze(0)
+        _, (h, _) = layer.lstm(box)
+        rows.append(h.reshape(D))
+    neigh = torch.stack(rows, 0)
+    ref = layer.fc_self(x) + layer.fc_neigh(neigh) + layer.bias
+    assert torch.allclose(out, ref, atol=1e-6)
+    out.sum().backward()
+    assert x.grad is not None and layer.lstm.weight_hh_l0.grad is not None

@@ -86,7 +86,7 @@ def main():
     dst = os.path.join(ROOT, "gpurun_out", "profiles", args.round)
     os.makedirs(dst, exist_ok=True)
     common = ["--noise", args.noise, "--feat", str(args.feat), "--graph", args.graph,
-              "--seg-len", str(args.seg_len), "--no-cpu-baseline"]
+              "--seg-len", str(args.seg_len), "--no-cpu-baseline", "--no-variants"]   # one workload per profile
     kernel_sub = "agg_kernel"
 
     out, line = run_prof("stats", ["--kernel-trace", "--stats"], ["--steps", "200", "--warmup", "20", *common], scratch)
