@@ -439,8 +439,6 @@ struct AggTeam {
   [[no_unique_address]] OwnRow<PEDGE == 3 || PEDGE == 4> XO;     // the unit's own row of a.xown (times own_scale)
   [[no_unique_address]] DpAcc<PEDGE == 4> DP;      // this lane's share of the two parameter gradients
   static constexpr bool P1 = PEDGE == 1 || PEDGE == 3;
-  int pbeg = 0;              // (STAG_RNG_HALF: iterations start at an even global position; edges before pbeg are masked)
-  __device__ __forceinline__ bool live(int p) const { return p < pend && (!STAG_RNG_HALF || p >= pbeg); }
 
   // every lane of the team reads the same BLK column ids: broadcast dword loads with
   // immediate offsets, no per-edge vector arithmetic
@@ -448,7 +446,7 @@ struct AggTeam {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int p = p0 + j;
-      if (live(p)) {
+      if (p < pend) {
         I.u[j] = a.indices[p];
         if constexpr (NEED_EID) I.ee[j] = a.eid ? a.eid[p] : p;
         if constexpr (KIND >= kNormal) I.nn[j] = a.pos_lo + (a.nidx ? (uint32_t)a.nidx[p] : (uint32_t)p);
@@ -459,7 +457,7 @@ struct AggTeam {
   __device__ __forceinline__ void fetch_rows(EdgeRows<NB, PEDGE>& R, const EdgeIdx<NB>& I, int p0) const {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      if (live(p0 + j)) {
+      if (p0 + j < pend) {
         if (x_buf) bufrow4(rx, I.u[j], a.ldxb, koff, R.xv[j]);
         else loadrow4(row_at(a.x, I.u[j], a.ldxb, koff, (a.wide & 1) != 0), k0, a.D, VEC, R.xv[j]);
         if (a.src_scale) R.xs[j] = a.src_scale[I.u[j]];
@@ -482,16 +480,9 @@ struct AggTeam {
     // block sums go into fresh accumulators (small magnitudes => small rounding)
     float t[4] = {0.f, 0.f, 0.f, 0.f};
     [[maybe_unused]] ExtraAcc<NX> TX;              // block sums of the extra outputs (acc only)
-#if STAG_RNG_HALF
-    [[maybe_unused]] uint32_t rr[4];
-    constexpr bool HALF = KIND >= kNormal && NX == 0 && PEDGE == 0 && BLK == 2;
-    if constexpr (HALF) {
-      if (STAG_RNG_HALF == 2 || !a.nidx) philox4x32_10((a.pos_lo + (uint32_t)(p0 + m * BLK)) >> 1, c1, key, rr);   // the pair's block
-    }
-#endif
 #pragma unroll
     for (int j = m * BLK; j < (m + 1) * BLK; ++j) {
-      if (live(p0 + j)) {
+      if (p0 + j < pend) {
         float w[4];
         [[maybe_unused]] ExtraAcc<NX> dd;          // dd.acc[o] = derivative o of this edge's draw
         [[maybe_unused]] float g0[4], g1[4];        // PEDGE 3: the two derivatives of this edge's draw
@@ -503,19 +494,6 @@ struct AggTeam {
         } else if constexpr (PEDGE == 4) {
           draw4_grad<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w, g0, g1);
         } else if constexpr (NX == 0) {
-#if STAG_RNG_HALF
-          if constexpr (HALF) {
-            if (STAG_RNG_HALF == 2 || !a.nidx) {
-              const int e = j - m * BLK;
-              draw4_half<KIND>(rr[2 * e], rr[2 * e + 1], pa, pb, a.relu, w);
-            } else {      // transposed walk: the edge's own block, its half by the parity of the forward position
-              uint32_t r1[4];
-              philox4x32_10(I.nn[j] >> 1, c1, key, r1);
-              const bool odd = I.nn[j] & 1u;
-              draw4_half<KIND>(odd ? r1[2] : r1[0], odd ? r1[3] : r1[1], pa, pb, a.relu, w);
-            }
-          } else
-#endif
           edge_weight(R, I, j, w);
         } else if constexpr (!MC) {
           draw4_grad<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w, dd.acc[0], dd.acc[1]);
@@ -613,7 +591,7 @@ struct AggTeam {
       for (int q = 0; q < 4; ++q) t[m][q] = 0.f;
 #pragma unroll
       for (int j = m * BLK; j < (m + 1) * BLK; ++j) {
-        if (live(p0 + j)) {
+        if (p0 + j < pend) {
           float w[4];
           edge_weight(R, I, j, w);
           if (a.src_scale) {
@@ -764,13 +742,6 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   const int pend = b + len;
   EdgeIdx<NB> I;
   EdgeRows<NB, PEDGE> R;
-#if STAG_RNG_HALF
-  // iterations take PAIRS of global positions (one Philox block each): start at the even position at or before b
-  const int b0 = (KIND >= kNormal && NOUT == 1 && PEDGE == 0 && !a.nidx) ? b - (int)((a.pos_lo + (uint32_t)b) & 1u) : b;
-  T.pbeg = b;
-#else
-  const int b0 = b;
-#endif
   {
     // the next block's edge records are fetched while this block's rows are in flight: one
     // round trip per block on the unit's critical path instead of two.  Narrow shapes only
@@ -780,7 +751,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
     if constexpr (SLOTS > 1) {
       constexpr int RB = SLOTS * NB;               // edges of the unit per round
       const int base = ((int)(threadIdx.x & 63) - sl * LPE) << 2;   // slot 0's lane of my channels (bpermute address)
-      for (int r0 = b0; r0 < pend; r0 += RB) {
+      for (int r0 = b; r0 < pend; r0 += RB) {
         const int p0 = r0 + sl * NB;
 #if STAG_LOAD_PRIO
         __builtin_amdgcn_s_setprio(3);
@@ -808,7 +779,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
               if (a.in_norm) {
 #pragma unroll
                 for (int e = 0; e < BLK; ++e) {
-                  if (T.live(pb + e)) {
+                  if (pb + e < pend) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                       T.wsum[q] += __int_as_float(__builtin_amdgcn_ds_bpermute(
@@ -822,8 +793,8 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
       }
     } else if constexpr (PREFETCH) {
     EdgeIdx<NB> In;
-    T.fetch_idx(I, b0);
-    for (int p0 = b0; p0 < pend; p0 += NB) {
+    T.fetch_idx(I, b);
+    for (int p0 = b; p0 < pend; p0 += NB) {
 #if STAG_LOAD_PRIO
       __builtin_amdgcn_s_setprio(3);   // get the loads out ahead of other waves' draws
 #endif
@@ -836,7 +807,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
       I = In;
     }
     } else {
-    for (int p0 = b0; p0 < pend; p0 += NB) {
+    for (int p0 = b; p0 < pend; p0 += NB) {
 #if STAG_LOAD_PRIO
       __builtin_amdgcn_s_setprio(3);   // get the loads out ahead of other waves' draws
 #endif

@@ -118,50 +118,6 @@ enum : int { kFlagRelu = 1, kDerivShift = 1, kDerivMask = 3, kFlagLogScale = 8 }
 
 __device__ __forceinline__ float exp_scale(float log_scale) { return __expf(log_scale); }
 
-#ifndef STAG_RNG_HALF
-#define STAG_RNG_HALF 0     // experiment (tools/ab_bench.py): one Philox block per PAIR of CSR positions
-#endif
-#if STAG_RNG_HALF
-// Two normals from ONE 32-bit word: the radius from its top 20 bits (u1 = 2 - f in (0, 1): |z| <= 5.27), the angle
-// from its low 12 bits at half-step offsets ((k + 1/2) / 4096 revolutions: never on an axis).
-__device__ __forceinline__ void box_muller_word(uint32_t w, float& za, float& zb) {
-  const float fr = __uint_as_float(((w >> 9) & 0x007FFFF8u) | 0x3F800004u);
-  const float fa = __uint_as_float(((w << 11) & 0x007FF800u) | 0x3F800400u);
-  const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(2.0f - fr));
-  za = rad * __builtin_amdgcn_cosf(fa);
-  zb = rad * __builtin_amdgcn_sinf(fa);
-}
-// u in (0, 1) from 16 bits: (k + 1/2) / 65536
-__device__ __forceinline__ float u01_16(uint32_t h) {
-  return __uint_as_float((h << 7) | 0x3F800040u) - 1.0f;
-}
-// the 4 draws of one (edge, chunk) from the edge's HALF of a Philox block: words ra, rb
-template <int KIND>
-__device__ __forceinline__ void draw4_half(uint32_t ra, uint32_t rb, const float (&a)[4], const float (&b)[4],
-                                           int flags, float (&w)[4]) {
-  float t[4];
-  if constexpr (KIND == kNormal) {
-    box_muller_word(ra, t[0], t[1]);
-    box_muller_word(rb, t[2], t[3]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = __builtin_fmaf(b[j], t[j], a[j]);
-  } else {
-    t[0] = u01_16(ra & 0xFFFFu); t[1] = u01_16(ra >> 16); t[2] = u01_16(rb & 0xFFFFu); t[3] = u01_16(rb >> 16);
-    if constexpr (KIND == kUniform) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = __builtin_fmaf(b[j] - a[j], t[j], a[j]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = t[j] < a[j] ? 1.0f : 0.0f;
-    }
-  }
-  if (flags & kFlagRelu) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = fmaxf(w[j], 0.0f);
-  }
-}
-#endif
-
 template <int KIND>
 __device__ __forceinline__ void draw4(uint32_t c0, uint32_t c1, const PhiloxKey& key,
                                       const float (&a)[4], const float (&b)[4], int flags,

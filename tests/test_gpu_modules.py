@@ -327,7 +327,7 @@ def test_shard_equals_whole_graph(dev):
         assert torch.equal(torch.cat(cols, 1), whole)
         assert torch.equal(torch.cat(cols_pc, 1), whole_pc)
         assert torch.equal(torch.cat(cols_bn, 1), whole_bn)
-    # partitioned GAT (cfg5 shape of the exchange: [ft | el] in one buffer), 2 emulated ranks
+    # partitioned GAT (cfg5 shape of the exchange: ft and el, two tables of one step), 2 emulated ranks
     H, F = 8, 16
     el, er, ft = torch.randn(n, H, device=dev), torch.randn(n, H, device=dev), torch.randn(n, H, F, device=dev)
     mkh = lambda graph: stag_amd.EdgeNoise(graph, H, _lib.NOISE_NORMAL, 1.0, 0.5, seed=9, offset=4)
@@ -336,7 +336,7 @@ def test_shard_equals_whole_graph(dev):
     for r in range(2):
         hs = GraphShard(src, dst, n, r, 2, device=dev, exchange="halo")
         ids = torch.cat([torch.arange(hs.row_lo, hs.row_hi, device=dev), torch.from_numpy(hs.recv_ids).to(dev)])
-        hs.halo_gather = lambda t, ids=ids, hs=hs, full=torch.cat([ft.reshape(n, H * F), el], 1): full[ids]
+        hs.halo_gather_multi = lambda ts, ids=ids: [ft[ids], el[ids]]        # what the two-table exchange delivers
         parts.append(hs.gat_aggregate(el[hs.row_lo:hs.row_hi], er[hs.row_lo:hs.row_hi], ft[hs.row_lo:hs.row_hi],
                                       0.2, mkh(hs)))
     assert torch.equal(torch.cat(parts, 0), whole_gat)
