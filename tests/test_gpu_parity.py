@@ -1176,3 +1176,59 @@ def test_gat_vi_parameter_gradients_in_the_kernels(dev, oracle, monkeypatch, H, 
     for got, ref, nm in ((p0.grad, q0.grad, "d p0"), (p1.grad, q1.grad, "d p1")):
         sc = max(1.0, float(ref.abs().max()), float(np.abs(dw).max()))
         assert_close(got / sc, (ref / sc).cpu().numpy(), what=nm + " fused vs materialised")
+
+
+def test_fuzz_gat_vi_parameter_gradients(dev, oracle):
+    """Seeded sweep of stag_gat_bwd_dp over graphs x head shapes x Normal / Uniform x scalar / per-head x relu x dropout:
+    the parameter gradients finished inside the kernels against the materialised form of the same layer (explicit
+    [E, H] weights + autograd: a different code path end to end), and d el / d er / d ft against the oracle."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    rng = np.random.default_rng(20261011)
+    shapes = [(1, 4), (2, 8), (3, 4), (4, 16), (8, 32), (8, 64), (16, 64), (5, 12), (2, 256), (16, 8), (6, 40), (8, 8)]
+    for it in range(24 * FUZZ_SCALE):
+        n = int(rng.integers(2, 400))
+        g = random_graph(n, int(rng.integers(1, 3000)), seed=15000 + it, hub=int(rng.choice([0, 0, 90, 600])) if n > 4 else 0, device=dev)
+        E = g.number_of_edges()
+        og = oracle_graph(oracle, g)
+        H, F = shapes[it % len(shapes)]
+        kind = ["normal", "uniform"][it % 2]
+        per_head, relu, drop = bool(rng.random() < 0.6), bool(rng.random() < 0.4), bool(rng.random() < 0.3)
+        K = _lib.NOISE_NORMAL if kind == "normal" else _lib.NOISE_UNIFORM
+        lo, hi = (0.2, 0.9), ((1.0, 1.8) if kind == "uniform" else (0.3, 0.8))
+        mkp = lambda r: (torch.tensor(rng.uniform(*r, H).astype(np.float32), device=dev) if per_head
+                         else torch.tensor(float(rng.uniform(*r)), device=dev))
+        p0v, p1v = mkp(lo), mkp(hi)
+        el, er = rng.standard_normal((n, H)).astype(np.float32), rng.standard_normal((n, H)).astype(np.float32)
+        ft, G = rng.standard_normal((n, H, F)).astype(np.float32), rng.standard_normal((n, H, F)).astype(np.float32)
+        seed, off = int(rng.integers(0, 2**40)), int(rng.integers(0, 99))
+        attn_drop = (float(rng.choice([0.2, 0.6])), int(rng.integers(0, 2**30)), int(rng.integers(0, 50))) if drop else None
+        what = f"gat vi fuzz {it}: n={n} E={E} H={H} F={F} {kind} per_head={per_head} relu={relu} drop={attn_drop}"
+        res = []
+        for fused in (True, False):
+            ops._GAT_VI_FUSED = fused
+            try:
+                p0, p1 = p0v.clone().requires_grad_(True), p1v.clone().requires_grad_(True)
+                nz = stag_amd.EdgeNoise(g, H, K, p0, p1, relu=relu, seed=seed, offset=off, differentiable=True)
+                t = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (el, er, ft)]
+                out = ops.gat_aggregate(g, *t, 0.2, nz, attn_drop=attn_drop)
+                out.backward(torch.from_numpy(G).to(dev))
+                zero = lambda p: p.grad if p.grad is not None else torch.zeros_like(p)
+                res.append((out.detach(), zero(p0), zero(p1), [a.grad for a in t]))
+            finally:
+                ops._GAT_VI_FUSED = True
+        (o_f, d0_f, d1_f, g_f), (o_m, d0_m, d1_m, g_m) = res
+        assert_close(o_f, o_m.cpu().numpy(), what=what + " out")
+        with torch.no_grad():
+            wm = stag_amd.EdgeNoise(g, H, K, p0v, p1v, relu=relu, seed=seed, offset=off).materialize() if E else torch.zeros(0, H, device=dev)
+        keep, keep_prob = None, 1.0
+        if drop and E:
+            keep_prob = float(np.float32(1.0 - attn_drop[0]))
+            keep = stag_amd.EdgeNoise(g, H, _lib.NOISE_BERNOULLI, keep_prob, seed=attn_drop[1], offset=attn_drop[2]).materialize().cpu().numpy()
+        spec = oracle.make_spec("explicit", wm.cpu().numpy()) if E else oracle.make_spec("none")
+        _, _, _, dw = oracle.gat_bwd(og, el, er, ft, G, 0.2, spec, keep=keep, keep_prob=keep_prob, want_dw=bool(E))
+        sc_p = max(1.0, float(np.abs(dw).sum(0).max()) if E else 0.0)          # a parameter gradient sums E terms of d w
+        assert_close(d0_f.reshape(-1) / sc_p, (d0_m.reshape(-1) / sc_p).cpu().numpy(), what=what + " d p0")
+        assert_close(d1_f.reshape(-1) / sc_p, (d1_m.reshape(-1) / sc_p).cpu().numpy(), what=what + " d p1")
+        if E:
+            assert_gat_grads_vs_oracle(oracle, og, el, er, ft, G, spec, g_f, keep=keep, keep_prob=keep_prob, what=what)

@@ -165,3 +165,84 @@ def test_cfg2_aggregation_eight_shards_forward_and_backward(dev, oracle, arxiv, 
         with hw_normals(oracle, dev):
             ref = oracle.agg_fwd(og, x0.cpu().numpy(), ospec(), src_scale=ss.cpu().numpy(), dst_scale=ds.cpu().numpy())
         assert_close(got, ref, what=f"cfg2 8 shards {kind} vs oracle")
+
+
+def test_cfg2_partitioned_backward_pieces_at_full_size(dev, arxiv, shards):
+    """The partitioned backward of `_ShardAggregate` at P = 8 and full size, its collective emulated: every shard reduces
+    its REMOTE buffer rows and its own rows in two launches over the sub-plans of the source-major twin
+    (`plan_split_t`), the rows the peers computed for a rank are placed behind its buffer rows in send-list order
+    (what the transposed all-to-all delivers), and ONE launch over `_combined_csr` adds own + received.  The result is
+    the whole graph's d x at 1e-5, equals — bit for bit — the same adds done with torch in the kernel's fixed order (own
+    row first, then the peers in rank order, two terms at a time), and does not depend on how the two sub-plan launches
+    are split."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    src, dst, n, g = arxiv
+    D = 128
+    gen = torch.Generator().manual_seed(57)
+    x0 = torch.randn(n, D, generator=gen).to(dev)
+    G = torch.randn(n, D, generator=gen).to(dev)
+    mk = lambda graph: stag_amd.EdgeNoise(graph, D, _lib.NOISE_NORMAL, 1.0, 0.5, seed=0x5747A6, offset=3)
+    x = x0.clone().requires_grad_(True)
+    ops.aggregate(g, x, mk(g)).backward(G)
+    lst = shards["halo"]
+    dx_bufs = []
+    for sh, gid in lst:
+        noise = mk(sh)
+        noise.pos_base = sh.pos_base
+        spec = ops._targs_or_c(ops._noise_spec(noise, in_norm=0))
+        gl = G[sh.row_lo:sh.row_hi].contiguous()
+        p_first, p_second = sh.plan_split_t(64)
+        assert p_first["n_units"] > 0 and p_second["n_units"] > 0
+        buf = torch.full((sh.n_buf, D), float("nan"), device=dev)
+        ops._agg_raw(sh.csr_t, gl, D, spec, _lib.REDUCE_SUM, None, None, 64, out=buf, plan_t=p_first)
+        assert not torch.isnan(buf[sh.n_rows:]).any(), "the remote rows are complete after the first launch"
+        ops._agg_raw(sh.csr_t, gl, D, spec, _lib.REDUCE_SUM, None, None, 64, out=buf, plan_t=p_second)
+        whole_launch, _ = ops._agg_raw(sh.csr_t, gl, D, spec, _lib.REDUCE_SUM, None, None, 64)
+        assert torch.equal(buf, whole_launch)
+        dx_bufs.append(buf)
+    # position of every global row in every shard's buffer (-1: not there)
+    where = []
+    for sh, gid in lst:
+        w = torch.full((n,), -1, dtype=torch.int64, device=dev)
+        w[gid] = torch.arange(sh.n_buf, device=dev)
+        where.append(w)
+    got = []
+    for r, (sh, gid) in enumerate(lst):
+        n_send = int(sh.send_idx.shape[0])
+        T = torch.empty((sh.n_buf + n_send, D), device=dev)
+        T[:sh.n_buf] = dx_bufs[r]
+        # the transposed all-to-all: peer q returns, in the order of my send list to q, the gradient of those rows
+        off = 0
+        terms = [[dx_bufs[r][:sh.n_rows], torch.ones(sh.n_rows, dtype=torch.bool, device=dev)]]   # (values, present)
+        for q, cnt in enumerate(sh.in_splits):
+            if cnt == 0:
+                continue
+            rows_local = sh.send_idx[off:off + cnt]
+            pos = where[q][rows_local + sh.row_lo]
+            assert bool((pos >= 0).all())
+            T[sh.n_buf + off:sh.n_buf + off + cnt] = dx_bufs[q][pos]
+            val = torch.zeros((sh.n_rows, D), device=dev)
+            has = torch.zeros(sh.n_rows, dtype=torch.bool, device=dev)
+            val[rows_local] = dx_bufs[q][pos]                       # (a row is sent to a peer at most once)
+            has[rows_local] = True
+            terms.append([val, has])
+            off += cnt
+        assert off == n_send
+        # the same adds with torch, in the kernel's order: a row's terms — its own gradient, then the peers' in rank
+        # order — are taken two at a time, each pair summed from zero, the pair sums added up in order
+        vals = torch.stack([t[0] for t in terms], 1)                # [n_rows, K, D]
+        has = torch.stack([t[1] for t in terms], 1)                 # [n_rows, K]
+        K = vals.shape[1]
+        rank_in_row = torch.cumsum(has.long(), 1) - 1               # position of a present term in the row's list
+        seq = torch.zeros((sh.n_rows, D), device=dev)
+        for pair in range((K + 1) // 2):
+            blk = torch.zeros((sh.n_rows, D), device=dev)
+            for j in (2 * pair, 2 * pair + 1):
+                pick = has & (rank_in_row == j)                     # the row's j-th term, whichever peer it came from
+                blk = blk + (vals * pick.unsqueeze(-1)).sum(1)      # at most one non-zero term: exact
+            seq = seq + blk
+        dx, _ = ops._agg_raw(sh._combined_csr(), T, D, ops._targs_or_c(ops._none_spec()), _lib.REDUCE_SUM, None, None, 64)
+        assert torch.equal(dx, seq), f"rank {r}: own row first, then the peers in rank order, summed in the kernel's pairs"
+        got.append(dx)
+    assert_close(*_rel(torch.cat(got, 0), x.grad), what="cfg2 8 shards: d x through the partitioned backward's pieces")
