@@ -1232,3 +1232,23 @@ def test_fuzz_gat_vi_parameter_gradients(dev, oracle):
         assert_close(d1_f.reshape(-1) / sc_p, (d1_m.reshape(-1) / sc_p).cpu().numpy(), what=what + " d p1")
         if E:
             assert_gat_grads_vs_oracle(oracle, og, el, er, ft, G, spec, g_f, keep=keep, keep_prob=keep_prob, what=what)
+
+
+@pytest.mark.parametrize("W", [1, 3, 8, 50, 128, 264])
+def test_gather_rows_entry_point(dev, W):
+    """stag_gather_rows (ABI v17): out[i, :] = x[idx[i], :] into an existing buffer — the send rows of the halo exchange.
+    Bit-exact (it copies); widths that are not a multiple of 4 and strided rows take the scalar path; n = 0 is a no-op."""
+    from stag_amd import _lib
+    rng = np.random.default_rng(W)
+    n_src, n = 1000, 3777
+    ld = W + (4 if W % 2 else 0)                          # a row stride wider than the row
+    xs = torch.randn(n_src, ld, device=dev)
+    idx = torch.from_numpy(rng.integers(0, n_src, n).astype(np.int32)).to(dev)
+    out = torch.full((n, W), float("nan"), device=dev)
+    with _lib.on_device(dev):
+        rc = _lib.lib().stag_gather_rows(_lib.ptr(xs), ld, _lib.ptr(idx), n, W, _lib.ptr(out), W, _lib.stream_of(dev))
+        assert rc == 0
+        assert torch.equal(out, xs[:, :W][idx.long()])
+        assert _lib.lib().stag_gather_rows(_lib.ptr(xs), ld, _lib.ptr(idx), 0, W, _lib.ptr(out), W, _lib.stream_of(dev)) == 0
+        assert _lib.lib().stag_gather_rows(_lib.ptr(xs), W - 1 if W > 1 else 0, _lib.ptr(idx), n, W, _lib.ptr(out), W, None) == -22
+        assert _lib.lib().stag_gather_rows(None, ld, _lib.ptr(idx), n, W, _lib.ptr(out), W, None) == -22
