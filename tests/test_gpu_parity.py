@@ -1252,3 +1252,45 @@ def test_gather_rows_entry_point(dev, W):
         assert _lib.lib().stag_gather_rows(_lib.ptr(xs), ld, _lib.ptr(idx), 0, W, _lib.ptr(out), W, _lib.stream_of(dev)) == 0
         assert _lib.lib().stag_gather_rows(_lib.ptr(xs), W - 1 if W > 1 else 0, _lib.ptr(idx), n, W, _lib.ptr(out), W, None) == -22
         assert _lib.lib().stag_gather_rows(None, ld, _lib.ptr(idx), n, W, _lib.ptr(out), W, None) == -22
+
+
+def test_fuzz_monte_carlo_batches(dev, oracle):
+    """Seeded sweep of stag_agg_fwd_mc over graphs x widths x kinds x in-norm x relu x reduce x S: every sample of the
+    batched launch equals its own launch bit for bit (2 samples per pass with in-norm, 4 without), and one sample per
+    case is held against the oracle."""
+    import copy
+    from stag_amd import ops
+    rng = np.random.default_rng(20261012)
+    for it in range(40 * FUZZ_SCALE):
+        n = int(rng.integers(2, 400))
+        g = random_graph(n, int(rng.integers(1, 4000)), seed=17000 + it, hub=int(rng.choice([0, 0, 100, 900])) if n > 4 else 0, device=dev)
+        D = int(rng.choice([1, 3, 8, 16, 50, 64, 128, 260]))
+        kind = ["normal", "uniform", "bernoulli"][it % 3]
+        in_norm, relu = bool(rng.random() < 0.5), bool(rng.random() < 0.3)
+        if kind == "normal" and in_norm:
+            relu = True       # (in-norm divides by the sum of a row's weights: signed Normal weights can cancel there, and
+                              #  the factor deg / sum then amplifies one rounding without bound — a conditioning matter
+                              #  of the statement itself, stag/layers.py:24-28, not of any implementation)
+        S, stride = int(rng.integers(2, 8)), int(rng.integers(1, 6))
+        seg_len = int(rng.choice([64, 64, 16, 0]))
+        reduce = "mean" if rng.random() < 0.3 else "sum"
+        p0 = torch.from_numpy(rng.uniform(0.3, 0.9, D).astype(np.float32)).to(dev)
+        p1 = None if kind == "bernoulli" else torch.from_numpy(rng.uniform(1.0, 1.6, D).astype(np.float32)).to(dev)
+        kw = dict(relu=relu, in_norm=in_norm, seed=int(rng.integers(0, 2**40)), offset=int(rng.integers(0, 99)))
+        noise = _noise(g, D, kind, p0, p1, **kw)
+        x = torch.from_numpy(rng.standard_normal((n, D)).astype(np.float32)).to(dev)
+        ds = torch.from_numpy(rng.uniform(0.5, 1.5, n).astype(np.float32)).to(dev)
+        what = f"mc fuzz {it}: n={n} E={g.number_of_edges()} D={D} {kind} in_norm={in_norm} relu={relu} S={S} seg={seg_len} {reduce}"
+        got = ops.aggregate_mc(g, x, noise, S, offset_stride=stride, reduce=reduce, dst_scale=ds, seg_len=seg_len)
+        assert got.shape == (S, n, D), what
+        for s in range(S):
+            nz = copy.copy(noise)
+            nz.offset = kw["offset"] + s * stride
+            assert torch.equal(got[s], ops.aggregate(g, x, nz, reduce=reduce, dst_scale=ds, seg_len=seg_len)), (what, s)
+        s = int(rng.integers(0, S))
+        spec = _ospec(oracle, g, D, kind, p0, p1, **{**kw, "offset": kw["offset"] + s * stride})
+        with hw_normals(oracle, dev):
+            ref = oracle.agg_fwd(oracle_graph(oracle, g), x.cpu().numpy(), spec,
+                                 reduce=oracle.REDUCE_MEAN if reduce == "mean" else oracle.REDUCE_SUM, dst_scale=ds.cpu().numpy())
+        tol = TOL if 0 < seg_len <= 64 else 2 * TOL
+        assert_close(got[s], ref, tol=tol, what=what + f" sample {s} vs oracle")
