@@ -311,6 +311,18 @@ constexpr int kKahanMinLen = STAG_KAHAN_MIN_LEN;
 #ifndef STAG_IDX_PREFETCH
 #define STAG_IDX_PREFETCH 1
 #endif
+#ifndef STAG_PIN_IDX
+#define STAG_PIN_IDX 1
+#endif
+#ifndef STAG_DRAW_FIRST
+#define STAG_DRAW_FIRST 1
+#endif
+#ifndef STAG_PREFETCH_MAX_LPE
+#define STAG_PREFETCH_MAX_LPE 16
+#endif
+#ifndef STAG_PREFETCH_MAX_LPE_MEM
+#define STAG_PREFETCH_MAX_LPE_MEM 32    // the gather-bound kinds (no draw): D = 128 gains 1.6 % (97.4 -> 95.9 us), D = 256 nothing
+#endif
 #ifndef STAG_MULT_LPE4
 #define STAG_MULT_LPE4 4
 #endif
@@ -454,6 +466,20 @@ struct AggTeam {
     }
   }
 
+  // The edge records are COMPLETE in registers before the row gathers are issued: the column ids have to be (the row
+  // addresses are made of them), and pinning the noise indices here as well keeps the draw free of any dependence on
+  // a load.  Without it the compiler sinks `pos_lo + nidx[p]` to the top of the Philox block and, unable to count
+  // the conditional loads issued since, guards it with `s_waitcnt vmcnt(0)` — which also waits for the ROWS: the whole
+  // draw of a block then ran after its rows had arrived instead of while they were in flight.
+  __device__ __forceinline__ void pin_idx(EdgeIdx<NB>& I) const {
+#if STAG_PIN_IDX
+    if constexpr (KIND >= kNormal) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) asm volatile("" : "+v"(I.nn[j]));
+    }
+#endif
+  }
+
   __device__ __forceinline__ void fetch_rows(EdgeRows<NB, PEDGE>& R, const EdgeIdx<NB>& I, int p0) const {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -480,6 +506,21 @@ struct AggTeam {
     // block sums go into fresh accumulators (small magnitudes => small rounding)
     float t[4] = {0.f, 0.f, 0.f, 0.f};
     [[maybe_unused]] ExtraAcc<NX> TX;              // block sums of the extra outputs (acc only)
+#if STAG_DRAW_FIRST
+    // The plain fused draw (one output, scalar / per-channel parameters): ALL the block's draws first, then the
+    // multiplies — the draws need nothing from memory (pin_idx), so they run while the block's rows are in flight and
+    // the wave meets its first `s_waitcnt` with the whole RNG of the block behind it.
+    constexpr bool DRAW_FIRST = KIND >= kNormal && NX == 0 && PEDGE == 0;
+    [[maybe_unused]] float wb[DRAW_FIRST ? BLK : 1][4];
+    if constexpr (DRAW_FIRST) {
+#pragma unroll
+      for (int j = m * BLK; j < (m + 1) * BLK; ++j)
+        if (p0 + j < pend) draw4<KIND>(I.nn[j], c1, key, pa, pb, a.relu, wb[j - m * BLK]);
+    }
+#else
+    constexpr bool DRAW_FIRST = false;
+    [[maybe_unused]] float wb[1][4];
+#endif
 #pragma unroll
     for (int j = m * BLK; j < (m + 1) * BLK; ++j) {
       if (p0 + j < pend) {
@@ -493,6 +534,9 @@ struct AggTeam {
           draw4_grad<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w, g0, g1);
         } else if constexpr (PEDGE == 4) {
           draw4_grad<KIND>(I.nn[j], c1, key, pa, pb, a.relu, w, g0, g1);
+        } else if constexpr (DRAW_FIRST) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) w[q] = wb[j - m * BLK][q];
         } else if constexpr (NX == 0) {
           edge_weight(R, I, j, w);
         } else if constexpr (!MC) {
@@ -585,6 +629,8 @@ struct AggTeam {
   // blocks past the unit's end stay zero and are never folded.
   __device__ __forceinline__ void block_sums(EdgeRows<NB, PEDGE>& R, const EdgeIdx<NB>& I, int p0,
                                              float (&t)[MULT][4], float (&we)[NB][4]) {
+    // (all the round's weights first, then the multiplies — what the one-slot loop does since round 3 — was measured
+    // here too: Bernoulli at D = 64 68.1 -> 69.9 us, everything else within noise; the narrow shapes keep draw-then-multiply)
 #pragma unroll
     for (int m = 0; m < MULT; ++m) {
 #pragma unroll
@@ -592,17 +638,15 @@ struct AggTeam {
 #pragma unroll
       for (int j = m * BLK; j < (m + 1) * BLK; ++j) {
         if (p0 + j < pend) {
-          float w[4];
-          edge_weight(R, I, j, w);
+          edge_weight(R, I, j, we[j]);       // (straight into the slot's weight record: no copy — at LPE 16 the copy
+                                             //  cost 2 VGPRs and with them the 6th wave per SIMD: D = 64 Normal 72.9 -> 66.9 us)
           if (a.src_scale) {
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int q = 0; q < 4; ++q) R.xv[j][q] *= R.xs[j];
           }
 #pragma unroll
-          for (int q = 0; q < 4; ++q) t[m][q] = __builtin_fmaf(w[q], R.xv[j][q], t[m][q]);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) we[j][q] = w[q];
+          for (int q = 0; q < 4; ++q) t[m][q] = __builtin_fmaf(we[j][q], R.xv[j][q], t[m][q]);
         }
       }
     }
@@ -747,7 +791,8 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
     // round trip per block on the unit's critical path instead of two.  Narrow shapes only
     // (their launch is latency-bound: -2..3 us); at LPE >= 32 the extra registers would cost
     // the RNG kinds their 8th wave per SIMD for no gain.
-    constexpr bool PREFETCH = STAG_IDX_PREFETCH && LPE <= 16;
+    // (with the draw, at LPE >= 32, it loses: 110 against 104 us at D = 128, 221 against 209 at D = 256, round 3)
+    constexpr bool PREFETCH = STAG_IDX_PREFETCH && LPE <= ((KIND >= kNormal) ? STAG_PREFETCH_MAX_LPE : STAG_PREFETCH_MAX_LPE_MEM);
     if constexpr (SLOTS > 1) {
       constexpr int RB = SLOTS * NB;               // edges of the unit per round
       const int base = ((int)(threadIdx.x & 63) - sl * LPE) << 2;   // slot 0's lane of my channels (bpermute address)
@@ -757,6 +802,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
         __builtin_amdgcn_s_setprio(3);
 #endif
         T.fetch_idx(I, p0);
+        T.pin_idx(I);
         T.fetch_rows(R, I, p0);
 #if STAG_LOAD_PRIO
         if (len > STAG_PRIO_MIN_LEN) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
@@ -798,6 +844,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
 #if STAG_LOAD_PRIO
       __builtin_amdgcn_s_setprio(3);   // get the loads out ahead of other waves' draws
 #endif
+      T.pin_idx(I);
       T.fetch_rows(R, I, p0);
       if (p0 + NB < pend) T.fetch_idx(In, p0 + NB);
 #if STAG_LOAD_PRIO
@@ -812,6 +859,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
       __builtin_amdgcn_s_setprio(3);   // get the loads out ahead of other waves' draws
 #endif
       T.fetch_idx(I, p0);
+      T.pin_idx(I);
       T.fetch_rows(R, I, p0);
 #if STAG_LOAD_PRIO
       if (len > STAG_PRIO_MIN_LEN) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);

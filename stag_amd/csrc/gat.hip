@@ -372,6 +372,19 @@ static_assert(kBlkUnits <= 64 && kBlkThreads % 64 == 0 && kBlkThreads <= 1024, "
 #ifndef STAG_GAT_NR
 #define STAG_GAT_NR 4     // rows in flight per team in phase 2
 #endif
+#ifndef STAG_GAT_BRANCHFREE
+#define STAG_GAT_BRANCHFREE 1
+#endif
+// Rows in flight per team in the FORWARD's gather.  Round 3: with the loads of a round really issued together
+// (STAG_GAT_BRANCHFREE) more of them is monotonically WORSE on cfg5 — 1: 222.2, 2: 238.1, 3: 249.6, 4: 252.8 us; the
+// branchy form that serialised its "4 in flight" by accident: 228.5 us — and so is any other number of workgroups per CU
+// than 4 (3: 246.9, 5: 239.0, 6: 253.9, 8: 255.8 us): a gather of 1-KB rows out of a 173 MB table wants ~16 rows in
+// flight per CU and no more.
+#ifndef STAG_GAT_NR_FWD
+#define STAG_GAT_NR_FWD 1
+#endif
+// (the one-gather backward keeps its branchy NR = 4 loop: branch-free loads there change nothing — cfg5 training step
+//  632.5 against 632.1 us — and fewer rows per round cost it: NR = 2 640.5, NR = 1 658 us)
 
 // (80 SGPRs: a CU admits 8 workgroups of 256 threads only up to that count — MI355X_MICROARCH.md,
 //  "Residency"; the argument block alone would take ~100, the rest spill to lanes of a VGPR.)
@@ -512,7 +525,7 @@ __global__ __launch_bounds__(kBlkThreads) STAG_GAT_SGPR_ATTR void gat_fwd_block_
 
   // ---- phase 2: a team per unit, weighted gather -------------------------------------------------------
   // lane c owns CPL chunks of 4 channels: [4 (c + LPE j), +4), j < CPL  (H*F <= 256: one; up to 1024: 2 or 4)
-  constexpr int TEAMS = kBlkThreads / LPE, NR = CPL >= 4 ? 2 : STAG_GAT_NR;
+  constexpr int TEAMS = kBlkThreads / LPE, NR = STAG_GAT_BRANCHFREE ? STAG_GAT_NR_FWD : (CPL >= 4 ? 2 : STAG_GAT_NR);
   const int team = t / LPE, c = t % LPE;
   const int team_lane0 = (int)(t & 63) - c;
   int k0[CPL], hl[CPL];
@@ -530,6 +543,43 @@ __global__ __launch_bounds__(kBlkThreads) STAG_GAT_SGPR_ATTR void gat_fwd_block_
     float acc[CPL][4];
 #pragma unroll
     for (int cj = 0; cj < CPL; ++cj) acc[cj][0] = acc[cj][1] = acc[cj][2] = acc[cj][3] = 0.f;
+#if STAG_GAT_BRANCHFREE
+    // The NR gathers of a round are issued back to back with NO control flow between them: a round's source ids and
+    // weights come out of LDS first (positions past the unit's end are clamped to its last edge and carry weight 0:
+    // a repeated row, which the L1 serves), lanes without a chunk load chunk 0 and store nothing.  With the
+    // `if (e + r < e1)` / `if (kin)` branches around each load the compiler could not count the loads in flight and put
+    // `s_waitcnt vmcnt(0)` in front of every next LDS read: the "NR rows in flight" went out one at a time.
+    for (int e = e0; e < e1; e += NR) {
+      float fv[NR][CPL][4], pe[NR][CPL];
+      int u[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int er = min(e + r, e1 - 1);
+        u[r] = s_u[er];
+#pragma unroll
+        for (int cj = 0; cj < CPL; ++cj) {
+          const float wv = s_w[er * H + (kin[cj] ? hl[cj] : 0)];
+          pe[r][cj] = (e + r < e1) ? wv : 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+#pragma unroll
+        for (int cj = 0; cj < CPL; ++cj) {
+          if (ft_buf) bufrow4(rft, u[r], (uint32_t)HF * 4u, (uint32_t)k0[cj] * 4u, fv[r][cj]);
+          else loadrow4(a.ft + (int64_t)u[r] * HF + k0[cj], k0[cj], HF, true, fv[r][cj]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+#pragma unroll
+        for (int cj = 0; cj < CPL; ++cj) {
+#pragma unroll
+          for (int x = 0; x < 4; ++x) acc[cj][x] = __builtin_fmaf(pe[r][cj], fv[r][cj][x], acc[cj][x]);
+        }
+      }
+    }
+#else
     for (int e = e0; e < e1; e += NR) {
       float fv[NR][CPL][4];
 #pragma unroll
@@ -559,6 +609,7 @@ __global__ __launch_bounds__(kBlkThreads) STAG_GAT_SGPR_ATTR void gat_fwd_block_
         }
       }
     }
+#endif
     if (q.w < 0) {
       // ---- whole row: normalise and store --------------------------------------------------------
 #pragma unroll
