@@ -478,6 +478,17 @@ struct AggTeam {
       for (int j = 0; j < NB; ++j) asm volatile("" : "+v"(I.nn[j]));
     }
 #endif
+    // ... and, for the narrowest shapes (4-8 blocks of rows fetched together), the column / edge ids: every row address
+    // is then made of registers and no `s_waitcnt` for an id stands between two row gathers.  Measured per shape, no
+    // draw | Normal, us: D = 16 31.6 -> 31.2 | 35.2 -> 35.1, D = 32 37.6 -> 35.0 | 45.7 -> 44.9; at LPE 16 it loses (D = 64 no
+    // draw 54.9 -> 57.2), wider shapes and the Monte-Carlo kernels do not move.
+    if constexpr (STAG_PIN_IDX && LPE <= 8) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        asm volatile("" : "+v"(I.u[j]));
+        if constexpr (NEED_EID) asm volatile("" : "+v"(I.ee[j]));
+      }
+    }
   }
 
   __device__ __forceinline__ void fetch_rows(EdgeRows<NB, PEDGE>& R, const EdgeIdx<NB>& I, int p0) const {

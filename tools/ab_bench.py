@@ -38,6 +38,7 @@ def run(argv):
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--feat", type=int, default=128)
     ap.add_argument("--seg-len", type=int, default=64)
+    ap.add_argument("--mc", type=int, default=0, help="time ops.aggregate_mc with this many Monte-Carlo samples per call")
     args = ap.parse_args(argv)
     import stag_amd
     from stag_amd import _lib, ops, synthetic
@@ -52,23 +53,27 @@ def run(argv):
     handles = {"current": base}
     for path in libs:
         l = C.CDLL(path)
-        for fn in ("stag_agg_fwd", "stag_plan_workspace_bytes"):
+        for fn in ("stag_agg_fwd", "stag_agg_fwd_mc", "stag_plan_workspace_bytes"):
             getattr(l, fn).argtypes = getattr(base, fn).argtypes
             getattr(l, fn).restype = getattr(base, fn).restype
         handles[os.path.basename(path)[len("libstag_"):-3]] = l
     times = {k: [] for k in handles}
     ref = None
+    if args.mc:
+        one = lambda i: ops.aggregate_mc(g, x, bench.make_noise(stag_amd, g, args.feat, args.noise, i), args.mc, seg_len=args.seg_len)
+    else:
+        one = lambda i: ops.aggregate(g, x, bench.make_noise(stag_amd, g, args.feat, args.noise, i), seg_len=args.seg_len)
     for r in range(args.rounds + 1):
         for name, l in handles.items():
             _lib._lib = l
             _lib.lib = lambda l=l: l
             for i in range(3):
-                out = ops.aggregate(g, x, bench.make_noise(stag_amd, g, args.feat, args.noise, i), seg_len=args.seg_len)
+                out = one(i)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for i in range(args.steps):
-                out = ops.aggregate(g, x, bench.make_noise(stag_amd, g, args.feat, args.noise, i), seg_len=args.seg_len)
+                out = one(i)
             e1.record()
             torch.cuda.synchronize()
             if r > 0:
