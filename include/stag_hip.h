@@ -250,8 +250,11 @@ int stag_agg_fwd(const stag_csr* csr, const stag_plan* plan, const float* x,
  * bit, written to out + s * sample_stride (floats).  The n_samples loop of the reference
  * (stag/models.py:45-55, 67-68) re-runs the whole forward per sample; on the first layer, whose
  * input is the same for every sample, the gather is shared and only the draws repeat.
- * kind NORMAL | UNIFORM | BERNOULLI, param_mode SCALAR | PER_CHANNEL, in_norm 0; the plan's
- * workspace must hold stag_plan_workspace_bytes(n_seg, 4 * D, 0) bytes.                       */
+ * kind NORMAL | UNIFORM | BERNOULLI, param_mode SCALAR | PER_CHANNEL; the plan's workspace must hold
+ * stag_plan_workspace_bytes(n_seg, 4 * D, 0) bytes.  (v17) spec.in_norm is allowed (`norm=True`,
+ * stag/layers.py:8-36; scripts/arxiv_mle/gcn/run.py:70-74): every sample then carries its own
+ * per-destination weight sums, two samples per pass (a segment's workspace row is
+ * [sum_0 | sum_1 | wsum_0 | wsum_1]: the same 4 * D floats).                                     */
 int stag_agg_fwd_mc(const stag_csr* csr, const stag_plan* plan, const float* x, int64_t ldx,
                     int32_t D, const stag_noise_spec* spec, int32_t n_samples,
                     int64_t offset_stride, int32_t reduce, const float* src_scale,
