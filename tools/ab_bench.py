@@ -39,6 +39,7 @@ def run(argv):
     ap.add_argument("--feat", type=int, default=128)
     ap.add_argument("--seg-len", type=int, default=64)
     ap.add_argument("--mc", type=int, default=0, help="time ops.aggregate_mc with this many Monte-Carlo samples per call")
+    ap.add_argument("--per-edge", action="store_true", help="Normal noise with [E, 1] parameters (an AmortizedDistribution's heads)")
     args = ap.parse_args(argv)
     import stag_amd
     from stag_amd import _lib, ops, synthetic
@@ -59,7 +60,12 @@ def run(argv):
         handles[os.path.basename(path)[len("libstag_"):-3]] = l
     times = {k: [] for k in handles}
     ref = None
-    if args.mc:
+    if args.per_edge:
+        E = g.number_of_edges()
+        loc = torch.rand(E, 1, device=dev) + 0.5
+        scale = torch.rand(E, 1, device=dev) * 0.5 + 0.1
+        one = lambda i: ops.aggregate(g, x, stag_amd.EdgeNoise(g, args.feat, _lib.NOISE_NORMAL, loc, scale, seed=5, offset=i), seg_len=args.seg_len)
+    elif args.mc:
         one = lambda i: ops.aggregate_mc(g, x, bench.make_noise(stag_amd, g, args.feat, args.noise, i), args.mc, seg_len=args.seg_len)
     else:
         one = lambda i: ops.aggregate(g, x, bench.make_noise(stag_amd, g, args.feat, args.noise, i), seg_len=args.seg_len)
