@@ -19,7 +19,9 @@ NOISE_NONE, NOISE_EXPLICIT, NOISE_NORMAL, NOISE_UNIFORM, NOISE_BERNOULLI = range
 PARAM_SCALAR, PARAM_PER_CHANNEL, PARAM_PER_EDGE1, PARAM_PER_EDGE = range(4)
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 HEAVY_LEN = 16   # STAG_HEAVY_LEN (include/stag_hip.h)
-BLOCK_EDGES, BLOCK_UNITS = 256, 32   # STAG_BLOCK_EDGES / STAG_BLOCK_UNITS
+# STAG_BLOCK_EDGES / STAG_BLOCK_UNITS of include/stag_hip.h (the environment override pairs with a build variant of the
+# library compiled with the same -D values: A/B tooling only)
+BLOCK_EDGES, BLOCK_UNITS = int(os.environ.get("STAG_BLOCK_EDGES", "256")), int(os.environ.get("STAG_BLOCK_UNITS", "32"))
 
 _vp = C.c_void_p
 

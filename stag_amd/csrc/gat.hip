@@ -379,7 +379,8 @@ static_assert(kBlkUnits <= 64 && kBlkThreads % 64 == 0 && kBlkThreads <= 1024, "
 // (STAG_GAT_BRANCHFREE) more of them is monotonically WORSE on cfg5 — 1: 222.2, 2: 238.1, 3: 249.6, 4: 252.8 us; the
 // branchy form that serialised its "4 in flight" by accident: 228.5 us — and so is any other number of workgroups per CU
 // than 4 (3: 246.9, 5: 239.0, 6: 253.9, 8: 255.8 us): a gather of 1-KB rows out of a 173 MB table wants ~16 rows in
-// flight per CU and no more.
+// flight per CU and no more.  (128-thread workgroups over 128-edge batches, 4 / 6 / 8 / 12 per CU: 314.6 / 239.6 / 220.8 / 249.9 us —
+// the same 16 waves per CU, the same time.)
 #ifndef STAG_GAT_NR_FWD
 #define STAG_GAT_NR_FWD 1
 #endif
