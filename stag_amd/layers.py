@@ -125,25 +125,42 @@ class StagLayer(torch.nn.Module):
         offset_stride offsets).  None when the layer cannot batch (the caller then loops)."""
         if not getattr(self.base_layer, "supports_edge_noise_mc", False):
             return None
-        if torch.is_grad_enabled() and (self.vi or feat.requires_grad):
-            # the batched aggregation has no backward of its own: under autograd it serves the case that needs none —
-            # fixed noise on an input that is data (the first layer of every `*_mle` script)
-            return None
         graph = graph.local_var()
         self.q_a.condition(graph, feat)
         dist = self.q_a.base_distribution
         if not fusable(dist):
             return None
+        reparam = type(dist) in (torch.distributions.Normal, torch.distributions.Uniform)
+        live = torch.is_grad_enabled() and self.vi
+        if live and not (reparam and getattr(self.base_layer, "supports_edge_noise_grad", False)):
+            return None          # (a learned distribution without a reparameterised in-kernel draw: the loop)
+        if torch.is_grad_enabled() and self.norm and (live or feat.requires_grad):
+            return None          # (in-norm's factor is differentiated by ops._AggregateVI / _Aggregate, per sample)
         dn = self._sample_dimension(feat)
         gen = self._generator()
-        w = EdgeNoise.from_distribution(graph, dn, dist, relu=self.relu, in_norm=self.norm, seed=gen.seed,
-                                        offset=gen.offset, epoch=gen.device_epoch)
+        # under autograd the batched forward shares the gathers and the backward is the loop's per-sample passes
+        # (ops._AggregateMC); with fixed noise on an input that is data (every `*_mle` script) there is no backward at all
+        w = self._descriptor(graph, dn, dist, relu=self.relu, in_norm=self.norm, differentiable=live, seed=gen.seed,
+                             offset=gen.offset, epoch=gen.device_epoch)
         if w.param_mode > _lib.PARAM_PER_CHANNEL:
             return None
         gen.next_offset()
         w.n_samples, w.offset_stride = int(n_samples), int(offset_stride)
-        self._edge_weight_handle = None      # no single [E, Dn] sample stands for this call
+        self._edge_weight_handle = None      # no single [E, Dn] sample stands for this call: mc_select(s) names one
+        self._mc_noise = w
         return self.base_layer.forward(graph=graph, feat=feat, edge_weight=w)
+
+    def mc_select(self, s):
+        """After forward_mc: make sample `s` the layer's current draw — what `_edge_weight_sample` (stag/layers.py:107)
+        and the sample-based KL fallback (:141-143) read, as they would after the s-th pass of the sequential loop."""
+        import copy
+        w = getattr(self, "_mc_noise", None)
+        if w is None:
+            return
+        one = copy.copy(w)
+        one.offset = w.offset + int(s) * w.offset_stride
+        one.n_samples = 1
+        self._edge_weight_handle = one
 
     def _descriptor(self, graph, dn, dist, **kw):
         """EdgeNoise of q_a.  An AmortizedDistribution's Normal hands over its heads' outputs as they are —

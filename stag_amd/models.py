@@ -66,9 +66,10 @@ class StagModel(torch.nn.Module):
         for every sample; `StagLayer.forward_mc` -> stag_agg_fwd_mc) and only the other layers run per sample.
         Every sample sees exactly the noise the sequential loop would give it: with L offsets consumed per sample
         (one per fused draw, one more per in-kernel attention-dropout mask) sample s draws its first layer at
-        base + s * L and its other layers from base + s * L + 1 on.  Under autograd this needs the first layer's
-        input to be data and its noise fixed (every `*_mle` script): the batched aggregation then needs no
-        backward, the dense transform differentiates through the S outputs."""
+        base + s * L and its other layers from base + s * L + 1 on.  Under autograd, with the first layer's input
+        data and its noise fixed (every `*_mle` script), the batched aggregation needs no backward at all — the dense
+        transform differentiates through the S outputs; with a learned (`vi=True`) first layer or an input that carries
+        a gradient the forward is still batched and the backward is the loop's per-sample passes (ops._AggregateMC)."""
         plan = self._mc_plan(graph, feat, n_samples)
         if plan is None:
             for _ in range(n_samples):
@@ -76,8 +77,10 @@ class StagModel(torch.nn.Module):
             return
         gen, L, base, first_used, h1, g = plan
         h1 = h1.unbind(0)       # ONE autograd node for the S slices (S separate selects would each zero-fill [S, N, out])
+        first = self.layers[0]
         for s in range(n_samples):
             gen.offset = base + s * L + first_used
+            first.mc_select(s)          # the first layer's "last draw" is sample s, as after the loop's s-th pass
             h = h1[s]
             for layer in self.layers[1:]:
                 h = layer(g, h)

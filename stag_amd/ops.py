@@ -916,26 +916,94 @@ def aggregate_mc(graph, x, noise, n_samples, offset_stride=1, reduce="sum", src_
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or (noise is not None and noise.grad_params is not None
                                                                   and any(torch.is_tensor(p) and p.requires_grad
                                                                           for p in noise.grad_params)))
-    if not fusable_mc or needs_grad or n_samples == 1:
+    if not fusable_mc or n_samples == 1:
         return torch.stack([one(s) for s in range(n_samples)], 0)
     if noise.dn != x.shape[1]:
         raise ValueError(f"noise width {noise.dn} != feature width {x.shape[1]}")
-    x = _f32c(x)
-    src_scale, dst_scale = _f32c(src_scale), _f32c(dst_scale)
-    csrv, D = graph.csr, x.shape[1]
+    if needs_grad:
+        # the batched FORWARD under autograd (x or the noise parameters carry a gradient): the gathers of the S samples
+        # are shared, the backward is the S per-sample transposed passes the loop would run (_AggregateMC).  Not with
+        # in-norm (its factor has a derivative of its own: ops._AggregateVI) or explicit / per-edge parameters.
+        live = noise.grad_params is not None and any(torch.is_tensor(p) and p.requires_grad for p in noise.grad_params)
+        if noise.in_norm or (live and noise.kind not in (_lib.NOISE_NORMAL, _lib.NOISE_UNIFORM)):
+            return torch.stack([one(s) for s in range(n_samples)], 0)
+        if live:
+            p0, p1 = (torch.as_tensor(p, dtype=torch.float32, device=x.device) for p in noise.grad_params)
+        else:
+            p0 = p1 = None
+        return _AggregateMC.apply(x, p0, p1, graph, noise, int(n_samples), int(offset_stride), _REDUCE[reduce],
+                                  _f32c(src_scale), _f32c(dst_scale), seg_len)
+    return _agg_fwd_mc_raw(graph.csr, _f32c(x), noise, n_samples, offset_stride, _REDUCE[reduce], _f32c(src_scale),
+                           _f32c(dst_scale), seg_len)
+
+
+def _agg_fwd_mc_raw(csrv, x, noise, n_samples, offset_stride, reduce, src_scale, dst_scale, seg_len):
+    """One stag_agg_fwd_mc call: [n_samples, n_dst, D]."""
+    D = x.shape[1]
     dev = _lib.require_device(x, csrv.indptr, src_scale, dst_scale)
     out = torch.empty((n_samples, csrv.n_dst, D), dtype=torch.float32, device=dev)
     plan_t = csrv.plan(seg_len)
     nbytes = _lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], 4 * D, 0) if plan_t is not None else 0
-    plan_c, _keep = _plan_struct(csrv, seg_len, (D + 255) // 256, nbytes, dev)
+    plan_c, _keep = _plan_struct(csrv, seg_len, (D + 255) // 256, nbytes, dev, plan_t=plan_t)
     cs, spec = csrv.struct(), noise.spec()
     with _lib.on_device(dev):
         rc = _lib.lib().stag_agg_fwd_mc(
             C.byref(cs), C.byref(plan_c) if plan_c is not None else None, _lib.ptr(x), x.stride(0), D,
-            C.byref(spec), n_samples, offset_stride, _REDUCE[reduce], _lib.ptr(src_scale), _lib.ptr(dst_scale),
+            C.byref(spec), n_samples, offset_stride, reduce, _lib.ptr(src_scale), _lib.ptr(dst_scale),
             _lib.ptr(out), D, csrv.n_dst * D, _lib.stream_of(dev))
     _lib.check(rc, "stag_agg_fwd_mc")
     return out
+
+
+class _AggregateMC(torch.autograd.Function):
+    """S Monte-Carlo samples of one aggregation (stag/models.py:67-68 on a layer whose input is the same for every
+    sample) with gradients: the forward is ONE batched pass (stag_agg_fwd_mc: the gathers are shared), the backward
+    the per-sample transposed passes of the sequential loop — d x summed over the samples, and for a reparameterised
+    draw (`vi=True`) the finished parameter gradients of every sample (stag_agg_bwd_dp), summed.  Sample s draws at
+    offset + s * stride, so values and gradients are those of the loop."""
+
+    @staticmethod
+    def forward(ctx, x, p0, p1, graph, noise, n_samples, stride, reduce, src_scale, dst_scale, seg_len):
+        x = _f32c(x)
+        out = _agg_fwd_mc_raw(graph.csr, x, noise, n_samples, stride, reduce, src_scale, dst_scale, seg_len)
+        ctx.graph, ctx.noise, ctx.S, ctx.stride, ctx.reduce, ctx.seg_len = _owner(graph), noise, n_samples, stride, reduce, seg_len
+        ctx.pshapes = None if p0 is None else (p0.shape, p1.shape)
+        ctx.save_for_backward(x, src_scale, dst_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        import copy
+        x, src_scale, dst_scale = ctx.saved_tensors
+        graph, D = ctx.graph, x.shape[1]
+        g_all = _f32c(grad_out)
+        dvec = dst_scale
+        if ctx.reduce == _lib.REDUCE_MEAN:
+            inv = 1.0 / graph.csr.degrees.clamp(min=1).to(torch.float32)
+            dvec = inv if dvec is None else dvec * inv
+        need_x = ctx.needs_input_grad[0]
+        need_p = ctx.pshapes is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        dx = d0 = d1 = None
+        for s_i in range(ctx.S):
+            nz = copy.copy(ctx.noise)
+            nz.offset = ctx.noise.offset + s_i * ctx.stride
+            spec = _targs_or_c(_noise_spec(nz, in_norm=0))
+            g = g_all[s_i]
+            if need_p:
+                dxs, c0, c1 = _agg_bwd_dp_raw(graph.csr_t, g, x, D, spec, dvec, src_scale, ctx.seg_len, want_dx=need_x)
+                d0 = c0 if d0 is None else d0 + c0
+                d1 = c1 if d1 is None else d1 + c1
+            else:
+                dxs, _ = _agg_raw(graph.csr_t, g, D, spec, _lib.REDUCE_SUM, dvec, src_scale, ctx.seg_len)
+            if need_x:
+                dx = dxs if dx is None else dx + dxs
+        dp = [None, None]
+        if need_p:
+            for i, d in enumerate((d0, d1)):
+                if ctx.needs_input_grad[1 + i]:
+                    shape = ctx.pshapes[i]
+                    dp[i] = d.sum().reshape(shape) if d.numel() != int(torch.Size(shape).numel()) else d.reshape(shape)
+        return dx, dp[0], dp[1], None, None, None, None, None, None, None, None
 
 
 def materialize_noise(graph, noise, seg_len=DEFAULT_SEG_LEN):

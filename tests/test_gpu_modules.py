@@ -943,7 +943,7 @@ def test_model_monte_carlo_first_layer_batched(dev):
             gen.manual_seed(5)
             ref = torch.stack([model._forward(g, x) for _ in range(5)], 0).mean(0)
             assert gen.offset == end == 15
-        assert calls, "the batched first layer was not used"
+        assert calls and all(calls), "the batched first layer was not used"
         assert torch.equal(got, ref)
     # an input that carries a gradient: the loop is the reference's
     gen.manual_seed(5)
@@ -951,7 +951,8 @@ def test_model_monte_carlo_first_layer_batched(dev):
     assert x.grad is not None
 
 
-@pytest.mark.parametrize("first", ["gcn_normal", "gcn_bernoulli_norm", "sage_normal", "gin_uniform"])
+@pytest.mark.parametrize("first", ["gcn_normal", "gcn_bernoulli_norm", "sage_normal", "gin_uniform", "gcn_vi", "gcn_vi_rc",
+                                   "gcn_vi_mixture", "gcn_normal_dx"])
 def test_training_monte_carlo_loop_batched_on_the_first_layer(dev, first):
     """`model.loss(..., n_samples=4)` — the training loop of stag/models.py:67-68 as the sweeps run it
     (`--n_samples_training 4`, scripts/arxiv_mle/graph_sage/meta_run.sh:29) — draws the first layer's 4 samples from
@@ -974,7 +975,20 @@ def test_training_monte_carlo_loop_batched_on_the_first_layer(dev, first):
     l0 = {"gcn_normal": lambda: L.StagLayer(Z.GCN(D, 16, activation=torch.relu), generator=gen, q_a=N(1.0, 0.5), relu=True),
           "gcn_bernoulli_norm": lambda: L.StagLayer(Z.GCN(D, 16, activation=torch.relu), generator=gen, q_a=B(0.7), norm=True),
           "sage_normal": lambda: L.StagLayer(Z.GraphSAGE(D, 16, activation=torch.relu), generator=gen, q_a=N(1.0, 0.5)),
-          "gin_uniform": lambda: L.StagLayer(Z.GIN(D, 16, activation=torch.relu), generator=gen, q_a=U(0.5, 1.5))}[first]()
+          "gin_uniform": lambda: L.StagLayer(Z.GIN(D, 16, activation=torch.relu), generator=gen, q_a=U(0.5, 1.5)),
+          # a LEARNED first layer (scripts/citation_r1, citation_rc with --n_samples_training): the forward is batched,
+          # the backward is the loop's per-sample passes; its KL term is read per sample
+          "gcn_vi": lambda: L.StagLayer(Z.GCN(D, 16, activation=torch.relu), generator=gen, q_a=N(1.0, 0.5), relu=True, vi=True),
+          "gcn_vi_rc": lambda: L.StagLayer(Z.GCN(D, 16, activation=torch.relu), generator=gen,
+                                           q_a=N(torch.ones(D), 0.5 * torch.ones(D)), vi=True),
+          # a prior without a closed-form KL: the sample-based estimate reads the layer's CURRENT sample (mc_select)
+          "gcn_vi_mixture": lambda: L.StagLayer(
+              Z.GCN(D, 16, activation=torch.relu), generator=gen, q_a=N(1.0, 0.5), vi=True,
+              p_a=torch.distributions.MixtureSameFamily(torch.distributions.Categorical(torch.tensor([0.5, 0.5], device=dev)),
+                                                        N(torch.tensor([0.0, 1.0], device=dev), torch.tensor([0.5, 0.5], device=dev)))),
+          "gcn_normal_dx": lambda: L.StagLayer(Z.GCN(D, 16, activation=torch.relu), generator=gen, q_a=N(1.0, 0.5))}[first]()
+    if first == "gcn_normal_dx":          # an input that carries a gradient
+        x = x.requires_grad_(True)
     layers = torch.nn.ModuleList([
         l0,
         L.StagLayer(Z.GAT(16, 4, num_heads=4, attn_drop=0.5, activation=torch.nn.functional.elu), generator=gen, q_a=N(1.0, 0.3)),
@@ -984,18 +998,27 @@ def test_training_monte_carlo_loop_batched_on_the_first_layer(dev, first):
     assert [l.offsets_per_forward() for l in layers] == [1, 2, 1]
     calls = []
     orig = l0.forward_mc
-    l0.forward_mc = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    def counted(*a, **k):
+        out = orig(*a, **k)
+        calls.append(out is not None)
+        return out
+    l0.forward_mc = counted
 
     def run(batched):
         model.zero_grad(set_to_none=True)
         model._mc_batching_off = not batched
         gen.manual_seed(5)
+        if x.requires_grad:
+            x.grad = None
         nll, reg = model.loss_terms(g, x, y, mask=mask, n_samples=4)
         (nll + reg).backward()
-        return nll.detach(), reg.detach(), gen.offset, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        if x.requires_grad:
+            grads["x"] = x.grad.clone()
+        return nll.detach(), reg.detach(), gen.offset, grads
 
     nll_b, reg_b, end_b, gr_b = run(True)
-    assert calls, "the batched first layer was not used"
+    assert calls and all(calls), "the batched first layer was not used"
     nll_s, reg_s, end_s, gr_s = run(False)
     assert end_b == end_s == 16
     assert_close(torch.stack([nll_b, reg_b]), torch.stack([nll_s, reg_s]).cpu().numpy(), what=f"{first}: nll, kl")
@@ -1007,7 +1030,7 @@ def test_training_monte_carlo_loop_batched_on_the_first_layer(dev, first):
     layers[1].offsets_per_forward = lambda: 1
     model._mc_batching_off = False
     gen.manual_seed(5)
-    nll_f, reg_f = model.loss_terms(g, x, y, mask=mask, n_samples=4)
+    nll_f, reg_f = model.loss_terms(g, x.detach(), y, mask=mask, n_samples=4)
     assert model._mc_batching_off and gen.offset == 16
     assert_close(torch.stack([nll_f, reg_f]), torch.stack([nll_s, reg_s]).cpu().numpy(), what="fallback loop")
 

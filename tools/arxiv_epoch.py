@@ -24,7 +24,7 @@ import stag_amd  # noqa: E402
 from stag_amd import synthetic  # noqa: E402
 
 
-def build(dev, distribution, std=0.3, hidden=128, depth=3, model="GCN"):
+def build(dev, distribution, std=0.3, hidden=128, depth=3, model="GCN", vi=False):
     if distribution == "Normal":
         q_a, norm = torch.distributions.Normal(1.0, std, validate_args=False), False
     elif distribution == "Uniform":
@@ -35,6 +35,8 @@ def build(dev, distribution, std=0.3, hidden=128, depth=3, model="GCN"):
     SL, FO, Z = stag_amd.layers.StagLayer, stag_amd.layers.FeatOnlyLayer, stag_amd.zoo
     mid = lambda: FO(torch.nn.Sequential(torch.nn.BatchNorm1d(hidden), torch.nn.ReLU(), torch.nn.Dropout(0.5)))
     conv = Z.GCN if model == "GCN" else Z.GraphSAGE       # scripts/arxiv_mle/gcn/run.py:60-66: --model
+    if vi:                                                # a learned q(A) on every layer (scripts/citation_r1/gcn/run.py:31-46)
+        SL = lambda base, q_a, norm, _SL=SL: _SL(base, q_a=q_a, norm=norm, vi=True, relu=True)
     layers = torch.nn.ModuleList([SL(conv(128, hidden), q_a=q_a, norm=norm), mid()])
     for _ in range(depth - 2):
         layers += [SL(conv(hidden, hidden), q_a=q_a, norm=norm), mid()]
@@ -48,6 +50,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=30)
     ap.add_argument("--n-samples-training", type=int, default=1)
     ap.add_argument("--model", default="GCN", choices=["GCN", "GraphSAGE"])
+    ap.add_argument("--vi", action="store_true", help="learn q(A) (Normal/Uniform): the KL term joins the loss")
     args = ap.parse_args()
     torch.distributions.Distribution.set_default_validate_args(False)
     dev = torch.device("cuda:0")
@@ -58,7 +61,7 @@ def main():
     x = torch.randn(n, 128, device=dev)
     y = torch.randint(0, 40, (n,), device=dev)
     mask = torch.rand(n, device=dev) < 0.54
-    model = build(dev, args.distribution, model=args.model)
+    model = build(dev, args.distribution, model=args.model, vi=args.vi)
     opt = torch.optim.Adam(model.parameters(), 1e-2)
 
     S = args.n_samples_training
@@ -83,7 +86,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / args.epochs
-        print(f"{args.model} {args.distribution} n_samples_training={S} [{tag}]: E = {g.number_of_edges()}, epoch {wall * 1e3:.2f} ms wall, "
+        print(f"{args.model} {args.distribution}{' vi' if args.vi else ''} n_samples_training={S} [{tag}]: E = {g.number_of_edges()}, epoch {wall * 1e3:.2f} ms wall, "
               f"{e0.elapsed_time(e1) / args.epochs:.2f} ms device, loss {loss.item():.4f}; "
               f"{3 * S * g.number_of_edges() / wall / 1e9:.2f} G edge-aggregations/s forward (3 layers x {S} samples)")
 
