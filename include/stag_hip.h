@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 17
+#define STAG_ABI_VERSION 18
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -166,6 +166,18 @@ typedef struct stag_plan {
                                   STAG_BLOCK_UNITS units each.  The GAT kernels draw the weights and
                                   form the logits of a whole batch edge-parallel, then gather.
                                   NULL: those kernels take one unit per team instead.        */
+  const int32_t* xcd_order;    /* NULL, or the XCD-aware order of the same unit records (stag_plan_xcd): workgroups
+                                  go to the chip's 8 XCDs round-robin and every XCD has its own 4 MB L2, so workgroup
+                                  b takes its units from stripe b mod 8 — the destination rows that hold the
+                                  (b mod 8)-th eighth of the edges.  A graph whose sources lie near its destinations (a
+                                  block-diagonal batch: scripts/ppi_mle, scripts/molhiv_mle) then gathers from an eighth
+                                  of the table per XCD.  16-byte aligned; a header of STAG_XCD_HEADER ints (units per
+                                  heavy stripe [0, 8), per other stripe [8, 16), the two strides), then 8 heavy stripes
+                                  of xcd_stride_heavy records and 8 stripes of xcd_stride_light records, each padded
+                                  with null records {-1, 0, 0, -1}.  Used by the aggregation launches (stag_agg_fwd[_mc],
+                                  stag_agg_bwd, stag_agg_bwd_edge); every result is bit-identical with and without it. */
+  int32_t xcd_stride_heavy;    /* records per heavy stripe = units in the longest one; per other stripe (stag_plan_xcd) */
+  int32_t xcd_stride_light;
 } stag_plan;
 
 int stag_abi_version(void);
@@ -191,6 +203,24 @@ size_t stag_plan_workspace_bytes(int32_t n_seg, int32_t D, int32_t in_norm);
 #endif
 int stag_plan_blocks(const stag_unit* units_host, int32_t n_units, int32_t max_edges,
                      int32_t max_units, int32_t* block_ptr_host, int32_t* n_blocks_out);
+
+/* The XCD-aware order of a plan's units (stag_plan.xcd_order), from host unit records.  Two calls: xcd_host == NULL
+ * reports strides_out[2] = xcd_stride_heavy, xcd_stride_light; the second fills xcd_host[stag_plan_xcd_ints(strides)]
+ * (upload it 16-byte aligned).  n_edges: the edges of the CSR the plan belongs to.
+ * On the device, from device unit records: stag_plan_xcd_device_count (a 4-bit stable radix sort of the stripe keys;
+ * one 64-byte read-back of the stripe sizes: it synchronises `stream`) leaves the sorted order in `workspace`
+ * (>= stag_plan_xcd_device_workspace_bytes(n_units)) and reports the strides; stag_plan_xcd_device_fill, given the
+ * same workspace and strides, writes the array.  Both builders produce the same ints.                            */
+#define STAG_XCD_STRIPES 8
+#define STAG_XCD_HEADER 32
+size_t stag_plan_xcd_ints(int32_t stride_heavy, int32_t stride_light);  /* STAG_XCD_HEADER + 4 * 8 * (the two strides) */
+int stag_plan_xcd(const stag_unit* units_host, int32_t n_units, int32_t n_heavy, int64_t n_edges,
+                  int32_t* xcd_host, int32_t* strides_out);
+size_t stag_plan_xcd_device_workspace_bytes(int32_t n_units);
+int stag_plan_xcd_device_count(const stag_unit* units, int32_t n_units, int32_t n_heavy, int64_t n_edges,
+                               int32_t* strides_out_host, void* workspace, size_t workspace_bytes, void* stream);
+int stag_plan_xcd_device_fill(const stag_unit* units, int32_t n_units, const int32_t* strides, int32_t* xcd,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same plan built ON THE DEVICE from a device indptr (rocPRIM sort + scan + one fill kernel), array for array
  * what stag_plan_count / stag_plan_fill produce on the host: a freshly batched minibatch graph (scripts/ppi_mle,

@@ -19,6 +19,7 @@ NOISE_NONE, NOISE_EXPLICIT, NOISE_NORMAL, NOISE_UNIFORM, NOISE_BERNOULLI = range
 PARAM_SCALAR, PARAM_PER_CHANNEL, PARAM_PER_EDGE1, PARAM_PER_EDGE = range(4)
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 HEAVY_LEN = 16   # STAG_HEAVY_LEN (include/stag_hip.h)
+XCD_HEADER, XCD_STRIPES = 32, 8   # STAG_XCD_HEADER, STAG_XCD_STRIPES
 # STAG_BLOCK_EDGES / STAG_BLOCK_UNITS of include/stag_hip.h (the environment override pairs with a build variant of the
 # library compiled with the same -D values: A/B tooling only)
 BLOCK_EDGES, BLOCK_UNITS = int(os.environ.get("STAG_BLOCK_EDGES", "256")), int(os.environ.get("STAG_BLOCK_UNITS", "32"))
@@ -47,7 +48,8 @@ class Plan(C.Structure):
     _fields_ = [("seg_len", C.c_int32), ("n_units", C.c_int32), ("n_long", C.c_int32),
                 ("n_seg", C.c_int32), ("units", _vp), ("long_rows", _vp), ("long_seg_ptr", _vp),
                 ("seg_counters", _vp), ("workspace", _vp), ("workspace_bytes", C.c_size_t),
-                ("n_heavy", C.c_int32), ("n_blocks", C.c_int32), ("block_ptr", _vp)]
+                ("n_heavy", C.c_int32), ("n_blocks", C.c_int32), ("block_ptr", _vp),
+                ("xcd_order", _vp), ("xcd_stride_heavy", C.c_int32), ("xcd_stride_light", C.c_int32)]
 
 
 class StagHipError(RuntimeError):
@@ -79,7 +81,13 @@ def lib():
             f"{_SO} not found: the HIP extension is not built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or make -C stag_amd/csrc). "
             "stag_amd has no CPU fallback.")
-    l = C.CDLL(_SO)
+    _lib = bind(_SO)
+    return _lib
+
+
+def bind(path):
+    """A build of the library with every prototype declared (lib() for the shipped one; the A/B tools load variants)."""
+    l = C.CDLL(path)
     rts = _hip_runtimes_mapped()
     if len(rts) > 1:
         raise StagHipError(f"two HIP runtimes are mapped into this process: {sorted(rts)}")
@@ -92,6 +100,13 @@ def lib():
     l.stag_plan_blocks.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, ip]
     l.stag_plan_workspace_bytes.restype = C.c_size_t
     l.stag_plan_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    l.stag_plan_xcd.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp]
+    l.stag_plan_xcd_ints.restype = C.c_size_t
+    l.stag_plan_xcd_ints.argtypes = [C.c_int32, C.c_int32]
+    l.stag_plan_xcd_device_workspace_bytes.restype = C.c_size_t
+    l.stag_plan_xcd_device_workspace_bytes.argtypes = [C.c_int32]
+    l.stag_plan_xcd_device_count.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp, C.c_size_t, _vp]
+    l.stag_plan_xcd_device_fill.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp]
     l.stag_plan_device_workspace_bytes.restype = C.c_size_t
     l.stag_plan_device_workspace_bytes.argtypes = [C.c_int32]
     l.stag_plan_device.argtypes = [_vp, C.c_int32, C.c_int64, C.c_int32, _vp, C.c_int64, _vp, _vp, C.c_int64,
@@ -167,9 +182,8 @@ def lib():
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]
     l.stag_halo_exchange_multi.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]
     l.stag_gather_rows.argtypes = [_vp, C.c_int64, _vp, C.c_int64, C.c_int32, _vp, C.c_int64, _vp]
-    if l.stag_abi_version() != 17:
+    if l.stag_abi_version() != 18:
         raise StagHipError("libstag_hip.so ABI version mismatch")
-    _lib = l
     return l
 
 

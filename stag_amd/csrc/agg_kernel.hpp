@@ -65,6 +65,22 @@ struct AggArgs {
   uint32_t chunk_base;       // global chunk (channel / 4) of this shard's channel 0
   int32_t n_heavy;           // leading units of the plan longer than STAG_HEAVY_LEN edges
   int32_t n_heavy_blocks;    // blocks that serve them (set per launch shape)
+  // Which units a workgroup walks — eight scalars the launch shape sets (one s_load): workgroup b serves stripe
+  // b & smask with its (b >> sshift)-th block.  XCD-aware (stag_plan.xcd_order; smask 7, sshift 3): workgroups go to
+  // the 8 XCDs round-robin and every XCD has its own L2, so each stripe is a range of destination rows (1/8 of the
+  // edges) whose units lie together — `units` then holds 8 heavy stripes of `sh` records and 8 light ones of `sl`,
+  // padded with null records (row < 0).  Plan order (smask 0, sshift 0): one stripe, sh = n_heavy, sl = the rest.
+  // Without a plan (unit i = row i): stripes of `sl` rows.
+  struct alignas(32) Walk {
+    int32_t smask, sshift;
+    int32_t jh_heavy;        // blocks per stripe that serve the heavy units with the slotted loop, or 0
+    int32_t jh_light;        // ... with the one-slot loop (shapes without edge slots), or 0: one of the two is 0
+    int32_t sh;              // heavy records per stripe
+    int32_t lbase;           // first light record
+    int32_t sl;              // light records per stripe
+    int32_t n_total;         // records in all
+  } walk;
+  const int32_t* xcd;        // stag_plan.xcd_order or null (host side only: agg_launch_shape reads the strides)
   // scaling / reduce
   const float* src_scale;
   const float* dst_scale;
@@ -736,6 +752,9 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   if (a.units) {
     const int4 q = *reinterpret_cast<const int4*>(a.units + unit);
     v = q.x; b = q.y; len = q.z; slot = q.w;
+#ifndef STAG_NO_NULLCHK
+    if (v < 0) return;        // a null record: the padding of an XCD stripe (stag_plan.xcd_order)
+#endif
   } else {
     v = unit;
     b = a.indptr[v];
@@ -1007,23 +1026,77 @@ constexpr int heavy_slots_of() {
          : LPE == 16 ? STAG_HSLOTS_LPE16 : LPE == 32 ? STAG_HSLOTS_LPE32 : 1;
 }
 
+// The kernel arguments a unit needs before its first gather, fetched TOGETHER at the top of the kernel: left to
+// itself the compiler loads each group at its first use, behind the early exits — a chain of 8 scalar loads, each
+// waited for on its own, before the unit record can even be asked for.  The empty asm makes every value live here,
+// so the loads are issued back to back and waited for once.  Measured at cfg2 (tools/ab_bench.py, one process): Normal
+// 102.3 -> 101.2 us, Bernoulli 101.9 -> 101.7; the no-noise kernel 96.3 -> 97.7 (its waves reach the gather sooner
+// than the fabric wants them), so the kinds that draw nothing keep the compiler's lazy loads.
+#ifndef STAG_HOIST_ARGS
+#define STAG_HOIST_ARGS 1
+#endif
+#ifndef STAG_HOIST_PLAIN
+#define STAG_HOIST_PLAIN 0      // the kinds that draw nothing: hoisting measured 1.5 us SLOWER at cfg2 (97.8 against 96.3)
+#endif
+#define STAG_PIN_S(x) asm volatile("" : "+s"(x))
+template <int KIND>
+__device__ __forceinline__ void hoist_args(AggArgs& l) {
+#if STAG_HOIST_ARGS
+  // the walk (one aligned s_load_dwordx8 instead of three loads and two waits) for every kind
+  STAG_PIN_S(l.walk.smask); STAG_PIN_S(l.walk.sshift); STAG_PIN_S(l.walk.jh_heavy); STAG_PIN_S(l.walk.jh_light);
+  STAG_PIN_S(l.walk.sh); STAG_PIN_S(l.walk.lbase); STAG_PIN_S(l.walk.sl); STAG_PIN_S(l.walk.n_total);
+  if constexpr (KIND >= kNormal || STAG_HOIST_PLAIN) {
+    STAG_PIN_S(l.D); STAG_PIN_S(l.units); STAG_PIN_S(l.indptr); STAG_PIN_S(l.indices);
+    STAG_PIN_S(l.x); STAG_PIN_S(l.ldxb); STAG_PIN_S(l.x_bytes); STAG_PIN_S(l.wide); STAG_PIN_S(l.src_scale);
+  }
+  if constexpr (KIND >= kNormal) {
+    STAG_PIN_S(l.eid); STAG_PIN_S(l.nidx);
+    STAG_PIN_S(l.p0); STAG_PIN_S(l.p1); STAG_PIN_S(l.p0s); STAG_PIN_S(l.p1s); STAG_PIN_S(l.pmode); STAG_PIN_S(l.relu);
+    STAG_PIN_S(l.in_norm);
+    STAG_PIN_S(l.key.k0); STAG_PIN_S(l.key.k1); STAG_PIN_S(l.key.o0); STAG_PIN_S(l.key.o1); STAG_PIN_S(l.key.epoch);
+    STAG_PIN_S(l.pos_lo); STAG_PIN_S(l.pos_hi); STAG_PIN_S(l.chunk_base);
+  }
+#endif
+}
+
 template <int KIND, int LPE, bool VEC, int PEDGE, int NOUT = 1, bool MC = false, bool WN = false>
-__global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_kernel(const AggArgs a) {
+__global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_kernel(const AggArgs a_in) {
+  AggArgs a = a_in;
+  hoist_args<KIND>(a);
   constexpr int HS = (NOUT == 1 && PEDGE != 3) ? heavy_slots_of<LPE>() : 1;
   const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
-  int first = 0, blk = blockIdx.x;
+  constexpr int TPB = STAG_BLOCK_THREADS / LPE, TPBH = STAG_BLOCK_THREADS / (LPE * HS);
+  // first unit of this block, the end of the range it walks, heavy: the slotted loop (all block-uniform)
+  const AggArgs::Walk w = a.walk;
+  const int stripe = blockIdx.x & w.smask;
+  int j = blockIdx.x >> w.sshift;
+  int unit0, end;
+  bool heavy = false;
+  if (HS > 1 && j < w.jh_heavy) {
+    heavy = true;
+    unit0 = stripe * w.sh + j * TPBH;
+    end = (stripe + 1) * w.sh;
+  } else {
+    if (HS > 1) j -= w.jh_heavy;
+    if (j < w.jh_light) {
+      unit0 = stripe * w.sh + j * TPB;
+      end = (stripe + 1) * w.sh;
+    } else {
+      j -= w.jh_light;
+      unit0 = w.lbase + stripe * w.sl + j * TPB;
+      end = min(w.lbase + (stripe + 1) * w.sl, w.n_total);
+    }
+  }
   if constexpr (HS > 1) {
-    if (blk < a.n_heavy_blocks) {                 // block-uniform
-      const int unit = blk * (STAG_BLOCK_THREADS / (LPE * HS)) + threadIdx.x / (LPE * HS);
-      if (unit >= a.n_heavy) return;              // teams never talk to each other: no barrier below
+    if (heavy) {
+      const int unit = unit0 + threadIdx.x / (LPE * HS);
+      if (unit >= end) return;                    // teams never talk to each other: no barrier below
       agg_unit<KIND, LPE, VEC, PEDGE, HS, STAG_HMULT>(a, unit, c, (threadIdx.x / LPE) % HS);
       return;
     }
-    first = a.n_heavy;
-    blk -= a.n_heavy_blocks;
   }
-  const int unit = first + blk * (STAG_BLOCK_THREADS / LPE) + threadIdx.x / LPE;
-  if (unit >= a.n_units) return;
+  const int unit = unit0 + threadIdx.x / LPE;
+  if (unit >= end) return;
   agg_unit<KIND, LPE, VEC, PEDGE, 1, NOUT == 1 ? mult_of<KIND, LPE>() : 1, NOUT, MC, WN>(a, unit, c, 0);
 }
 
@@ -1061,6 +1134,9 @@ hipError_t agg_launch(const AggArgs& a, bool vec, hipStream_t stream);
 // Dynamic LDS the launch asks for although the kernel uses none: caps the workgroups a CU admits
 // (160 KB / bytes).  A/B knob (tools/ab_bench.py): the gather saturates the fabric with fewer waves in
 // flight than the register budget allows, and past that point more of them slow it down.
+#ifndef STAG_XCD_PLANLESS
+#define STAG_XCD_PLANLESS 1     // A/B knob: 0 = launches without a plan keep the linear block -> row mapping
+#endif
 #ifndef STAG_AGG_LDS_BYTES
 #define STAG_AGG_LDS_BYTES 0
 #endif
@@ -1070,9 +1146,27 @@ inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles
   constexpr int TPB = STAG_BLOCK_THREADS / LPE;
   constexpr int HS = heavy_slots_of<LPE>();
   constexpr int TPBH = STAG_BLOCK_THREADS / (LPE * HS);
-  if (HS == 1 || a.outx[0] || pedge == 3 || a.dp_part) a.n_heavy = 0;
+  const bool slotted = !(HS == 1 || a.outx[0] || pedge == 3 || a.dp_part);
+  if (!slotted) a.n_heavy = 0;
   a.n_heavy_blocks = (a.n_heavy + TPBH - 1) / TPBH;
-  dim3 grid(a.n_heavy_blocks + (a.n_units - a.n_heavy + TPB - 1) / TPB, tiles);
+  dim3 grid(1, tiles);
+  AggArgs::Walk& w = a.walk;
+  if (a.xcd) {                     // a.walk.sh / sl arrive holding the plan's stripe lengths
+    w.smask = STAG_XCD_STRIPES - 1; w.sshift = 3;
+    w.jh_heavy = slotted ? (w.sh + TPBH - 1) / TPBH : 0;
+    w.jh_light = slotted ? 0 : (w.sh + TPB - 1) / TPB;
+    w.lbase = STAG_XCD_STRIPES * w.sh;
+    w.n_total = STAG_XCD_STRIPES * (w.sh + w.sl);
+    grid.x = STAG_XCD_STRIPES * (w.jh_heavy + w.jh_light + (w.sl + TPB - 1) / TPB);
+  } else if (STAG_XCD_PLANLESS && !a.units && !a.dp_part && a.n_units >= STAG_XCD_STRIPES * TPB) {
+    // a graph that runs without a plan (short rows only: a freshly batched minibatch of molecules) is striped by rows
+    w = AggArgs::Walk{STAG_XCD_STRIPES - 1, 3, 0, 0, 0, 0, 0, a.n_units};
+    w.sl = ((a.n_units + STAG_XCD_STRIPES - 1) / STAG_XCD_STRIPES + TPB - 1) / TPB * TPB;
+    grid.x = STAG_XCD_STRIPES * (w.sl / TPB);
+  } else {                         // the plan's own order (or row order): one stripe
+    w = AggArgs::Walk{0, 0, a.n_heavy_blocks, 0, a.n_heavy, a.n_heavy, a.n_units - a.n_heavy, a.n_units};
+    grid.x = a.n_heavy_blocks + (a.n_units - a.n_heavy + TPB - 1) / TPB;
+  }
   if (grid.x == 0) return;
   const dim3 block(STAG_BLOCK_THREADS);
   if constexpr (KIND >= kNormal) {

@@ -558,6 +558,48 @@ int stag_plan_fill(const int32_t* indptr_host, int32_t n_dst, int32_t seg_len,
   return STAG_OK;
 }
 
+size_t stag_plan_xcd_ints(int32_t stride_heavy, int32_t stride_light) {
+  if (stride_heavy < 0 || stride_light < 0) return 0;
+  return (size_t)STAG_XCD_HEADER + 4u * (size_t)STAG_XCD_STRIPES * ((size_t)stride_heavy + (size_t)stride_light);
+}
+
+int stag_plan_xcd(const stag_unit* units_host, int32_t n_units, int32_t n_heavy, int64_t n_edges,
+                  int32_t* xcd_host, int32_t* strides_out) {
+  if (n_units < 0 || n_heavy < 0 || n_heavy > n_units || n_edges < 0 || !strides_out || (n_units > 0 && !units_host))
+    return STAG_EINVAL;
+  // stripe of a unit: where its first edge lies in the CSR, in eighths — contiguous destination-row ranges with an
+  // eighth of the edges each.  A stable partition of the heavy prefix and of the rest: inside a stripe the plan's
+  // order (segments, then longest first) stands.
+  const int64_t E = n_edges > 0 ? n_edges : 1;
+  auto key = [&](int32_t i) {
+    const int64_t k = (int64_t)units_host[i].start * STAG_XCD_STRIPES / E;
+    return (int)(i >= n_heavy ? STAG_XCD_STRIPES : 0) + (int)(k < 0 ? 0 : k >= STAG_XCD_STRIPES ? STAG_XCD_STRIPES - 1 : k);
+  };
+  int32_t count[2 * STAG_XCD_STRIPES] = {0};
+  for (int32_t i = 0; i < n_units; ++i) count[key(i)] += 1;
+  int32_t sh = 0, sl = 0;
+  for (int k = 0; k < STAG_XCD_STRIPES; ++k) {
+    sh = std::max(sh, count[k]);
+    sl = std::max(sl, count[STAG_XCD_STRIPES + k]);
+  }
+  strides_out[0] = sh; strides_out[1] = sl;
+  if (!xcd_host) return STAG_OK;
+  for (int k = 0; k < STAG_XCD_HEADER; ++k) xcd_host[k] = 0;
+  for (int k = 0; k < 2 * STAG_XCD_STRIPES; ++k) xcd_host[k] = count[k];
+  xcd_host[2 * STAG_XCD_STRIPES] = sh;
+  xcd_host[2 * STAG_XCD_STRIPES + 1] = sl;
+  stag_unit* rec = reinterpret_cast<stag_unit*>(xcd_host + STAG_XCD_HEADER);
+  const int64_t n_rec = (int64_t)STAG_XCD_STRIPES * ((int64_t)sh + sl);
+  for (int64_t i = 0; i < n_rec; ++i) rec[i] = stag_unit{-1, 0, 0, -1};
+  int64_t cursor[2 * STAG_XCD_STRIPES];
+  for (int k = 0; k < STAG_XCD_STRIPES; ++k) {
+    cursor[k] = (int64_t)k * sh;
+    cursor[STAG_XCD_STRIPES + k] = (int64_t)STAG_XCD_STRIPES * sh + (int64_t)k * sl;
+  }
+  for (int32_t i = 0; i < n_units; ++i) rec[cursor[key(i)]++] = units_host[i];
+  return STAG_OK;
+}
+
 int stag_plan_blocks(const stag_unit* units_host, int32_t n_units, int32_t max_edges, int32_t max_units,
                      int32_t* block_ptr_host, int32_t* n_blocks_out) {
   if (n_units < 0 || max_edges <= 0 || max_units <= 0 || !n_blocks_out || (n_units > 0 && !units_host))
@@ -677,6 +719,17 @@ static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x
     a.n_units = plan->n_units;
     if (plan->n_heavy < 0 || plan->n_heavy > plan->n_units) return STAG_EINVAL;
     a.n_heavy = plan->n_heavy;
+    // the XCD-aware order of the same records (stag_plan_xcd).  Not for the block partials of stag_agg_bwd_dp: they
+    // are added in block order, which stays the plan's own
+    if (plan->xcd_order && !(eg && eg->dp_part)) {
+      const int64_t sh = plan->xcd_stride_heavy, sl = plan->xcd_stride_light;
+      if (!aligned16(plan->xcd_order) || sh < 0 || sl < 0 || sh > plan->n_heavy || sl > plan->n_units - plan->n_heavy ||
+          STAG_XCD_STRIPES * (sh + sl) < plan->n_units || STAG_XCD_STRIPES * (sh + sl) > 0x7FFFFFFFll) return STAG_EINVAL;
+      a.xcd = plan->xcd_order;
+      a.units = reinterpret_cast<const stag_unit*>(plan->xcd_order + STAG_XCD_HEADER);
+      a.walk.sh = (int32_t)sh;     // agg_launch_shape completes the walk for its block size
+      a.walk.sl = (int32_t)sl;
+    }
   }
   if (has_segs) {
     if (!plan->long_rows || !plan->long_seg_ptr || !plan->workspace || !plan->seg_counters)

@@ -30,8 +30,8 @@ void check_rc(int rc, const char* what) {
   TORCH_CHECK(rc == STAG_OK, what, ": ", stag_strerror(rc), " (rc=", rc, ")");
 }
 
-// graph = (indptr, indices, eid?, nidx?), n_src; plan = (units?, long_rows?, long_seg_ptr?, block_ptr?,
-// counters?) + plan_ints = [seg_len, n_units, n_long, n_seg, n_heavy, n_blocks]
+// graph = (indptr, indices, eid?, nidx?), n_src; plan = (units?, long_rows?, long_seg_ptr?, block_ptr?, xcd?,
+// counters?) + plan_ints = [seg_len, n_units, n_long, n_seg, n_heavy, n_blocks, xcd_stride_heavy, xcd_stride_light]
 struct Graph {
   stag_csr csr;
   stag_plan plan;
@@ -39,7 +39,7 @@ struct Graph {
 };
 
 Graph make_graph(const Tensor& indptr, const Tensor& indices, OptT eid, OptT nidx, int64_t n_src, OptT units,
-                 OptT long_rows, OptT long_seg_ptr, OptT block_ptr, OptT counters, at::IntArrayRef plan_ints) {
+                 OptT long_rows, OptT long_seg_ptr, OptT block_ptr, OptT xcd, OptT counters, at::IntArrayRef plan_ints) {
   TORCH_CHECK(indptr.is_cuda() && indptr.scalar_type() == at::kInt && indptr.is_contiguous(), "indptr: int32 on the device");
   TORCH_CHECK(indices.scalar_type() == at::kInt && indices.is_contiguous(), "indices: int32, contiguous");
   Graph g{};
@@ -50,7 +50,7 @@ Graph make_graph(const Tensor& indptr, const Tensor& indices, OptT eid, OptT nid
   g.csr.indices = indices.numel() ? indices.data_ptr<int32_t>() : nullptr;
   g.csr.eid = ptr_of<int32_t>(eid);
   g.csr.nidx = ptr_of<int32_t>(nidx);
-  g.has_plan = units.has_value() && units->defined() && plan_ints.size() == 6 && plan_ints[1] > 0;
+  g.has_plan = units.has_value() && units->defined() && plan_ints.size() == 8 && plan_ints[1] > 0;
   if (g.has_plan) {
     g.plan.seg_len = (int32_t)plan_ints[0];
     g.plan.n_units = (int32_t)plan_ints[1];
@@ -62,6 +62,9 @@ Graph make_graph(const Tensor& indptr, const Tensor& indices, OptT eid, OptT nid
     g.plan.long_rows = ptr_of<int32_t>(long_rows);
     g.plan.long_seg_ptr = ptr_of<int32_t>(long_seg_ptr);
     g.plan.block_ptr = ptr_of<int32_t>(block_ptr);
+    g.plan.xcd_order = ptr_of<int32_t>(xcd);
+    g.plan.xcd_stride_heavy = (int32_t)plan_ints[6];
+    g.plan.xcd_stride_light = (int32_t)plan_ints[7];
     g.plan.seg_counters = const_cast<int32_t*>(ptr_of<int32_t>(counters));
   }
   return g;
@@ -82,13 +85,13 @@ stag_noise_spec make_spec(at::IntArrayRef ni, at::IntArrayRef nu, at::ArrayRef<d
 }
 
 std::tuple<Tensor, Tensor> agg_fwd(const Tensor& indptr, const Tensor& indices, OptT eid, OptT nidx, int64_t n_src,
-                                   OptT units, OptT long_rows, OptT long_seg_ptr, OptT block_ptr, OptT counters,
+                                   OptT units, OptT long_rows, OptT long_seg_ptr, OptT block_ptr, OptT xcd, OptT counters,
                                    at::IntArrayRef plan_ints, const Tensor& x, bool broadcast_x, at::IntArrayRef noise_ints,
                                    at::IntArrayRef noise_u64, at::ArrayRef<double> noise_floats, OptT p0, OptT p1,
                                    OptT epoch, int64_t reduce, OptT src_scale, OptT dst_scale, bool want_norm_scale) {
   TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.is_contiguous(), "x: fp32, contiguous, on the device");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
-  Graph g = make_graph(indptr, indices, eid, nidx, n_src, units, long_rows, long_seg_ptr, block_ptr, counters, plan_ints);
+  Graph g = make_graph(indptr, indices, eid, nidx, n_src, units, long_rows, long_seg_ptr, block_ptr, xcd, counters, plan_ints);
   const stag_noise_spec spec = make_spec(noise_ints, noise_u64, noise_floats, p0, p1, epoch);
   const int64_t D = broadcast_x ? x.numel() : x.size(1);
   Tensor out = at::empty({(int64_t)g.csr.n_dst, D}, x.options());
@@ -111,7 +114,7 @@ std::tuple<Tensor, Tensor> agg_fwd(const Tensor& indptr, const Tensor& indices, 
 }
 
 std::tuple<Tensor, Tensor> agg_fwd_meta(const Tensor& indptr, const Tensor&, OptT, OptT, int64_t, OptT, OptT, OptT, OptT, OptT,
-                                        at::IntArrayRef, const Tensor& x, bool broadcast_x, at::IntArrayRef, at::IntArrayRef,
+                                        OptT, at::IntArrayRef, const Tensor& x, bool broadcast_x, at::IntArrayRef, at::IntArrayRef,
                                         at::ArrayRef<double>, OptT, OptT, OptT, int64_t, OptT, OptT, bool want_norm_scale) {
   const int64_t D = broadcast_x ? x.numel() : x.size(1), n = indptr.numel() - 1;
   return {at::empty({n, D}, x.options()), at::empty({want_norm_scale ? n : 0, want_norm_scale ? D : 0}, x.options())};
@@ -119,13 +122,13 @@ std::tuple<Tensor, Tensor> agg_fwd_meta(const Tensor& indptr, const Tensor&, Opt
 
 // dx and (want_dp) the two parameter-derivative aggregates over the source-major CSR (stag_agg_bwd)
 std::tuple<Tensor, Tensor, Tensor> agg_bwd(const Tensor& indptr, const Tensor& indices, OptT eid, OptT nidx, int64_t n_src,
-                                           OptT units, OptT long_rows, OptT long_seg_ptr, OptT block_ptr, OptT counters,
+                                           OptT units, OptT long_rows, OptT long_seg_ptr, OptT block_ptr, OptT xcd, OptT counters,
                                            at::IntArrayRef plan_ints, const Tensor& g_in, at::IntArrayRef noise_ints,
                                            at::IntArrayRef noise_u64, at::ArrayRef<double> noise_floats, OptT p0, OptT p1,
                                            OptT epoch, OptT g_scale, OptT row_scale, bool want_dp) {
   TORCH_CHECK(g_in.is_cuda() && g_in.scalar_type() == at::kFloat && g_in.is_contiguous(), "g: fp32, contiguous, on the device");
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(g_in.device());
-  Graph g = make_graph(indptr, indices, eid, nidx, n_src, units, long_rows, long_seg_ptr, block_ptr, counters, plan_ints);
+  Graph g = make_graph(indptr, indices, eid, nidx, n_src, units, long_rows, long_seg_ptr, block_ptr, xcd, counters, plan_ints);
   const stag_noise_spec spec = make_spec(noise_ints, noise_u64, noise_floats, p0, p1, epoch);
   const int64_t D = g_in.size(1);
   Tensor dx = at::empty({(int64_t)g.csr.n_dst, D}, g_in.options());
@@ -149,7 +152,7 @@ std::tuple<Tensor, Tensor, Tensor> agg_bwd(const Tensor& indptr, const Tensor& i
 }
 
 std::tuple<Tensor, Tensor, Tensor> agg_bwd_meta(const Tensor& indptr, const Tensor&, OptT, OptT, int64_t, OptT, OptT, OptT, OptT,
-                                                OptT, at::IntArrayRef, const Tensor& g_in, at::IntArrayRef, at::IntArrayRef,
+                                                OptT, OptT, at::IntArrayRef, const Tensor& g_in, at::IntArrayRef, at::IntArrayRef,
                                                 at::ArrayRef<double>, OptT, OptT, OptT, OptT, OptT, bool want_dp) {
   const int64_t D = g_in.size(1), n = indptr.numel() - 1;
   Tensor dx = at::empty({n, D}, g_in.options());
@@ -162,11 +165,11 @@ std::tuple<Tensor, Tensor, Tensor> agg_bwd_meta(const Tensor& indptr, const Tens
 TORCH_LIBRARY(stag, m) {
   m.def("abi_version() -> int", []() -> int64_t { return stag_abi_version(); });
   m.def("agg_fwd(Tensor indptr, Tensor indices, Tensor? eid, Tensor? nidx, int n_src, Tensor? units, "
-        "Tensor? long_rows, Tensor? long_seg_ptr, Tensor? block_ptr, Tensor? counters, int[] plan_ints, Tensor x, "
+        "Tensor? long_rows, Tensor? long_seg_ptr, Tensor? block_ptr, Tensor? xcd, Tensor? counters, int[] plan_ints, Tensor x, "
         "bool broadcast_x, int[] noise_ints, int[] noise_u64, float[] noise_floats, Tensor? p0, Tensor? p1, "
         "Tensor? epoch, int reduce, Tensor? src_scale, Tensor? dst_scale, bool want_norm_scale) -> (Tensor, Tensor)");
   m.def("agg_bwd(Tensor indptr, Tensor indices, Tensor? eid, Tensor? nidx, int n_src, Tensor? units, "
-        "Tensor? long_rows, Tensor? long_seg_ptr, Tensor? block_ptr, Tensor? counters, int[] plan_ints, Tensor g, "
+        "Tensor? long_rows, Tensor? long_seg_ptr, Tensor? block_ptr, Tensor? xcd, Tensor? counters, int[] plan_ints, Tensor g, "
         "int[] noise_ints, int[] noise_u64, float[] noise_floats, Tensor? p0, Tensor? p1, Tensor? epoch, "
         "Tensor? g_scale, Tensor? row_scale, bool want_dp) -> (Tensor, Tensor, Tensor)");
 }

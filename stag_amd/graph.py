@@ -17,6 +17,8 @@ Device layout (all int32, built once, kept resident in HBM):
 import contextlib
 import ctypes as C
 
+import os
+
 import numpy as np
 import torch
 
@@ -27,6 +29,12 @@ DEFAULT_SEG_LEN = 64
 
 
 DEVICE_PLANNER = True        # plans of device-resident graphs come from stag_plan_device (False: the host planner)
+# Plans carry the XCD-aware unit order (stag_plan.xcd_order): "auto" = when at least XCD_MIN_LOCALITY of the edges have
+# their source in the same eighth of the rows as their destination (a block-diagonal batch: 1.0; uniformly random
+# sources: 0.125, where the striped order has nothing to offer and costs 1 % — tools/xcd_stripe_probe.py), "1" always,
+# "0" never.
+XCD_ORDER = os.environ.get("STAG_XCD_ORDER", "auto")
+XCD_MIN_LOCALITY = 0.25
 PLAN_AFTER_LAUNCHES = 16     # launches a short-row view runs without a plan before one is built for it
 
 
@@ -36,6 +44,7 @@ class CsrView:
     def __init__(self, n_dst, n_src, indptr, indices, eid=None, nidx=None):
         self.n_dst, self.n_src = int(n_dst), int(n_src)
         self._short = None
+        self._locality = None
         self._plan_requests = 0
         self.indptr, self.indices, self.eid, self.nidx = indptr, indices, eid, nidx
         self.n_edges = int(indices.shape[0])
@@ -59,6 +68,26 @@ class CsrView:
         if self._degrees is None:
             self._degrees = (self.indptr[1:] - self.indptr[:-1])
         return self._degrees
+
+    def stripe_locality(self):
+        """Fraction of the edges whose source row lies in the same stripe as their destination row — the stripes being the
+        STAG_XCD_STRIPES contiguous row ranges that hold an eighth of the edges each (what stag_plan_xcd cuts the units
+        into).  What one XCD's L2 can hope to find again when it walks one stripe.  One device reduction, kept."""
+        if self._locality is None:
+            E = self.n_edges
+            if E == 0 or self.n_src != self.n_dst:
+                self._locality = 0.0
+            else:
+                pos = torch.arange(E, device=self.indptr.device, dtype=torch.int64)
+                src_pos = self.indptr[:-1][self.indices.long()].long()      # where the source's own row starts
+                same = (pos * _lib.XCD_STRIPES // E) == torch.clamp(src_pos * _lib.XCD_STRIPES // E, max=_lib.XCD_STRIPES - 1)
+                self._locality = float(same.float().mean())
+        return self._locality
+
+    def _wants_xcd_order(self):
+        if XCD_ORDER == "auto":
+            return self.stripe_locality() >= XCD_MIN_LOCALITY
+        return XCD_ORDER != "0"
 
     def _short_rows(self):
         """Every row has at most HEAVY_LEN edges (one device reduction and a one-number read-back, kept)."""
@@ -112,7 +141,8 @@ class CsrView:
                 units=torch.from_numpy(units).to(dev),
                 long_rows=torch.from_numpy(long_rows).to(dev),
                 long_seg_ptr=torch.from_numpy(long_seg_ptr).to(dev),
-                counters={}, **_block_plan(units, nu, dev))
+                counters={}, **_block_plan(units, nu, dev),
+                **_xcd_order(units, nu, nh, self.n_edges, dev, self._wants_xcd_order()))
         plan = self._plans[seg_len]
         if need and plan.get("block_ptr") is None:
             # the unit batches of the cooperative GAT kernels: a greedy pass over the unit records on the host
@@ -138,8 +168,22 @@ class CsrView:
                                       _lib.ptr(long_seg_ptr), lcap + 1, counts, _lib.ptr(ws), nbytes, _lib.stream_of(dev))
         _lib.check(rc, "stag_plan_device")
         nu, nl, ns, nh = (int(v) for v in counts)
+        xcd = dict(xcd=None, xcd_strides=(0, 0))
+        if nu > 0 and self._wants_xcd_order():
+            # the XCD-aware order of the same records, built where they are (one more small read-back)
+            nbytes = lib.stag_plan_xcd_device_workspace_bytes(nu)
+            if nbytes > ws.numel():
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            st = (C.c_int32 * 2)()
+            with _lib.on_device(dev):
+                _lib.check(lib.stag_plan_xcd_device_count(_lib.ptr(units), nu, nh, E, st, _lib.ptr(ws), ws.numel(),
+                                                          _lib.stream_of(dev)), "stag_plan_xcd_device_count")
+                order = torch.empty(lib.stag_plan_xcd_ints(st[0], st[1]), dtype=torch.int32, device=dev)
+                _lib.check(lib.stag_plan_xcd_device_fill(_lib.ptr(units), nu, st, _lib.ptr(order), _lib.ptr(ws), ws.numel(),
+                                                         _lib.stream_of(dev)), "stag_plan_xcd_device_fill")
+            xcd = dict(xcd=order, xcd_strides=(int(st[0]), int(st[1])))
         return dict(seg_len=seg_len, n_units=nu, n_long=nl, n_seg=ns, n_heavy=nh, units=units, long_rows=long_rows,
-                    long_seg_ptr=long_seg_ptr, counters={}, n_blocks=0, block_ptr=None)
+                    long_seg_ptr=long_seg_ptr, counters={}, n_blocks=0, block_ptr=None, **xcd)
 
     def subplan(self, seg_len, keep):
         """The plan of `seg_len` restricted to the units keep[i] is True for (a host bool array over
@@ -155,10 +199,25 @@ class CsrView:
         dev = self.indptr.device
         buf = np.zeros((max(len(sel), 1), 4), np.int32)
         buf[:len(sel)] = sel
+        n_heavy = n_seg + int((sel[n_seg:, 2] > _lib.HEAVY_LEN).sum()) if len(sel) else 0
         return dict(seg_len=seg_len, n_units=int(len(sel)), n_long=full["n_long"] if n_seg else 0, n_seg=n_seg,
-                    n_heavy=n_seg + int((sel[n_seg:, 2] > _lib.HEAVY_LEN).sum()) if len(sel) else 0,
-                    units=torch.from_numpy(buf).to(dev), long_rows=full["long_rows"],
-                    long_seg_ptr=full["long_seg_ptr"], counters={}, **_block_plan(buf, int(len(sel)), dev))
+                    n_heavy=n_heavy, units=torch.from_numpy(buf).to(dev), long_rows=full["long_rows"],
+                    long_seg_ptr=full["long_seg_ptr"], counters={}, **_block_plan(buf, int(len(sel)), dev),
+                    **_xcd_order(buf, int(len(sel)), n_heavy, self.n_edges, dev, self._wants_xcd_order()))
+
+
+def _xcd_order(units_host, n_units, n_heavy, n_edges, dev, wanted=True):
+    """stag_plan.xcd_order of host unit records (stag_plan_xcd), uploaded: the same units grouped by the eighth of the
+    CSR their rows lie in, for workgroup b to take stripe b mod 8 — the chip's 8 XCDs each have their own L2."""
+    if not wanted or n_units <= 0:
+        return dict(xcd=None, xcd_strides=(0, 0))
+    units_host = np.ascontiguousarray(units_host, dtype=np.int32)
+    st = (C.c_int32 * 2)()
+    lib = _lib.lib()
+    _lib.check(lib.stag_plan_xcd(units_host.ctypes.data, n_units, n_heavy, n_edges, None, st), "stag_plan_xcd")
+    order = np.zeros(lib.stag_plan_xcd_ints(st[0], st[1]), np.int32)
+    _lib.check(lib.stag_plan_xcd(units_host.ctypes.data, n_units, n_heavy, n_edges, order.ctypes.data, st), "stag_plan_xcd")
+    return dict(xcd=torch.from_numpy(order).to(dev), xcd_strides=(int(st[0]), int(st[1])))
 
 
 def _block_plan(units_host, n_units, dev):

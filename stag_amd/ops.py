@@ -95,7 +95,8 @@ def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None):
         plan_c = _lib.Plan(plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"],
                            _lib.ptr(plan_t["units"]), _lib.ptr(plan_t["long_rows"]),
                            _lib.ptr(plan_t["long_seg_ptr"]), _lib.ptr(counters), None, 0,
-                           plan_t["n_heavy"], plan_t["n_blocks"], _lib.ptr(plan_t["block_ptr"]))
+                           plan_t["n_heavy"], plan_t["n_blocks"], _lib.ptr(plan_t["block_ptr"]),
+                           _lib.ptr(plan_t.get("xcd")), *plan_t.get("xcd_strides", (0, 0)))
         plan_t["_structs"][key] = plan_c
     plan_c.workspace, plan_c.workspace_bytes = _lib.ptr(ws), nbytes
     return plan_c, (ws, counters)
@@ -105,9 +106,9 @@ _NONE_ARGS = ([_lib.NOISE_NONE, 0, 0, 0, 0, 0, 0, 0], [0, 0, 0], [0.0, 0.0], Non
 
 
 def _plan_args(csrv, plan_t, tiles, dev):
-    """(units, long_rows, long_seg_ptr, block_ptr, counters, plan_ints) of torch.ops.stag.*"""
+    """(units, long_rows, long_seg_ptr, block_ptr, xcd, counters, plan_ints) of torch.ops.stag.*"""
     if plan_t is None:
-        return (None, None, None, None, None, [0, 0, 0, 0, 0, 0])
+        return (None, None, None, None, None, None, [0, 0, 0, 0, 0, 0, 0, 0])
     key = (tiles, _lib.stream_of(dev))
     counters = plan_t["counters"].get(key)
     if counters is None:
@@ -116,8 +117,9 @@ def _plan_args(csrv, plan_t, tiles, dev):
     ints = plan_t.get("_ints")
     if ints is None:
         ints = plan_t["_ints"] = [plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"],
-                                  plan_t["n_heavy"], plan_t["n_blocks"]]
-    return (plan_t["units"], plan_t["long_rows"], plan_t["long_seg_ptr"], plan_t["block_ptr"], counters, ints)
+                                  plan_t["n_heavy"], plan_t["n_blocks"], *plan_t.get("xcd_strides", (0, 0))]
+    return (plan_t["units"], plan_t["long_rows"], plan_t["long_seg_ptr"], plan_t["block_ptr"], plan_t.get("xcd"), counters,
+            ints)
 
 
 def _agg_fwd_torch(csrv, x, noise_args, reduce, src_scale, dst_scale, seg_len, want_norm_scale, broadcast_x):

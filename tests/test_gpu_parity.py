@@ -955,7 +955,7 @@ def test_gat_layer_trains_with_attention_dropout_on_the_fused_path(dev):
 
 
 @pytest.mark.parametrize("seg_len", [16, 64, 256])
-def test_device_planner_equals_host_planner(dev, seg_len):
+def test_device_planner_equals_host_planner(dev, seg_len, monkeypatch):
     """stag_plan_device builds, from the device indptr, the plan stag_plan_count / stag_plan_fill build on the host:
     the same unit records in the same order (long rows first, most edges first, balanced segments; whole rows
     longest first; ties by row), long_rows, long_seg_ptr and counts — hubs, empty rows, a one-row graph, a graph
@@ -963,6 +963,7 @@ def test_device_planner_equals_host_planner(dev, seg_len):
     import importlib
     import stag_amd
     G = importlib.import_module("stag_amd.graph")
+    monkeypatch.setattr(G, "XCD_ORDER", "1")           # (auto would leave it out on these random graphs)
     rng = np.random.default_rng(seg_len)
     cases = [random_graph(300, 5000, seed=1, hub=700, device=dev), random_graph(50, 30, seed=2, device=dev),
              random_graph(2000, 30000, seed=3, hub=3000, device=dev),
@@ -987,14 +988,79 @@ def test_device_planner_equals_host_planner(dev, seg_len):
             assert torch.equal(dplan["long_rows"][:nl].cpu(), hplan["long_rows"][:nl].cpu())
             assert torch.equal(dplan["long_seg_ptr"][:nl + 1].cpu(), hplan["long_seg_ptr"][:nl + 1].cpu())
             assert torch.equal(dplan["block_ptr"].cpu(), hplan["block_ptr"].cpu())
+            assert dplan["xcd_strides"] == hplan["xcd_strides"]          # stag_plan_xcd_device == stag_plan_xcd
+            if nu:
+                assert torch.equal(dplan["xcd"].cpu(), hplan["xcd"].cpu())
+            else:
+                assert dplan["xcd"] is None and hplan["xcd"] is None
 
 
-def test_fuzz_device_planner_equals_host_planner(dev):
+def _without_xcd_order(view, seg_len):
+    p = view.plan(seg_len, need=True)
+    p["xcd"], p["xcd_strides"] = None, (0, 0)
+    p.pop("_structs", None)
+    p.pop("_ints", None)
+
+
+@pytest.mark.parametrize("D", [1, 8, 24, 50, 64, 128, 200, 256, 300])
+def test_xcd_aware_unit_order_changes_no_bit(dev, oracle, D, monkeypatch):
+    """stag_plan.xcd_order only changes WHICH workgroup walks a unit (workgroup b takes stripe b mod 8 of the
+    destination rows): forward (every kind, in-norm, mean), the Monte-Carlo batch and the backward pass are
+    bit-identical with and without it — hubs cut into segments, empty rows, a block-diagonal batch (the case it is for)
+    and a graph with fewer units than stripes — and the forward equals the oracle."""
+    import importlib
+    import stag_amd
+    from stag_amd import ops, synthetic
+    monkeypatch.setattr(importlib.import_module("stag_amd.graph"), "XCD_ORDER", "1")
+    s3, d3, sizes = synthetic.ppi_like(n_graphs=6, n_nodes=3000, n_edges=40000, seed=5)
+    graphs = [("hubs", lambda: random_graph(2500, 30000, seed=3, hub=3000, device=dev)),
+              ("batch", lambda: stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), int(sizes.sum()), device=dev)),
+              ("tiny", lambda: random_graph(5, 12, seed=9, device=dev))]
+    rng = np.random.default_rng(D)
+    for name, mk in graphs:
+        ga, gb = mk(), mk()
+        for view in (gb.csr, gb.csr_t):
+            _without_xcd_order(view, 64)
+        assert ga.csr.plan(64, need=True)["xcd"] is not None and gb.csr.plan(64)["xcd"] is None
+        og = oracle_graph(oracle, ga)
+        n = ga.number_of_nodes()
+        xh = rng.standard_normal((n, D)).astype(np.float32)
+        x = torch.from_numpy(xh).to(dev)
+        gout = torch.randn(n, D, device=dev)
+        for kind, p0, p1 in (("none", None, None), ("normal", 1.0, 0.5), ("uniform", 0.2, 1.7), ("bernoulli", 0.6, None)):
+            for in_norm, reduce in ((False, "sum"), (True, "mean")):
+                if kind == "none" and in_norm:
+                    continue
+                what = f"{name} {kind} D={D} in_norm={in_norm}"
+                relu = in_norm and kind == "normal"        # deg / sum(w) of signed weights is ill-conditioned: not this test's subject
+                mk_noise = lambda g: None if kind == "none" else _noise(g, D, kind, p0, p1, seed=11, offset=3, in_norm=in_norm,
+                                                                        relu=relu)
+                ya = ops.aggregate(ga, x, mk_noise(ga), reduce=reduce)
+                yb = ops.aggregate(gb, x, mk_noise(gb), reduce=reduce)
+                assert torch.equal(ya, yb), what
+                spec = oracle.make_spec("none") if kind == "none" else _ospec(oracle, ga, D, kind, p0, p1, seed=11, offset=3,
+                                                                              in_norm=in_norm, relu=relu)
+                ref = oracle.agg_fwd(og, xh, spec, reduce=oracle.REDUCE_MEAN if reduce == "mean" else oracle.REDUCE_SUM)
+                assert_close(ya, ref, what=what)
+                if kind != "none":
+                    ma = ops.aggregate_mc(ga, x, mk_noise(ga), 4, reduce=reduce)
+                    mb = ops.aggregate_mc(gb, x, mk_noise(gb), 4, reduce=reduce)
+                    assert torch.equal(ma, mb) and torch.equal(ma[0], ya), what + " mc"
+            outs = []                     # backward: dx on the transposed plan, the noise regenerated
+            for g in (ga, gb):
+                xr = x.clone().requires_grad_(True)
+                ops.aggregate(g, xr, None if kind == "none" else _noise(g, D, kind, p0, p1, seed=11, offset=3)).backward(gout)
+                outs.append(xr.grad)
+            assert torch.equal(outs[0], outs[1]), f"{name} {kind} D={D} dx"
+
+
+def test_fuzz_device_planner_equals_host_planner(dev, monkeypatch):
     """Seeded sweep of test_device_planner_equals_host_planner: random multigraphs (1 ... 3000 nodes, 0 ... 40,000
     edges, with and without hubs, a few nodes with thousands of parallel edges) x segment lengths, both CSR views,
     element for element."""
     import importlib
     G = importlib.import_module("stag_amd.graph")
+    monkeypatch.setattr(G, "XCD_ORDER", "1")
     rng = np.random.default_rng(20261008)
     keys = ("units", "long_rows", "long_seg_ptr", "block_ptr")
     for it in range(20 * FUZZ_SCALE):
@@ -1019,6 +1085,8 @@ def test_fuzz_device_planner_equals_host_planner(dev):
             nu, nl = hplan["n_units"], hplan["n_long"]
             for k, m in zip(keys, (nu, nl, nl + 1, None)):
                 assert torch.equal(dplan[k][:m].cpu(), hplan[k][:m].cpu()), (what, k)
+            assert dplan["xcd_strides"] == hplan["xcd_strides"], what
+            assert (dplan["xcd"] is None and hplan["xcd"] is None) or torch.equal(dplan["xcd"].cpu(), hplan["xcd"].cpu()), what
 
 
 def test_fuzz_backward_passes_against_oracle(dev, oracle):

@@ -20,7 +20,7 @@ def test_abi_exports_every_declared_symbol():
     assert {"stag_agg_fwd", "stag_noise_materialize", "stag_gat_fwd", "stag_plan_fill"} <= names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/stag_hip.h but not exported"
-    assert lib.stag_abi_version() == 17
+    assert lib.stag_abi_version() == 18
     assert lib.stag_strerror(-22) == b"invalid argument"
 
 
@@ -30,12 +30,12 @@ def test_torch_library_front_end_loads_and_traces():
     from stag_amd import _torch_ext
     assert os.path.exists(os.path.join(ROOT, "stag_amd", "_stag_torch.so")), "build with make -C stag_amd/csrc"
     assert _torch_ext.loaded() and not _torch_ext.available()      # eager mode keeps ctypes (it is faster)
-    assert int(torch.ops.stag.abi_version()) == 17
+    assert int(torch.ops.stag.abi_version()) == 18
     ip = torch.zeros(6, dtype=torch.int32, device="meta")
     ix = torch.zeros(9, dtype=torch.int32, device="meta")
     x = torch.zeros(5, 12, device="meta")
     noise = ([2, 0, 0, 1, 0, 0, 0, 0], [1, 2, 0], [1.0, 0.5], None, None, None)
-    plan = (None, None, None, None, None, [0] * 6)
+    plan = (None, None, None, None, None, None, [0] * 8)
     out, ns = torch.ops.stag.agg_fwd(ip, ix, None, None, 5, *plan, x, False, *noise, 0, None, None, True)
     assert out.shape == (5, 12) and ns.shape == (5, 12) and out.device.type == "meta"
     dx, t0, t1 = torch.ops.stag.agg_bwd(ip, ix, None, None, 5, *plan, x, *noise, None, None, True)
@@ -51,7 +51,7 @@ def test_abi_struct_layouts_match_header():
     from stag_amd import _lib
     assert ctypes.sizeof(_lib.Csr) == 48
     assert ctypes.sizeof(_lib.NoiseSpec) == 88
-    assert ctypes.sizeof(_lib.Plan) == 80
+    assert ctypes.sizeof(_lib.Plan) == 96 and _lib.Plan.xcd_order.offset == 80
     assert _lib.NoiseSpec.deriv.offset == 40 and _lib.NoiseSpec.seed.offset == 48 and _lib.NoiseSpec.pos_base.offset == 64
 
 
@@ -130,6 +130,60 @@ def test_plan_covers_every_edge_once(seg_len):
     ld = deg[long_rows[:p["n_long"]]]
     assert (np.diff(ld) <= 0).all(), "hub rows first"
     assert set(units[units[:, 3] >= 0][:, 3]) == set(range(p["n_seg"]))
+
+
+@pytest.mark.parametrize("seg_len", [3, 64])
+def test_xcd_order_is_a_stable_partition_of_the_plan(seg_len, monkeypatch):
+    """stag_plan_xcd (stag_plan.xcd_order): the plan's unit records grouped by the eighth of the CSR their first edge lies
+    in — heavy prefix and the rest separately, the plan's own order inside a stripe, every stripe padded with null
+    records to the longest one — with the stripe sizes and the two strides in the header."""
+    import importlib
+    import stag_amd
+    from stag_amd import _lib
+    G = importlib.import_module("stag_amd.graph")
+    rng = np.random.default_rng(seg_len)
+    n = 3000
+    dst = np.concatenate([rng.integers(0, n - 40, 20000), np.full(900, 7), np.full(200, 2500)])
+    src = rng.integers(0, n, len(dst))
+    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n)
+    # "auto": only where an XCD's L2 would find its rows again — not on uniformly random sources (1/8 of the edges stay
+    # inside their stripe), yes on a block-diagonal batch
+    assert G.XCD_ORDER == "auto" and abs(g.csr.stripe_locality() - 0.125) < 0.02 and g.csr.plan(seg_len)["xcd"] is None
+    from stag_amd import synthetic
+    s3, d3, sizes = synthetic.ppi_like(n_graphs=12, n_nodes=2400, n_edges=20000, seed=2)
+    gb = stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), int(sizes.sum()))
+    assert gb.csr.stripe_locality() > 0.6 and gb.csr.plan(seg_len)["xcd"] is not None
+    monkeypatch.setattr(G, "XCD_ORDER", "1")
+    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n)
+    p = g.csr.plan(seg_len)
+    nu, nh, E = p["n_units"], p["n_heavy"], len(dst)
+    units = p["units"].numpy()[:nu]
+    xcd = p["xcd"].numpy()
+    sh, sl = p["xcd_strides"]
+    assert len(xcd) == _lib.XCD_HEADER + 4 * 8 * (sh + sl)
+    ch, cl = xcd[0:8], xcd[8:16]                    # units per heavy stripe, per other stripe
+    assert ch.sum() == nh and cl.sum() == nu - nh and (sh, sl) == (ch.max(), cl.max()) == (xcd[16], xcd[17])
+    assert (xcd[18:_lib.XCD_HEADER] == 0).all()
+    rec = xcd[_lib.XCD_HEADER:].reshape(8 * (sh + sl), 4)
+    stripe = np.minimum(units[:, 1].astype(np.int64) * 8 // E, 7)
+    null = np.array([-1, 0, 0, -1], np.int32)
+    for cnt, base, stride, lo, hi in ((ch, 0, sh, 0, nh), (cl, 8 * sh, sl, nh, nu)):
+        for k in range(8):
+            want = units[lo:hi][stripe[lo:hi] == k]                  # the plan's order, restricted to the stripe
+            got = rec[base + k * stride: base + (k + 1) * stride]
+            assert len(want) == cnt[k] and (got[:cnt[k]] == want).all() and (got[cnt[k]:] == null).all()
+    # stripes are contiguous destination-row ranges: whole rows of stripe k lie below those of stripe k + 1
+    tops = [rec[8 * sh + k * sl: 8 * sh + k * sl + cl[k], 0] for k in range(8)]
+    for a, b in zip(tops[:-1], tops[1:]):
+        if len(a) and len(b):
+            assert a.max() < b.min()
+    # a sub-plan carries its own
+    keep = np.ones(nu, bool)
+    keep[p["n_seg"]::3] = False
+    sp = g.csr.subplan(seg_len, keep)
+    srec = sp["xcd"].numpy()[_lib.XCD_HEADER:].reshape(-1, 4)
+    srec = srec[srec[:, 0] >= 0]
+    assert sorted(map(tuple, srec)) == sorted(map(tuple, units[keep]))
 
 
 @pytest.mark.parametrize("seg_len", [64, 16, 300])
