@@ -29,12 +29,14 @@ DEFAULT_SEG_LEN = 64
 
 
 DEVICE_PLANNER = True        # plans of device-resident graphs come from stag_plan_device (False: the host planner)
-# Plans carry the XCD-aware unit order (stag_plan.xcd_order): "auto" = when at least XCD_MIN_LOCALITY of the edges have
-# their source in the same eighth of the rows as their destination (a block-diagonal batch: 1.0; uniformly random
-# sources: 0.125, where the striped order has nothing to offer and costs 1 % — tools/xcd_stripe_probe.py), "1" always,
-# "0" never.
+# Plans carry the XCD-aware unit order (stag_plan.xcd_order): "auto" = once a view has been launched XCD_AFTER_LAUNCHES
+# times (a static graph: a freshly batched minibatch graph would pay 0.2-0.4 ms for what saves it 5-30 us a launch) AND
+# at least XCD_MIN_LOCALITY of its edges have their source in the same eighth of the rows as their destination (a
+# block-diagonal batch: 0.86-1.0; uniformly random sources: 0.125, where the striped order has nothing to offer and
+# costs 1 % — tools/xcd_stripe_probe.py); "1" always, with the plan; "0" never.
 XCD_ORDER = os.environ.get("STAG_XCD_ORDER", "auto")
 XCD_MIN_LOCALITY = 0.25
+XCD_AFTER_LAUNCHES = 16
 PLAN_AFTER_LAUNCHES = 16     # launches a short-row view runs without a plan before one is built for it
 
 
@@ -84,10 +86,48 @@ class CsrView:
                 self._locality = float(same.float().mean())
         return self._locality
 
-    def _wants_xcd_order(self):
+    def _add_xcd_order(self, plan):
+        """stag_plan.xcd_order for `plan` (stag_plan_xcd on host records, stag_plan_xcd_device_* on device records: the same
+        ints): the units grouped by the eighth of the CSR their rows lie in, for workgroup b to take stripe b mod 8."""
+        plan["xcd_decided"] = True
+        nu, nh = plan["n_units"], plan["n_heavy"]
+        if nu <= 0:
+            return
+        lib, units, dev = _lib.lib(), plan["units"], plan["units"].device
+        st = (C.c_int32 * 2)()
+        if units.is_cuda:
+            nbytes = lib.stag_plan_xcd_device_workspace_bytes(nu)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            with _lib.on_device(dev):
+                _lib.check(lib.stag_plan_xcd_device_count(_lib.ptr(units), nu, nh, self.n_edges, st, _lib.ptr(ws), nbytes,
+                                                          _lib.stream_of(dev)), "stag_plan_xcd_device_count")
+                order = torch.empty(lib.stag_plan_xcd_ints(st[0], st[1]), dtype=torch.int32, device=dev)
+                _lib.check(lib.stag_plan_xcd_device_fill(_lib.ptr(units), nu, st, _lib.ptr(order), _lib.ptr(ws), nbytes,
+                                                         _lib.stream_of(dev)), "stag_plan_xcd_device_fill")
+        else:
+            units_h = np.ascontiguousarray(units[:nu].numpy(), dtype=np.int32)
+            _lib.check(lib.stag_plan_xcd(units_h.ctypes.data, nu, nh, self.n_edges, None, st), "stag_plan_xcd")
+            order_h = np.zeros(lib.stag_plan_xcd_ints(st[0], st[1]), np.int32)
+            _lib.check(lib.stag_plan_xcd(units_h.ctypes.data, nu, nh, self.n_edges, order_h.ctypes.data, st), "stag_plan_xcd")
+            order = torch.from_numpy(order_h)
+        plan.update(xcd=order, xcd_strides=(int(st[0]), int(st[1])))
+        plan.pop("_structs", None)
+        plan.pop("_ints", None)
+
+    def _xcd_policy(self, plan):
+        """Called on every request for `plan`: see XCD_ORDER."""
+        if plan.get("xcd_decided") or XCD_ORDER == "0":
+            return
         if XCD_ORDER == "auto":
-            return self.stripe_locality() >= XCD_MIN_LOCALITY
-        return XCD_ORDER != "0"
+            plan["uses"] = plan.get("uses", 0) + 1
+            if plan["uses"] <= XCD_AFTER_LAUNCHES:
+                return
+            if self.indptr.is_cuda and torch.cuda.is_current_stream_capturing():
+                return                           # (read-backs: not inside a hipGraph capture; the next eager launch decides)
+            if self.stripe_locality() < XCD_MIN_LOCALITY:
+                plan["xcd_decided"] = True
+                return
+        self._add_xcd_order(plan)
 
     def _short_rows(self):
         """Every row has at most HEAVY_LEN edges (one device reduction and a one-number read-back, kept)."""
@@ -141,9 +181,9 @@ class CsrView:
                 units=torch.from_numpy(units).to(dev),
                 long_rows=torch.from_numpy(long_rows).to(dev),
                 long_seg_ptr=torch.from_numpy(long_seg_ptr).to(dev),
-                counters={}, **_block_plan(units, nu, dev),
-                **_xcd_order(units, nu, nh, self.n_edges, dev, self._wants_xcd_order()))
+                counters={}, xcd=None, xcd_strides=(0, 0), **_block_plan(units, nu, dev))
         plan = self._plans[seg_len]
+        self._xcd_policy(plan)
         if need and plan.get("block_ptr") is None:
             # the unit batches of the cooperative GAT kernels: a greedy pass over the unit records on the host
             units_h = plan["units"][:max(plan["n_units"], 1)].cpu().numpy()
@@ -168,22 +208,8 @@ class CsrView:
                                       _lib.ptr(long_seg_ptr), lcap + 1, counts, _lib.ptr(ws), nbytes, _lib.stream_of(dev))
         _lib.check(rc, "stag_plan_device")
         nu, nl, ns, nh = (int(v) for v in counts)
-        xcd = dict(xcd=None, xcd_strides=(0, 0))
-        if nu > 0 and self._wants_xcd_order():
-            # the XCD-aware order of the same records, built where they are (one more small read-back)
-            nbytes = lib.stag_plan_xcd_device_workspace_bytes(nu)
-            if nbytes > ws.numel():
-                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            st = (C.c_int32 * 2)()
-            with _lib.on_device(dev):
-                _lib.check(lib.stag_plan_xcd_device_count(_lib.ptr(units), nu, nh, E, st, _lib.ptr(ws), ws.numel(),
-                                                          _lib.stream_of(dev)), "stag_plan_xcd_device_count")
-                order = torch.empty(lib.stag_plan_xcd_ints(st[0], st[1]), dtype=torch.int32, device=dev)
-                _lib.check(lib.stag_plan_xcd_device_fill(_lib.ptr(units), nu, st, _lib.ptr(order), _lib.ptr(ws), ws.numel(),
-                                                         _lib.stream_of(dev)), "stag_plan_xcd_device_fill")
-            xcd = dict(xcd=order, xcd_strides=(int(st[0]), int(st[1])))
         return dict(seg_len=seg_len, n_units=nu, n_long=nl, n_seg=ns, n_heavy=nh, units=units, long_rows=long_rows,
-                    long_seg_ptr=long_seg_ptr, counters={}, n_blocks=0, block_ptr=None, **xcd)
+                    long_seg_ptr=long_seg_ptr, counters={}, n_blocks=0, block_ptr=None, xcd=None, xcd_strides=(0, 0))
 
     def subplan(self, seg_len, keep):
         """The plan of `seg_len` restricted to the units keep[i] is True for (a host bool array over
@@ -200,24 +226,13 @@ class CsrView:
         buf = np.zeros((max(len(sel), 1), 4), np.int32)
         buf[:len(sel)] = sel
         n_heavy = n_seg + int((sel[n_seg:, 2] > _lib.HEAVY_LEN).sum()) if len(sel) else 0
-        return dict(seg_len=seg_len, n_units=int(len(sel)), n_long=full["n_long"] if n_seg else 0, n_seg=n_seg,
-                    n_heavy=n_heavy, units=torch.from_numpy(buf).to(dev), long_rows=full["long_rows"],
-                    long_seg_ptr=full["long_seg_ptr"], counters={}, **_block_plan(buf, int(len(sel)), dev),
-                    **_xcd_order(buf, int(len(sel)), n_heavy, self.n_edges, dev, self._wants_xcd_order()))
-
-
-def _xcd_order(units_host, n_units, n_heavy, n_edges, dev, wanted=True):
-    """stag_plan.xcd_order of host unit records (stag_plan_xcd), uploaded: the same units grouped by the eighth of the
-    CSR their rows lie in, for workgroup b to take stripe b mod 8 — the chip's 8 XCDs each have their own L2."""
-    if not wanted or n_units <= 0:
-        return dict(xcd=None, xcd_strides=(0, 0))
-    units_host = np.ascontiguousarray(units_host, dtype=np.int32)
-    st = (C.c_int32 * 2)()
-    lib = _lib.lib()
-    _lib.check(lib.stag_plan_xcd(units_host.ctypes.data, n_units, n_heavy, n_edges, None, st), "stag_plan_xcd")
-    order = np.zeros(lib.stag_plan_xcd_ints(st[0], st[1]), np.int32)
-    _lib.check(lib.stag_plan_xcd(units_host.ctypes.data, n_units, n_heavy, n_edges, order.ctypes.data, st), "stag_plan_xcd")
-    return dict(xcd=torch.from_numpy(order).to(dev), xcd_strides=(int(st[0]), int(st[1])))
+        sub = dict(seg_len=seg_len, n_units=int(len(sel)), n_long=full["n_long"] if n_seg else 0, n_seg=n_seg,
+                   n_heavy=n_heavy, units=torch.from_numpy(buf).to(dev), long_rows=full["long_rows"],
+                   long_seg_ptr=full["long_seg_ptr"], counters={}, xcd=None, xcd_strides=(0, 0),
+                   **_block_plan(buf, int(len(sel)), dev))
+        if XCD_ORDER == "1":
+            self._add_xcd_order(sub)
+        return sub
 
 
 def _block_plan(units_host, n_units, dev):

@@ -148,11 +148,13 @@ def test_xcd_order_is_a_stable_partition_of_the_plan(seg_len, monkeypatch):
     g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n)
     # "auto": only where an XCD's L2 would find its rows again — not on uniformly random sources (1/8 of the edges stay
     # inside their stripe), yes on a block-diagonal batch
-    assert G.XCD_ORDER == "auto" and abs(g.csr.stripe_locality() - 0.125) < 0.02 and g.csr.plan(seg_len)["xcd"] is None
+    # ... and only for a view that keeps being launched (a fresh minibatch graph would pay more than it gains)
+    many = lambda view: [view.plan(seg_len) for _ in range(G.XCD_AFTER_LAUNCHES + 1)][-1]
+    assert G.XCD_ORDER == "auto" and abs(g.csr.stripe_locality() - 0.125) < 0.02 and many(g.csr)["xcd"] is None
     from stag_amd import synthetic
     s3, d3, sizes = synthetic.ppi_like(n_graphs=12, n_nodes=2400, n_edges=20000, seed=2)
     gb = stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), int(sizes.sum()))
-    assert gb.csr.stripe_locality() > 0.6 and gb.csr.plan(seg_len)["xcd"] is not None
+    assert gb.csr.stripe_locality() > 0.6 and gb.csr.plan(seg_len)["xcd"] is None and many(gb.csr)["xcd"] is not None
     monkeypatch.setattr(G, "XCD_ORDER", "1")
     g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n)
     p = g.csr.plan(seg_len)

@@ -28,7 +28,19 @@ from stag_amd import _lib, ops, synthetic  # noqa: E402
 ALL = ["cfg5", "cfg5_train", "cfg3", "cfg3_l1", "cfg4", "cfg4_l1"]
 
 
+SETTLE_MS = 300.0     # untimed launches before the warm-up, as bench.py does (--settle-ms): a 50-step run started cold
+                      # reads a VALU-bound kernel 15-20 % slow (cfg3 with noise: 147 against 123 us) — clocks, not code
+
+
 def timeit(fn, steps, warmup):
+    if SETTLE_MS > 0:
+        import time
+        t0, i = time.perf_counter(), 0
+        while (time.perf_counter() - t0) * 1e3 < SETTLE_MS:
+            for _ in range(20):
+                fn(i)
+                i += 1
+            torch.cuda.synchronize()
     for i in range(warmup):
         fn(i)
     torch.cuda.synchronize()
@@ -52,12 +64,14 @@ def report(name, what, t_us, E, b_alg, extra=None):
 
 
 def main():
+    global SETTLE_MS
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=",".join(ALL))
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--noise", default="normal", choices=["normal", "none"])
     ap.add_argument("--json", default=None)
+    ap.add_argument("--settle-ms", type=float, default=SETTLE_MS, help="untimed launches before each timed loop (0: start cold)")
     ap.add_argument("--lib", default=None, help="A/B: a build variant tools/_bin/libstag_<name>.so (tools/ab_bench.py build)")
     ap.add_argument("--blk", default=None, help="A/B: batch budget of the cooperative GAT kernels, 'edges,units' (at most the library's STAG_BLOCK_EDGES, STAG_BLOCK_UNITS)")
     ap.add_argument("--gat-old-bwd", action="store_true",
@@ -66,6 +80,7 @@ def main():
                     help="cfg5_train: stag_gat_bwd_two_pass (edge pass + source pass: two gathers) for A/B")
     args = ap.parse_args()
     only = [s for s in args.only.split(",") if s]
+    SETTLE_MS = args.settle_ms
     if args.gat_two_pass:
         ops._GAT_BWD_ONE_GATHER = False
     if args.blk:

@@ -84,7 +84,7 @@ def main():
         summary = {"config": cfg, "noise": args.noise, "script_lines": lines, "kernels": {}}
         passes = {}
         for ptag, ctrs in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_sq", SQ)):
-            out, _ = run_prof(ptag, ["--pmc", *ctrs], [*prog, "--steps", "10", "--warmup", "2"], scratch)
+            out, _ = run_prof(ptag, ["--pmc", *ctrs], [*prog, "--steps", "10", "--warmup", "2", "--settle-ms", "0"], scratch)
             passes[ptag] = counters(out)
         for name in sorted(set().union(*[set(p) for p in passes.values()])):
             k = {"avg_us_stats_pass": avg_ns.get(name, (None, 0))[0] and avg_ns[name][0] / 1e3,
