@@ -172,7 +172,7 @@ typedef struct stag_plan {
                                   (b mod 8)-th eighth of the edges.  A graph whose sources lie near its destinations (a
                                   block-diagonal batch: scripts/ppi_mle, scripts/molhiv_mle) then gathers from an eighth
                                   of the table per XCD.  16-byte aligned; a header of STAG_XCD_HEADER ints (units per
-                                  heavy stripe [0, 8), per other stripe [8, 16), the two strides), then 8 heavy stripes
+                                  heavy stripe [0, 8), per other stripe [8, 16), the two strides, fine), then 8 heavy stripes
                                   of xcd_stride_heavy records and 8 stripes of xcd_stride_light records, each padded
                                   with null records {-1, 0, 0, -1}.  Used by the aggregation launches (stag_agg_fwd[_mc],
                                   stag_agg_bwd, stag_agg_bwd_edge); every result is bit-identical with and without it. */
@@ -206,20 +206,25 @@ int stag_plan_blocks(const stag_unit* units_host, int32_t n_units, int32_t max_e
 
 /* The XCD-aware order of a plan's units (stag_plan.xcd_order), from host unit records.  Two calls: xcd_host == NULL
  * reports strides_out[2] = xcd_stride_heavy, xcd_stride_light; the second fills xcd_host[stag_plan_xcd_ints(strides)]
- * (upload it 16-byte aligned).  n_edges: the edges of the CSR the plan belongs to.
- * On the device, from device unit records: stag_plan_xcd_device_count (a 4-bit stable radix sort of the stripe keys;
- * one 64-byte read-back of the stripe sizes: it synchronises `stream`) leaves the sorted order in `workspace`
+ * (upload it 16-byte aligned).  n_edges: the edges of the CSR the plan belongs to.  fine (1 ... STAG_XCD_FINE_MAX;
+ * stag_plan_xcd_fine(n_dst) proposes one): inside its stripe an XCD walks `fine` finer row ranges one after the other —
+ * about STAG_XCD_FINE_ROWS rows each, so that the rows one of them gathers fit the XCD's 4 MB L2 at D <= 256.
+ * On the device, from device unit records: stag_plan_xcd_device_count (a stable radix sort of the stripe keys;
+ * one read-back of the stripe sizes: it synchronises `stream`) leaves the sorted order in `workspace`
  * (>= stag_plan_xcd_device_workspace_bytes(n_units)) and reports the strides; stag_plan_xcd_device_fill, given the
- * same workspace and strides, writes the array.  Both builders produce the same ints.                            */
+ * same workspace, strides and fine, writes the array.  Both builders produce the same ints.                       */
 #define STAG_XCD_STRIPES 8
 #define STAG_XCD_HEADER 32
+#define STAG_XCD_FINE_ROWS 2048
+#define STAG_XCD_FINE_MAX 16
 size_t stag_plan_xcd_ints(int32_t stride_heavy, int32_t stride_light);  /* STAG_XCD_HEADER + 4 * 8 * (the two strides) */
-int stag_plan_xcd(const stag_unit* units_host, int32_t n_units, int32_t n_heavy, int64_t n_edges,
+int32_t stag_plan_xcd_fine(int32_t n_dst);
+int stag_plan_xcd(const stag_unit* units_host, int32_t n_units, int32_t n_heavy, int64_t n_edges, int32_t fine,
                   int32_t* xcd_host, int32_t* strides_out);
 size_t stag_plan_xcd_device_workspace_bytes(int32_t n_units);
-int stag_plan_xcd_device_count(const stag_unit* units, int32_t n_units, int32_t n_heavy, int64_t n_edges,
+int stag_plan_xcd_device_count(const stag_unit* units, int32_t n_units, int32_t n_heavy, int64_t n_edges, int32_t fine,
                                int32_t* strides_out_host, void* workspace, size_t workspace_bytes, void* stream);
-int stag_plan_xcd_device_fill(const stag_unit* units, int32_t n_units, const int32_t* strides, int32_t* xcd,
+int stag_plan_xcd_device_fill(const stag_unit* units, int32_t n_units, const int32_t* strides, int32_t fine, int32_t* xcd,
                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same plan built ON THE DEVICE from a device indptr (rocPRIM sort + scan + one fill kernel), array for array

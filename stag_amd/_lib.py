@@ -19,7 +19,7 @@ NOISE_NONE, NOISE_EXPLICIT, NOISE_NORMAL, NOISE_UNIFORM, NOISE_BERNOULLI = range
 PARAM_SCALAR, PARAM_PER_CHANNEL, PARAM_PER_EDGE1, PARAM_PER_EDGE = range(4)
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 HEAVY_LEN = 16   # STAG_HEAVY_LEN (include/stag_hip.h)
-XCD_HEADER, XCD_STRIPES = 32, 8   # STAG_XCD_HEADER, STAG_XCD_STRIPES
+XCD_HEADER, XCD_STRIPES, XCD_FINE_MAX = 32, 8, 16   # STAG_XCD_HEADER, STAG_XCD_STRIPES, STAG_XCD_FINE_MAX
 # STAG_BLOCK_EDGES / STAG_BLOCK_UNITS of include/stag_hip.h (the environment override pairs with a build variant of the
 # library compiled with the same -D values: A/B tooling only)
 BLOCK_EDGES, BLOCK_UNITS = int(os.environ.get("STAG_BLOCK_EDGES", "256")), int(os.environ.get("STAG_BLOCK_UNITS", "32"))
@@ -100,13 +100,15 @@ def bind(path):
     l.stag_plan_blocks.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, ip]
     l.stag_plan_workspace_bytes.restype = C.c_size_t
     l.stag_plan_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
-    l.stag_plan_xcd.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp]
+    l.stag_plan_xcd.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _vp, _vp]
     l.stag_plan_xcd_ints.restype = C.c_size_t
     l.stag_plan_xcd_ints.argtypes = [C.c_int32, C.c_int32]
+    l.stag_plan_xcd_fine.restype = C.c_int32
+    l.stag_plan_xcd_fine.argtypes = [C.c_int32]
     l.stag_plan_xcd_device_workspace_bytes.restype = C.c_size_t
     l.stag_plan_xcd_device_workspace_bytes.argtypes = [C.c_int32]
-    l.stag_plan_xcd_device_count.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp, C.c_size_t, _vp]
-    l.stag_plan_xcd_device_fill.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp]
+    l.stag_plan_xcd_device_count.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _vp, _vp, C.c_size_t, _vp]
+    l.stag_plan_xcd_device_fill.argtypes = [_vp, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_size_t, _vp]
     l.stag_plan_device_workspace_bytes.restype = C.c_size_t
     l.stag_plan_device_workspace_bytes.argtypes = [C.c_int32]
     l.stag_plan_device.argtypes = [_vp, C.c_int32, C.c_int64, C.c_int32, _vp, C.c_int64, _vp, _vp, C.c_int64,

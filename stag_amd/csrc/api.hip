@@ -563,38 +563,50 @@ size_t stag_plan_xcd_ints(int32_t stride_heavy, int32_t stride_light) {
   return (size_t)STAG_XCD_HEADER + 4u * (size_t)STAG_XCD_STRIPES * ((size_t)stride_heavy + (size_t)stride_light);
 }
 
-int stag_plan_xcd(const stag_unit* units_host, int32_t n_units, int32_t n_heavy, int64_t n_edges,
+int32_t stag_plan_xcd_fine(int32_t n_dst) {
+  // fine stripes per XCD stripe: row ranges of about STAG_XCD_FINE_ROWS rows, walked one after the other
+  if (n_dst <= 0) return 1;
+  const int64_t m = ((int64_t)n_dst + (int64_t)STAG_XCD_STRIPES * STAG_XCD_FINE_ROWS - 1) / ((int64_t)STAG_XCD_STRIPES * STAG_XCD_FINE_ROWS);
+  return (int32_t)(m < 1 ? 1 : m > STAG_XCD_FINE_MAX ? STAG_XCD_FINE_MAX : m);
+}
+
+int stag_plan_xcd(const stag_unit* units_host, int32_t n_units, int32_t n_heavy, int64_t n_edges, int32_t fine,
                   int32_t* xcd_host, int32_t* strides_out) {
-  if (n_units < 0 || n_heavy < 0 || n_heavy > n_units || n_edges < 0 || !strides_out || (n_units > 0 && !units_host))
-    return STAG_EINVAL;
+  if (n_units < 0 || n_heavy < 0 || n_heavy > n_units || n_edges < 0 || !strides_out || (n_units > 0 && !units_host) ||
+      fine < 1 || fine > STAG_XCD_FINE_MAX) return STAG_EINVAL;
   // stripe of a unit: where its first edge lies in the CSR, in eighths — contiguous destination-row ranges with an
-  // eighth of the edges each.  A stable partition of the heavy prefix and of the rest: inside a stripe the plan's
-  // order (segments, then longest first) stands.
+  // eighth of the edges each — and inside the eighth in `fine` finer ranges, which the XCD walks one after the other
+  // (the rows one of them gathers should fit its L2).  A stable partition of the heavy prefix and of the rest by
+  // fine stripe: inside one the plan's order (segments, then longest first) stands.
   const int64_t E = n_edges > 0 ? n_edges : 1;
+  const int S = STAG_XCD_STRIPES * fine;
   auto key = [&](int32_t i) {
-    const int64_t k = (int64_t)units_host[i].start * STAG_XCD_STRIPES / E;
-    return (int)(i >= n_heavy ? STAG_XCD_STRIPES : 0) + (int)(k < 0 ? 0 : k >= STAG_XCD_STRIPES ? STAG_XCD_STRIPES - 1 : k);
+    const int64_t k = (int64_t)units_host[i].start * S / E;
+    return (int)(i >= n_heavy ? S : 0) + (int)(k < 0 ? 0 : k >= S ? S - 1 : k);
   };
-  int32_t count[2 * STAG_XCD_STRIPES] = {0};
+  std::vector<int32_t> count((size_t)2 * S, 0);
   for (int32_t i = 0; i < n_units; ++i) count[key(i)] += 1;
+  int32_t per[2 * STAG_XCD_STRIPES] = {0};           // units per XCD stripe: heavy [0, 8), the others [8, 16)
+  for (int k = 0; k < 2 * S; ++k) per[k / fine] += count[k];
   int32_t sh = 0, sl = 0;
   for (int k = 0; k < STAG_XCD_STRIPES; ++k) {
-    sh = std::max(sh, count[k]);
-    sl = std::max(sl, count[STAG_XCD_STRIPES + k]);
+    sh = std::max(sh, per[k]);
+    sl = std::max(sl, per[STAG_XCD_STRIPES + k]);
   }
   strides_out[0] = sh; strides_out[1] = sl;
   if (!xcd_host) return STAG_OK;
   for (int k = 0; k < STAG_XCD_HEADER; ++k) xcd_host[k] = 0;
-  for (int k = 0; k < 2 * STAG_XCD_STRIPES; ++k) xcd_host[k] = count[k];
+  for (int k = 0; k < 2 * STAG_XCD_STRIPES; ++k) xcd_host[k] = per[k];
   xcd_host[2 * STAG_XCD_STRIPES] = sh;
   xcd_host[2 * STAG_XCD_STRIPES + 1] = sl;
+  xcd_host[2 * STAG_XCD_STRIPES + 2] = fine;
   stag_unit* rec = reinterpret_cast<stag_unit*>(xcd_host + STAG_XCD_HEADER);
   const int64_t n_rec = (int64_t)STAG_XCD_STRIPES * ((int64_t)sh + sl);
   for (int64_t i = 0; i < n_rec; ++i) rec[i] = stag_unit{-1, 0, 0, -1};
-  int64_t cursor[2 * STAG_XCD_STRIPES];
-  for (int k = 0; k < STAG_XCD_STRIPES; ++k) {
-    cursor[k] = (int64_t)k * sh;
-    cursor[STAG_XCD_STRIPES + k] = (int64_t)STAG_XCD_STRIPES * sh + (int64_t)k * sl;
+  std::vector<int64_t> cursor((size_t)2 * S);
+  for (int x = 0; x < 2 * STAG_XCD_STRIPES; ++x) {   // fine stripes of one XCD stripe lie one after the other
+    int64_t at = x < STAG_XCD_STRIPES ? (int64_t)x * sh : (int64_t)STAG_XCD_STRIPES * sh + (int64_t)(x - STAG_XCD_STRIPES) * sl;
+    for (int f = 0; f < fine; ++f) { cursor[(size_t)x * fine + f] = at; at += count[(size_t)x * fine + f]; }
   }
   for (int32_t i = 0; i < n_units; ++i) rec[cursor[key(i)]++] = units_host[i];
   return STAG_OK;

@@ -213,24 +213,27 @@ extern "C" int stag_plan_device(const int32_t* indptr, int32_t n_dst, int64_t n_
 }
 
 // ---- the XCD-aware order of a plan's units on the device (stag_plan_xcd_device_count / _fill) ---------------
-// stag_plan_xcd's stable partition as a 4-bit stable radix sort of (stripe key, unit index); the 16 stripe starts by
-// lower-bound search; then every record goes to (its stripe's base) + (its rank inside the stripe).
+// stag_plan_xcd's stable partition as a stable radix sort of (fine stripe key, unit index); the stripe starts by
+// lower-bound search; then every record goes to (its XCD stripe's base) + (its rank inside that stripe) — the fine
+// stripes of one XCD stripe are neighbours in the sorted order.
 namespace {
 
-__global__ void xcd_keys_kernel(const stag_unit* units, int32_t n_units, int32_t n_heavy, int64_t E, uint32_t* keys,
-                                int32_t* idx) {
+constexpr int kXcdMaxKeys = 2 * STAG_XCD_STRIPES * STAG_XCD_FINE_MAX;      // 256
+
+__global__ void xcd_keys_kernel(const stag_unit* units, int32_t n_units, int32_t n_heavy, int64_t E, int32_t S,
+                                uint32_t* keys, int32_t* idx) {
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_units) return;
-  int64_t k = (int64_t)units[i].start * STAG_XCD_STRIPES / E;
-  k = k < 0 ? 0 : k >= STAG_XCD_STRIPES ? STAG_XCD_STRIPES - 1 : k;
-  keys[i] = (uint32_t)((i >= n_heavy ? STAG_XCD_STRIPES : 0) + (int)k);
+  int64_t k = (int64_t)units[i].start * S / E;
+  k = k < 0 ? 0 : k >= S ? S - 1 : k;
+  keys[i] = (uint32_t)((i >= n_heavy ? S : 0) + (int)k);
   idx[i] = i;
 }
 
-// starts[k] = first sorted position with key >= k, k in [0, 16]
-__global__ void xcd_starts_kernel(const uint32_t* keys_s, int32_t n_units, int32_t* starts) {
-  const int t = threadIdx.x;
-  if (t > 2 * STAG_XCD_STRIPES) return;
+// starts[k] = first sorted position with key >= k, k in [0, 2 S]
+__global__ void xcd_starts_kernel(const uint32_t* keys_s, int32_t n_units, int32_t S, int32_t* starts) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > 2 * S) return;
   int32_t lo = 0, hi = n_units;
   while (lo < hi) {
     const int32_t mid = lo + (hi - lo) / 2;
@@ -239,26 +242,27 @@ __global__ void xcd_starts_kernel(const uint32_t* keys_s, int32_t n_units, int32
   starts[t] = lo;
 }
 
-__global__ void xcd_clear_kernel(int32_t* xcd, int64_t n_rec, const int32_t* starts, int32_t sh, int32_t sl) {
+__global__ void xcd_clear_kernel(int32_t* xcd, int64_t n_rec, const int32_t* starts, int32_t fine, int32_t sh, int32_t sl) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < STAG_XCD_HEADER) {
     int32_t v = 0;
-    if (i < 2 * STAG_XCD_STRIPES) v = starts[i + 1] - starts[i];
+    if (i < 2 * STAG_XCD_STRIPES) v = starts[(i + 1) * fine] - starts[i * fine];
     else if (i == 2 * STAG_XCD_STRIPES) v = sh;
     else if (i == 2 * STAG_XCD_STRIPES + 1) v = sl;
+    else if (i == 2 * STAG_XCD_STRIPES + 2) v = fine;
     xcd[i] = v;
   }
   if (i < n_rec) reinterpret_cast<int4*>(xcd + STAG_XCD_HEADER)[i] = make_int4(-1, 0, 0, -1);
 }
 
 __global__ void xcd_fill_kernel(const stag_unit* units, const uint32_t* keys_s, const int32_t* idx_s, int32_t n_units,
-                                const int32_t* starts, int32_t sh, int32_t sl, int32_t* xcd) {
+                                const int32_t* starts, int32_t fine, int32_t sh, int32_t sl, int32_t* xcd) {
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_units) return;
-  const int k = (int)keys_s[i];
-  const int64_t base = k < STAG_XCD_STRIPES ? (int64_t)k * sh
-                                            : (int64_t)STAG_XCD_STRIPES * sh + (int64_t)(k - STAG_XCD_STRIPES) * sl;
-  reinterpret_cast<int4*>(xcd + STAG_XCD_HEADER)[base + (i - starts[k])] = reinterpret_cast<const int4*>(units)[idx_s[i]];
+  const int x = (int)keys_s[i] / fine;               // XCD stripe: heavy [0, 8), the others [8, 16)
+  const int64_t base = x < STAG_XCD_STRIPES ? (int64_t)x * sh
+                                            : (int64_t)STAG_XCD_STRIPES * sh + (int64_t)(x - STAG_XCD_STRIPES) * sl;
+  reinterpret_cast<int4*>(xcd + STAG_XCD_HEADER)[base + (i - starts[x * fine])] = reinterpret_cast<const int4*>(units)[idx_s[i]];
 }
 
 struct XcdWs {
@@ -267,17 +271,18 @@ struct XcdWs {
   void* tmp;
   size_t tmp_bytes;
 };
+constexpr size_t kXcdStartsBytes = 2048;     // >= (kXcdMaxKeys + 1) ints
 XcdWs xcd_ws(void* workspace, size_t workspace_bytes, int32_t n_units) {
   char* w = static_cast<char*>(workspace);
   const size_t slot = align_up((size_t)(n_units > 0 ? n_units : 1) * 4);
   XcdWs x;
-  x.keys_s = reinterpret_cast<uint32_t*>(w);                 // the two _fill reads come first
+  x.keys_s = reinterpret_cast<uint32_t*>(w);                 // what _fill reads comes first
   x.idx_s = reinterpret_cast<int32_t*>(w + slot);
   x.starts = reinterpret_cast<int32_t*>(w + 2 * slot);
-  x.keys = reinterpret_cast<uint32_t*>(w + 2 * slot + 256);
-  x.idx = reinterpret_cast<int32_t*>(w + 3 * slot + 256);
-  x.tmp = w + 4 * slot + 256;
-  x.tmp_bytes = workspace_bytes - (4 * slot + 256);
+  x.keys = reinterpret_cast<uint32_t*>(w + 2 * slot + kXcdStartsBytes);
+  x.idx = reinterpret_cast<int32_t*>(w + 3 * slot + kXcdStartsBytes);
+  x.tmp = w + 4 * slot + kXcdStartsBytes;
+  x.tmp_bytes = workspace_bytes - (4 * slot + kXcdStartsBytes);
   return x;
 }
 
@@ -288,50 +293,53 @@ extern "C" size_t stag_plan_xcd_device_workspace_bytes(int32_t n_units) {
   size_t sort_tmp = 0;
   uint32_t* ku = nullptr;
   int32_t* null = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, ku, ku, null, null, (size_t)n_units, 0u, 5u);
-  return align_up((size_t)n_units * 4) * 4 + 256 + align_up(sort_tmp);
+  (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, ku, ku, null, null, (size_t)n_units, 0u, 9u);
+  return align_up((size_t)n_units * 4) * 4 + kXcdStartsBytes + align_up(sort_tmp);
 }
 
 extern "C" int stag_plan_xcd_device_count(const stag_unit* units, int32_t n_units, int32_t n_heavy, int64_t n_edges,
-                                          int32_t* strides_out_host, void* workspace, size_t workspace_bytes,
-                                          void* stream) {
-  if (n_units < 0 || n_heavy < 0 || n_heavy > n_units || n_edges < 0 || !strides_out_host ||
-      (n_units > 0 && !units) || ((uintptr_t)units & 15)) return STAG_EINVAL;
+                                          int32_t fine, int32_t* strides_out_host, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  if (n_units < 0 || n_heavy < 0 || n_heavy > n_units || n_edges < 0 || !strides_out_host || fine < 1 ||
+      fine > STAG_XCD_FINE_MAX || (n_units > 0 && !units) || ((uintptr_t)units & 15)) return STAG_EINVAL;
   if (!workspace || workspace_bytes < stag_plan_xcd_device_workspace_bytes(n_units)) return STAG_ENOMEM;
   strides_out_host[0] = strides_out_host[1] = 0;
   if (n_units == 0) return STAG_OK;
   hipStream_t s = (hipStream_t)stream;
   const XcdWs x = xcd_ws(workspace, workspace_bytes, n_units);
+  const int S = STAG_XCD_STRIPES * fine;
+  unsigned bits = 1;
+  while ((1u << bits) < (unsigned)(2 * S)) ++bits;
   const dim3 grid((unsigned)((n_units + 255) / 256)), block(256);
-  hipLaunchKernelGGL(xcd_keys_kernel, grid, block, 0, s, units, n_units, n_heavy, n_edges > 0 ? n_edges : (int64_t)1,
+  hipLaunchKernelGGL(xcd_keys_kernel, grid, block, 0, s, units, n_units, n_heavy, n_edges > 0 ? n_edges : (int64_t)1, S,
                      x.keys, x.idx);
   size_t tmp_bytes = x.tmp_bytes;
-  if (rocprim::radix_sort_pairs(x.tmp, tmp_bytes, x.keys, x.keys_s, x.idx, x.idx_s, (size_t)n_units, 0u, 5u, s) != hipSuccess)
+  if (rocprim::radix_sort_pairs(x.tmp, tmp_bytes, x.keys, x.keys_s, x.idx, x.idx_s, (size_t)n_units, 0u, bits, s) != hipSuccess)
     return STAG_EIO;
-  hipLaunchKernelGGL(xcd_starts_kernel, dim3(1), dim3(64), 0, s, x.keys_s, n_units, x.starts);
-  int32_t h[2 * STAG_XCD_STRIPES + 1];
-  if (hipMemcpyAsync(h, x.starts, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess) return STAG_EIO;
+  hipLaunchKernelGGL(xcd_starts_kernel, dim3((2 * S + 1 + 63) / 64), dim3(64), 0, s, x.keys_s, n_units, S, x.starts);
+  int32_t h[kXcdMaxKeys + 1];
+  if (hipMemcpyAsync(h, x.starts, sizeof(int32_t) * (2 * S + 1), hipMemcpyDeviceToHost, s) != hipSuccess) return STAG_EIO;
   if (hipStreamSynchronize(s) != hipSuccess) return STAG_EIO;
   for (int k = 0; k < STAG_XCD_STRIPES; ++k) {
-    strides_out_host[0] = std::max(strides_out_host[0], h[k + 1] - h[k]);
-    strides_out_host[1] = std::max(strides_out_host[1], h[STAG_XCD_STRIPES + k + 1] - h[STAG_XCD_STRIPES + k]);
+    strides_out_host[0] = std::max(strides_out_host[0], h[(k + 1) * fine] - h[k * fine]);
+    strides_out_host[1] = std::max(strides_out_host[1], h[S + (k + 1) * fine] - h[S + k * fine]);
   }
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }
 
-extern "C" int stag_plan_xcd_device_fill(const stag_unit* units, int32_t n_units, const int32_t* strides, int32_t* xcd,
-                                         void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int stag_plan_xcd_device_fill(const stag_unit* units, int32_t n_units, const int32_t* strides, int32_t fine,
+                                         int32_t* xcd, void* workspace, size_t workspace_bytes, void* stream) {
   if (n_units <= 0 || !units || !strides || !xcd || ((uintptr_t)xcd & 15) || ((uintptr_t)units & 15) ||
-      strides[0] < 0 || strides[1] < 0) return STAG_EINVAL;
+      strides[0] < 0 || strides[1] < 0 || fine < 1 || fine > STAG_XCD_FINE_MAX) return STAG_EINVAL;
   if (!workspace || workspace_bytes < stag_plan_xcd_device_workspace_bytes(n_units)) return STAG_ENOMEM;
   hipStream_t s = (hipStream_t)stream;
   const XcdWs x = xcd_ws(workspace, workspace_bytes, n_units);
   const int64_t n_rec = (int64_t)STAG_XCD_STRIPES * ((int64_t)strides[0] + strides[1]);
   if (n_rec < n_units || n_rec > 0x7FFFFFFFll) return STAG_EINVAL;
   const int64_t n_clear = n_rec > STAG_XCD_HEADER ? n_rec : STAG_XCD_HEADER;
-  hipLaunchKernelGGL(xcd_clear_kernel, dim3((unsigned)((n_clear + 255) / 256)), dim3(256), 0, s, xcd, n_rec, x.starts,
+  hipLaunchKernelGGL(xcd_clear_kernel, dim3((unsigned)((n_clear + 255) / 256)), dim3(256), 0, s, xcd, n_rec, x.starts, fine,
                      strides[0], strides[1]);
   hipLaunchKernelGGL(xcd_fill_kernel, dim3((unsigned)((n_units + 255) / 256)), dim3(256), 0, s, units, x.keys_s, x.idx_s,
-                     n_units, x.starts, strides[0], strides[1], xcd);
+                     n_units, x.starts, fine, strides[0], strides[1], xcd);
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }

@@ -36,6 +36,8 @@ DEVICE_PLANNER = True        # plans of device-resident graphs come from stag_pl
 # costs 1 % — tools/xcd_stripe_probe.py); "1" always, with the plan; "0" never.
 XCD_ORDER = os.environ.get("STAG_XCD_ORDER", "auto")
 XCD_MIN_LOCALITY = 0.25
+XCD_FINE = int(os.environ.get("STAG_XCD_FINE", "0"))   # finer row ranges inside an XCD's stripe; 0: CsrView.xcd_fine_for(width)
+XCD_RANGE_BYTES = 2_500_000
 XCD_AFTER_LAUNCHES = 16
 PLAN_AFTER_LAUNCHES = 16     # launches a short-row view runs without a plan before one is built for it
 
@@ -86,31 +88,61 @@ class CsrView:
                 self._locality = float(same.float().mean())
         return self._locality
 
-    def _add_xcd_order(self, plan):
+    def xcd_fine_for(self, width):
+        """Finer row ranges inside an XCD's stripe for launches that gather rows of `width` floats: the rows one range
+        gathers should fit the XCD's 4 MB L2 beside the streams that pass through it — 2.5 MB measured best on the PPI
+        batch (D = 50 | 128 | 256: 1 | 2 | 3 ranges; tools/xcd_stripe_probe.py).  STAG_XCD_FINE overrides."""
+        if XCD_FINE > 0:
+            return XCD_FINE
+        rows = -(-self.n_dst // _lib.XCD_STRIPES)
+        nbytes = rows * 4 * min(max(int(width), 1), 256)
+        return int(min(_lib.XCD_FINE_MAX, max(1, -(-nbytes // XCD_RANGE_BYTES))))
+
+    def _build_xcd_order(self, plan, fine):
         """stag_plan.xcd_order for `plan` (stag_plan_xcd on host records, stag_plan_xcd_device_* on device records: the same
-        ints): the units grouped by the eighth of the CSR their rows lie in, for workgroup b to take stripe b mod 8."""
-        plan["xcd_decided"] = True
+        ints): the units grouped by the eighth of the CSR their rows lie in — inside it by `fine` finer ranges — for
+        workgroup b to take stripe b mod 8."""
         nu, nh = plan["n_units"], plan["n_heavy"]
-        if nu <= 0:
-            return
         lib, units, dev = _lib.lib(), plan["units"], plan["units"].device
         st = (C.c_int32 * 2)()
         if units.is_cuda:
             nbytes = lib.stag_plan_xcd_device_workspace_bytes(nu)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             with _lib.on_device(dev):
-                _lib.check(lib.stag_plan_xcd_device_count(_lib.ptr(units), nu, nh, self.n_edges, st, _lib.ptr(ws), nbytes,
+                _lib.check(lib.stag_plan_xcd_device_count(_lib.ptr(units), nu, nh, self.n_edges, fine, st, _lib.ptr(ws), nbytes,
                                                           _lib.stream_of(dev)), "stag_plan_xcd_device_count")
                 order = torch.empty(lib.stag_plan_xcd_ints(st[0], st[1]), dtype=torch.int32, device=dev)
-                _lib.check(lib.stag_plan_xcd_device_fill(_lib.ptr(units), nu, st, _lib.ptr(order), _lib.ptr(ws), nbytes,
+                _lib.check(lib.stag_plan_xcd_device_fill(_lib.ptr(units), nu, st, fine, _lib.ptr(order), _lib.ptr(ws), nbytes,
                                                          _lib.stream_of(dev)), "stag_plan_xcd_device_fill")
         else:
             units_h = np.ascontiguousarray(units[:nu].numpy(), dtype=np.int32)
-            _lib.check(lib.stag_plan_xcd(units_h.ctypes.data, nu, nh, self.n_edges, None, st), "stag_plan_xcd")
+            _lib.check(lib.stag_plan_xcd(units_h.ctypes.data, nu, nh, self.n_edges, fine, None, st), "stag_plan_xcd")
             order_h = np.zeros(lib.stag_plan_xcd_ints(st[0], st[1]), np.int32)
-            _lib.check(lib.stag_plan_xcd(units_h.ctypes.data, nu, nh, self.n_edges, order_h.ctypes.data, st), "stag_plan_xcd")
+            _lib.check(lib.stag_plan_xcd(units_h.ctypes.data, nu, nh, self.n_edges, fine, order_h.ctypes.data, st),
+                       "stag_plan_xcd")
             order = torch.from_numpy(order_h)
-        plan.update(xcd=order, xcd_strides=(int(st[0]), int(st[1])))
+        return order, (int(st[0]), int(st[1]))
+
+    def xcd_order(self, plan, width):
+        """(order, strides, fine) of `plan` for launches of this row width, or (None, (0, 0), 0): the plan has none (see
+        XCD_ORDER), or the one for this width is not built yet and a hipGraph is being captured (it reads counts back)."""
+        if not plan.get("xcd_on"):
+            return None, (0, 0), 0
+        fine = self.xcd_fine_for(width)
+        got = plan["xcd_orders"].get(fine)
+        if got is None:
+            if plan["units"].is_cuda and torch.cuda.is_current_stream_capturing():
+                return None, (0, 0), 0
+            got = plan["xcd_orders"][fine] = self._build_xcd_order(plan, fine)
+        return got[0], got[1], fine
+
+    def _add_xcd_order(self, plan):
+        """Switch the XCD-aware order on for `plan`; plan["xcd"] / ["xcd_strides"] show the one for 128-wide rows."""
+        plan["xcd_decided"] = True
+        if plan["n_units"] <= 0:
+            return
+        plan["xcd_on"], plan["xcd_orders"] = True, {}
+        plan["xcd"], plan["xcd_strides"], _ = self.xcd_order(plan, 128)
         plan.pop("_structs", None)
         plan.pop("_ints", None)
 

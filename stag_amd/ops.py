@@ -72,9 +72,10 @@ def _spec_in_norm(spec):
     return bool(spec[0][3]) if isinstance(spec, tuple) else bool(spec.in_norm)
 
 
-def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None):
+def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None, width=None):
     """ctypes stag_plan for csrv (None when planning is off), plus the tensors it points into.
-    plan_t: a sub-plan of csrv (CsrView.subplan) instead of its whole plan."""
+    plan_t: a sub-plan of csrv (CsrView.subplan) instead of its whole plan.  width: the row width of an aggregation
+    launch — it may walk the plan's XCD-aware order (stag_plan.xcd_order; the other entry points do not use one)."""
     if plan_t is None:
         plan_t = csrv.plan(seg_len)
     if plan_t is None:
@@ -88,16 +89,17 @@ def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None):
     if counters is None:
         counters = torch.zeros(max(plan_t["n_long"], 1) * tiles, dtype=torch.int32, device=dev)
         plan_t["counters"][key] = counters
-    # the struct is kept per (tiles, stream): only the workspace changes from call to call (host time of a
+    order, strides, fine = csrv.xcd_order(plan_t, width) if width and plan_t.get("xcd_on") else (None, (0, 0), 0)
+    # the struct is kept per (tiles, stream, order): only the workspace changes from call to call (host time of a
     # call matters on launch-bound graphs).  Safe to reuse: the library reads it during the call only.
-    plan_c = plan_t.setdefault("_structs", {}).get(key)
+    plan_c = plan_t.setdefault("_structs", {}).get(key + (fine,))
     if plan_c is None:
         plan_c = _lib.Plan(plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"],
                            _lib.ptr(plan_t["units"]), _lib.ptr(plan_t["long_rows"]),
                            _lib.ptr(plan_t["long_seg_ptr"]), _lib.ptr(counters), None, 0,
                            plan_t["n_heavy"], plan_t["n_blocks"], _lib.ptr(plan_t["block_ptr"]),
-                           _lib.ptr(plan_t.get("xcd")), *plan_t.get("xcd_strides", (0, 0)))
-        plan_t["_structs"][key] = plan_c
+                           _lib.ptr(order), *strides)
+        plan_t["_structs"][key + (fine,)] = plan_c
     plan_c.workspace, plan_c.workspace_bytes = _lib.ptr(ws), nbytes
     return plan_c, (ws, counters)
 
@@ -105,7 +107,7 @@ def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None):
 _NONE_ARGS = ([_lib.NOISE_NONE, 0, 0, 0, 0, 0, 0, 0], [0, 0, 0], [0.0, 0.0], None, None, None)
 
 
-def _plan_args(csrv, plan_t, tiles, dev):
+def _plan_args(csrv, plan_t, tiles, dev, width=None):
     """(units, long_rows, long_seg_ptr, block_ptr, xcd, counters, plan_ints) of torch.ops.stag.*"""
     if plan_t is None:
         return (None, None, None, None, None, None, [0, 0, 0, 0, 0, 0, 0, 0])
@@ -114,12 +116,10 @@ def _plan_args(csrv, plan_t, tiles, dev):
     if counters is None:
         counters = torch.zeros(max(plan_t["n_long"], 1) * tiles, dtype=torch.int32, device=dev)
         plan_t["counters"][key] = counters
-    ints = plan_t.get("_ints")
-    if ints is None:
-        ints = plan_t["_ints"] = [plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"],
-                                  plan_t["n_heavy"], plan_t["n_blocks"], *plan_t.get("xcd_strides", (0, 0))]
-    return (plan_t["units"], plan_t["long_rows"], plan_t["long_seg_ptr"], plan_t["block_ptr"], plan_t.get("xcd"), counters,
-            ints)
+    order, strides, _ = csrv.xcd_order(plan_t, width) if width and plan_t.get("xcd_on") else (None, (0, 0), 0)
+    ints = [plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"], plan_t["n_heavy"], plan_t["n_blocks"],
+            *strides]
+    return (plan_t["units"], plan_t["long_rows"], plan_t["long_seg_ptr"], plan_t["block_ptr"], order, counters, ints)
 
 
 def _agg_fwd_torch(csrv, x, noise_args, reduce, src_scale, dst_scale, seg_len, want_norm_scale, broadcast_x):
@@ -127,7 +127,7 @@ def _agg_fwd_torch(csrv, x, noise_args, reduce, src_scale, dst_scale, seg_len, w
     dev = _lib.require_device(x, csrv.indptr, src_scale, dst_scale)
     D = x.numel() if broadcast_x else x.shape[1]
     plan_t = csrv.plan(seg_len)
-    out, ns = torch.ops.stag.agg_fwd(*csrv.torch_args(), *_plan_args(csrv, plan_t, (D + 255) // 256, dev), x,
+    out, ns = torch.ops.stag.agg_fwd(*csrv.torch_args(), *_plan_args(csrv, plan_t, (D + 255) // 256, dev, width=D), x,
                                      broadcast_x, *noise_args, reduce, src_scale, dst_scale, want_norm_scale)
     return out, (ns if want_norm_scale else None)
 
@@ -150,7 +150,7 @@ def _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len, want_norm_
         plan_t = csrv.plan(seg_len)
     nbytes = (_lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], D, int(spec.in_norm))
               if plan_t is not None else 0)
-    plan_c, _keep = _plan_struct(csrv, seg_len, (D + 255) // 256, nbytes, dev, plan_t)
+    plan_c, _keep = _plan_struct(csrv, seg_len, (D + 255) // 256, nbytes, dev, plan_t, width=D)
     # (spec is the ctypes form from here on)
     cs = csrv.struct()
     with _lib.on_device(dev):
@@ -179,7 +179,7 @@ def _agg_bwd_raw(csrv_t, g, D, spec, g_scale, row_scale, seg_len, want_dp):
     if isinstance(spec, tuple):
         dev = _lib.require_device(g, csrv_t.indptr, g_scale, row_scale)
         plan_t = csrv_t.plan(seg_len)
-        dx, t0, t1 = torch.ops.stag.agg_bwd(*csrv_t.torch_args(), *_plan_args(csrv_t, plan_t, (D + 255) // 256, dev),
+        dx, t0, t1 = torch.ops.stag.agg_bwd(*csrv_t.torch_args(), *_plan_args(csrv_t, plan_t, (D + 255) // 256, dev, width=D),
                                             g, *spec, g_scale, row_scale, want_dp)
         return dx, (t0 if want_dp else None), (t1 if want_dp else None)
     dev = _lib.require_device(g, csrv_t.indptr, g_scale, row_scale)
@@ -189,7 +189,7 @@ def _agg_bwd_raw(csrv_t, g, D, spec, g_scale, row_scale, seg_len, want_dp):
     plan_t = csrv_t.plan(seg_len)
     nbytes = (_lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], (3 if want_dp else 1) * D, 0)
               if plan_t is not None else 0)
-    plan_c, _keep = _plan_struct(csrv_t, seg_len, (D + 255) // 256, nbytes, dev, plan_t=plan_t)
+    plan_c, _keep = _plan_struct(csrv_t, seg_len, (D + 255) // 256, nbytes, dev, plan_t=plan_t, width=D)
     cs = csrv_t.struct()
     with _lib.on_device(dev):
         rc = _lib.lib().stag_agg_bwd(
@@ -232,7 +232,7 @@ def _agg_bwd_dp_raw(csrv_t, g, x, D, spec, g_scale, row_scale, seg_len, want_dx=
     dp1 = torch.empty(D, dtype=torch.float32, device=dev)
     plan_t = csrv_t.plan(seg_len)
     nbytes = _lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], D, 0) if plan_t is not None else 0
-    plan_c, _keep = _plan_struct(csrv_t, seg_len, (D + 255) // 256, nbytes, dev, plan_t=plan_t)
+    plan_c, _keep = _plan_struct(csrv_t, seg_len, (D + 255) // 256, nbytes, dev, plan_t=plan_t, width=D)
     n_units = plan_t["n_units"] if plan_t is not None else csrv_t.n_dst
     wbytes = _lib.lib().stag_agg_bwd_dp_workspace_bytes(n_units, D)
     ws = torch.empty(max(wbytes // 4, 1), dtype=torch.float32, device=dev)
@@ -946,7 +946,7 @@ def _agg_fwd_mc_raw(csrv, x, noise, n_samples, offset_stride, reduce, src_scale,
     out = torch.empty((n_samples, csrv.n_dst, D), dtype=torch.float32, device=dev)
     plan_t = csrv.plan(seg_len)
     nbytes = _lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], 4 * D, 0) if plan_t is not None else 0
-    plan_c, _keep = _plan_struct(csrv, seg_len, (D + 255) // 256, nbytes, dev, plan_t=plan_t)
+    plan_c, _keep = _plan_struct(csrv, seg_len, (D + 255) // 256, nbytes, dev, plan_t=plan_t, width=D)
     cs, spec = csrv.struct(), noise.spec()
     with _lib.on_device(dev):
         rc = _lib.lib().stag_agg_fwd_mc(

@@ -997,7 +997,7 @@ def test_device_planner_equals_host_planner(dev, seg_len, monkeypatch):
 
 def _without_xcd_order(view, seg_len):
     p = view.plan(seg_len, need=True)
-    p["xcd"], p["xcd_strides"] = None, (0, 0)
+    p["xcd"], p["xcd_strides"], p["xcd_on"], p["xcd_decided"] = None, (0, 0), False, True
     p.pop("_structs", None)
     p.pop("_ints", None)
 
@@ -1021,7 +1021,7 @@ def test_xcd_aware_unit_order_changes_no_bit(dev, oracle, D, monkeypatch):
         ga, gb = mk(), mk()
         for view in (gb.csr, gb.csr_t):
             _without_xcd_order(view, 64)
-        assert ga.csr.plan(64, need=True)["xcd"] is not None and gb.csr.plan(64)["xcd"] is None
+        assert ga.csr.plan(64, need=True)["xcd_on"] and not gb.csr.plan(64)["xcd_on"]
         og = oracle_graph(oracle, ga)
         n = ga.number_of_nodes()
         xh = rng.standard_normal((n, D)).astype(np.float32)
@@ -1068,6 +1068,7 @@ def test_fuzz_device_planner_equals_host_planner(dev, monkeypatch):
         e = int(rng.choice([0, 1, int(rng.integers(0, 40000))]))
         hub = int(rng.choice([0, 0, 65, 1000, 5000])) if n > 4 else 0
         seg_len = int(rng.choice([8, 16, 64, 64, 100, 256]))
+        monkeypatch.setattr(G, "XCD_FINE", int(rng.choice([0, 1, 3, 16])))      # finer row ranges inside the XCD stripes
         g = random_graph(n, e, seed=11000 + it, hub=hub, device=dev)
         for view_name in ("csr", "csr_t"):
             view = getattr(g, view_name)

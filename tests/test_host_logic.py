@@ -132,11 +132,12 @@ def test_plan_covers_every_edge_once(seg_len):
     assert set(units[units[:, 3] >= 0][:, 3]) == set(range(p["n_seg"]))
 
 
-@pytest.mark.parametrize("seg_len", [3, 64])
-def test_xcd_order_is_a_stable_partition_of_the_plan(seg_len, monkeypatch):
+@pytest.mark.parametrize("seg_len,fine", [(3, 1), (64, 1), (64, 3), (16, 16)])
+def test_xcd_order_is_a_stable_partition_of_the_plan(seg_len, fine, monkeypatch):
     """stag_plan_xcd (stag_plan.xcd_order): the plan's unit records grouped by the eighth of the CSR their first edge lies
-    in — heavy prefix and the rest separately, the plan's own order inside a stripe, every stripe padded with null
-    records to the longest one — with the stripe sizes and the two strides in the header."""
+    in (and inside the eighth by `fine` finer row ranges, walked one after the other) — heavy prefix and the rest
+    separately, the plan's own order inside a fine stripe, every XCD stripe padded with null records to the longest one —
+    with the stripe sizes, the two strides and `fine` in the header."""
     import importlib
     import stag_amd
     from stag_amd import _lib
@@ -156,6 +157,9 @@ def test_xcd_order_is_a_stable_partition_of_the_plan(seg_len, monkeypatch):
     gb = stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), int(sizes.sum()))
     assert gb.csr.stripe_locality() > 0.6 and gb.csr.plan(seg_len)["xcd"] is None and many(gb.csr)["xcd"] is not None
     monkeypatch.setattr(G, "XCD_ORDER", "1")
+    monkeypatch.setattr(G, "XCD_FINE", fine)
+    assert _lib.lib().stag_plan_xcd_fine(56944) == 4 and _lib.lib().stag_plan_xcd_fine(100) == 1 \
+        and _lib.lib().stag_plan_xcd_fine(10 ** 7) == 16
     g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n)
     p = g.csr.plan(seg_len)
     nu, nh, E = p["n_units"], p["n_heavy"], len(dst)
@@ -165,13 +169,14 @@ def test_xcd_order_is_a_stable_partition_of_the_plan(seg_len, monkeypatch):
     assert len(xcd) == _lib.XCD_HEADER + 4 * 8 * (sh + sl)
     ch, cl = xcd[0:8], xcd[8:16]                    # units per heavy stripe, per other stripe
     assert ch.sum() == nh and cl.sum() == nu - nh and (sh, sl) == (ch.max(), cl.max()) == (xcd[16], xcd[17])
-    assert (xcd[18:_lib.XCD_HEADER] == 0).all()
+    assert (xcd[19:_lib.XCD_HEADER] == 0).all() and xcd[18] == fine
     rec = xcd[_lib.XCD_HEADER:].reshape(8 * (sh + sl), 4)
-    stripe = np.minimum(units[:, 1].astype(np.int64) * 8 // E, 7)
+    fstripe = np.minimum(units[:, 1].astype(np.int64) * (8 * fine) // E, 8 * fine - 1)     # fine stripe of every unit
     null = np.array([-1, 0, 0, -1], np.int32)
     for cnt, base, stride, lo, hi in ((ch, 0, sh, 0, nh), (cl, 8 * sh, sl, nh, nu)):
         for k in range(8):
-            want = units[lo:hi][stripe[lo:hi] == k]                  # the plan's order, restricted to the stripe
+            # the XCD stripe's fine stripes one after the other, the plan's order inside each
+            want = np.concatenate([units[lo:hi][fstripe[lo:hi] == k * fine + f] for f in range(fine)])
             got = rec[base + k * stride: base + (k + 1) * stride]
             assert len(want) == cnt[k] and (got[:cnt[k]] == want).all() and (got[cnt[k]:] == null).all()
     # stripes are contiguous destination-row ranges: whole rows of stripe k lie below those of stripe k + 1

@@ -21,7 +21,7 @@ import bench  # noqa: E402
 
 def without_xcd_order(view, seg_len):
     p = view.plan(seg_len, need=True)
-    p["xcd"], p["xcd_strides"] = None, (0, 0)
+    p["xcd"], p["xcd_strides"], p["xcd_on"], p["xcd_decided"] = None, (0, 0), False, True
     p.pop("_structs", None)
     p.pop("_ints", None)
 
