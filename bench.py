@@ -391,6 +391,29 @@ def main():
                                        "E": Ev, "steps": ks, "ms_per_step": w_ / ks * 1e3, "device_ms_per_step": d_ms,
                                        "edges_per_s": Ev / (w_ / ks), "algorithmic_bytes_per_step": balg,
                                        "frac": balg / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # BASELINE configs[2]: the PPI-sized block-diagonal batch (scripts/ppi_mle/run.py:12-14; GraphSAGE mean, hidden
+        # 256) — the workload the XCD-aware walk is for: the same launches with it and in plan order
+        s3, d3, sizes3 = synthetic.ppi_like()
+        n3, E3, D3 = int(sizes3.sum()), len(s3), 256
+        x3 = torch.randn(n3, D3, device=dev)
+        balg3 = 4 * (n3 + 1) + 4 * E3 + 8 * n3 * D3
+        for order in ("xcd", "plan_order"):
+            g3 = stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), n3, device=dev)
+            p3 = g3.csr.plan(args.seg_len)
+            if order == "xcd":
+                g3.csr._add_xcd_order(p3)                 # what "auto" does for this graph after 16 launches
+            else:
+                p3["xcd_decided"] = True                  # never
+            for noise in ("normal", "none"):
+                st = lambda i, noise=noise: ops.aggregate(g3, x3, make_noise(stag_amd, g3, D3, noise, i), reduce="mean",
+                                                          seg_len=args.seg_len)
+                settle(st)                     # a VALU-bound launch reads its clocks: the headline's settle phase again
+                w_, d_ms = timed(st, ks, kw)
+                out[f"ppi_batch/{noise}/{order}"] = {
+                    "graph": "24 PPI-sized graphs batched (block-diagonal), SAGE mean, D=256", "noise": noise, "unit_order": order,
+                    "stripe_locality": g3.csr.stripe_locality(), "E": E3, "steps": ks, "ms_per_step": w_ / ks * 1e3,
+                    "device_ms_per_step": d_ms, "edges_per_s": E3 / (w_ / ks), "algorithmic_bytes_per_step": balg3,
+                    "frac": balg3 / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         return out
 
     variants = variant_loops() if (world == 1 and not rehearse and not args.no_variants) else None
