@@ -204,6 +204,17 @@ size_t stag_plan_workspace_bytes(int32_t n_seg, int32_t D, int32_t in_norm);
 int stag_plan_blocks(const stag_unit* units_host, int32_t n_units, int32_t max_edges,
                      int32_t max_units, int32_t* block_ptr_host, int32_t* n_blocks_out);
 
+/* The XCD-aware form of stag_plan_blocks for the workgroup-cooperative GAT kernels (which walk `units` through
+ * `block_ptr`, one batch per workgroup): the unit records re-ordered (units_out_host[n_units]) and batched so that batch b
+ * belongs to stripe b mod 8 of the destination rows (stag_plan.xcd_order's stripes, `fine` finer row ranges inside each,
+ * batched one after the other); a stripe that has run out of batches gets empty ones (block_ptr[b] == block_ptr[b + 1]:
+ * the kernels return at once).  Hand the two arrays to the GAT entry points as plan.units / plan.block_ptr /
+ * plan.n_blocks (the other fields as they are): every output is the same — the forward bit for bit, the block partials
+ * of stag_gat_bwd_dp added in the new batch order.  units_out_host == block_ptr_host == NULL: count only.
+ * On the PPI-sized batch the forward takes 100 instead of 140 us (H*F = 256), 395 instead of 510 us (4 x 256).      */
+int stag_plan_blocks_xcd(const stag_unit* units_host, int32_t n_units, int64_t n_edges, int32_t fine, int32_t max_edges,
+                         int32_t max_units, stag_unit* units_out_host, int32_t* block_ptr_host, int32_t* n_blocks_out);
+
 /* The XCD-aware order of a plan's units (stag_plan.xcd_order), from host unit records.  Two calls: xcd_host == NULL
  * reports strides_out[2] = xcd_stride_heavy, xcd_stride_light; the second fills xcd_host[stag_plan_xcd_ints(strides)]
  * (upload it 16-byte aligned).  n_edges: the edges of the CSR the plan belongs to.  fine (1 ... STAG_XCD_FINE_MAX;

@@ -1158,7 +1158,7 @@ inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles
     w.lbase = STAG_XCD_STRIPES * w.sh;
     w.n_total = STAG_XCD_STRIPES * (w.sh + w.sl);
     grid.x = STAG_XCD_STRIPES * (w.jh_heavy + w.jh_light + (w.sl + TPB - 1) / TPB);
-  } else if (STAG_XCD_PLANLESS && !a.units && !a.dp_part && a.n_units >= STAG_XCD_STRIPES * TPB) {
+  } else if (STAG_XCD_PLANLESS && !a.units && !a.dp_part && a.n_units >= STAG_XCD_STRIPES * TPB && a.n_units < (1 << 30)) {
     // a graph that runs without a plan (short rows only: a freshly batched minibatch of molecules) is striped by rows
     w = AggArgs::Walk{STAG_XCD_STRIPES - 1, 3, 0, 0, 0, 0, 0, a.n_units};
     w.sl = ((a.n_units + STAG_XCD_STRIPES - 1) / STAG_XCD_STRIPES + TPB - 1) / TPB * TPB;

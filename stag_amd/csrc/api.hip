@@ -636,6 +636,60 @@ int stag_plan_blocks(const stag_unit* units_host, int32_t n_units, int32_t max_e
   return STAG_OK;
 }
 
+int stag_plan_blocks_xcd(const stag_unit* units_host, int32_t n_units, int64_t n_edges, int32_t fine, int32_t max_edges,
+                         int32_t max_units, stag_unit* units_out_host, int32_t* block_ptr_host, int32_t* n_blocks_out) {
+  if (n_units < 0 || n_edges < 0 || fine < 1 || fine > STAG_XCD_FINE_MAX || max_edges <= 0 || max_units <= 0 ||
+      !n_blocks_out || (n_units > 0 && !units_host) || ((units_out_host == nullptr) != (block_ptr_host == nullptr)))
+    return STAG_EINVAL;
+  // units by fine stripe (stable: the plan's order inside one), batched greedily inside each fine stripe, then the
+  // batches of the 8 XCD stripes dealt out in turn: batch b belongs to stripe b mod 8, a stripe that has run out of
+  // batches gets empty ones
+  const int64_t E = n_edges > 0 ? n_edges : 1;
+  const int S = STAG_XCD_STRIPES * fine;
+  std::vector<int32_t> key((size_t)n_units), start((size_t)S + 1, 0), order((size_t)n_units);
+  for (int32_t i = 0; i < n_units; ++i) {
+    if (units_host[i].len < 0) return STAG_EINVAL;
+    const int64_t k = (int64_t)units_host[i].start * S / E;
+    key[i] = (int32_t)(k < 0 ? 0 : k >= S ? S - 1 : k);
+    start[(size_t)key[i] + 1] += 1;
+  }
+  for (int k = 0; k < S; ++k) start[(size_t)k + 1] += start[k];
+  {
+    std::vector<int32_t> cur(start.begin(), start.end() - 1);
+    for (int32_t i = 0; i < n_units; ++i) order[(size_t)cur[key[i]]++] = i;
+  }
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> batches(STAG_XCD_STRIPES);   // (first position in `order`, units)
+  for (int x = 0; x < STAG_XCD_STRIPES; ++x)
+    for (int f = 0; f < fine; ++f) {
+      const int32_t lo = start[(size_t)x * fine + f], hi = start[(size_t)x * fine + f + 1];
+      int32_t first = lo, edges = 0, units = 0;
+      for (int32_t p = lo; p < hi; ++p) {
+        const int32_t len = units_host[order[p]].len;
+        if (units > 0 && (edges + len > max_edges || units == max_units)) {
+          batches[x].emplace_back(first, units);
+          first = p; edges = 0; units = 0;
+        }
+        edges += len; ++units;
+      }
+      if (units > 0) batches[x].emplace_back(first, units);
+    }
+  size_t per = 0;
+  for (auto& b : batches) per = std::max(per, b.size());
+  const int64_t nb = (int64_t)per * STAG_XCD_STRIPES;
+  if (nb > 0x7FFFFFFFll) return STAG_EINVAL;
+  *n_blocks_out = (int32_t)nb;
+  if (!units_out_host) return STAG_OK;
+  int32_t at = 0;
+  block_ptr_host[0] = 0;
+  for (size_t j = 0; j < per; ++j)
+    for (int x = 0; x < STAG_XCD_STRIPES; ++x) {
+      if (j < batches[x].size())
+        for (int32_t p = 0; p < batches[x][j].second; ++p) units_out_host[at++] = units_host[order[(size_t)batches[x][j].first + p]];
+      block_ptr_host[j * STAG_XCD_STRIPES + x + 1] = at;
+    }
+  return STAG_OK;
+}
+
 size_t stag_plan_workspace_bytes(int32_t n_seg, int32_t D, int32_t in_norm) {
   if (n_seg <= 0 || D <= 0) return 0;
   return (size_t)n_seg * (size_t)D * (in_norm ? 2u : 1u) * sizeof(float);

@@ -88,14 +88,36 @@ class CsrView:
                 self._locality = float(same.float().mean())
         return self._locality
 
-    def xcd_fine_for(self, width):
+    def gat_blocks(self, plan, width):
+        """(units, block_ptr, n_blocks, fine) for the cooperative GAT kernels on rows of `width` floats when `plan` has the
+        XCD-aware order switched on (stag_plan_blocks_xcd: batch b belongs to stripe b mod 8), else None — also while a
+        hipGraph is being captured and the arrays for this width do not exist yet (they are built on the host)."""
+        if not plan.get("xcd_on"):
+            return None
+        fine = self.xcd_fine_for(width, cap=None)
+        got = plan.setdefault("gat_orders", {}).get(fine)
+        if got is None:
+            if plan["units"].is_cuda and torch.cuda.is_current_stream_capturing():
+                return None
+            lib, nu, dev = _lib.lib(), plan["n_units"], plan["units"].device
+            units_h = np.ascontiguousarray(plan["units"][:nu].cpu().numpy(), dtype=np.int32)
+            nb = C.c_int32(0)
+            args = (units_h.ctypes.data, nu, self.n_edges, fine, _lib.BLOCK_EDGES, _lib.BLOCK_UNITS)
+            _lib.check(lib.stag_plan_blocks_xcd(*args, None, None, C.byref(nb)), "stag_plan_blocks_xcd")
+            out = np.zeros((max(nu, 1), 4), np.int32)
+            ptr = np.zeros(nb.value + 1, np.int32)
+            _lib.check(lib.stag_plan_blocks_xcd(*args, out.ctypes.data, ptr.ctypes.data, C.byref(nb)), "stag_plan_blocks_xcd")
+            got = plan["gat_orders"][fine] = (torch.from_numpy(out).to(dev), torch.from_numpy(ptr).to(dev), nb.value, fine)
+        return got
+
+    def xcd_fine_for(self, width, cap=256):
         """Finer row ranges inside an XCD's stripe for launches that gather rows of `width` floats: the rows one range
         gathers should fit the XCD's 4 MB L2 beside the streams that pass through it — 2.5 MB measured best on the PPI
         batch (D = 50 | 128 | 256: 1 | 2 | 3 ranges; tools/xcd_stripe_probe.py).  STAG_XCD_FINE overrides."""
         if XCD_FINE > 0:
             return XCD_FINE
         rows = -(-self.n_dst // _lib.XCD_STRIPES)
-        nbytes = rows * 4 * min(max(int(width), 1), 256)
+        nbytes = rows * 4 * (min(max(int(width), 1), cap) if cap else max(int(width), 1))   # (wider rows are tiled at 256)
         return int(min(_lib.XCD_FINE_MAX, max(1, -(-nbytes // XCD_RANGE_BYTES))))
 
     def _build_xcd_order(self, plan, fine):

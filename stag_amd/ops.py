@@ -72,10 +72,11 @@ def _spec_in_norm(spec):
     return bool(spec[0][3]) if isinstance(spec, tuple) else bool(spec.in_norm)
 
 
-def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None, width=None):
+def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None, width=None, gat_width=None):
     """ctypes stag_plan for csrv (None when planning is off), plus the tensors it points into.
     plan_t: a sub-plan of csrv (CsrView.subplan) instead of its whole plan.  width: the row width of an aggregation
-    launch — it may walk the plan's XCD-aware order (stag_plan.xcd_order; the other entry points do not use one)."""
+    launch — it may walk the plan's XCD-aware order (stag_plan.xcd_order).  gat_width: H * F of a cooperative GAT
+    launch — its unit batches may be the XCD-aware ones (stag_plan_blocks_xcd).  The other entry points use neither."""
     if plan_t is None:
         plan_t = csrv.plan(seg_len)
     if plan_t is None:
@@ -90,14 +91,19 @@ def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None, width=None):
         counters = torch.zeros(max(plan_t["n_long"], 1) * tiles, dtype=torch.int32, device=dev)
         plan_t["counters"][key] = counters
     order, strides, fine = csrv.xcd_order(plan_t, width) if width and plan_t.get("xcd_on") else (None, (0, 0), 0)
+    units, block_ptr, n_blocks = plan_t["units"], plan_t["block_ptr"], plan_t["n_blocks"]
+    if gat_width and plan_t.get("xcd_on"):
+        blocks = csrv.gat_blocks(plan_t, gat_width)
+        if blocks is not None:
+            units, block_ptr, n_blocks, fine = blocks[0], blocks[1], blocks[2], -blocks[3]
     # the struct is kept per (tiles, stream, order): only the workspace changes from call to call (host time of a
     # call matters on launch-bound graphs).  Safe to reuse: the library reads it during the call only.
     plan_c = plan_t.setdefault("_structs", {}).get(key + (fine,))
     if plan_c is None:
         plan_c = _lib.Plan(plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"],
-                           _lib.ptr(plan_t["units"]), _lib.ptr(plan_t["long_rows"]),
+                           _lib.ptr(units), _lib.ptr(plan_t["long_rows"]),
                            _lib.ptr(plan_t["long_seg_ptr"]), _lib.ptr(counters), None, 0,
-                           plan_t["n_heavy"], plan_t["n_blocks"], _lib.ptr(plan_t["block_ptr"]),
+                           plan_t["n_heavy"] if units is plan_t["units"] else 0, n_blocks, _lib.ptr(block_ptr),
                            _lib.ptr(order), *strides)
         plan_t["_structs"][key + (fine,)] = plan_c
     plan_c.workspace, plan_c.workspace_bytes = _lib.ptr(ws), nbytes
@@ -1178,7 +1184,7 @@ class _GatAggregate(torch.autograd.Function):
                  if (want_attn or need_grad) else None)
         plan_t = csrv.plan(seg_len, need=True)       # the cooperative kernels want the plan's unit batches
         nbytes = _lib.lib().stag_gat_workspace_bytes(plan_t["n_seg"], H, F) if plan_t is not None else 0
-        plan_c, _keep = _plan_struct(csrv, seg_len, 1, nbytes, dev, plan_t=plan_t)
+        plan_c, _keep = _plan_struct(csrv, seg_len, 1, nbytes, dev, plan_t=plan_t, gat_width=H * F)
         cs = csrv.struct()
         attn = None
         drop = _gat_drop_struct(attn_drop)
@@ -1291,8 +1297,8 @@ def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec,
         return None
     plan_f, plan_b = csrv.plan(seg_len, need=True), csrt.plan(seg_len, need=True)
     nbytes = _lib.lib().stag_gat_bwd_workspace_bytes(plan_f["n_seg"], plan_b["n_seg"], H, F)
-    pf, _k1 = _plan_struct(csrv, seg_len, 1, nbytes, dev, plan_t=plan_f)
-    pb, _k2 = _plan_struct(csrt, seg_len, 1, 0, dev, plan_t=plan_b)
+    pf, _k1 = _plan_struct(csrv, seg_len, 1, nbytes, dev, plan_t=plan_f, gat_width=H * F)
+    pb, _k2 = _plan_struct(csrt, seg_len, 1, 0, dev, plan_t=plan_b, gat_width=H * F)
     d_el = torch.empty((csrt.n_dst, H), dtype=torch.float32, device=dev)
     d_er = torch.empty((csrv.n_dst, H), dtype=torch.float32, device=dev)
     d_ft = torch.empty((csrt.n_dst, H, F), dtype=torch.float32, device=dev)
@@ -1303,7 +1309,7 @@ def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec,
     if want_dp:        # the one-gather backward that also finishes the gradients of scalar / per-head noise parameters
         dp0 = torch.empty(H, dtype=torch.float32, device=dev)
         dp1 = torch.empty(H, dtype=torch.float32, device=dev)
-        wbytes = _lib.lib().stag_gat_bwd_dp_workspace_bytes(plan_b["n_blocks"], H)
+        wbytes = _lib.lib().stag_gat_bwd_dp_workspace_bytes(max(pb.n_blocks, pf.n_blocks), H)   # (the structs': XCD batches count more)
         ws = torch.empty(max(wbytes // 4, 1), dtype=torch.float32, device=dev)
         with _lib.on_device(dev):
             rc = _lib.lib().stag_gat_bwd_dp(C.byref(cs), C.byref(pf), C.byref(ct), C.byref(pb), _lib.ptr(el), _lib.ptr(er),

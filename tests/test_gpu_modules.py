@@ -1684,3 +1684,87 @@ def test_cached_parameter_rows_follow_their_tensors(dev):
     assert abs(mean_out() - 7.0) < 1e-3
     layer.q_a.loc = layer.q_a.loc.clone() * 0 + 9.0                                 # a new buffer tensor
     assert abs(mean_out() - 9.0) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,F", [(4, 64), (8, 32), (2, 16), (4, 256)])
+def test_gat_with_xcd_aware_batches_equals_plan_order(dev, oracle, monkeypatch, H, F):
+    """stag_plan_blocks_xcd only changes WHICH workgroup takes a batch of units (batch b belongs to stripe b mod 8 of the
+    destination rows; empty batches where a stripe has run out): the cooperative GAT forward (noise, in-norm, attention
+    dropout, get_attention), the one-gather and the two-pass backward and the in-kernel parameter gradients give what
+    they give in plan order — forward and input gradients bit for bit — on a block-diagonal batch (the case it is for),
+    on hubs cut into segments and on a graph with fewer units than stripes; forward also against the oracle."""
+    import importlib
+    import stag_amd
+    from stag_amd import _lib, ops, synthetic
+    from util import random_graph
+    G = importlib.import_module("stag_amd.graph")
+    s3, d3, sizes = synthetic.ppi_like(n_graphs=6, n_nodes=3000, n_edges=40000, seed=5)
+    graphs = [("batch", lambda: stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), int(sizes.sum()), device=dev)),
+              ("hubs", lambda: random_graph(1500, 12000, seed=3, hub=2500, device=dev)),
+              ("tiny", lambda: random_graph(5, 12, seed=9, device=dev))]
+    if H * F > 256:
+        graphs = graphs[:1]
+    rng = np.random.default_rng(H * 100 + F)
+    for name, mk in graphs:
+        monkeypatch.setattr(G, "XCD_ORDER", "1")
+        monkeypatch.setattr(G, "XCD_FINE", 3)
+        ga = mk()
+        pa = ga.csr.plan(64, need=True)                # (the policy is read when a plan is asked for)
+        ga.csr_t.plan(64, need=True)
+        monkeypatch.setattr(G, "XCD_ORDER", "0")
+        gb = mk()
+        pb = gb.csr.plan(64, need=True)
+        gb.csr_t.plan(64, need=True)
+        assert pa["xcd_on"] and not pb.get("xcd_on")
+        n, E = ga.number_of_nodes(), ga.number_of_edges()
+        t = lambda *shape: torch.tensor(rng.standard_normal(shape).astype(np.float32), device=dev)
+        el0, er0, ft0, gout = t(n, H), t(n, H), t(n, H, F), t(n, H, F)
+        og = oracle_graph(oracle, ga)
+        cases = [("none", lambda g: None, oracle.make_spec("none"), None),
+                 ("normal", lambda g: stag_amd.EdgeNoise(g, H, _lib.NOISE_NORMAL, 1.0, 0.3, seed=3, offset=1),
+                  oracle.make_spec("normal", 1.0, 0.3, seed=3, offset=1, Dn=H, n_edges=E), None),
+                 ("bernoulli+norm", lambda g: stag_amd.EdgeNoise(g, H, _lib.NOISE_BERNOULLI, 0.7, None, seed=3, offset=1, in_norm=True),
+                  oracle.make_spec("bernoulli", 0.7, None, in_norm=True, seed=3, offset=1, Dn=H, n_edges=E), None),
+                 ("normal+drop", lambda g: stag_amd.EdgeNoise(g, H, _lib.NOISE_NORMAL, 1.0, 0.3, seed=3, offset=1), None, (0.4, 11, 5))]
+        for what, noise, spec, drop in cases:
+            res = []
+            for g in (ga, gb):
+                el, er, ft = (v.clone().requires_grad_(True) for v in (el0, er0, ft0))
+                out = ops.gat_aggregate(g, el, er, ft, 0.2, noise(g), attn_drop=drop)
+                out.backward(gout)
+                res.append((out.detach(), el.grad, er.grad, ft.grad))
+            for a, b, nm in zip(res[0], res[1], ("out", "d el", "d er", "d ft")):
+                assert torch.equal(a, b), f"{name} {what} H={H} F={F}: {nm}"
+            if spec is not None:
+                ref = oracle.gat_fwd(og, el0.cpu().numpy(), er0.cpu().numpy(), ft0.cpu().numpy(), 0.2, spec)
+                ref = ref[0] if isinstance(ref, tuple) else ref
+                assert_close(res[0][0], ref, what=f"{name} {what} forward vs oracle")
+        if H * F <= 256:
+            # get_attention and the two-pass backward
+            with torch.no_grad():
+                oa, aa = ops.gat_aggregate(ga, el0, er0, ft0, 0.2, cases[1][1](ga), want_attn=True)
+                ob, ab = ops.gat_aggregate(gb, el0, er0, ft0, 0.2, cases[1][1](gb), want_attn=True)
+            assert torch.equal(oa, ob) and torch.equal(aa, ab)
+            monkeypatch.setattr(ops, "_GAT_BWD_ONE_GATHER", False)
+            res = []
+            for g in (ga, gb):
+                el, er, ft = (v.clone().requires_grad_(True) for v in (el0, er0, ft0))
+                ops.gat_aggregate(g, el, er, ft, 0.2, cases[1][1](g)).backward(gout)
+                res.append((el.grad, er.grad, ft.grad))
+            monkeypatch.setattr(ops, "_GAT_BWD_ONE_GATHER", True)
+            for a, b, nm in zip(res[0], res[1], ("d el", "d er", "d ft")):
+                assert torch.equal(a, b), f"{name} two-pass H={H} F={F}: {nm}"
+            # vi=True: the parameter gradients finished in the kernels (block partials added in the new batch order)
+            res = []
+            for g in (ga, gb):
+                loc = torch.full((H,), 1.0, device=dev, requires_grad=True)
+                scale = torch.full((H,), 0.3, device=dev, requires_grad=True)
+                el, er, ft = (v.clone().requires_grad_(True) for v in (el0, er0, ft0))
+                noise = stag_amd.EdgeNoise(g, H, _lib.NOISE_NORMAL, loc, scale, seed=3, offset=1, differentiable=True)
+                ops.gat_aggregate(g, el, er, ft, 0.2, noise).backward(gout)
+                res.append((ft.grad, loc.grad, scale.grad))
+            assert torch.equal(res[0][0], res[1][0])
+            for a, b, nm in zip(res[0][1:], res[1][1:], ("d loc", "d scale")):
+                sc = max(1.0, float(b.abs().max()))
+                assert_close(a / sc, (b / sc).cpu().numpy(), what=f"{name} vi H={H} F={F}: {nm}")

@@ -193,6 +193,48 @@ def test_xcd_order_is_a_stable_partition_of_the_plan(seg_len, fine, monkeypatch)
     assert sorted(map(tuple, srec)) == sorted(map(tuple, units[keep]))
 
 
+@pytest.mark.parametrize("fine", [1, 3])
+def test_xcd_block_plan_deals_batches_to_stripes(fine, monkeypatch):
+    """stag_plan_blocks_xcd: the cooperative GAT kernels' unit batches, dealt out so that batch b belongs to stripe
+    b mod 8 of the destination rows — a permutation of the plan's units, every batch inside one fine stripe and inside
+    the budget, the plan's order inside a fine stripe, empty batches where a stripe has run out."""
+    import importlib
+    import stag_amd
+    from stag_amd import _lib
+    G = importlib.import_module("stag_amd.graph")
+    monkeypatch.setattr(G, "XCD_ORDER", "1")
+    monkeypatch.setattr(G, "XCD_FINE", fine)
+    rng = np.random.default_rng(fine)
+    n = 3000
+    dst = np.concatenate([rng.integers(0, n - 40, 20000), np.full(900, 7), np.full(200, 2500)])
+    src = rng.integers(0, n, len(dst))
+    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n)
+    p = g.csr.plan(64, need=True)
+    nu, E = p["n_units"], len(dst)
+    units = p["units"].numpy()[:nu]
+    U, bp, nb, f = g.csr.gat_blocks(p, 256)
+    U, bp = U.numpy()[:nu], bp.numpy()
+    assert f == fine and nb % 8 == 0 and len(bp) == nb + 1 and bp[0] == 0 and bp[-1] == nu and (np.diff(bp) >= 0).all()
+    assert sorted(map(tuple, U)) == sorted(map(tuple, units))
+    fstripe = lambda rec: np.minimum(rec[:, 1].astype(np.int64) * (8 * fine) // E, 8 * fine - 1)
+    seen = [[] for _ in range(8)]
+    for b in range(nb):
+        rec = U[bp[b]:bp[b + 1]]
+        if len(rec) == 0:
+            continue
+        fs = fstripe(rec)
+        assert (fs == fs[0]).all() and fs[0] // fine == b % 8, "a batch lies in one fine stripe of stripe b mod 8"
+        assert len(rec) <= _lib.BLOCK_UNITS and (rec[:, 2].sum() <= _lib.BLOCK_EDGES or len(rec) == 1)
+        seen[b % 8].append(rec)
+    for k in range(8):                       # a stripe's batches, in turn, restate its units: fine stripes in order, plan order inside
+        got = np.concatenate(seen[k]) if seen[k] else np.zeros((0, 4), np.int32)
+        fs = fstripe(units)
+        want = np.concatenate([units[fs == k * fine + j] for j in range(fine)])
+        assert (got == want).all()
+    empty = int((np.diff(bp) == 0).sum())
+    assert empty < 8 * 40, "only the tails of the shorter stripes are empty"
+
+
 @pytest.mark.parametrize("seg_len", [64, 16, 300])
 def test_block_plan_batches_units(seg_len):
     """stag_plan_blocks: consecutive units of the plan in batches of at most STAG_BLOCK_EDGES edges and

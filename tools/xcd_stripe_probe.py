@@ -99,6 +99,59 @@ def planless():
                   flush=True)
 
 
+
+
+def gat():
+    """The cooperative GAT kernels with the XCD-aware unit batches (stag_plan_blocks_xcd) and in plan order: forward, and
+    forward + backward, on the PPI-sized batch (scripts/ppi_mle/gat/run.py: 4 heads x 256) and on cfg5's arxiv graph."""
+    import importlib
+    G = importlib.import_module("stag_amd.graph")
+    dev = torch.device("cuda:0")
+    s, d, sizes = synthetic.ppi_like()
+    s2, d2 = synthetic.arxiv_like(seed=1)
+    for gname, src, dst, n, shapes in (("PPI batch", s, d, int(sizes.sum()), ((4, 64), (8, 32), (4, 256))),
+                                       ("cfg5 arxiv", s2, d2, synthetic.ARXIV_NODES, ((8, 32),))):
+        graphs = {}
+        for mode in ("0", "1"):
+            G.XCD_ORDER = mode
+            g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
+            for view in (g.csr, g.csr_t):
+                view.plan(64, need=True)["xcd_decided"] = True       # (the policy is read at every request for a plan)
+            graphs[mode] = g
+        for H, F in shapes:
+            el, er = torch.randn(n, H, device=dev), torch.randn(n, H, device=dev)
+            ft = torch.randn(n, H, F, device=dev)
+            gout = torch.randn(n, H, F, device=dev)
+            elg, erg, ftg = (t_.clone().requires_grad_(True) for t_ in (el, er, ft))
+            mk = lambda g, i: stag_amd.EdgeNoise(g, H, _lib.NOISE_NORMAL, 1.0, 0.5, seed=1, offset=i)
+
+            def fwd(g):
+                def f(i):
+                    with torch.no_grad():
+                        return ops.gat_aggregate(g, el, er, ft, 0.2, mk(g, i))
+                return f
+
+            def train(g):
+                def f(i):
+                    elg.grad = erg.grad = ftg.grad = None
+                    ops.gat_aggregate(g, elg, erg, ftg, 0.2, mk(g, i)).backward(gout)
+                    return ftg.grad
+                return f
+            for what, mkf in (("forward", fwd), ("forward + backward", train)):
+                fa, fb = mkf(graphs["0"]), mkf(graphs["1"])
+                same = torch.equal(fa(0), fb(0))
+                ta, tb = [], []
+                for r in range(4):
+                    ta.append(timeit(fa, steps=100))
+                    tb.append(timeit(fb, steps=100))
+                print(f"GAT {what:18s} {gname:10s} H={H} F={F:3d} plan order {np.median(ta):7.1f} us   XCD-aware batches "
+                      f"{np.median(tb):7.1f} us   (bit-identical: {same}; stripe locality {graphs['1'].csr.stripe_locality():.3f})",
+                      flush=True)
+
+
 if __name__ == "__main__":
-    planless()
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "gat":
+        gat()
+    else:
+        planless()
+        main()
