@@ -238,6 +238,13 @@ int stag_plan_xcd_device_count(const stag_unit* units, int32_t n_units, int32_t 
 int stag_plan_xcd_device_fill(const stag_unit* units, int32_t n_units, const int32_t* strides, int32_t fine, int32_t* xcd,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* How many of a SQUARE CSR's edges (n_src == n_dst, device arrays) have their source row in the same eighth of the CSR —
+ * the stripe of stag_plan_xcd — as the edge itself: what one XCD's L2 can hope to find again when it walks one stripe.
+ * A block-diagonal batch: most of them; uniformly random sources: an eighth.  workspace: 8 bytes of device memory;
+ * synchronises `stream` for the 8-byte read-back.                                                                  */
+int stag_stripe_locality(const int32_t* indptr, const int32_t* indices, int32_t n_dst, int64_t n_edges,
+                         int64_t* same_out_host, void* workspace, void* stream);
+
 /* The same plan built ON THE DEVICE from a device indptr (rocPRIM sort + scan + one fill kernel), array for array
  * what stag_plan_count / stag_plan_fill produce on the host: a freshly batched minibatch graph (scripts/ppi_mle,
  * scripts/molhiv_mle build one per step) is planned where it was built — no indptr read-back, no host loops, no

@@ -343,3 +343,42 @@ extern "C" int stag_plan_xcd_device_fill(const stag_unit* units, int32_t n_units
                      n_units, x.starts, fine, strides[0], strides[1], xcd);
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }
+
+// ---- stripe locality of a square CSR (what "auto" decides the XCD-aware order by) ---------------------------
+// edges whose source row starts in the same eighth of the CSR as the edge itself lies in: integer count, any order
+namespace {
+__global__ void stripe_locality_kernel(const int32_t* indptr, const int32_t* indices, int32_t n_dst, int64_t E,
+                                       unsigned long long* same) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int hit = 0;
+  if (p < E) {
+    const int32_t u = indices[p];
+    if (u >= 0 && u < n_dst) {
+      int64_t ks = (int64_t)indptr[u] * STAG_XCD_STRIPES / E;
+      ks = ks >= STAG_XCD_STRIPES ? STAG_XCD_STRIPES - 1 : ks;
+      hit = (p * STAG_XCD_STRIPES / E) == ks;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) hit += __shfl_xor(hit, d);
+  if ((threadIdx.x & 63) == 0 && hit) atomicAdd(same, (unsigned long long)hit);
+}
+}  // namespace
+
+extern "C" int stag_stripe_locality(const int32_t* indptr, const int32_t* indices, int32_t n_dst, int64_t n_edges,
+                                    int64_t* same_out_host, void* workspace, void* stream) {
+  if (!same_out_host || n_dst < 0 || n_edges < 0 || !workspace) return STAG_EINVAL;
+  *same_out_host = 0;
+  if (n_edges == 0 || n_dst == 0) return STAG_OK;
+  if (!indptr || !indices) return STAG_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long* same = static_cast<unsigned long long*>(workspace);
+  if (hipMemsetAsync(same, 0, 8, s) != hipSuccess) return STAG_EIO;
+  hipLaunchKernelGGL(stripe_locality_kernel, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, s, indptr, indices, n_dst,
+                     n_edges, same);
+  unsigned long long h = 0;
+  if (hipMemcpyAsync(&h, same, 8, hipMemcpyDeviceToHost, s) != hipSuccess) return STAG_EIO;
+  if (hipStreamSynchronize(s) != hipSuccess) return STAG_EIO;
+  *same_out_host = (int64_t)h;
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}

@@ -81,6 +81,15 @@ class CsrView:
             E = self.n_edges
             if E == 0 or self.n_src != self.n_dst:
                 self._locality = 0.0
+            elif self.indptr.is_cuda:
+                # (the library's own kernel: a chain of torch ops costs 0.3 s of lazy kernel loading on first use)
+                dev, same = self.indptr.device, C.c_int64(0)
+                ws = torch.empty(8, dtype=torch.uint8, device=dev)
+                with _lib.on_device(dev):
+                    _lib.check(_lib.lib().stag_stripe_locality(_lib.ptr(self.indptr), _lib.ptr(self.indices), self.n_dst, E,
+                                                               C.byref(same), _lib.ptr(ws), _lib.stream_of(dev)),
+                               "stag_stripe_locality")
+                self._locality = same.value / E
             else:
                 pos = torch.arange(E, device=self.indptr.device, dtype=torch.int64)
                 src_pos = self.indptr[:-1][self.indices.long()].long()      # where the source's own row starts

@@ -995,6 +995,22 @@ def test_device_planner_equals_host_planner(dev, seg_len, monkeypatch):
                 assert dplan["xcd"] is None and hplan["xcd"] is None
 
 
+def test_stripe_locality_device_equals_host(dev):
+    """stag_stripe_locality (what "auto" decides the XCD-aware order by) counts what the host-side statement counts."""
+    import stag_amd
+    from stag_amd import synthetic
+    s3, d3, sizes = synthetic.ppi_like(n_graphs=6, n_nodes=3000, n_edges=40000, seed=5)
+    cases = [(torch.from_numpy(s3), torch.from_numpy(d3), int(sizes.sum()))]
+    g = random_graph(2500, 30000, seed=3, hub=3000)
+    cases.append((*g.edges(), 2500))
+    cases.append((torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64), 7))
+    for src, dst, n in cases:
+        gd, gh = stag_amd.Graph(src, dst, n, device=dev), stag_amd.Graph(src, dst, n)
+        for v in ("csr", "csr_t"):
+            assert getattr(gd, v).stripe_locality() == pytest.approx(getattr(gh, v).stripe_locality(), abs=1e-6)
+    assert stag_amd.Graph(cases[0][0], cases[0][1], cases[0][2], device=dev).csr.stripe_locality() > 0.6
+
+
 def _without_xcd_order(view, seg_len):
     p = view.plan(seg_len, need=True)
     p["xcd"], p["xcd_strides"], p["xcd_on"], p["xcd_decided"] = None, (0, 0), False, True
