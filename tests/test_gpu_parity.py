@@ -1008,7 +1008,7 @@ def test_stripe_locality_device_equals_host(dev):
         gd, gh = stag_amd.Graph(src, dst, n, device=dev), stag_amd.Graph(src, dst, n)
         for v in ("csr", "csr_t"):
             assert getattr(gd, v).stripe_locality() == pytest.approx(getattr(gh, v).stripe_locality(), abs=1e-6)
-    assert stag_amd.Graph(cases[0][0], cases[0][1], cases[0][2], device=dev).csr.stripe_locality() > 0.6
+    assert stag_amd.Graph(cases[0][0], cases[0][1], cases[0][2], device=dev).csr.stripe_locality() > 0.5        # 6 graphs in 8 stripes
 
 
 def _without_xcd_order(view, seg_len):
