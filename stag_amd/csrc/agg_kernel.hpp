@@ -105,6 +105,7 @@ struct AggArgs {
   float* dp_part;          // [gridDim.y][gridDim.x][2][LPE * 4] block partials, or null
   // plan
   const stag_unit* units;  // null: unit i = row i, unsplit
+  const stag_unit* units_plan;   // (host side) the plan's own order, for the launch families that do not take the walk
   int32_t n_units;
   const int32_t* long_rows;
   const int32_t* long_seg_ptr;
@@ -721,7 +722,8 @@ struct AggTeam {
 
 // One unit (a whole row or a segment of a long row) on LPE x SLOTS lanes of a wave:
 // c = this lane's chunk (4 channels) of the channel tile, sl = its edge slot.
-template <int KIND, int LPE, bool VEC, int PEDGE, int SLOTS, int MULT, int NOUT = 1, bool MC = false, bool WN = false>
+template <int KIND, int LPE, bool VEC, int PEDGE, int SLOTS, int MULT, int NOUT = 1, bool MC = false, bool WN = false,
+          bool NULLS = false>
 __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const int c, const int sl,
                                          float (*dp_out)[4] = nullptr) {
   static_assert(LPE * SLOTS <= 64 && 64 % (LPE * SLOTS) == 0, "a unit's lanes stay inside one wave");
@@ -752,9 +754,9 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
   if (a.units) {
     const int4 q = *reinterpret_cast<const int4*>(a.units + unit);
     v = q.x; b = q.y; len = q.z; slot = q.w;
-#ifndef STAG_NO_NULLCHK
-    if (v < 0) return;        // a null record: the padding of an XCD stripe (stag_plan.xcd_order)
-#endif
+    if constexpr (NULLS) {
+      if (v < 0) return;        // a null record: the padding of an XCD stripe (stag_plan.xcd_order)
+    }
   } else {
     v = unit;
     b = a.indptr[v];
@@ -1039,17 +1041,21 @@ constexpr int heavy_slots_of() {
 #define STAG_HOIST_PLAIN 0      // the kinds that draw nothing: hoisting measured 1.5 us SLOWER at cfg2 (97.8 against 96.3)
 #endif
 #define STAG_PIN_S(x) asm volatile("" : "+s"(x))
-template <int KIND>
+#ifndef STAG_HOIST_MIN_LPE
+#define STAG_HOIST_MIN_LPE 32   // the narrow shapes (two inlined loops, SGPRs spilling already) lose 2 us of 35 to it
+#endif
+template <int KIND, int LPE, bool WALK>
 __device__ __forceinline__ void hoist_args(AggArgs& l) {
 #if STAG_HOIST_ARGS
-  // the walk (one aligned s_load_dwordx8 instead of three loads and two waits) for every kind
-  STAG_PIN_S(l.walk.smask); STAG_PIN_S(l.walk.sshift); STAG_PIN_S(l.walk.jh_heavy); STAG_PIN_S(l.walk.jh_light);
-  STAG_PIN_S(l.walk.sh); STAG_PIN_S(l.walk.lbase); STAG_PIN_S(l.walk.sl); STAG_PIN_S(l.walk.n_total);
-  if constexpr (KIND >= kNormal || STAG_HOIST_PLAIN) {
+  if constexpr (WALK) {     // the walk (one aligned s_load_dwordx8 instead of three loads and two waits) for every kind
+    STAG_PIN_S(l.walk.smask); STAG_PIN_S(l.walk.sshift); STAG_PIN_S(l.walk.jh_heavy); STAG_PIN_S(l.walk.jh_light);
+    STAG_PIN_S(l.walk.sh); STAG_PIN_S(l.walk.lbase); STAG_PIN_S(l.walk.sl); STAG_PIN_S(l.walk.n_total);
+  }
+  if constexpr ((KIND >= kNormal || STAG_HOIST_PLAIN) && LPE >= STAG_HOIST_MIN_LPE) {
     STAG_PIN_S(l.D); STAG_PIN_S(l.units); STAG_PIN_S(l.indptr); STAG_PIN_S(l.indices);
     STAG_PIN_S(l.x); STAG_PIN_S(l.ldxb); STAG_PIN_S(l.x_bytes); STAG_PIN_S(l.wide); STAG_PIN_S(l.src_scale);
   }
-  if constexpr (KIND >= kNormal) {
+  if constexpr (KIND >= kNormal && LPE >= STAG_HOIST_MIN_LPE) {
     STAG_PIN_S(l.eid); STAG_PIN_S(l.nidx);
     STAG_PIN_S(l.p0); STAG_PIN_S(l.p1); STAG_PIN_S(l.p0s); STAG_PIN_S(l.p1s); STAG_PIN_S(l.pmode); STAG_PIN_S(l.relu);
     STAG_PIN_S(l.in_norm);
@@ -1059,45 +1065,68 @@ __device__ __forceinline__ void hoist_args(AggArgs& l) {
 #endif
 }
 
-template <int KIND, int LPE, bool VEC, int PEDGE, int NOUT = 1, bool MC = false, bool WN = false>
+// WALK = false: block b takes units [b * teams, (b + 1) * teams) of the plan's order (heavy blocks first).  WALK = true
+// (the plain family only: one output, scalar / per-channel parameters): the stripes of AggArgs::Walk — its own
+// instantiation, so that the plan-order kernels keep the code they were tuned with (as one kernel with a run-time
+// walk the narrow shapes lost 2 us of 35 with noise, tools/ab_bench.py).
+template <int KIND, int LPE, bool VEC, int PEDGE, int NOUT = 1, bool MC = false, bool WN = false, bool WALK = false>
 __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_kernel(const AggArgs a_in) {
   AggArgs a = a_in;
-  hoist_args<KIND>(a);
+  hoist_args<KIND, LPE, WALK>(a);
   constexpr int HS = (NOUT == 1 && PEDGE != 3) ? heavy_slots_of<LPE>() : 1;
   const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
   constexpr int TPB = STAG_BLOCK_THREADS / LPE, TPBH = STAG_BLOCK_THREADS / (LPE * HS);
-  // first unit of this block, the end of the range it walks, heavy: the slotted loop (all block-uniform)
-  const AggArgs::Walk w = a.walk;
-  const int stripe = blockIdx.x & w.smask;
-  int j = blockIdx.x >> w.sshift;
-  int unit0, end;
-  bool heavy = false;
-  if (HS > 1 && j < w.jh_heavy) {
-    heavy = true;
-    unit0 = stripe * w.sh + j * TPBH;
-    end = (stripe + 1) * w.sh;
+  if constexpr (!WALK) {
+    int first = 0, blk = blockIdx.x;
+    if constexpr (HS > 1) {
+      if (blk < a.n_heavy_blocks) {                 // block-uniform
+        const int unit = blk * TPBH + threadIdx.x / (LPE * HS);
+        if (unit >= a.n_heavy) return;              // teams never talk to each other: no barrier below
+        agg_unit<KIND, LPE, VEC, PEDGE, HS, STAG_HMULT>(a, unit, c, (threadIdx.x / LPE) % HS);
+        return;
+      }
+      first = a.n_heavy;
+      blk -= a.n_heavy_blocks;
+    }
+    const int unit = first + blk * TPB + threadIdx.x / LPE;
+    if (unit >= a.n_units) return;
+    agg_unit<KIND, LPE, VEC, PEDGE, 1, NOUT == 1 ? mult_of<KIND, LPE>() : 1, NOUT, MC, WN>(a, unit, c, 0);
   } else {
-    if (HS > 1) j -= w.jh_heavy;
-    if (j < w.jh_light) {
-      unit0 = stripe * w.sh + j * TPB;
+    // first unit of this block, the end of the range it walks, heavy: the slotted loop (all block-uniform).  An XCD
+    // stripe is padded with null records, which agg_unit skips (reading the stripe's own length from the order's
+    // header instead is one more dependent load in every block's prologue: the molecule batch with noise 27.0 -> 29.9 us).
+    const AggArgs::Walk w = a.walk;
+    const int stripe = blockIdx.x & w.smask;
+    int j = blockIdx.x >> w.sshift;
+    int unit0, end;
+    bool heavy = false;
+    if (HS > 1 && j < w.jh_heavy) {
+      heavy = true;
+      unit0 = stripe * w.sh + j * TPBH;
       end = (stripe + 1) * w.sh;
     } else {
-      j -= w.jh_light;
-      unit0 = w.lbase + stripe * w.sl + j * TPB;
-      end = min(w.lbase + (stripe + 1) * w.sl, w.n_total);
+      if (HS > 1) j -= w.jh_heavy;
+      if (j < w.jh_light) {
+        unit0 = stripe * w.sh + j * TPB;
+        end = (stripe + 1) * w.sh;
+      } else {
+        j -= w.jh_light;
+        unit0 = w.lbase + stripe * w.sl + j * TPB;
+        end = min(w.lbase + (stripe + 1) * w.sl, w.n_total);
+      }
     }
-  }
-  if constexpr (HS > 1) {
-    if (heavy) {
-      const int unit = unit0 + threadIdx.x / (LPE * HS);
-      if (unit >= end) return;                    // teams never talk to each other: no barrier below
-      agg_unit<KIND, LPE, VEC, PEDGE, HS, STAG_HMULT>(a, unit, c, (threadIdx.x / LPE) % HS);
-      return;
+    if constexpr (HS > 1) {
+      if (heavy) {
+        const int unit = unit0 + threadIdx.x / (LPE * HS);
+        if (unit >= end) return;
+        agg_unit<KIND, LPE, VEC, PEDGE, HS, STAG_HMULT, 1, false, false, true>(a, unit, c, (threadIdx.x / LPE) % HS);
+        return;
+      }
     }
+    const int unit = unit0 + threadIdx.x / LPE;
+    if (unit >= end) return;
+    agg_unit<KIND, LPE, VEC, PEDGE, 1, NOUT == 1 ? mult_of<KIND, LPE>() : 1, NOUT, MC, WN, true>(a, unit, c, 0);
   }
-  const int unit = unit0 + threadIdx.x / LPE;
-  if (unit >= end) return;
-  agg_unit<KIND, LPE, VEC, PEDGE, 1, NOUT == 1 ? mult_of<KIND, LPE>() : 1, NOUT, MC, WN>(a, unit, c, 0);
 }
 
 // The dx pass that also sums the gradients of scalar / per-channel parameters (PEDGE 4; stag_agg_bwd_dp).  A unit's
@@ -1148,24 +1177,27 @@ inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles
   constexpr int TPBH = STAG_BLOCK_THREADS / (LPE * HS);
   const bool slotted = !(HS == 1 || a.outx[0] || pedge == 3 || a.dp_part);
   if (!slotted) a.n_heavy = 0;
+  // the walk (XCD-aware order, row stripes without a plan) is the plain family's: one output, no per-edge parameters
+  const bool plain = !a.outx[0] && !a.dp_part && pedge == 0;
+  if (a.xcd && !plain) { a.xcd = nullptr; a.units = a.units_plan; }
   a.n_heavy_blocks = (a.n_heavy + TPBH - 1) / TPBH;
-  dim3 grid(1, tiles);
+  dim3 grid(a.n_heavy_blocks + (a.n_units - a.n_heavy + TPB - 1) / TPB, tiles);
+  bool walk = false;
   AggArgs::Walk& w = a.walk;
   if (a.xcd) {                     // a.walk.sh / sl arrive holding the plan's stripe lengths
+    walk = true;
     w.smask = STAG_XCD_STRIPES - 1; w.sshift = 3;
     w.jh_heavy = slotted ? (w.sh + TPBH - 1) / TPBH : 0;
     w.jh_light = slotted ? 0 : (w.sh + TPB - 1) / TPB;
     w.lbase = STAG_XCD_STRIPES * w.sh;
     w.n_total = STAG_XCD_STRIPES * (w.sh + w.sl);
     grid.x = STAG_XCD_STRIPES * (w.jh_heavy + w.jh_light + (w.sl + TPB - 1) / TPB);
-  } else if (STAG_XCD_PLANLESS && !a.units && !a.dp_part && a.n_units >= STAG_XCD_STRIPES * TPB && a.n_units < (1 << 30)) {
+  } else if (STAG_XCD_PLANLESS && plain && !a.units && a.n_units >= STAG_XCD_STRIPES * TPB && a.n_units < (1 << 30)) {
     // a graph that runs without a plan (short rows only: a freshly batched minibatch of molecules) is striped by rows
+    walk = true;
     w = AggArgs::Walk{STAG_XCD_STRIPES - 1, 3, 0, 0, 0, 0, 0, a.n_units};
     w.sl = ((a.n_units + STAG_XCD_STRIPES - 1) / STAG_XCD_STRIPES + TPB - 1) / TPB * TPB;
     grid.x = STAG_XCD_STRIPES * (w.sl / TPB);
-  } else {                         // the plan's own order (or row order): one stripe
-    w = AggArgs::Walk{0, 0, a.n_heavy_blocks, 0, a.n_heavy, a.n_heavy, a.n_units - a.n_heavy, a.n_units};
-    grid.x = a.n_heavy_blocks + (a.n_units - a.n_heavy + TPB - 1) / TPB;
   }
   if (grid.x == 0) return;
   const dim3 block(STAG_BLOCK_THREADS);
@@ -1216,6 +1248,11 @@ inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles
       else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 2>), grid, block, STAG_AGG_LDS_BYTES, s, a);
       return;
     }
+  }
+  if (walk) {
+    if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 1, false, false, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+    else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 1, false, false, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+    return;
   }
   if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0>), grid, block, STAG_AGG_LDS_BYTES, s, a);
   else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0>), grid, block, STAG_AGG_LDS_BYTES, s, a);

@@ -781,7 +781,7 @@ static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x
   a.n_units = csr->n_dst;
   if (use_plan) {
     if (!plan->units || !aligned16(plan->units)) return STAG_EINVAL;
-    a.units = static_cast<const stag_unit*>(plan->units);
+    a.units = a.units_plan = static_cast<const stag_unit*>(plan->units);
     a.n_units = plan->n_units;
     if (plan->n_heavy < 0 || plan->n_heavy > plan->n_units) return STAG_EINVAL;
     a.n_heavy = plan->n_heavy;

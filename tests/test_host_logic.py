@@ -570,10 +570,11 @@ def test_hot_kernel_register_budget():
         return out
     normal, none = usage("agg_normal"), usage("agg_none")
     for lpe in (32, 64):         # D = 128 (the headline) and D >= 256
-        v, occ = normal[f"void stag::agg_kernel<2, {lpe}, true, 0, 1, false, false>(stag::AggArgs)"]
-        assert occ >= 7 and v <= 72, f"Normal, LPE {lpe}: {v} VGPRs, {occ} waves/SIMD"
-        v, occ = none[f"void stag::agg_kernel<0, {lpe}, true, 0, 1, false, false>(stag::AggArgs)"]
-        assert occ >= 7 and v <= 72, f"no noise, LPE {lpe}: {v} VGPRs, {occ} waves/SIMD"
+        for walk in ("false", "true"):       # the plan-order kernel and its XCD-aware twin
+            v, occ = normal[f"void stag::agg_kernel<2, {lpe}, true, 0, 1, false, false, {walk}>(stag::AggArgs)"]
+            assert occ >= 7 and v <= 72, f"Normal, LPE {lpe}, walk {walk}: {v} VGPRs, {occ} waves/SIMD"
+            v, occ = none[f"void stag::agg_kernel<0, {lpe}, true, 0, 1, false, false, {walk}>(stag::AggArgs)"]
+            assert occ >= 7 and v <= 72, f"no noise, LPE {lpe}, walk {walk}: {v} VGPRs, {occ} waves/SIMD"
 
 
 def test_round2_host_helpers_on_cpu():
