@@ -618,12 +618,47 @@ def batch(graphs):
     src = torch.cat([g._src for g in graphs]).to(torch.int64) + edge_off
     dst = torch.cat([g._dst for g in graphs]).to(torch.int64) + edge_off
     out = Graph(src, dst, total, batch_num_nodes=torch.tensor(sizes, dtype=torch.int64, device=dev))
+    if 1 < len(graphs) <= BATCH_CONCAT_MAX_GRAPHS and sum(n_edges) > 0:
+        # a block-diagonal union's CSRs are its parts' CSRs laid end to end: no sort per batch (the parts keep theirs —
+        # a data loader hands the same graphs out again every epoch)
+        out._csr, out._csr_t = _concat_csr(graphs, node_off, n_edges, edge_off.to(torch.int32), total)
     keys = set(graphs[0].ndata)
     for k in keys:
         out.ndata[k] = torch.cat([g.ndata[k] for g in graphs], 0)
     for k in set(graphs[0].edata):
         out.edata[k] = torch.cat([g.edata[k] for g in graphs], 0)
     return out
+
+
+BATCH_CONCAT_MAX_GRAPHS = 64    # (a batch of 4096 molecules: 4096-way concatenations cost the host more than two device sorts)
+
+
+def _concat_csr(graphs, node_off, n_edges, node_off_per_edge, total):
+    """(csr, csr_t) of batch(graphs) from the parts' own views: row pointers shifted by the edges before the part, column
+    ids by the nodes before it, edge ids and forward positions by the edges before it — array for array what build_csr
+    makes of the batch's COO (rows stay in part order, a row's edges in ascending edge id)."""
+    dev = graphs[0].device
+    E = int(sum(n_edges))
+    sizes = [g._n for g in graphs]
+    e_off = np.concatenate([[0], np.cumsum(n_edges[:-1])]).astype(np.int64)
+    if dev.type == "cuda":
+        rep = lambda vals, counts, size: torch.repeat_interleave(
+            torch.from_numpy(vals).to(dev), torch.tensor(counts, dtype=torch.int64, device=dev), output_size=size).to(torch.int32)
+    else:
+        rep = lambda vals, counts, size: torch.from_numpy(np.repeat(vals, counts)).to(torch.int32)
+    e_off_per_node = rep(e_off, sizes, total)
+    e_off_per_edge = rep(e_off, n_edges, E)
+    last = torch.tensor([E], dtype=torch.int32, device=dev)
+    views = []
+    for name in ("csr", "csr_t"):
+        parts = [getattr(g, name) for g in graphs]
+        indptr = torch.cat([v.indptr[:-1] for v in parts] + [last])
+        indptr[:-1] += e_off_per_node
+        indices = torch.cat([v.indices for v in parts]) + node_off_per_edge
+        eid = torch.cat([v.eid for v in parts]) + e_off_per_edge
+        nidx = (torch.cat([v.nidx for v in parts]) + e_off_per_edge) if name == "csr_t" else None
+        views.append(CsrView(total, total, indptr, indices, eid, nidx))
+    return views
 
 
 def _readout(g, name, reduce):

@@ -305,3 +305,32 @@ def test_amortized_vi_layer_kl_and_gradients_golden(dev, golden, oracle):
         ref = golden[f"amort_kl_grad_{k}"]
         sc = max(1.0, float(np.abs(ref).max()))
         assert_close(got / sc, ref / sc, tol=2e-5, what=f"d loss / d {k}")
+
+
+@pytest.mark.gpu
+def test_batch_concatenates_the_parts_csr_on_the_device(dev, oracle):
+    """graph.batch on the device: the union's CSR views come from the parts' views (no sort per batch) and equal, array
+    for array, the views built from the union's COO; a GraphSAGE-mean aggregation with noise on the batch equals the
+    oracle's on the union."""
+    import stag_amd
+    from stag_amd import _lib, ops, synthetic
+    from util import assert_close, oracle_graph
+    s, d, sizes = synthetic.ppi_like(n_graphs=5, n_nodes=2000, n_edges=30000, seed=4)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    gid = np.searchsorted(off, s, side="right") - 1
+    parts = [stag_amd.Graph(torch.from_numpy(s[gid == i] - off[i]).to(dev), torch.from_numpy(d[gid == i] - off[i]).to(dev),
+                            int(sizes[i]), device=dev) for i in range(len(sizes))]
+    b = stag_amd.batch(parts)
+    assert b._csr is not None and b._csr.indptr.is_cuda
+    ref = stag_amd.Graph(*b.edges(), b.number_of_nodes(), device=dev)
+    for v in ("csr", "csr_t"):
+        for f in ("indptr", "indices", "eid", "nidx"):
+            x, y = getattr(getattr(b, v), f), getattr(getattr(ref, v), f)
+            assert (x is None and y is None) or torch.equal(x, y), (v, f)
+    n, D = b.number_of_nodes(), 50
+    x = torch.randn(n, D, device=dev)
+    noise = stag_amd.EdgeNoise(b, D, _lib.NOISE_NORMAL, 1.0, 0.3, seed=5, offset=2)
+    got = ops.aggregate(b, x, noise, reduce="mean")
+    spec = oracle.make_spec("normal", 1.0, 0.3, seed=5, offset=2, Dn=D, n_edges=b.number_of_edges())
+    want = oracle.agg_fwd(oracle_graph(oracle, ref), x.cpu().numpy(), spec, reduce=oracle.REDUCE_MEAN)
+    assert_close(got, want, what="aggregation on a batch whose CSR was concatenated")

@@ -193,6 +193,37 @@ def test_xcd_order_is_a_stable_partition_of_the_plan(seg_len, fine, monkeypatch)
     assert sorted(map(tuple, srec)) == sorted(map(tuple, units[keep]))
 
 
+def test_batch_concatenates_the_parts_csr():
+    """graph.batch (dgl.batch, scripts/ppi_mle/run.py:12-14): the union's CSR views are the parts' own views laid end to
+    end — array for array what build_csr makes of the union's COO (edge ids and the transposed view's forward positions
+    included), so the noise a batched graph draws does not depend on how its CSR came about; parts without edges, a
+    one-node part; beyond BATCH_CONCAT_MAX_GRAPHS parts the union is sorted as before."""
+    import importlib
+    import stag_amd
+    G = importlib.import_module("stag_amd.graph")
+    rng = np.random.default_rng(0)
+    parts = []
+    for i in range(7):
+        n = int(rng.integers(1, 40)) if i != 3 else 1
+        e = int(rng.integers(0, 200)) if i not in (2, 3) else 0
+        parts.append(stag_amd.Graph(torch.from_numpy(rng.integers(0, n, e)), torch.from_numpy(rng.integers(0, n, e)), n))
+    b = stag_amd.batch(parts)
+    assert b._csr is not None and b._csr_t is not None, "taken from the parts"
+    ref = stag_amd.Graph(*b.edges(), b.number_of_nodes())
+    for v in ("csr", "csr_t"):
+        got, want = getattr(b, v), getattr(ref, v)
+        for f in ("indptr", "indices", "eid", "nidx"):
+            x, y = getattr(got, f), getattr(want, f)
+            assert (x is None and y is None) or (x.dtype == torch.int32 and torch.equal(x, y)), (v, f)
+    assert b.batch_num_nodes().tolist() == [g.number_of_nodes() for g in parts]
+    old = G.BATCH_CONCAT_MAX_GRAPHS
+    G.BATCH_CONCAT_MAX_GRAPHS = 3
+    try:
+        assert stag_amd.batch(parts)._csr is None
+    finally:
+        G.BATCH_CONCAT_MAX_GRAPHS = old
+
+
 @pytest.mark.parametrize("fine", [1, 3])
 def test_xcd_block_plan_deals_batches_to_stripes(fine, monkeypatch):
     """stag_plan_blocks_xcd: the cooperative GAT kernels' unit batches, dealt out so that batch b belongs to stripe
