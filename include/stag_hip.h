@@ -240,6 +240,22 @@ int stag_plan_xcd_device_count(const stag_unit* units, int32_t n_units, int32_t 
 int stag_plan_xcd_device_fill(const stag_unit* units, int32_t n_units, const int32_t* strides, int32_t fine, int32_t* xcd,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* int32 arrays laid end to end with offsets, every piece of every array in ONE launch: what a block-diagonal batch
+ * (`dgl.batch`, scripts/ppi_mle/run.py:12-14) needs to take its CSR views from its parts' — row pointers shifted by the
+ * edges before the part, column ids by its nodes, edge ids and forward positions by its edges (stag_amd/graph.py: batch).
+ * `jobs` and `chunk_start` are DEVICE arrays: job j writes dst[i] = src[i] + add for i < count (FILL: dst[i] = add),
+ * chunk_start[j] = sum over earlier jobs of ceil(count / 1024), chunk_start[n_jobs] = n_chunks.                        */
+#define STAG_CONCAT_I32 0
+#define STAG_CONCAT_FILL 2
+typedef struct stag_concat_job {
+  const int32_t* src;
+  int32_t* dst;
+  int64_t count;
+  int32_t add;
+  int32_t kind;
+} stag_concat_job;
+int stag_concat_jobs(const stag_concat_job* jobs, const int64_t* chunk_start, int32_t n_jobs, int64_t n_chunks, void* stream);
+
 /* How many of a SQUARE CSR's edges (n_src == n_dst, device arrays) have their source row in the same eighth of the CSR —
  * the stripe of stag_plan_xcd — as the edge itself: what one XCD's L2 can hope to find again when it walks one stripe.
  * A block-diagonal batch: most of them; uniformly random sources: an eighth.  workspace: 8 bytes of device memory;

@@ -382,3 +382,34 @@ extern "C" int stag_stripe_locality(const int32_t* indptr, const int32_t* indice
   *same_out_host = (int64_t)h;
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
 }
+
+// ---- laying int32 arrays end to end with offsets (stag_concat_jobs) -------------------------------------------
+// A block-diagonal batch's CSR views are its parts' arrays one after the other, shifted by the nodes / edges before the
+// part.  ONE launch copies every piece of every array: a table of jobs on the device, a block per 1024 elements of a job.
+namespace {
+__global__ void concat_jobs_kernel(const stag_concat_job* jobs, const int64_t* chunk_start, int32_t n_jobs) {
+  // the job of this block: chunk_start[j] <= blockIdx.x < chunk_start[j + 1]   (block-uniform binary search)
+  int lo = 0, hi = n_jobs;
+  const int64_t b = blockIdx.x;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (chunk_start[mid] <= b) lo = mid; else hi = mid;
+  }
+  const stag_concat_job j = jobs[lo];
+  const int64_t first = (b - chunk_start[lo]) * 1024;
+  for (int k = 0; k < 4; ++k) {
+    const int64_t i = first + k * 256 + threadIdx.x;
+    if (i >= j.count) return;
+    j.dst[i] = (j.kind == STAG_CONCAT_FILL ? 0 : j.src[i]) + j.add;
+  }
+}
+}  // namespace
+
+extern "C" int stag_concat_jobs(const stag_concat_job* jobs, const int64_t* chunk_start, int32_t n_jobs, int64_t n_chunks,
+                                void* stream) {
+  if (n_jobs < 0 || n_chunks < 0 || n_chunks > 0x7FFFFFFFll) return STAG_EINVAL;
+  if (n_jobs == 0 || n_chunks == 0) return STAG_OK;
+  if (!jobs || !chunk_start) return STAG_EINVAL;
+  hipLaunchKernelGGL(concat_jobs_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, jobs, chunk_start, n_jobs);
+  return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}

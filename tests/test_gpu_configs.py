@@ -334,3 +334,4 @@ def test_batch_concatenates_the_parts_csr_on_the_device(dev, oracle):
     spec = oracle.make_spec("normal", 1.0, 0.3, seed=5, offset=2, Dn=D, n_edges=b.number_of_edges())
     want = oracle.agg_fwd(oracle_graph(oracle, ref), x.cpu().numpy(), spec, reduce=oracle.REDUCE_MEAN)
     assert_close(got, want, what="aggregation on a batch whose CSR was concatenated")
+
