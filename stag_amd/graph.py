@@ -362,7 +362,7 @@ class _EdgeBatch:
 class Graph:
     is_block = False
 
-    def __init__(self, src, dst, num_nodes=None, batch_num_nodes=None, device=None):
+    def __init__(self, src, dst, num_nodes=None, batch_num_nodes=None, device=None, _trusted=False):
         src = torch.as_tensor(src)
         dst = torch.as_tensor(dst)
         if device is not None:
@@ -371,8 +371,8 @@ class Graph:
             raise ValueError("src and dst must be 1-D tensors of equal length")
         if num_nodes is None:
             num_nodes = int(max(src.max().item(), dst.max().item())) + 1 if src.numel() else 0
-        elif src.numel() and int(max(src.max().item(), dst.max().item())) >= num_nodes:
-            raise ValueError("node id out of range")
+        elif not _trusted and src.numel() and int(max(src.max().item(), dst.max().item())) >= num_nodes:
+            raise ValueError("node id out of range")      # (_trusted: a union of checked graphs — two read-backs saved)
         if src.numel() >= 2 ** 31:
             raise ValueError("more than 2^31-1 edges: shard the graph (stag_amd.partition)")
         self._src = src.to(torch.int32).contiguous()
@@ -610,6 +610,21 @@ def batch(graphs):
     n_edges = [int(g._src.shape[0]) for g in graphs]
     total = int(sum(sizes))
     node_off = np.concatenate([[0], np.cumsum(sizes[:-1])]).astype(np.int64) if graphs else np.zeros(0, np.int64)
+    E = int(sum(n_edges))
+    if dev.type == "cuda" and 1 < len(graphs) <= BATCH_CONCAT_MAX_GRAPHS and E > 0:
+        # the union's COO and both CSR views are the parts' arrays laid end to end (the parts keep their views: a data
+        # loader hands the same graphs out again every epoch) — every piece of every array in one launch, no sort
+        jobs = _ConcatJobs()
+        e_off = np.concatenate([[0], np.cumsum(n_edges[:-1])]).astype(np.int64)
+        src = torch.empty(E, dtype=torch.int32, device=dev)
+        dst = torch.empty(E, dtype=torch.int32, device=dev)
+        jobs.add([g._src.data_ptr() for g in graphs], src, e_off, n_edges, add=node_off)
+        jobs.add([g._dst.data_ptr() for g in graphs], dst, e_off, n_edges, add=node_off)
+        views = _concat_csr(graphs, node_off, n_edges, None, total, jobs)
+        jobs.run(dev)
+        out = Graph(src, dst, total, batch_num_nodes=torch.tensor(sizes, dtype=torch.int64, device=dev), _trusted=True)
+        out._csr, out._csr_t = views
+        return _batch_frames(out, graphs)
     if dev.type == "cuda":      # on the device, output size given: no host pass over the edges, no read-back
         edge_off = torch.repeat_interleave(torch.from_numpy(node_off).to(dev), torch.tensor(n_edges, dtype=torch.int64, device=dev),
                                            output_size=int(sum(n_edges)))
@@ -622,8 +637,11 @@ def batch(graphs):
         # a block-diagonal union's CSRs are its parts' CSRs laid end to end: no sort per batch (the parts keep theirs —
         # a data loader hands the same graphs out again every epoch)
         out._csr, out._csr_t = _concat_csr(graphs, node_off, n_edges, edge_off.to(torch.int32), total)
-    keys = set(graphs[0].ndata)
-    for k in keys:
+    return _batch_frames(out, graphs)
+
+
+def _batch_frames(out, graphs):
+    for k in set(graphs[0].ndata):
         out.ndata[k] = torch.cat([g.ndata[k] for g in graphs], 0)
     for k in set(graphs[0].edata):
         out.edata[k] = torch.cat([g.edata[k] for g in graphs], 0)
@@ -667,7 +685,7 @@ class _ConcatJobs:
                                                    _lib.stream_of(dev)), "stag_concat_jobs")
 
 
-def _concat_csr(graphs, node_off, n_edges, node_off_per_edge, total):
+def _concat_csr(graphs, node_off, n_edges, node_off_per_edge, total, jobs=None):
     """(csr, csr_t) of batch(graphs) from the parts' own views: row pointers shifted by the edges before the part, column
     ids by the nodes before it, edge ids and forward positions by the edges before it — array for array what build_csr
     makes of the batch's COO (rows stay in part order, a row's edges in ascending edge id)."""
@@ -675,8 +693,8 @@ def _concat_csr(graphs, node_off, n_edges, node_off_per_edge, total):
     E = int(sum(n_edges))
     sizes = [g._n for g in graphs]
     e_off = np.concatenate([[0], np.cumsum(n_edges[:-1])]).astype(np.int64)
-    if dev.type == "cuda":
-        jobs, views = _ConcatJobs(), []
+    if jobs is not None:         # on the device: pieces of a job table (the caller runs it)
+        views = []
         n0, e0 = np.asarray(node_off, np.int64), np.asarray(e_off, np.int64)
         for name in ("csr", "csr_t"):
             parts = [getattr(g, name) for g in graphs]
@@ -691,7 +709,6 @@ def _concat_csr(graphs, node_off, n_edges, node_off_per_edge, total):
                 jobs.add([v.nidx.data_ptr() for v in parts], nidx, e0, n_edges, add=e0)
             jobs.add([0], indptr, [total], [1], add=E, kind=2)
             views.append(CsrView(total, total, indptr, indices, eid, nidx))
-        jobs.run(dev)
         return views
     rep = lambda vals, counts, size: torch.from_numpy(np.repeat(vals, counts)).to(torch.int32)
     e_off_per_node = rep(e_off, sizes, total)
