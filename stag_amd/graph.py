@@ -632,7 +632,7 @@ def batch(graphs):
         edge_off = torch.from_numpy(np.repeat(node_off, n_edges))
     src = torch.cat([g._src for g in graphs]).to(torch.int64) + edge_off
     dst = torch.cat([g._dst for g in graphs]).to(torch.int64) + edge_off
-    out = Graph(src, dst, total, batch_num_nodes=torch.tensor(sizes, dtype=torch.int64, device=dev))
+    out = Graph(src, dst, total, batch_num_nodes=torch.tensor(sizes, dtype=torch.int64, device=dev), _trusted=True)
     if 1 < len(graphs) <= BATCH_CONCAT_MAX_GRAPHS and sum(n_edges) > 0:
         # a block-diagonal union's CSRs are its parts' CSRs laid end to end: no sort per batch (the parts keep theirs —
         # a data loader hands the same graphs out again every epoch)
