@@ -14,10 +14,12 @@ Device layout (all int32, built once, kept resident in HBM):
              of the edge, so the backward redraws the forward's noise
     plan     long-row segment lists (stag_plan_*)  per seg_len
 """
+import collections
 import contextlib
 import ctypes as C
 
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -601,8 +603,49 @@ def add_reverse_edges(g, copy_ndata=True, copy_edata=False):
     return new
 
 
+# batch() keeps the structure (COO, CSR views, plans) of the last BATCH_CACHE_SIZE unions, keyed by WHICH graphs were
+# batched in WHICH order: a data loader that shuffles 20 PPI graphs into batches of 2 (scripts/ppi_mle/run.py:14) meets the
+# same combination again within a few epochs, and a validation set batched once per epoch always does.  A hit costs the
+# frames' concatenation only and inherits the cached union's plans (and, once it has been launched 16 times, its
+# XCD-aware order).  The parts are held weakly; 0 switches it off.
+BATCH_CACHE_SIZE = int(os.environ.get("STAG_BATCH_CACHE", "128"))
+_batch_cache = collections.OrderedDict()
+
+
+def _batch_cached(graphs):
+    if BATCH_CACHE_SIZE <= 0 or len(graphs) > BATCH_CONCAT_MAX_GRAPHS:
+        return None, None
+    owners = [g._cache_owner() for g in graphs]
+    key = tuple(id(o) for o in owners)
+    hit = _batch_cache.get(key)
+    if hit is not None and all(r() is o for r, o in zip(hit[0], owners)):
+        _batch_cache.move_to_end(key)
+        out = hit[1]._share_structure()
+        out.ndata, out.edata, out._origin = {}, {}, hit[1]
+        return out, key
+    return None, key
+
+
+def _batch_remember(key, graphs, out):
+    if key is None:
+        return
+    _batch_cache[key] = ([weakref.ref(g._cache_owner()) for g in graphs], out)
+    while len(_batch_cache) > BATCH_CACHE_SIZE:
+        _batch_cache.popitem(last=False)
+
+
 def batch(graphs):
     """Block-diagonal union (`dgl.batch`, scripts/ppi_mle/run.py:12-14)."""
+    graphs = list(graphs)
+    cached, key = _batch_cached(graphs)
+    if cached is not None:
+        return _batch_frames(cached, graphs)
+    out = _batch_build(graphs)
+    _batch_remember(key, graphs, out)
+    return _batch_frames(out, graphs)
+
+
+def _batch_build(graphs):
     # one concatenation per array and ONE offset add over all edges (a batch of 4096 molecules is 4096 graphs: an add
     # per graph would be 8192 launches of a few bytes each)
     dev = graphs[0].device
@@ -624,7 +667,7 @@ def batch(graphs):
         jobs.run(dev)
         out = Graph(src, dst, total, batch_num_nodes=torch.tensor(sizes, dtype=torch.int64, device=dev), _trusted=True)
         out._csr, out._csr_t = views
-        return _batch_frames(out, graphs)
+        return out
     if dev.type == "cuda":      # on the device, output size given: no host pass over the edges, no read-back
         edge_off = torch.repeat_interleave(torch.from_numpy(node_off).to(dev), torch.tensor(n_edges, dtype=torch.int64, device=dev),
                                            output_size=int(sum(n_edges)))
@@ -637,7 +680,7 @@ def batch(graphs):
         # a block-diagonal union's CSRs are its parts' CSRs laid end to end: no sort per batch (the parts keep theirs —
         # a data loader hands the same graphs out again every epoch)
         out._csr, out._csr_t = _concat_csr(graphs, node_off, n_edges, edge_off.to(torch.int32), total)
-    return _batch_frames(out, graphs)
+    return out
 
 
 def _batch_frames(out, graphs):

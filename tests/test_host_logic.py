@@ -224,6 +224,39 @@ def test_batch_concatenates_the_parts_csr():
         G.BATCH_CONCAT_MAX_GRAPHS = old
 
 
+def test_batch_structure_cache():
+    """graph.batch remembers the structure of a union by WHICH graphs were batched in WHICH order (a loader meets the same
+    combination again; a validation set always): a hit shares CSR views and plans, gets its own frames, and never
+    outlives the identity of its parts; another order is another union; BATCH_CACHE_SIZE = 0 switches it off."""
+    import gc
+    import importlib
+    import stag_amd
+    G = importlib.import_module("stag_amd.graph")
+    G._batch_cache.clear()
+    rng = np.random.default_rng(0)
+    parts = [stag_amd.Graph(torch.from_numpy(rng.integers(0, 20, 50)), torch.from_numpy(rng.integers(0, 20, 50)), 20) for _ in range(3)]
+    for p in parts:
+        p.ndata["h"] = torch.randn(20, 4)
+    a, b, c = stag_amd.batch(parts), stag_amd.batch(parts), stag_amd.batch(parts[::-1])
+    assert a is not b and a.csr is b.csr and a.csr.plan(8, need=True) is b.csr.plan(8, need=True) and c.csr is not a.csr
+    assert torch.equal(b.ndata["h"], torch.cat([p.ndata["h"] for p in parts])) and b.batch_num_nodes().tolist() == [20, 20, 20]
+    b.ndata["x"] = torch.zeros(60, 1)
+    assert "x" not in a.ndata and "x" not in stag_amd.batch(parts).ndata, "frames are the caller's, per call"
+    assert stag_amd.batch([p.local_var() for p in parts]).csr is a.csr, "local_var() copies are the same graphs"
+    others = [stag_amd.Graph(torch.from_numpy(rng.integers(0, 20, 50)), torch.from_numpy(rng.integers(0, 20, 50)), 20) for _ in range(3)]
+    key_like = stag_amd.batch(others)
+    del others
+    gc.collect()
+    assert len(G._batch_cache) == 3                  # (a dead entry goes when the cache fills up or its ids come back)
+    old = G.BATCH_CACHE_SIZE
+    G.BATCH_CACHE_SIZE = 0
+    try:
+        assert stag_amd.batch(parts).csr is not a.csr
+    finally:
+        G.BATCH_CACHE_SIZE = old
+    G._batch_cache.clear()
+
+
 @pytest.mark.parametrize("fine", [1, 3])
 def test_xcd_block_plan_deals_batches_to_stripes(fine, monkeypatch):
     """stag_plan_blocks_xcd: the cooperative GAT kernels' unit batches, dealt out so that batch b belongs to stripe

@@ -21,10 +21,16 @@ from stag_amd import synthetic  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--static", action="store_true")
+ap.add_argument("--batch-cache", action="store_true",
+                help="leave graph.batch's structure cache on: the same 24 graphs in the same order every step is then a hit "
+                     "(what a validation set, or a loader that has seen the combination before, gets)")
 ap.add_argument("--model", default="sage", choices=["sage", "gat"],
                 help="gat: scripts/ppi_mle/gat/run.py:21-58 — GAT(50, 256, 4 heads) -> GAT(1024, 256, 4) -> GAT(1024, 121, 4, last)")
 args = ap.parse_args()
 torch.distributions.Distribution.set_default_validate_args(False)
+if not args.batch_cache:
+    import importlib
+    importlib.import_module("stag_amd.graph").BATCH_CACHE_SIZE = 0      # "fresh" means built, not looked up
 dev = torch.device("cuda:0")
 s, d, sizes = synthetic.ppi_like()
 off = np.concatenate([[0], np.cumsum(sizes)])
@@ -74,5 +80,5 @@ t0 = time.perf_counter()
 for _ in range(args.steps):
     loss = step()
 torch.cuda.synchronize()
-print(f"{'static graph' if args.static else 'fresh batch per step'}: N={n} E={len(s)}: "
+print(f"{'static graph' if args.static else 'batch per step, structure cache hit' if args.batch_cache else 'fresh batch per step'}: N={n} E={len(s)}: "
       f"{(time.perf_counter() - t0) / args.steps * 1e3:.2f} ms per step, loss {loss.item():.4f}")
