@@ -372,8 +372,8 @@ class Graph:
         if src.shape != dst.shape or src.dim() != 1:
             raise ValueError("src and dst must be 1-D tensors of equal length")
         if num_nodes is None:
-            num_nodes = int(max(src.max().item(), dst.max().item())) + 1 if src.numel() else 0
-        elif not _trusted and src.numel() and int(max(src.max().item(), dst.max().item())) >= num_nodes:
+            num_nodes = int(torch.maximum(src.max(), dst.max()).item()) + 1 if src.numel() else 0      # (one read-back)
+        elif not _trusted and src.numel() and int(torch.maximum(src.max(), dst.max()).item()) >= num_nodes:
             raise ValueError("node id out of range")      # (_trusted: a union of checked graphs — two read-backs saved)
         if src.numel() >= 2 ** 31:
             raise ValueError("more than 2^31-1 edges: shard the graph (stag_amd.partition)")
