@@ -2,6 +2,7 @@
 """Timings of the other BASELINE configs' hot ops on one GPU (not the bench line).
   cfg3     PPI-like GraphSAGE (24 graphs batched): mean aggregation, D=256
   cfg3_l1  the same batch at D=50 (PPI's input width: the first layer)
+  cfg3_gat (not in the default list) GAT forward, 4 heads x 256, on the same batch (scripts/ppi_mle/gat)
   cfg4     molhiv-like GIN: 4096 small graphs batched, sum, D=128, + mean readout
   cfg4_l1  the same batch at D=9 (molhiv's atom features: the first layer)
   cfg5     arxiv GAT: H=8, F=32, noise [E,8], forward
@@ -140,6 +141,17 @@ def main():
                 t = timeit(lambda i: ops.aggregate(g3, x3, noise(i), reduce="mean"), args.steps, args.warmup)
             b = 4 * (n3 + 1) + 4 * E3 + 8 * n3 * D
             out.append(report(name, f"SAGE mean D={D}, 24 PPI-like graphs batched (N={n3}, E={E3}) noise={args.noise}",
+                              t, E3, b))
+        if "cfg3_gat" in only:      # scripts/ppi_mle/gat/run.py:21-58: 4 heads x 256 on the same batch (not a BASELINE config)
+            H, F = 4, 256
+            g3.csr.plan(64, need=True)
+            el, er = torch.randn(n3, H, device=dev), torch.randn(n3, H, device=dev)
+            ft = torch.randn(n3, H, F, device=dev)
+            noise = mk(g3, H)
+            with torch.no_grad():
+                t = timeit(lambda i: ops.gat_aggregate(g3, el, er, ft, 0.2, noise(i)), args.steps, args.warmup)
+            b = 4 * (n3 + 1) + 4 * E3 + 8 * n3 * H + 2 * 4 * n3 * H * F
+            out.append(report("cfg3_gat", f"GAT forward H={H} F={F}, 24 PPI-like graphs batched (N={n3}, E={E3}) noise[E,{H}]={args.noise}",
                               t, E3, b))
         del g3
 
