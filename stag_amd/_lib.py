@@ -52,6 +52,10 @@ class Plan(C.Structure):
                 ("xcd_order", _vp), ("xcd_stride_heavy", C.c_int32), ("xcd_stride_light", C.c_int32)]
 
 
+class ConcatJob(C.Structure):      # stag_concat_job: graph._ConcatJobs writes these records with numpy (4 int64 per job)
+    _fields_ = [("src", _vp), ("dst", _vp), ("count", C.c_int64), ("add", C.c_int32), ("kind", C.c_int32)]
+
+
 class StagHipError(RuntimeError):
     pass
 

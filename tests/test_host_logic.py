@@ -52,6 +52,9 @@ def test_abi_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.Csr) == 48
     assert ctypes.sizeof(_lib.NoiseSpec) == 88
     assert ctypes.sizeof(_lib.Plan) == 96 and _lib.Plan.xcd_order.offset == 80
+    # stag_concat_job: graph._ConcatJobs lays these out with numpy — int64 columns 0..2, int32 columns 6 and 7
+    assert ctypes.sizeof(_lib.ConcatJob) == 32 and _lib.ConcatJob.count.offset == 16 \
+        and _lib.ConcatJob.add.offset == 24 and _lib.ConcatJob.kind.offset == 28
     assert _lib.NoiseSpec.deriv.offset == 40 and _lib.NoiseSpec.seed.offset == 48 and _lib.NoiseSpec.pos_base.offset == 64
 
 
