@@ -5,28 +5,42 @@ D=128, fp32, Normal(1, 0.5) per-edge per-channel noise, one Monte-Carlo sample).
 
 A "step" = one pass of the hot path: `ops.aggregate(graph, x, EdgeNoise)` =
 noise draw + gather + weighted segmented sum, fresh Philox offset per step.  Inputs
-are resident in HBM before the timed region.
+are resident in HBM before the timed region.  `--workload gat` makes BASELINE configs[4]'s
+layer-forward the step instead (arxiv GAT, 8 heads x 32, noise [E, 8]: `ops.gat_aggregate`).
 
 `--gpus N` with N > 1: the SAME graph is node-range partitioned over N ranks
 (stag_amd.partition.GraphShard: contiguous destination-row ranges cut at equal edge counts) and
 a step is the RCCL exchange of the referenced source rows over xGMI + the local kernel, the rows
 with only local sources overlapping the collective.  Total work is fixed => "strong" scaling.
-Started without a launcher (`python bench.py --gpus N`), the script spawns its N ranks itself
-before anything touches a GPU; under `python -m torch.distributed.run` it reads RANK / LOCAL_RANK /
-WORLD_SIZE from the environment.  `--partition channels` (the exchange-free alternative for graphs
-that fit one GPU) is timed in a second, shorter loop and reported as `alt_partition`.
+Started without a launcher (`python bench.py --gpus N`), the script spawns its N ranks itself —
+the parent counts the node's GPUs from the KFD topology in sysfs and never loads the HIP runtime —;
+under `python -m torch.distributed.run` it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
+
+The N > 1 line carries its own correctness evidence (`partition_check`: every rank also runs the
+WHOLE-graph launch once and compares its rows bit for bit with what the partitioned step produced
+through the real collective; the backward against the whole graph's at 1e-5), the GAT partition of
+BASELINE configs[4] in a second, shorter loop (`gat_partition`, with the same check), the
+exchange-free channel partition (`alt_partition`), per-rank device times, the exchange alone and the
+kernels alone (`exchange`), the RCCL version, and the two transports of the exchange as timed
+variants (`comm_variants`: torch.distributed's all_to_all_single | the library's own grouped
+ncclSend/ncclRecv, `stag_halo_exchange_multi`).  Everything after the headline loop is best-effort:
+an exception becomes an `error` string in its object, and a watchdog prints the line as far as it
+got if an extra hangs.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects: `roofline`
 (algorithmic bytes / device time of the op, measured with HIP events on the launch stream, against
 the 8 TB/s HBM peak; `ceilings` = the two limits that bind before HBM does), `cpu_baseline` (the
-oracle's reference-dataflow twin on the host cores; N=1 only; a baseline, not a target) and, for
-N > 1, `exchange` (bytes and device time of the collective alone and of the kernels alone).
+oracle's reference-dataflow twin on the host cores; N=1 only; a baseline, not a target), `variants`
+(N=1: the other single-GPU BASELINE configs and forms, each with its own device time and fraction).
 """
 import argparse
+import glob
 import json
 import os
 import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 import numpy as np
@@ -37,16 +51,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+GAT_H, GAT_F = 8, 32    # BASELINE configs[4]: 8 heads, hidden 256
+CHECK_OFFSET = 7777     # Philox offset of the launches the partition check compares
 
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # 2000 x ~115 us: a quarter of a second.  The first ~15 launches after any host sync run at
+    # 2000 x ~100 us: a fifth of a second.  The first ~15 launches after any host sync run at
     # ~140 us and the clocks keep rising for ~25 ms of sustained load (rocprofv3 kernel trace:
-    # 121 -> 112.5 us over 200 launches), so a 200-step run reads 121 us, 1000+ steps 113 us.
+    # 121 -> 112.5 us over 200 launches), so a 200-step run reads higher than 1000+ steps.
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="agg", choices=["agg", "gat"],
+                    help="agg (default): BASELINE configs[1], the metric's configuration; gat: configs[4]'s layer-forward "
+                         "(arxiv GAT 8 x 32, noise [E, 8]) as the step — at N > 1 the node-range partitioned GAT")
     ap.add_argument("--feat", type=int, default=128)
     ap.add_argument("--noise", default="normal", choices=["normal", "uniform", "bernoulli", "none"])
     ap.add_argument("--graph", default="arxiv", choices=["arxiv", "arxiv_sym"],
@@ -60,71 +79,136 @@ def parse(argv=None):
     ap.add_argument("--no-alt", action="store_true",
                     help="N>1: skip the second, shorter timed loop over the partition NOT chosen "
                          "(reported as `alt_partition` in the same JSON line)")
+    ap.add_argument("--no-gat", action="store_true",
+                    help="N>1, --workload agg: skip the shorter loop over the partitioned GAT step (`gat_partition`)")
+    ap.add_argument("--no-check", action="store_true",
+                    help="N>1: skip `partition_check` (whole-graph launch on every rank, bitwise comparison)")
+    ap.add_argument("--no-comm-variants", action="store_true",
+                    help="N>1 over RCCL: skip the second timed loop over the other transport of the exchange")
     ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"])
     ap.add_argument("--no-overlap", action="store_true",
                     help="N>1, nodes: launch all rows behind the collective instead of overlapping the "
                          "local-source rows with it")
     ap.add_argument("--native-comm", action="store_true",
-                    help="N>1, nodes: the exchange through the library's own RCCL communicator "
-                         "(stag_halo_exchange, include/stag_hip.h) instead of torch.distributed")
+                    help="N>1, nodes: the HEADLINE exchange through the library's own RCCL communicator "
+                         "(stag_halo_exchange_multi, include/stag_hip.h) instead of torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
-                    help="N=1: skip the short loops over the other workload variants (`variants` in the line: the "
-                         "script's preprocessed graph arxiv_sym, Bernoulli + in-norm, no noise) and the cold reading")
+                    help="N=1: skip the short loops over the other workload variants (`variants` in the line) and the "
+                         "cold reading")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--settle-ms", type=float, default=300.0,
                     help="untimed launches of the same step before the W warm-up steps, until this much wall time "
                          "has passed: the card raises its clocks over the first ~100 ms of load, and a 20-step run "
                          "(2 ms of work) would otherwise time the ramp (DESIGN.md section 5); 0 = none")
+    ap.add_argument("--extras-timeout-s", type=float, default=float(os.environ.get("STAG_BENCH_EXTRAS_TIMEOUT_S", "420")),
+                    help="N>1: wall-clock budget of everything after the headline loop; when it runs out rank 0 prints "
+                         "the line as far as it got and every rank exits")
     ap.add_argument("--rehearse", action="store_true",
                     help="plumbing check without a GPU: ranks, rendezvous (gloo), partition and exchange run on "
                          "CPU tensors, NO kernel is launched; the line carries rehearsal=true and value=null")
     return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------- launcher
+def node_gpu_count(topology="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs of this node as the KFD driver lists them, WITHOUT loading the HIP runtime (the launcher parent must
+    not initialise a GPU before it starts its ranks): topology nodes with a non-zero simd_count are GPUs, the
+    CPUs have simd_count 0.  Narrowed by ROCR_/HIP_/CUDA_VISIBLE_DEVICES.  Falls back to a throw-away child
+    interpreter when sysfs is not readable.  -> (count, how)"""
+    n, how = 0, "kfd topology (sysfs)"
+    files = sorted(glob.glob(os.path.join(topology, "*", "properties")))
+    readable = False
+    for f in files:
+        try:
+            with open(f) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            readable = True
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        except (OSError, ValueError):
+            pass
+    if not readable:
+        how = "child interpreter (torch.cuda.device_count)"
+        try:
+            r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                               capture_output=True, text=True, timeout=300)
+            n = int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
+        except (subprocess.SubprocessError, ValueError):
+            n = 0
+    else:
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            v = os.environ.get(var)
+            if v is not None:
+                n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n, how
+
+
 def self_launch(args):
     """`--gpus N` without a launcher: start the N ranks as child processes (fresh interpreters — this
-    process has not touched a GPU and never will) and relay rank 0's line.  -> exit code."""
+    process never loads the HIP runtime) and relay rank 0's line.  A rank that fails is named with its
+    exit code and the tail of its stderr.  -> exit code."""
     import socket
     backend = "gloo" if args.rehearse else os.environ.get("STAG_BENCH_BACKEND", "nccl")
     if backend == "nccl":
-        ndev = torch.cuda.device_count()          # counts devices without initialising the runtime
+        ndev, how = node_gpu_count()
         if ndev < args.gpus:
-            sys.stderr.write(f"bench.py: --gpus {args.gpus} but this node exposes {ndev} GPU(s); RCCL needs one "
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but this node exposes {ndev} GPU(s) [{how}]; RCCL needs one "
                              f"device per rank. Nothing was measured.\n")
             return 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, logs = [], []
+    tmp = tempfile.mkdtemp(prefix="stag_bench_")
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        log = open(os.path.join(tmp, f"rank{r}.stderr"), "w+")
+        logs.append(log)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
+                                      stdout=None if r == 0 else subprocess.DEVNULL, stderr=log))
+    rank_of = {p.pid: r for r, p in enumerate(procs)}
+    rc, failed = 0, None
     deadline = time.time() + float(os.environ.get("STAG_BENCH_TIMEOUT_S", "1500"))
-    while procs:
-        for p in list(procs):
+    live = list(procs)
+    while live:
+        for p in list(live):
             code = p.poll()
             if code is None:
                 continue
-            procs.remove(p)
+            live.remove(p)
             if code != 0 and rc == 0:
-                rc = code
+                rc, failed = code, rank_of[p.pid]
         if rc != 0 or time.time() > deadline:      # one rank failed (or hung): stop the others, exactly these PIDs
-            for p in procs:
+            for p in live:
                 p.terminate()
-            for p in procs:
+            for p in live:
                 try:
                     p.wait(10)
                 except subprocess.TimeoutExpired:
                     p.kill()
-            return rc or 124
+            rc = rc or 124
+            break
         time.sleep(0.05)
+    for r, log in enumerate(logs):
+        log.flush()
+        log.seek(0)
+        text = log.read()
+        log.close()
+        if rc != 0 and (r == failed or (failed is None and text.strip())):
+            sys.stderr.write(f"bench.py: rank {r} " + (f"exited with code {rc}" if r == failed else "(stopped)") +
+                             f"; last lines of its stderr:\n" + "\n".join(text.strip().splitlines()[-25:]) + "\n")
+        elif rc == 0 and r == 0 and text.strip():
+            sys.stderr.write(text)          # rank 0's warnings, as if it had written them itself
+    if rc == 124 and failed is None:
+        sys.stderr.write("bench.py: the ranks did not finish within STAG_BENCH_TIMEOUT_S; stopped.\n")
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
     return rc
 
 
+# ------------------------------------------------------------------------------------------------- helpers
 def make_noise(stag_amd, graph, D, kind, offset):
     from stag_amd import _lib
     if kind == "none":
@@ -182,9 +266,9 @@ def committed_profile(args, world):
     this run: PMC collection needs its own rocprofv3 passes (tools/profile_bench.py)."""
     if world != 1:
         return None, None
-    key = f"{args.graph}/{args.noise}/D{args.feat}/seg{args.seg_len}"
+    key = f"{args.graph}/{args.noise}/D{args.feat}/seg{args.seg_len}" if args.workload == "agg" else \
+        f"{args.graph}/gat{GAT_H}x{GAT_F}/{args.noise}/seg{args.seg_len}"
     best = (None, None)
-    import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "bench_*_pmc_summary.json"))):
         try:
             t = json.load(open(f)).get("traffic", {})
@@ -195,6 +279,32 @@ def committed_profile(args, world):
     return best
 
 
+class Watchdog:
+    """Everything after the headline loop of an N > 1 run is best-effort.  If it has not finished after `seconds`
+    (a collective that never completes), rank 0 prints the line as far as it got and every rank leaves."""
+
+    def __init__(self, seconds, rank, line_fn):
+        self.rank, self.line_fn, self.done = rank, line_fn, threading.Event()
+        self.t = threading.Thread(target=self._run, args=(seconds,), daemon=True)
+        self.t.start()
+
+    def _run(self, seconds):
+        if self.done.wait(seconds):
+            return
+        if self.rank == 0:
+            line = self.line_fn()
+            line["extras_timed_out_after_s"] = seconds
+            print(json.dumps(line), flush=True)
+        sys.stderr.write(f"bench.py: rank {self.rank}: the extra loops did not finish in {seconds:.0f} s; "
+                         f"the headline measurement stands, leaving.\n")
+        sys.stderr.flush()
+        os._exit(0)
+
+    def cancel(self):
+        self.done.set()
+
+
+# ------------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
     if args.gpus < 1:
@@ -207,6 +317,8 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     rehearse = args.rehearse
+    if os.environ.get("STAG_BENCH_FAIL_RANK") == str(rank) and world > 1:      # test hook: how the launcher reports a dead rank
+        raise SystemExit(f"bench.py: rank {rank} asked to fail (STAG_BENCH_FAIL_RANK)")
     if not rehearse and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the stochastic-aggregation path has no CPU fallback "
                          "(--rehearse checks the multi-rank plumbing without one)")
@@ -217,6 +329,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL ("nccl") always in a real run; STAG_BENCH_BACKEND=gloo only rehearses the N>1 code
@@ -230,7 +343,7 @@ def main():
             dist.init_process_group(backend, timeout=datetime.timedelta(minutes=5))
 
     import stag_amd
-    from stag_amd import ops, synthetic
+    from stag_amd import _lib, ops, synthetic
     from stag_amd.partition import GraphShard
 
     src, dst = synthetic.arxiv_like(seed=1)
@@ -238,7 +351,18 @@ def main():
     if args.graph == "arxiv_sym":
         src, dst = synthetic.with_self_loops_and_reverse(src, dst, n)
     E, D = len(src), args.feat
-    x_host = torch.randn(n, D, generator=torch.Generator().manual_seed(0))
+    H, F = GAT_H, GAT_F
+    gen0 = torch.Generator().manual_seed(0)
+    x_host = torch.randn(n, D, generator=gen0)
+    gat_host = None
+
+    def gat_inputs():
+        """el, er [N, H], ft [N, H, F] of the GAT step (seeded, the same on every rank)."""
+        nonlocal gat_host
+        if gat_host is None:
+            g = torch.Generator().manual_seed(5)
+            gat_host = (torch.randn(n, H, generator=g), torch.randn(n, H, generator=g), torch.randn(n, H, F, generator=g))
+        return gat_host
 
     def sync():
         if not rehearse:
@@ -250,38 +374,95 @@ def main():
             dist.barrier()
             sync()
 
-    def make_step(partition):
+    _whole = {}
+
+    def whole_graph():
+        if "g" not in _whole:
+            _whole["g"] = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
+            _whole["g"].csr.plan(args.seg_len)
+        return _whole["g"]
+
+    _shards = {}
+
+    def node_shard():
+        if "s" not in _shards:
+            _shards["s"] = GraphShard(src, dst, n, rank, world, device=dev, exchange=args.exchange)
+        return _shards["s"]
+
+    def use_native(shard, on):
+        """Switch the shard's exchange between torch.distributed (None) and the library's own communicator."""
+        if not on:
+            shard.native_comm = None
+            return
+        if "native" not in _shards:
+            from stag_amd.partition import NativeComm
+            _shards["native"] = NativeComm(rank, world, dev)
+        shard.native_comm = _shards["native"]
+
+    def gat_noise(graph, i, pos_base=None):
+        nz = make_noise(stag_amd, graph, H, args.noise, i)
+        if nz is not None and pos_base is not None:
+            nz.pos_base = pos_base
+        return nz
+
+    def make_step(workload, partition):
         """-> (step(i), description, parts).  All inputs end up resident in HBM here.  parts: for the node
         partition, the exchange alone and the kernels alone (timed separately for the `exchange` object)."""
         if world == 1:
-            graph = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
-            graph.csr.plan(args.seg_len)
+            graph = whole_graph()
+            if workload == "gat":
+                el, er, ft = (t.to(dev) for t in gat_inputs())
+                graph.csr.plan(args.seg_len, need=True)
+                return (lambda i: ops.gat_aggregate(graph, el, er, ft, 0.2, gat_noise(graph, i),
+                                                    seg_len=args.seg_len)), "single GPU", None
             x = x_host.to(dev)
             return (lambda i: ops.aggregate(graph, x, make_noise(stag_amd, graph, D, args.noise, i),
                                             seg_len=args.seg_len)), "single GPU", None
         if partition == "channels":
+            if workload == "gat":
+                raise ValueError("the channel partition is for the aggregation workload")
             from stag_amd.partition import ChannelShard
-            whole = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
-            whole.csr.plan(args.seg_len)
+            whole = whole_graph()
             shard = ChannelShard(whole, D, rank, world)
             x = shard.scatter_cols(x_host).to(dev)
             return (lambda i: shard.aggregate(x, make_noise(stag_amd, whole, shard.dn, args.noise, i),
                                               seg_len=args.seg_len)), (
                 f"channel shards x{world}: whole CSR per rank, D/{world} channels each, "
                 f"no exchange in the step"), None
-        shard = GraphShard(src, dst, n, rank, world, device=dev, exchange=args.exchange)
-        # this rank's rows live INSIDE the shard's persistent exchange buffer (where a previous layer would have
-        # written them): the step copies nothing into it, the send rows go into a persistent send buffer
-        x = shard.local_rows(D, device=dev)
-        x.copy_(x_host[shard.row_lo:shard.row_hi])
-        if args.native_comm and not rehearse:
-            from stag_amd.partition import NativeComm
-            shard.native_comm = NativeComm(rank, world, dev)
+        shard = node_shard()
         overlap = not args.no_overlap
         coll = "RCCL" if dist.get_backend() == "nccl" else f"{dist.get_backend()} (rehearsal backend, not RCCL)"
         desc = (f"node-range partition x{world}: dst-row ranges cut at equal edge counts, {coll} "
                 f"{'all-to-all of the referenced source rows (halo)' if args.exchange == 'halo' else 'all-gather of padded row shards'}"
                 f" per step over xGMI" + (", local-source rows overlap the collective" if overlap else ""))
+        if workload == "gat":
+            el_h, er_h, ft_h = gat_inputs()
+            lo, hi = shard.row_lo, shard.row_hi
+            el, er, ft = el_h[lo:hi].to(dev), er_h[lo:hi].to(dev), ft_h[lo:hi].to(dev)
+
+            def exchange_only(i):
+                bufs, work = shard.halo_start_multi([ft, el], persistent=True)
+                if work is not None:
+                    work.wait()
+                return bufs[0]
+            if rehearse:
+                return (lambda i: exchange_only(i)), desc, {"shard": shard}
+            shard.csr.plan(args.seg_len, need=True)
+            p_loc, p_rem = shard.plan_split(args.seg_len)
+            ft0, el0 = (b.clone() for b in shard.halo_gather_multi([ft, el]))
+
+            def kernels_only(i):
+                return ops.gat_aggregate(shard, el0, er, ft0, 0.2, gat_noise(shard, i, shard.pos_base),
+                                         seg_len=args.seg_len, _gathered=True)
+            return (lambda i: shard.gat_aggregate(el, er, ft, 0.2, gat_noise(shard, i), seg_len=args.seg_len,
+                                                  overlap=overlap)), desc + "; two tables per step: ft [n, 8, 32], el [n, 8]", {
+                "shard": shard, "exchange_only": exchange_only, "kernels_only": kernels_only,
+                "local_units": p_loc["n_units"], "remote_units": p_rem["n_units"], "inputs": (el, er, ft)}
+        # this rank's rows live INSIDE the shard's persistent exchange buffer (where a previous layer would have
+        # written them): the step copies nothing into it, the send rows go into a persistent send buffer
+        x = shard.local_rows(D, device=dev)
+        x.copy_(x_host[shard.row_lo:shard.row_hi])
+
         def exchange_only(i):
             buf, work = shard.halo_start(x, persistent=True)
             if work is not None:
@@ -292,23 +473,24 @@ def main():
             return (lambda i: exchange_only(i)), desc, {"shard": shard}
         shard.csr.plan(args.seg_len)
         p_loc, p_rem = shard.plan_split(args.seg_len)
-        buf0 = shard.halo_gather(x)         # a filled buffer for the kernels-only loop
-
-        def kernels_only(i):
-            return ops.aggregate(shard, buf0, make_noise_on_shard(i), seg_len=args.seg_len, _gathered=True)
+        buf0 = shard.halo_gather(x).clone()         # a filled buffer for the kernels-only loop
 
         def make_noise_on_shard(i):
             nz = make_noise(stag_amd, shard, D, args.noise, i)
             if nz is not None:
                 nz.pos_base = shard.pos_base
             return nz
+
+        def kernels_only(i):
+            return ops.aggregate(shard, buf0, make_noise_on_shard(i), seg_len=args.seg_len, _gathered=True)
         return (lambda i: shard.aggregate(x, make_noise(stag_amd, shard, D, args.noise, i),
                                           seg_len=args.seg_len, overlap=overlap)), desc, {
             "shard": shard, "exchange_only": exchange_only, "kernels_only": kernels_only,
-            "local_units": p_loc["n_units"], "remote_units": p_rem["n_units"]}
+            "local_units": p_loc["n_units"], "remote_units": p_rem["n_units"], "inputs": (x,)}
 
-    def timed(step, steps, warmup):
-        """-> (wall seconds, device ms per step), MAX over ranks; barrier + sync both sides."""
+    def timed(step, steps, warmup, per_rank=False):
+        """-> (wall seconds, device ms per step), MAX over ranks; barrier + sync both sides.
+        per_rank: also every rank's own device ms per step."""
         with torch.no_grad():
             for i in range(warmup):
                 step(i)
@@ -328,12 +510,18 @@ def main():
             t1 = time.perf_counter()
         wall = t1 - t0
         dev_ms = ev0.elapsed_time(ev1) / steps if not rehearse else wall / steps * 1e3
+        ranks_ms = None
         if world > 1:
+            if per_rank:
+                own = torch.tensor([dev_ms], dtype=torch.float64, device=dev)
+                allr = [torch.zeros_like(own) for _ in range(world)]
+                dist.all_gather(allr, own)
+                ranks_ms = [float(t[0]) for t in allr]
             t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall, dev_ms = float(t[0]), float(t[1])
         assert torch.isfinite(out).all()
-        return wall, dev_ms
+        return (wall, dev_ms, ranks_ms) if per_rank else (wall, dev_ms)
 
     def settle(step):
         """Untimed launches of the step until --settle-ms of wall time has gone by (every rank, same count)."""
@@ -352,8 +540,114 @@ def main():
                 if float(more) == 0.0:
                     return done
 
+    def b_alg_of(workload, n_, E_, D_=None):
+        """indptr + indices + the source table once + the output once (+ el / er for GAT)."""
+        if workload == "gat":
+            return 4 * (n_ + 1) + 4 * E_ + 8 * n_ * H + 2 * 4 * n_ * H * F
+        return 4 * (n_ + 1) + 4 * E_ + 8 * n_ * D_
+
+    # ---------------------------------------------------------------------------- partition check (N > 1)
+    def scaled_err(a, b):
+        return float(((a - b).abs() / (1.0 + b.abs())).max()) if a.numel() else 0.0
+
+    def partition_check(workload, parts):
+        """Every rank runs the WHOLE-graph launch once and compares ITS rows with what the partitioned step —
+        through the real collective — produced: forward bit for bit, with and without the overlap; backward
+        (`_ShardAggregate` / `_ShardGat`: the transposed exchange, fixed-order adds) at 1e-5 against the
+        whole graph's gradient rows (one GPU adds a source row's out-edges in one sum, P ranks add P partial
+        sums: fp32 does not regroup)."""
+        shard = parts["shard"]
+        lo, hi = shard.row_lo, shard.row_hi
+        whole = whole_graph()
+        res = {}
+        if workload == "gat":
+            el_h, er_h, ft_h = gat_inputs()
+            el_w, er_w, ft_w = (t.to(dev).requires_grad_(True) for t in (el_h, er_h, ft_h))
+            gout = torch.randn(n, H, F, generator=torch.Generator().manual_seed(11)).to(dev)
+            whole.csr.plan(args.seg_len, need=True)
+            ref = ops.gat_aggregate(whole, el_w, er_w, ft_w, 0.2, gat_noise(whole, CHECK_OFFSET), seg_len=args.seg_len)
+            ref.backward(gout)
+            el, er, ft = (t.detach().clone().requires_grad_(True) for t in parts["inputs"])
+            got = shard.gat_aggregate(el, er, ft, 0.2, gat_noise(shard, CHECK_OFFSET), seg_len=args.seg_len, overlap=True)
+            got.backward(gout[lo:hi])
+            with torch.no_grad():
+                got2 = shard.gat_aggregate(el, er, ft, 0.2, gat_noise(shard, CHECK_OFFSET), seg_len=args.seg_len,
+                                           overlap=False)
+            berr = max(scaled_err(ft.grad, ft_w.grad[lo:hi]), scaled_err(el.grad, el_w.grad[lo:hi]),
+                       scaled_err(er.grad, er_w.grad[lo:hi]))
+        else:
+            x_w = x_host.to(dev).requires_grad_(True)
+            gout = torch.randn(n, D, generator=torch.Generator().manual_seed(11)).to(dev)
+            ref = ops.aggregate(whole, x_w, make_noise(stag_amd, whole, D, args.noise, CHECK_OFFSET), seg_len=args.seg_len)
+            ref.backward(gout)
+            x = parts["inputs"][0].detach().clone().requires_grad_(True)
+            got = shard.aggregate(x, make_noise(stag_amd, shard, D, args.noise, CHECK_OFFSET), seg_len=args.seg_len,
+                                  overlap=True)
+            got.backward(gout[lo:hi])
+            with torch.no_grad():
+                got2 = shard.aggregate(x, make_noise(stag_amd, shard, D, args.noise, CHECK_OFFSET), seg_len=args.seg_len,
+                                       overlap=False)
+            berr = scaled_err(x.grad, x_w.grad[lo:hi])
+        ref_rows = ref.detach()[lo:hi].reshape(hi - lo, -1)
+        got_rows, got2_rows = got.detach().reshape(hi - lo, -1), got2.reshape(hi - lo, -1)
+        bad = int((got_rows.view(torch.int32) != ref_rows.view(torch.int32)).any(1).sum())
+        bad2 = int((got2_rows.view(torch.int32) != ref_rows.view(torch.int32)).any(1).sum())
+        # a 64-bit checksum of this rank's output bits, position-weighted: listed per rank in the line
+        bits = got_rows.view(torch.int32).to(torch.int64)
+        wts = (torch.arange(bits.shape[1], device=dev, dtype=torch.int64) * 2 + 1).unsqueeze(0)
+        cks = int(((bits * wts).sum(1) * (torch.arange(lo, hi, device=dev, dtype=torch.int64) * 2 + 1)).sum())
+        t = torch.tensor([bad, bad2, hi - lo], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        e = torch.tensor([berr], dtype=torch.float64, device=dev)
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        own = torch.tensor([cks], dtype=torch.int64, device=dev)
+        allc = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(allc, own)
+        res.update({"partition_bit_identical": bool(int(t[0]) == 0 and int(t[1]) == 0),
+                    "rows_compared": int(t[2]), "rows_differing": int(t[0]), "rows_differing_without_overlap": int(t[1]),
+                    "backward_max_scaled_err_vs_whole_graph": float(e[0]), "backward_within_1e-5": bool(float(e[0]) <= 1e-5),
+                    "row_checksums_per_rank": [f"{int(c[0]) & ((1 << 64) - 1):016x}" for c in allc],
+                    "what": "every rank launched the whole graph once (Philox offset %d) and compared its own rows with the "
+                            "partitioned step's through the real collective: forward bitwise (overlap on and off), "
+                            "backward (transposed exchange) at 1e-5" % CHECK_OFFSET})
+        return res
+
+    def exchange_report(parts, width_floats, steps_cap):
+        """bytes of the exchange and, from separate short loops, the collective alone / the kernels alone."""
+        shard = parts["shard"]
+        rb, sb = shard.exchange_bytes(width_floats)
+        own = torch.tensor([rb, sb, shard.number_of_edges(), shard.n_rows], dtype=torch.float64, device=dev)
+        cnt, mx = own.clone(), own.clone()
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        allr = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(allr, own)
+        ex = {"kind": args.exchange, "bytes_received_all_ranks": float(cnt[0]),
+              "bytes_received_max_rank": float(mx[0]), "bytes_sent_max_rank": float(mx[1]),
+              "edges_max_rank": float(mx[2]), "rows_max_rank": float(mx[3]),
+              "bytes_received_per_rank": [float(t[0]) for t in allr], "edges_per_rank": [float(t[2]) for t in allr]}
+        if not rehearse:
+            k2 = max(1, min(args.steps, steps_cap))
+            _, ex_ms, ex_ranks = timed(parts["exchange_only"], k2, min(args.warmup, 10), per_rank=True)
+            _, kr_ms, kr_ranks = timed(parts["kernels_only"], k2, min(args.warmup, 10), per_rank=True)
+            ex.update({"exchange_only_us": ex_ms * 1e3, "kernels_only_us": kr_ms * 1e3, "steps": k2,
+                       "exchange_only_us_per_rank": [v * 1e3 for v in ex_ranks],
+                       "kernels_only_us_per_rank": [v * 1e3 for v in kr_ranks],
+                       "exchange_GBs_max_rank": float(mx[0]) / (ex_ms * 1e-3) / 1e9 if ex_ms > 0 else None,
+                       "exchange_GBs_per_rank": [float(t[0]) / (v * 1e-3) / 1e9 if v > 0 else None
+                                                 for t, v in zip(allr, ex_ranks)],
+                       "local_units": parts["local_units"], "remote_units": parts["remote_units"],
+                       "note": "separate short loops after the headline loop: the collective alone "
+                               "(the send rows gathered into the persistent send buffer + all-to-all) and the local kernels alone "
+                               "on an already exchanged buffer; device time, max over ranks and per rank"})
+        return ex
+
+    # ---------------------------------------------------------------------------- the headline loop
     partition = args.partition
-    step, parallelism, parts = make_step(partition)
+    workload = args.workload
+    step, parallelism, parts = make_step(workload, partition)
+    if world > 1 and args.native_comm and not rehearse and parts is not None:
+        use_native(parts["shard"], True)
     cold = None
     if world == 1 and not rehearse and not args.no_variants:
         # the same K steps BEFORE the settle phase: what a short run reads while the card is still raising its
@@ -363,42 +657,62 @@ def main():
                 "warmup": args.warmup, "note": "timed before the settle phase (clocks still rising); the headline "
                                                "loop below runs after it"}
     settle_steps = settle(step)
-    wall, dev_ms = timed(step, args.steps, args.warmup)
+    if world > 1:
+        wall, dev_ms, dev_ms_ranks = timed(step, args.steps, args.warmup, per_rank=True)
+    else:
+        (wall, dev_ms), dev_ms_ranks = timed(step, args.steps, args.warmup), None
 
     def variant_loops():
-        """Short timed loops over the other workload variants of BASELINE configs[1]: the graph after
-        the script's own preprocessing (scripts/arxiv_mle/gcn/run.py:53-55: E = 2,671,154), the script's
-        Bernoulli + in-norm noise (:70-74), and no noise (the plain gather); each with its own device time and
-        fraction of the HBM roofline on its own algorithmic bytes."""
+        """Short timed loops over the other single-GPU BASELINE configs and forms, each with its own
+        device time and fraction of the HBM roofline on its own algorithmic bytes: configs[1] after the script's own
+        preprocessing (scripts/arxiv_mle/gcn/run.py:53-55: E = 2,671,154), with the script's Bernoulli + in-norm
+        noise (:70-74) and without noise; configs[2] (PPI batch, GraphSAGE mean, D = 256: XCD-aware walk and plan
+        order); configs[3] (4096 molecules, GIN sum, D = 128); configs[4]'s layer on one GPU (arxiv GAT 8 x 32)."""
         out = {}
         ks, kw = 200, 20
         graphs = {"arxiv": (src, dst)}
-        for gname, noise in (("arxiv", "bernoulli"), ("arxiv", "none"), ("arxiv_sym", "normal"), ("arxiv_sym", "bernoulli")):
-            if gname == args.graph and noise == args.noise:
-                continue
-            if gname not in graphs:
-                graphs[gname] = synthetic.with_self_loops_and_reverse(*synthetic.arxiv_like(seed=1), n)
-            s_, d_ = graphs[gname]
-            gkey = "_g_" + gname
-            if gkey not in graphs:
-                graphs[gkey] = stag_amd.Graph(torch.from_numpy(s_), torch.from_numpy(d_), n, device=dev)
-                graphs[gkey].csr.plan(args.seg_len)
-            gr, xv, Ev = graphs[gkey], x_host.to(dev), len(s_)
-            st = lambda i, gr=gr, xv=xv, noise=noise: ops.aggregate(gr, xv, make_noise(stag_amd, gr, D, noise, i), seg_len=args.seg_len)
-            w_, d_ms = timed(st, ks, kw)
-            balg = 4 * (n + 1) + 4 * Ev + 8 * n * D
-            out[f"{gname}/{noise}"] = {"graph": gname, "noise": noise + ("+in_norm" if noise == "bernoulli" else ""),
-                                       "E": Ev, "steps": ks, "ms_per_step": w_ / ks * 1e3, "device_ms_per_step": d_ms,
-                                       "edges_per_s": Ev / (w_ / ks), "algorithmic_bytes_per_step": balg,
-                                       "frac": balg / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+        def entry(Ev, w_, d_ms, balg, **kv):
+            return dict(kv, E=Ev, steps=ks, ms_per_step=w_ / ks * 1e3, device_ms_per_step=d_ms, edges_per_s=Ev / (w_ / ks),
+                        algorithmic_bytes_per_step=balg, frac=balg / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        if workload == "agg":
+            for gname, noise in (("arxiv", "bernoulli"), ("arxiv", "none"), ("arxiv_sym", "normal"), ("arxiv_sym", "bernoulli")):
+                if gname == args.graph and noise == args.noise:
+                    continue
+                if gname not in graphs:
+                    graphs[gname] = synthetic.with_self_loops_and_reverse(*synthetic.arxiv_like(seed=1), n)
+                s_, d_ = graphs[gname]
+                gkey = "_g_" + gname
+                if gkey not in graphs:
+                    graphs[gkey] = stag_amd.Graph(torch.from_numpy(s_), torch.from_numpy(d_), n, device=dev)
+                    graphs[gkey].csr.plan(args.seg_len)
+                gr, xv, Ev = graphs[gkey], x_host.to(dev), len(s_)
+                st = lambda i, gr=gr, xv=xv, noise=noise: ops.aggregate(gr, xv, make_noise(stag_amd, gr, D, noise, i), seg_len=args.seg_len)
+                w_, d_ms = timed(st, ks, kw)
+                out[f"{gname}/{noise}"] = entry(Ev, w_, d_ms, b_alg_of("agg", n, Ev, D), graph=gname,
+                                                noise=noise + ("+in_norm" if noise == "bernoulli" else ""))
+        # BASELINE configs[4]'s layer-forward on ONE GPU (the partitioned form is the N > 1 line's gat_partition)
+        if workload == "agg":
+            gw = whole_graph()
+            gw.csr.plan(args.seg_len, need=True)
+            el, er, ft = (t.to(dev) for t in gat_inputs())
+            for noise in ("normal", "none"):
+                st = lambda i, noise=noise: ops.gat_aggregate(gw, el, er, ft, 0.2, make_noise(stag_amd, gw, H, noise, i),
+                                                              seg_len=args.seg_len)
+                settle(st)
+                w_, d_ms = timed(st, ks, kw)
+                out[f"arxiv_gat/{noise}"] = entry(E, w_, d_ms, b_alg_of("gat", n, E), noise=noise,
+                                                  graph="BASELINE configs[4] on one GPU: arxiv GAT forward, H=8, F=32, noise [E, 8]")
+            del el, er, ft
         # BASELINE configs[2]: the PPI-sized block-diagonal batch (scripts/ppi_mle/run.py:12-14; GraphSAGE mean, hidden
         # 256) — the workload the XCD-aware walk is for (DESIGN.md 4.1): the same launches with it and in plan order
         s3, d3, sizes3 = synthetic.ppi_like()
         n3, E3, D3 = int(sizes3.sum()), len(s3), 256
         x3 = torch.randn(n3, D3, device=dev)
-        balg3 = 4 * (n3 + 1) + 4 * E3 + 8 * n3 * D3
+        balg3 = b_alg_of("agg", n3, E3, D3)
         for order in ("xcd", "plan_order"):
-            g3 = stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), n3, device=dev)
+            g3 = stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), n3,
+                                batch_num_nodes=torch.from_numpy(sizes3).to(dev), device=dev)
             p3 = g3.csr.plan(args.seg_len)
             if order == "xcd":
                 g3.csr._add_xcd_order(p3)                 # what "auto" does for this graph after 16 launches
@@ -409,56 +723,49 @@ def main():
                                                           seg_len=args.seg_len)
                 settle(st)                     # a VALU-bound launch reads its clocks: the headline's settle phase again
                 w_, d_ms = timed(st, ks, kw)
-                out[f"ppi_batch/{noise}/{order}"] = {
-                    "graph": "24 PPI-sized graphs batched (block-diagonal), SAGE mean, D=256", "noise": noise, "unit_order": order,
-                    "stripe_locality": g3.csr.stripe_locality(), "E": E3, "steps": ks, "ms_per_step": w_ / ks * 1e3,
-                    "device_ms_per_step": d_ms, "edges_per_s": E3 / (w_ / ks), "algorithmic_bytes_per_step": balg3,
-                    "frac": balg3 / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                out[f"ppi_batch/{noise}/{order}"] = entry(
+                    E3, w_, d_ms, balg3, graph="BASELINE configs[2]: 24 PPI-sized graphs batched (block-diagonal), SAGE mean, D=256",
+                    noise=noise, unit_order=order, stripe_locality=g3.csr.stripe_locality())
+        del x3, g3
+        # BASELINE configs[3]: 4096 molecules batched, GIN sum aggregation at the hidden width
+        s4, d4, sizes4 = synthetic.molecules_like(4096)
+        n4, E4, D4 = int(sizes4.sum()), len(s4), 128
+        g4 = stag_amd.Graph(torch.from_numpy(s4), torch.from_numpy(d4), n4,
+                            batch_num_nodes=torch.from_numpy(sizes4).to(dev), device=dev)
+        x4 = torch.randn(n4, D4, device=dev)
+        for noise in ("normal", "none"):
+            st = lambda i, noise=noise: ops.aggregate(g4, x4, make_noise(stag_amd, g4, D4, noise, i), seg_len=args.seg_len)
+            settle(st)                         # (also takes the view past the launches after which it gets its plan and order)
+            w_, d_ms = timed(st, ks, kw)
+            out[f"molecule_batch/{noise}"] = entry(E4, w_, d_ms, b_alg_of("agg", n4, E4, D4), noise=noise,
+                                                   graph="BASELINE configs[3]: 4096 molecules batched (block-diagonal), GIN sum, D=128",
+                                                   stripe_locality=g4.csr.stripe_locality())
         return out
 
     variants = variant_loops() if (world == 1 and not rehearse and not args.no_variants) else None
 
-    exchange = None
-    if world > 1 and parts is not None:
-        shard = parts["shard"]
-        rb, sb = shard.exchange_bytes(D)
-        cnt = torch.tensor([rb, sb, shard.number_of_edges(), shard.n_rows], dtype=torch.float64, device=dev)
-        mx = cnt.clone()
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        exchange = {"kind": args.exchange, "bytes_received_all_ranks": float(cnt[0]),
-                    "bytes_received_max_rank": float(mx[0]), "bytes_sent_max_rank": float(mx[1]),
-                    "edges_max_rank": float(mx[2]), "rows_max_rank": float(mx[3])}
-        if not rehearse:
-            k2 = max(1, min(args.steps, 200))
-            _, ex_ms = timed(parts["exchange_only"], k2, min(args.warmup, 10))
-            _, kr_ms = timed(parts["kernels_only"], k2, min(args.warmup, 10))
-            exchange.update({"exchange_only_us": ex_ms * 1e3, "kernels_only_us": kr_ms * 1e3, "steps": k2,
-                             "exchange_GBs_max_rank": float(mx[0]) / (ex_ms * 1e-3) / 1e9 if ex_ms > 0 else None,
-                             "local_units": parts["local_units"], "remote_units": parts["remote_units"],
-                             "note": "separate short loops after the headline loop: the collective alone "
-                                     "(the send rows gathered into the persistent send buffer + all-to-all) and the local kernels alone "
-                                     "on an already exchanged buffer; device time, max over ranks"})
-
-    alt = None
-    if world > 1 and not args.no_alt and not rehearse:
-        other = "nodes" if partition == "channels" else "channels"
-        try:
-            step2, par2, _ = make_step(other)
-            k2 = max(1, min(args.steps, 50))
-            w2, d2 = timed(step2, k2, min(args.warmup, 5))
-            alt = {"partition": other, "parallelism": par2, "steps": k2, "ms_per_step": w2 / k2 * 1e3,
-                   "value": E / (w2 / k2), "unit": "edges/s", "device_ms_per_step": d2}
-        except Exception as exc:   # the headline partition's numbers stand on their own
-            alt = {"partition": other, "error": f"{type(exc).__name__}: {exc}"}
-
+    # ---------------------------------------------------------------------------- the line, as far as the headline
+    line = None
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3
-        b_alg = 4 * (n + 1) + 4 * E + 4 * n * D + 4 * n * D   # indptr + indices + x once + out once
+        b_alg = b_alg_of(workload, n, E, D)
         achieved = b_alg / (dev_ms * 1e-3) / 1e9
         traffic, traffic_source = committed_profile(args, world)
-        b_gather = 4 * (n + 1) + 4 * E + 4 * E * D + 4 * n * D   # SURVEY §8d B_gather: every edge pulls its row
-        n_blocks = E * ((D + 3) // 4)
+        row_bytes = 4 * (H * F if workload == "gat" else D)
+        b_gather = b_alg - 4 * n * (row_bytes // 4) + E * row_bytes   # SURVEY §8d B_gather: every edge pulls its row
+        n_blocks = E * (((H if workload == "gat" else D) + 3) // 4)
+        if workload == "gat":
+            wl = (f"BASELINE configs[4]'s layer-forward: ogbn-arxiv-shaped synthetic CSR ({args.graph}), N={n}, E={E}, "
+                  f"GAT {H} heads x {F}, fp32, int32 CSR, noise={args.noise}(per edge, per head, Philox4x32-10) on the "
+                  f"logits, edge softmax + weighted sum, 1 MC sample")
+            note = ("one step = one stag_gat_fwd call = ONE kernel launch (gat_fwd_block_kernel); device time = HIP event "
+                    "pair around the K launches on the launch stream / K; gather-bound (1-KB rows), see DESIGN.md 4.2")
+        else:
+            wl = (f"BASELINE configs[1]: ogbn-arxiv-shaped synthetic CSR ({args.graph}), N={n}, E={E}, D={D}, fp32, "
+                  f"int32 CSR, noise={args.noise}(per edge, per channel, Philox4x32-10), 1 layer-forward, 1 MC sample")
+            note = ("one step = one stag_agg_fwd call = ONE kernel launch (agg_kernel); device time = "
+                    "HIP event pair around the K launches on the launch stream / K; D=128 per-channel "
+                    "Normal noise is RNG(VALU)- and gather-bound, see DESIGN.md")
         line = {
             "metric": "aggregated edges/sec, stochastic-aggregation layer-forward, ogbn-arxiv-shaped CSR",
             "value": None if rehearse else E / (wall / args.steps), "unit": "edges/s", "n_gpus": world,
@@ -466,11 +773,7 @@ def main():
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: ogbn-arxiv-shaped synthetic CSR "
-                                   f"({args.graph}), N={n}, E={E}, D={D}, fp32, int32 CSR, "
-                                   f"noise={args.noise}(per edge, per channel, Philox4x32-10), "
-                                   f"1 layer-forward, 1 MC sample",
-                       "parallelism": parallelism, "partition": "none" if world == 1 else partition,
+            "config": {"workload": wl, "parallelism": parallelism, "partition": "none" if world == 1 else partition,
                        "seg_len": args.seg_len},
             # N > 1: whole-job algorithmic bytes over the slowest rank's device time, against N x 8 TB/s
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
@@ -484,17 +787,15 @@ def main():
                          "ceilings": {
                              "gather": {"bytes": b_gather, "rate_TBs": 7.4,
                                         "us": b_gather / 7.4e12 * 1e6,
-                                        "why": "uniform-random sources: every edge pulls a D*4-byte row that misses the "
-                                               "4 MB per-XCD L2 (PMC: FETCH x2 = E*D*4); rows come from the Infinity "
-                                               "Cache at the guide's measured random-row rate, 7.4-7.9 TB/s"},
+                                        "why": "uniform-random sources: every edge pulls its whole source row, which misses "
+                                               "the 4 MB per-XCD L2 (PMC: FETCH x2 = E * row bytes); rows come from the "
+                                               "Infinity Cache at the guide's measured random-row rate, 7.4-7.9 TB/s"},
                              "valu_rng": {"philox_blocks": n_blocks, "cycles_per_block_per_wave": 315,
                                           "us": n_blocks / 64 * 315 / 1024 / 2.3e9 * 1e6 if args.noise == "normal" else None,
                                           "why": "one Philox4x32-10 block + 4 Box-Muller normals = 315 issue cycles per "
                                                  "wave (20 v_mad_u64_u32 at 7.6 + transcendentals), 1024 SIMDs at 2.3 GHz"},
                              "frac_if_at_max_of_ceilings": None},
-                         "note": "one step = one stag_agg_fwd call = ONE kernel launch (agg_kernel); device time = "
-                                 "HIP event pair around the K launches on the launch stream / K; D=128 per-channel "
-                                 "Normal noise is RNG(VALU)- and gather-bound, see DESIGN.md"},
+                         "note": note},
         }
         c = line["roofline"]["ceilings"]
         lim = max(c["gather"]["us"], c["valu_rng"]["us"] or 0.0)
@@ -504,21 +805,116 @@ def main():
             line["roofline"] = None
             line["note"] = ("plumbing rehearsal on CPU tensors over gloo: ranks, rendezvous, partition and "
                             "exchange ran, NO kernel was launched, nothing here is a measurement")
-        if world == 1 and not args.no_cpu_baseline and not rehearse:
-            line["cpu_baseline"] = cpu_baseline(src, dst, n, x_host.numpy(), args.noise, args.cpu_budget_s)
-        else:
-            line["cpu_baseline"] = None
+        line["cpu_baseline"] = None
         if cold is not None:
             line["cold"] = cold
         if variants is not None:
             line["variants"] = variants
-        if exchange is not None:
-            line["exchange"] = exchange
-        if alt is not None:
-            line["alt_partition"] = alt
+        if world > 1:
+            line["device_ms_per_step_per_rank"] = dev_ms_ranks
+            line["comm"] = {"backend": dist.get_backend(),
+                            "headline_transport": "stag_halo_exchange_multi (library-owned RCCL communicator)"
+                            if (args.native_comm and not rehearse) else "torch.distributed all_to_all_single / all_gather_into_tensor"}
+            if not rehearse:
+                try:
+                    line["comm"]["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+                except Exception as exc:        # noqa: BLE001 — diagnostics only
+                    line["comm"]["rccl_version"] = f"unavailable ({type(exc).__name__})"
+                line["comm"]["hip"], line["comm"]["torch"] = torch.version.hip, torch.__version__
+
+    # ---------------------------------------------------------------------------- N > 1: everything after the headline
+    def extra(name, fn):
+        """Run one best-effort extra on EVERY rank; rank 0 records its result, or the error."""
+        try:
+            val = fn()
+        except Exception as exc:        # noqa: BLE001 — the headline stands on its own
+            import traceback
+            val = {"error": f"{type(exc).__name__}: {exc}", "where": traceback.format_exc().strip().splitlines()[-3:]}
+        if line is not None and val is not None:
+            line[name] = val
+
+    if world > 1 and parts is not None:
+        dog = Watchdog(args.extras_timeout_s, rank, lambda: dict(line or {})) if not rehearse else None
+        width = (H * F + H) if workload == "gat" else D
+        extra("exchange", lambda: exchange_report(parts, width, 200))
+        if not rehearse and not args.no_check:
+            extra("partition_check", lambda: partition_check(workload, parts))
+
+        if workload == "agg" and not rehearse and not args.no_gat and partition == "nodes":
+            def gat_partition():
+                """BASELINE configs[4] as written: the node-range partitioned GAT layer-forward, timed in its own
+                shorter loop, with its own exchange report and partition check."""
+                step_g, par_g, parts_g = make_step("gat", "nodes")
+                kg = max(1, min(args.steps, 200))
+                settle(step_g)
+                w_, d_ms, ranks_ms = timed(step_g, kg, min(args.warmup, 10), per_rank=True)
+                balg = b_alg_of("gat", n, E)
+                res = {"workload": f"BASELINE configs[4]: arxiv GAT {H} heads x {F}, noise [E, {H}] = {args.noise}, "
+                                   f"node-range partitioned x{world}", "parallelism": par_g, "steps": kg,
+                       "ms_per_step": w_ / kg * 1e3, "value": E / (w_ / kg), "unit": "edges/s",
+                       "device_ms_per_step": d_ms, "device_ms_per_step_per_rank": ranks_ms,
+                       "algorithmic_bytes_per_step": balg,
+                       "frac": balg / (d_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)}
+                try:
+                    res["exchange"] = exchange_report(parts_g, H * F + H, 100)
+                except Exception as exc:        # noqa: BLE001
+                    res["exchange"] = {"error": f"{type(exc).__name__}: {exc}"}
+                if not args.no_check:
+                    try:
+                        res["partition_check"] = partition_check("gat", parts_g)
+                    except Exception as exc:        # noqa: BLE001
+                        res["partition_check"] = {"error": f"{type(exc).__name__}: {exc}"}
+                return res
+            extra("gat_partition", gat_partition)
+
+        if not args.no_alt and not rehearse and workload == "agg":
+            def alt():
+                other = "nodes" if partition == "channels" else "channels"
+                step2, par2, _ = make_step("agg", other)
+                k2 = max(1, min(args.steps, 50))
+                w2, d2 = timed(step2, k2, min(args.warmup, 5))
+                return {"partition": other, "parallelism": par2, "steps": k2, "ms_per_step": w2 / k2 * 1e3,
+                        "value": E / (w2 / k2), "unit": "edges/s", "device_ms_per_step": d2}
+            extra("alt_partition", alt)
+
+        if not rehearse and not args.no_comm_variants and partition == "nodes" and backend == "nccl":
+            def comm_variants():
+                """The same headline step over the OTHER transport of the exchange (last: the library's own
+                communicator has only ever run with one rank before the first multi-GPU run)."""
+                shard = parts["shard"]
+                k2 = max(1, min(args.steps, 200))
+                res = {}
+                head = "native_rccl_group" if args.native_comm else "torch_distributed"
+                res[head] = {"ms_per_step": wall / args.steps * 1e3, "device_ms_per_step": dev_ms, "steps": args.steps,
+                             "headline": True}
+                other = "torch_distributed" if args.native_comm else "native_rccl_group"
+                use_native(shard, not args.native_comm)
+                try:
+                    w2, d2 = timed(step, k2, min(args.warmup, 10))
+                    res[other] = {"ms_per_step": w2 / k2 * 1e3, "device_ms_per_step": d2, "steps": k2}
+                    _, ex2 = timed(parts["exchange_only"], k2, min(args.warmup, 10))
+                    res[other]["exchange_only_us"] = ex2 * 1e3
+                    if not args.no_check:
+                        res[other]["partition_check"] = partition_check(workload, parts)
+                finally:
+                    use_native(shard, args.native_comm)
+                res["what"] = ("torch_distributed: dist.all_to_all_single on RCCL's stream; native_rccl_group: "
+                               "stag_halo_exchange_multi — grouped ncclSend/ncclRecv on a library-owned communicator "
+                               "and side stream, no torch.distributed on the data path")
+                return res
+            extra("comm_variants", comm_variants)
+        if dog is not None:
+            dog.cancel()
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline and not rehearse and workload == "agg":
+            line["cpu_baseline"] = cpu_baseline(src, dst, n, x_host.numpy(), args.noise, args.cpu_budget_s)
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:        # noqa: BLE001 — the line is out
+            pass
 
 
 if __name__ == "__main__":

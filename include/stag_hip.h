@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define STAG_ABI_VERSION 18
+#define STAG_ABI_VERSION 19
 
 #define STAG_OK 0
 #define STAG_EINVAL (-22)   /* bad argument (shape, enum, NULL where required) */
@@ -585,6 +585,25 @@ int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr
                  float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
                  const stag_gat_drop* drop, float* d_el, float* d_er, float* d_ft, float* dw, float* scratch,
                  void* stream);
+/* (v19) stag_gat_bwd one STAGE at a time, for a caller that has something to do between them — a node-range shard
+ * (BASELINE configs[4]; stag_amd/partition.py: _ShardGat) sends the gradient rows of the REMOTE sources back to their
+ * owners while the local ones are still being computed:
+ *     stages = ROWDOT                      step 1 of stag_gat_bwd (sdot and the per-destination records in `scratch`)
+ *     stages = SOURCE, plan_t = sub-plan   step 2 over the units of that sub-plan only: writes d_ft / d_el of ITS rows
+ *                                          (the segments of long rows must all be in one sub-plan) and d s of its edges
+ *     stages = DER                         step 3 (d er), once every SOURCE call has been issued on the stream
+ * with the SAME scratch, plan->workspace and output arrays in every call; plan_t is validated in every call (pass any
+ * of the sub-plans for ROWDOT / DER).  ROWDOT | SOURCE | DER with the whole plan_t is stag_gat_bwd (dw = NULL).
+ * The arithmetic of a unit does not depend on the call it rides in: results are bit-identical to stag_gat_bwd. */
+#define STAG_GAT_BWD_ROWDOT 1
+#define STAG_GAT_BWD_SOURCE 2
+#define STAG_GAT_BWD_DER 4
+int stag_gat_bwd_stages(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
+                        const stag_plan* plan_t, const float* el, const float* er, const float* ft,
+                        const float* stats, const float* g, const float* out, int32_t H, int32_t F,
+                        float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
+                        const stag_gat_drop* drop, float* d_el, float* d_er, float* d_ft, float* scratch,
+                        int32_t stages, void* stream);
 /* (v17) stag_gat_bwd for a REPARAMETERISED draw whose parameters carry gradients (`vi=True`: `rsample`,
  * stag/layers.py:123-124, through the logits of stag/zoo/gat.py:117-119): the same pass also returns the FINISHED
  *   dp_i[h] = sum_e dL/dw[e,h] * dw/dp_i[e,h]      (p0 = loc | low, p1 = scale | high; d/dlog under spec.p1_log;

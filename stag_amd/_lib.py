@@ -18,6 +18,7 @@ _SO = os.environ.get("STAG_HIP_SO") or os.path.join(_HERE, "libstag_hip.so")
 NOISE_NONE, NOISE_EXPLICIT, NOISE_NORMAL, NOISE_UNIFORM, NOISE_BERNOULLI = range(5)
 PARAM_SCALAR, PARAM_PER_CHANNEL, PARAM_PER_EDGE1, PARAM_PER_EDGE = range(4)
 REDUCE_SUM, REDUCE_MEAN = 0, 1
+GAT_BWD_ROWDOT, GAT_BWD_SOURCE, GAT_BWD_DER = 1, 2, 4   # STAG_GAT_BWD_* (stag_gat_bwd_stages)
 HEAVY_LEN = 16   # STAG_HEAVY_LEN (include/stag_hip.h)
 XCD_HEADER, XCD_STRIPES, XCD_FINE_MAX = 32, 8, 16   # STAG_XCD_HEADER, STAG_XCD_STRIPES, STAG_XCD_FINE_MAX
 # STAG_BLOCK_EDGES / STAG_BLOCK_UNITS of include/stag_hip.h (the environment override pairs with a build variant of the
@@ -191,7 +192,10 @@ def bind(path):
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]
     l.stag_halo_exchange_multi.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]
     l.stag_gather_rows.argtypes = [_vp, C.c_int64, _vp, C.c_int64, C.c_int32, _vp, C.c_int64, _vp]
-    if l.stag_abi_version() != 18:
+    l.stag_gat_bwd_stages.argtypes = [C.POINTER(Csr), C.POINTER(Plan), C.POINTER(Csr), C.POINTER(Plan), _vp, _vp, _vp,
+                                      _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_float, C.POINTER(NoiseSpec), _vp,
+                                      C.POINTER(GatDrop), _vp, _vp, _vp, _vp, C.c_int32, _vp]
+    if l.stag_abi_version() != 19:
         raise StagHipError("libstag_hip.so ABI version mismatch")
     return l
 

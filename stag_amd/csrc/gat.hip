@@ -1900,7 +1900,7 @@ static int gat_bwd_impl(const stag_csr* csr, const stag_plan* plan, const stag_c
                         const float* stats, const float* g, const float* out, int32_t H, int32_t F,
                         float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
                         const stag_gat_drop* drop, float* d_el, float* d_er, float* d_ft, float* dw,
-                        float* scratch, void* stream, float* dp0, float* dp1, float* dp_ws);
+                        float* scratch, void* stream, float* dp0, float* dp1, float* dp_ws, int stages = 7);
 
 extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
                             const stag_plan* plan_t, const float* el, const float* er, const float* ft,
@@ -1910,6 +1910,17 @@ extern "C" int stag_gat_bwd(const stag_csr* csr, const stag_plan* plan, const st
                             float* scratch, void* stream) {
   return gat_bwd_impl(csr, plan, csr_t, plan_t, el, er, ft, stats, g, out, H, F, neg_slope, spec, norm_scale, drop,
                       d_el, d_er, d_ft, dw, scratch, stream, nullptr, nullptr, nullptr);
+}
+
+extern "C" int stag_gat_bwd_stages(const stag_csr* csr, const stag_plan* plan, const stag_csr* csr_t,
+                                   const stag_plan* plan_t, const float* el, const float* er, const float* ft,
+                                   const float* stats, const float* g, const float* out, int32_t H, int32_t F,
+                                   float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
+                                   const stag_gat_drop* drop, float* d_el, float* d_er, float* d_ft, float* scratch,
+                                   int32_t stages, void* stream) {
+  if (stages <= 0 || (stages & ~(STAG_GAT_BWD_ROWDOT | STAG_GAT_BWD_SOURCE | STAG_GAT_BWD_DER))) return STAG_EINVAL;
+  return gat_bwd_impl(csr, plan, csr_t, plan_t, el, er, ft, stats, g, out, H, F, neg_slope, spec, norm_scale, drop,
+                      d_el, d_er, d_ft, nullptr, scratch, stream, nullptr, nullptr, nullptr, stages);
 }
 
 extern "C" size_t stag_gat_bwd_dp_workspace_bytes(int32_t n_blocks_t, int32_t H) {
@@ -1943,7 +1954,7 @@ static int gat_bwd_impl(const stag_csr* csr, const stag_plan* plan, const stag_c
                         const float* stats, const float* g, const float* out, int32_t H, int32_t F,
                         float neg_slope, const stag_noise_spec* spec, const float* norm_scale,
                         const stag_gat_drop* drop, float* d_el, float* d_er, float* d_ft, float* dw,
-                        float* scratch, void* stream, float* dp0, float* dp1, float* dp_ws) {
+                        float* scratch, void* stream, float* dp0, float* dp1, float* dp_ws, int stages) {
   if (!csr || !csr_t || !csr->indptr || !csr_t->indptr || csr->n_dst < 0 || csr->n_edges < 0) return STAG_EINVAL;
   if (csr_t->n_edges != csr->n_edges || csr_t->n_dst != csr->n_src || csr_t->n_src != csr->n_dst) return STAG_EINVAL;
   if (!spec || spec->kind < STAG_NOISE_NONE || spec->kind > STAG_NOISE_BERNOULLI || spec->deriv) return STAG_EINVAL;
@@ -1982,7 +1993,7 @@ static int gat_bwd_impl(const stag_csr* csr, const stag_plan* plan, const stag_c
   const int cpl = nchunk <= 64 ? 1 : (nchunk <= 128 ? 2 : 4);
 
   // 1. sdot[v,h] = <G[v,h,:], out[v,h,:]>
-  {
+  if (stages & STAG_GAT_BWD_ROWDOT) {
     const int rl = lpe < lph ? lph : lpe;                       // a head's lanes inside one team
     const int64_t rpb = (int64_t)(256 / rl) * kRowdotRows;
     const dim3 gr((unsigned)((csr->n_dst + rpb - 1) / rpb));
@@ -1996,6 +2007,7 @@ static int gat_bwd_impl(const stag_csr* csr, const stag_plan* plan, const stag_c
   }
 
   // 2. the source-major pass
+  if (stages & STAG_GAT_BWD_SOURCE) {
   GatBwd1Args ba{};
   GatArgs& a = ba.f;
   int rc = fill_edge_args(a, csr_t, plan_t, el, er, H, neg_slope, spec, norm_scale, stats);
@@ -2031,8 +2043,10 @@ static int gat_bwd_impl(const stag_csr* csr, const stag_plan* plan, const stag_c
     hipLaunchKernelGGL(gat_seg_finish_kernel, dim3(plan_t->n_long, (H + 15) / 16), dim3(256), 0, s,
                        plan->workspace, HF + H, HF, H, plan_t->long_rows, plan_t->long_seg_ptr, d_el, H);
   }
+  }
 
   // 3. d er: the in-edges of a row are contiguous in dsl (the source pass's partials are consumed by now)
+  if (stages & STAG_GAT_BWD_DER) {
   const int n_units_f = fplan ? plan->n_units : csr->n_dst;
   const int64_t nth = (int64_t)n_units_f * H;
   hipLaunchKernelGGL(gat_der_kernel, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, s,
@@ -2041,6 +2055,7 @@ static int gat_bwd_impl(const stag_csr* csr, const stag_plan* plan, const stag_c
   if (fplan && plan->n_long > 0)
     hipLaunchKernelGGL(gat_seg_finish_kernel, dim3(plan->n_long, (H + 15) / 16), dim3(256), 0, s,
                        plan->workspace, H, 0, H, plan->long_rows, plan->long_seg_ptr, d_er, H);
+  }
   if (dp_ws) {
     const int rc2 = stag::dp_reduce_partials(dp_ws, plan_t->n_blocks, H, dp_ws + (size_t)plan_t->n_blocks * 2u * (size_t)H, dp0, dp1, s);
     if (rc2) return rc2;

@@ -1333,6 +1333,63 @@ def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec,
     return d_el, d_er, d_ft, dw
 
 
+def _gat_fwd_into(csrv, plan_t, el, er, ft, H, F, neg_slope, spec, nscale, drop, out, stats, dev):
+    """One stag_gat_fwd launch over the units of `plan_t` (the whole plan of csrv or a sub-plan of it: a shard's
+    all-local rows, then the rest — partition._ShardGat) into existing out [n_dst, H, F] / stats [n_dst, 2H]."""
+    nbytes = _lib.lib().stag_gat_workspace_bytes(plan_t["n_seg"], H, F)
+    plan_c, _keep = _plan_struct(csrv, plan_t["seg_len"], 1, nbytes, dev, plan_t=plan_t, gat_width=H * F)
+    cs = csrv.struct()
+    with _lib.on_device(dev):
+        rc = _lib.lib().stag_gat_fwd(C.byref(cs), C.byref(plan_c), _lib.ptr(el), _lib.ptr(er), _lib.ptr(ft), H, F,
+                                     float(neg_slope), C.byref(spec), _lib.ptr(nscale),
+                                     C.byref(drop) if drop is not None else None,
+                                     _lib.ptr(out), _lib.ptr(stats), _lib.stream_of(dev))
+    _lib.check(rc, "stag_gat_fwd")
+
+
+class _GatBwdStages:
+    """stag_gat_bwd one stage at a time (include/stag_hip.h, v19) with the arguments every stage shares held once:
+    `rowdot()`, `source(sub-plan of csr_t)` as often as there are sub-plans, `der()`.  d_ft [csr_t.n_dst, H, F] and
+    d_el [csr_t.n_dst, H] may be the head of larger allocations (the caller's)."""
+
+    def __init__(self, csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec, nscale, attn_drop, seg_len,
+                 d_el, d_er, d_ft, dev):
+        lib = _lib.lib()
+        self.csrv, self.csrt, self.dev, self.H, self.F, self.seg_len = csrv, csrt, dev, H, F, seg_len
+        self.plan_f, self.plan_b = csrv.plan(seg_len, need=True), csrt.plan(seg_len, need=True)
+        nbytes = lib.stag_gat_bwd_workspace_bytes(self.plan_f["n_seg"], self.plan_b["n_seg"], H, F)
+        # ONE forward-plan struct (and so one workspace) for every stage: the segment partials of step 2 and step 3
+        self.pf, self._k1 = _plan_struct(csrv, seg_len, 1, nbytes, dev, plan_t=self.plan_f)
+        self.scratch = torch.empty(lib.stag_gat_bwd_scratch_bytes(csrv.n_dst, csrv.n_edges, H) // 4, dtype=torch.float32,
+                                   device=dev)
+        self.drop = _gat_drop_struct(attn_drop)
+        self.t = (el, er, ft, stats, G, out, nscale, d_el, d_er, d_ft)
+        self.neg_slope, self.spec = float(neg_slope), spec
+        self._keep = []
+
+    def _call(self, plan_b, stages):
+        pb, k = _plan_struct(self.csrt, self.seg_len, 1, 0, self.dev, plan_t=plan_b)
+        self._keep.append(k)
+        el, er, ft, stats, G, out, nscale, d_el, d_er, d_ft = self.t
+        cs, ct = self.csrv.struct(), self.csrt.struct()
+        with _lib.on_device(self.dev):
+            rc = _lib.lib().stag_gat_bwd_stages(
+                C.byref(cs), C.byref(self.pf), C.byref(ct), C.byref(pb), _lib.ptr(el), _lib.ptr(er), _lib.ptr(ft),
+                _lib.ptr(stats), _lib.ptr(G), _lib.ptr(out), self.H, self.F, self.neg_slope, C.byref(self.spec),
+                _lib.ptr(nscale), C.byref(self.drop) if self.drop is not None else None, _lib.ptr(d_el), _lib.ptr(d_er),
+                _lib.ptr(d_ft), _lib.ptr(self.scratch), stages, _lib.stream_of(self.dev))
+        _lib.check(rc, "stag_gat_bwd_stages")
+
+    def rowdot(self):
+        self._call(self.plan_b, _lib.GAT_BWD_ROWDOT)
+
+    def source(self, plan_b=None):
+        self._call(self.plan_b if plan_b is None else plan_b, _lib.GAT_BWD_SOURCE)
+
+    def der(self):
+        self._call(self.plan_b, _lib.GAT_BWD_DER)
+
+
 _GAT_VI_FUSED = True       # vi=True parameter gradients inside the GAT kernels (stag_gat_bwd_dp) | materialised [E, H] weights
 _GAT_BWD_FUSED = True      # tools/bench_configs.py --gat-old-bwd flips it for A/B runs
 _GAT_BWD_ONE_GATHER = True  # stag_gat_bwd (one gather of [H*F] rows) | stag_gat_bwd_two_pass; --gat-two-pass for A/B

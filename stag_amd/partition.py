@@ -175,6 +175,101 @@ class _ShardAggregate(torch.autograd.Function):
         return (dx,) + (None,) * 7
 
 
+class _ShardGat(torch.autograd.Function):
+    """One partitioned GAT layer-forward (BASELINE configs[4]; stag/zoo/gat.py:109-126) AND its backward, with the
+    exchange overlapped on both sides — `_ShardAggregate`'s shape for the two-table step.
+
+    forward : start the exchange of ft [n, H, F] and el [n, H] (two tables, one step); launch the unit batches whose
+              sources are all local rows; wait; launch the rest (two stag_gat_fwd calls over sub-plans, same `out`).
+    backward: stag_gat_bwd one stage at a time (include/stag_hip.h v19): the row dots, then the source pass over the
+              REMOTE buffer rows (their d ft / d el have to travel; the segments of long rows ride with them), the
+              transposed exchange of both tables starts on them, the source pass over this rank's own rows runs while
+              it is in flight, then d er; ONE launch per table adds every local row's own gradient and what its peers
+              sent, own first, peers in rank order (`GraphShard._combined_csr`): no atomics, the same bits every run.
+    Covers weight = None | an EdgeNoise without parameter gradients, with or without in-kernel attention dropout, on
+    the workgroup-cooperative shapes; everything else takes halo_gather_multi + ops.gat_aggregate."""
+
+    @staticmethod
+    def forward(ctx, el_local, er_local, ft_local, shard, noise, neg_slope, seg_len, attn_drop, overlap):
+        from . import _lib, ops
+        o = shard._origin
+        el, er, ft = ops._f32c(el_local), ops._f32c(er_local), ops._f32c(ft_local)
+        H, F = ft.shape[1], ft.shape[2]
+        dev = _lib.require_device(el, er, ft, shard._csr.indptr)
+        (ft_buf, el_buf), work = shard.halo_start_multi([ft, el], persistent=False)
+        spec = noise.spec() if noise is not None else ops._targs_or_c(ops._none_spec())
+        spec.pos_base = int(shard.pos_base)        # noise and the dropout mask are the whole graph's
+        csrv = shard._csr
+        nscale = ops._gat_norm_scale(csrv, noise, H, seg_len, dev) if spec.in_norm else None
+        need_grad = any(ctx.needs_input_grad[:3])
+        out = torch.empty((shard.n_rows, H, F), dtype=torch.float32, device=dev)
+        stats = torch.empty((shard.n_rows, 2 * H), dtype=torch.float32, device=dev) if need_grad else None
+        drop = ops._gat_drop_struct(attn_drop)
+        p_loc, p_rem = shard.plan_split(seg_len)
+        run = lambda plan: ops._gat_fwd_into(csrv, plan, el_buf, er, ft_buf, H, F, neg_slope, spec, nscale, drop, out, stats, dev)
+        if overlap and work is not None and p_loc["n_units"] and p_rem["n_units"]:
+            run(p_loc)
+            work.wait()
+            run(p_rem)
+        else:
+            if work is not None:
+                work.wait()
+            run(csrv.plan(seg_len, need=True))
+        if need_grad:
+            ctx.shard, ctx.noise, ctx.neg_slope, ctx.seg_len, ctx.attn_drop, ctx.overlap = o, noise, float(neg_slope), seg_len, attn_drop, overlap
+            ctx.save_for_backward(el_buf, er, ft_buf, stats, out, nscale)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import _lib, ops
+        el_buf, er, ft_buf, stats, out, nscale = ctx.saved_tensors
+        sh, noise, seg_len = ctx.shard, ctx.noise, ctx.seg_len
+        H, F = ft_buf.shape[1], ft_buf.shape[2]
+        HF, dev = H * F, ft_buf.device
+        G = ops._f32c(grad_out)
+        spec = noise.spec() if noise is not None else ops._targs_or_c(ops._none_spec())
+        spec.pos_base = int(sh.pos_base)
+        n_send = int(sh.send_idx.shape[0])
+        halo = sh.exchange == "halo" and sh.world > 1
+        # T_* = [gradient of every buffer row | rows received back from the peers]: one allocation per table
+        extra = n_send if halo else 0
+        T_ft = torch.empty((sh.n_buf + extra, HF), dtype=torch.float32, device=dev)
+        T_el = torch.empty((sh.n_buf + extra, H), dtype=torch.float32, device=dev)
+        d_er = torch.empty((sh.n_rows, H), dtype=torch.float32, device=dev)
+        st = ops._GatBwdStages(sh._csr, sh.csr_t, el_buf, er, ft_buf, stats, G, out, H, F, ctx.neg_slope, spec, nscale,
+                               ctx.attn_drop, seg_len, T_el, d_er, T_ft, dev)
+        st.rowdot()
+        p_first, p_second = sh.plan_split_t(seg_len)
+        if halo and ctx.overlap and p_first["n_units"] and p_second["n_units"]:
+            st.source(p_first)
+            work = sh._transpose_start_multi([T_ft[sh.n_rows:sh.n_buf], T_el[sh.n_rows:sh.n_buf]],
+                                             [T_ft[sh.n_buf:], T_el[sh.n_buf:]])
+            st.source(p_second)
+            st.der()
+        else:
+            st.source()
+            st.der()
+            work = (sh._transpose_start_multi([T_ft[sh.n_rows:sh.n_buf], T_el[sh.n_rows:sh.n_buf]],
+                                              [T_ft[sh.n_buf:], T_el[sh.n_buf:]]) if halo else None)
+        if not halo:
+            if sh.world == 1:
+                d_ft = T_ft[sh.loc_off:sh.loc_off + sh.n_rows].clone()
+                d_el = T_el[sh.loc_off:sh.loc_off + sh.n_rows].clone()
+            else:
+                d_ft, d_el = sh.halo_transpose_multi([T_ft, T_el])
+        else:
+            if work is not None:
+                work.wait()
+            none = ops._targs_or_c(ops._none_spec())
+            comb = sh._combined_csr()
+            d_ft, _ = ops._agg_raw(comb, T_ft, HF, none, _lib.REDUCE_SUM, None, None, seg_len)
+            d_el, _ = ops._agg_raw(comb, T_el, H, none, _lib.REDUCE_SUM, None, None, seg_len)
+        ni = ctx.needs_input_grad
+        return (d_el if ni[0] else None, d_er if ni[1] else None, d_ft.reshape(-1, H, F) if ni[2] else None,
+                None, None, None, None, None, None)
+
+
 class NativeComm:
     """An RCCL communicator owned by libstag_hip.so (include/stag_hip.h: stag_comm_*): the halo exchange
     as calls into the C ABI on a HIP stream, without torch.distributed on the data path.  torch.distributed
@@ -637,6 +732,17 @@ class GraphShard:
             return native.exchange_async(g_remote, self.out_splits, back, self.in_splits, W)
         return dist.all_to_all_single(back, g_remote, self.in_splits, self.out_splits, group=self.group, async_op=True)
 
+    def _transpose_start_multi(self, g_remotes, backs):
+        """_transpose_start for several tables bound for the same peers (GAT: d ft and d el): ONE RCCL group through
+        the native communicator, back-to-back collectives through torch.distributed.  -> work | None."""
+        if self.world == 1 or self.exchange != "halo":
+            return None
+        native = self.native_comm if all(g.is_cuda and g.dtype == torch.float32 for g in g_remotes) else None
+        if native is not None:
+            widths = [int(np.prod(g.shape[1:])) if g.dim() > 1 else 1 for g in g_remotes]
+            return native.exchange_multi_async(list(g_remotes), self.out_splits, list(backs), self.in_splits, widths)
+        return _wait_all([self._transpose_start(g, b) for g, b in zip(g_remotes, backs)])
+
     def _send_csr(self):
         """CSR over the send list: row i of this rank -> the positions j with send_idx[j] == i, ascending (peers in
         rank order).  A segmented sum over it on the aggregation kernel is the deterministic scatter-add."""
@@ -777,20 +883,33 @@ class GraphShard:
                              dst_scale=dst_scale_local, seg_len=seg_len, _gathered=True)
 
     def gat_aggregate(self, el_local, er_local, ft_local, neg_slope=0.2, weight=None, seg_len=None,
-                      want_attn=False, attn_drop=None):
+                      want_attn=False, attn_drop=None, overlap=True):
         """Partitioned GAT layer-forward (BASELINE cfg5): ft [n, H, F] and el [n, H] of the referenced source rows
         travel as two tables of ONE exchange step (one RCCL group through the native communicator) — no packed
         [ft | el] copy before, no column slices after —, then the single-GPU fused kernel runs on this
-        rank's rows.  `weight`: None or an EdgeNoise(dn=H) built on this shard."""
+        rank's rows.  `weight`: None or an EdgeNoise(dn=H) built on this shard.  The unit batches whose sources are all
+        local are launched while the exchange is in flight, and the backward sends the remote rows' gradients while the
+        local ones are computed (`_ShardGat`; `overlap=False`: everything behind the collective, same bits)."""
         from . import ops
         from .noise import EdgeNoise
-        ft_full, el_full = self.halo_gather_multi([ft_local, el_local])
+        seg_len = DEFAULT_SEG_LEN if seg_len is None else seg_len
         if isinstance(weight, EdgeNoise):
             weight.pos_base = self.pos_base
+        live = (isinstance(weight, EdgeNoise) and weight.grad_params is not None and torch.is_grad_enabled()
+                and any(torch.is_tensor(p_) and p_.requires_grad for p_ in weight.grad_params))
+        H, F = (ft_local.shape[1], ft_local.shape[2]) if ft_local.dim() == 3 else (0, 0)
+        if ((weight is None or (isinstance(weight, EdgeNoise) and weight.n_samples == 1 and not live)) and not want_attn
+                and ft_local.is_cuda and self._csr.n_edges > 0 and ops.gat_cooperative_shape(H, F, seg_len)
+                and (self.world == 1 or dist.is_initialized())      # (a caller that supplies its own exchange: below)
+                and ops._GAT_BWD_FUSED and (attn_drop is None or ops.attn_drop_fusable(H, F, seg_len))):
+            if isinstance(weight, EdgeNoise) and weight.dn != H:
+                raise ValueError(f"noise width {weight.dn} != number of heads {H}")
+            return _ShardGat.apply(el_local, er_local, ft_local, self, weight, float(neg_slope), seg_len, attn_drop,
+                                   bool(overlap))
+        ft_full, el_full = self.halo_gather_multi([ft_local, el_local])
         # attn_drop: the mask is keyed by GLOBAL forward position (pos_base), so shards draw the whole graph's mask
         return ops.gat_aggregate(self, el_full, er_local, ft_full, neg_slope, weight, want_attn=want_attn,
-                                 seg_len=DEFAULT_SEG_LEN if seg_len is None else seg_len, _gathered=True,
-                                 attn_drop=attn_drop)
+                                 seg_len=seg_len, _gathered=True, attn_drop=attn_drop)
 
     # ---- per-edge endpoints over the buffer (AmortizedDistribution on a shard) ---------------------------------
     def edge_endpoints(self):

@@ -50,6 +50,32 @@ def test_gpus2_without_devices_fails_loudly():
     assert '"n_gpus"' not in r.stdout
 
 
+def test_launcher_counts_gpus_from_the_kfd_topology_without_hip(tmp_path, monkeypatch):
+    """The launcher parent must not initialise a GPU before it starts its ranks: it reads the KFD
+    topology — nodes with simd_count > 0 are GPUs — and honours the *_VISIBLE_DEVICES lists."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):         # two CPU nodes, three GPUs
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.node_gpu_count(str(tmp_path)) == (3, "kfd topology (sysfs)")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.node_gpu_count(str(tmp_path))[0] == 2
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    launcher = src[src.index("def self_launch"):src.index("# ---", src.index("def self_launch"))]
+    assert "torch.cuda" not in launcher, "the launcher parent must never ask the HIP runtime for anything"
+
+
+def test_a_failing_rank_is_named_with_its_stderr():
+    r = _run(["--gpus", "2", "--rehearse", "--steps", "1", "--warmup", "0", "--exchange", "halo"],
+             env={"STAG_BENCH_FAIL_RANK": "1"})
+    assert r.returncode != 0 and "rank 1 exited with code" in r.stderr and "STAG_BENCH_FAIL_RANK" in r.stderr
+    assert '"n_gpus"' not in r.stdout
+
+
 def test_world_size_mismatch_is_an_error():
     r = _run(["--gpus", "2", "--rehearse", "--steps", "1", "--warmup", "0"],
              env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
@@ -68,6 +94,32 @@ def test_gpus2_real_kernels_two_gloo_ranks_on_one_card():
     assert line["alt_partition"]["partition"] == "channels" and "error" not in line["alt_partition"]
     ex = line["exchange"]
     assert ex["exchange_only_us"] > 0 and ex["kernels_only_us"] > 0 and ex["local_units"] + ex["remote_units"] > 0
+
+
+@pytest.mark.gpu
+def test_gpus4_full_size_through_the_real_collective_is_bit_identical():
+    """`bench.py --gpus 4` as the driver's multi-GPU run executes it, FOUR gloo ranks sharing the one card (the box
+    admits six GPU processes: this test's own, and four ranks; never eight), the cfg2 graph and the cfg5 GAT at full
+    size: the line's own `partition_check` — every rank launches the whole graph once and compares its rows with what
+    the partitioned step produced through the REAL collective — must read bit-identical, forward with and without
+    the overlap, for the aggregation (`_ShardAggregate`) and for BASELINE configs[4]'s GAT step (`_ShardGat`), and the
+    backward through the transposed exchange within 1e-5 of the whole graph's."""
+    r = _run(["--gpus", "4", "--steps", "5", "--warmup", "2", "--no-alt"], env={"STAG_BENCH_BACKEND": "gloo"}, timeout=1100)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = _line(r)
+    assert line["n_gpus"] == 4 and len(line["device_ms_per_step_per_rank"]) == 4 and line["comm"]["backend"] == "gloo"
+    for pc in (line["partition_check"], line["gat_partition"]["partition_check"]):
+        assert "error" not in pc, pc
+        assert pc["partition_bit_identical"] is True and pc["rows_compared"] == 169343 and pc["rows_differing"] == 0
+        assert pc["backward_within_1e-5"] is True, pc
+        assert len(set(pc["row_checksums_per_rank"])) == 4
+    gp = line["gat_partition"]
+    assert gp["value"] > 0 and gp["exchange"]["bytes_received_max_rank"] > 0 and gp["exchange"]["kernels_only_us"] > 0
+    assert len(line["exchange"]["exchange_GBs_per_rank"]) == 4
+    out = os.environ.get("STAG_REHEARSAL_OUT")
+    if out:
+        with open(out, "w") as f:
+            f.write(json.dumps(line, indent=1) + "\n")
 
 
 def _torchrun(args, env=None, timeout=600):

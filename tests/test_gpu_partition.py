@@ -48,6 +48,69 @@ def test_subplans_reproduce_the_whole_plan(dev):
             assert torch.equal(out, whole)
 
 
+def test_gat_subplans_and_staged_backward_reproduce_the_single_calls(dev):
+    """What `_ShardGat` is made of, in one process: stag_gat_fwd over two complementary sub-plans writes what one launch
+    over the whole plan writes, and stag_gat_bwd_stages (ABI v19) — row dots, the source pass over two complementary
+    sub-plans of the source-major twin, d er — writes what ONE stag_gat_bwd call writes, bit for bit; with noise, in-norm
+    and in-kernel attention dropout."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    src, dst, n = _graph()
+    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
+    csrv, csrt = g.csr, g.csr_t
+    for (H, F), kind, in_norm, drop in (((4, 16), _lib.NOISE_NORMAL, False, None), ((8, 32), _lib.NOISE_BERNOULLI, True, None),
+                                        ((4, 40), _lib.NOISE_NORMAL, False, (0.4, 9, 2)), ((2, 256), _lib.NOISE_NONE, False, None)):
+        el, er = torch.randn(n, H, device=dev), torch.randn(n, H, device=dev)
+        ft, G = torch.randn(n, H, F, device=dev), torch.randn(n, H, F, device=dev)
+        noise = None if kind == _lib.NOISE_NONE else stag_amd.EdgeNoise(
+            g, H, kind, 1.0 if kind == _lib.NOISE_NORMAL else 0.6, 0.5 if kind == _lib.NOISE_NORMAL else None, seed=3,
+            offset=9, in_norm=in_norm)
+        spec = noise.spec() if noise is not None else ops._targs_or_c(ops._none_spec())
+        nscale = ops._gat_norm_scale(csrv, noise, H, 64, dev) if in_norm else None
+        dstruct = ops._gat_drop_struct(drop)
+        full = csrv.plan(64, need=True)
+        out = torch.empty(n, H, F, device=dev)
+        stats = torch.empty(n, 2 * H, device=dev)
+        ops._gat_fwd_into(csrv, full, el, er, ft, H, F, 0.2, spec, nscale, dstruct, out, stats, dev)
+        with torch.no_grad():
+            assert torch.equal(out, ops.gat_aggregate(g, el, er, ft, 0.2, noise, attn_drop=drop))
+        units = full["units"].cpu().numpy()[:full["n_units"]]
+        rng = np.random.default_rng(H * F)
+        keep = (units[:, 3] < 0) & (rng.random(len(units)) < 0.4)
+        a, b = csrv.subplan(64, keep), csrv.subplan(64, ~keep)
+        out2 = torch.full((n, H, F), float("nan"), device=dev)
+        stats2 = torch.full((n, 2 * H), float("nan"), device=dev)
+        ops._gat_fwd_into(csrv, a, el, er, ft, H, F, 0.2, spec, nscale, dstruct, out2, stats2, dev)
+        assert torch.isnan(out2).any()
+        ops._gat_fwd_into(csrv, b, el, er, ft, H, F, 0.2, spec, nscale, dstruct, out2, stats2, dev)
+        assert torch.equal(out2, out) and torch.equal(stats2, stats)
+        # backward: one call
+        d_el, d_er, d_ft, _ = ops._gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, 0.2, spec, nscale, False, 64,
+                                                 dev, drop)
+        # ... against the stages, the source pass cut in two
+        full_t = csrt.plan(64, need=True)
+        units_t = full_t["units"].cpu().numpy()[:full_t["n_units"]]
+        keep_t = (units_t[:, 3] < 0) & (rng.random(len(units_t)) < 0.5)
+        first, second = csrt.subplan(64, ~keep_t), csrt.subplan(64, keep_t)          # (the segments ride in `first`)
+        assert first["n_units"] > 0 and second["n_units"] > 0 and first["n_seg"] == full_t["n_seg"]
+        T_ft = torch.full((n + 5, H * F), float("nan"), device=dev)     # the outputs may be the head of larger allocations
+        T_el = torch.full((n + 5, H), float("nan"), device=dev)
+        e_r = torch.full((n, H), float("nan"), device=dev)
+        st = ops._GatBwdStages(csrv, csrt, el, er, ft, stats, G, out, H, F, 0.2, spec, nscale, drop, 64, T_el, e_r, T_ft, dev)
+        st.rowdot()
+        st.source(first)
+        rows_first = torch.from_numpy(units_t[~keep_t][:, 0].astype(np.int64)).to(dev).unique()
+        assert torch.equal(T_ft[rows_first], d_ft.reshape(n, -1)[rows_first]), "a sub-plan's rows are complete after its call"
+        assert torch.isnan(T_ft[:n]).any()
+        st.source(second)
+        st.der()
+        what = f"H={H} F={F} kind={kind} in_norm={in_norm} drop={drop}"
+        assert torch.equal(T_ft[:n], d_ft.reshape(n, -1)), what + ": d ft"
+        assert torch.equal(T_el[:n], d_el), what + ": d el"
+        assert torch.equal(e_r, d_er), what + ": d er"
+        assert torch.isnan(T_ft[n:]).all() and torch.isnan(T_el[n:]).all()
+
+
 LAYERS = ("gcn", "sage", "gin", "gat", "gat_drop", "gcn_vi", "gcn_bern_norm", "gcn_re", "gcn_rec")
 
 
@@ -140,6 +203,28 @@ def _worker(rank, world, port, tmp):
         xg = x[lo:hi].to(dev).requires_grad_(True)
         sa.aggregate(xg, mka()).backward(gl)
         res["agg_allgather_dx"] = xg.grad.cpu()
+        # ---- the partitioned GAT step (`_ShardGat`, BASELINE configs[4]'s step): the two-table exchange overlapped with
+        #      the all-local unit batches, the staged backward (stag_gat_bwd_stages) with the transposed exchange of
+        #      d ft / d el in flight while the local rows are computed: identical bits with and without the overlap and
+        #      from run to run, with and without in-kernel attention dropout, in both exchange layouts
+        Hh, Fh = 4, 16
+        g2 = torch.Generator().manual_seed(21)
+        el_h, er_h = torch.randn(n, Hh, generator=g2), torch.randn(n, Hh, generator=g2)
+        ft_h, gG = torch.randn(n, Hh, Fh, generator=g2), torch.randn(n, Hh, Fh, generator=g2)
+        for shard_, tag in ((sh, "halo"), (sa, "allgather")):
+            mkg = lambda: stag_amd.EdgeNoise(shard_, Hh, _lib.NOISE_NORMAL, 1.0, 0.5, seed=6, offset=4)
+            for drop in (None, (0.5, 77, 3)):
+                runs = []
+                for ov in (True, False, True):
+                    el, er, ft = (t[lo:hi].to(dev).requires_grad_(True) for t in (el_h, er_h, ft_h))
+                    o = shard_.gat_aggregate(el, er, ft, 0.2, mkg(), attn_drop=drop, overlap=ov)
+                    assert o.grad_fn is not None and "ShardGat" in type(o.grad_fn).__name__
+                    o.backward(gG[lo:hi].to(dev))
+                    runs.append((o.detach(), ft.grad, el.grad, er.grad))
+                for r_ in runs[1:]:
+                    for a_, b_ in zip(r_, runs[0]):
+                        assert torch.equal(a_, b_), f"partitioned GAT step ({tag}, drop={drop}): overlap / rerun changed bits"
+                res[f"gat_step_{tag}{'_drop' if drop else ''}"] = tuple(t.cpu() for t in runs[0])
         # the persistent exchange buffer: rows produced in place are not copied again, and the result is the same
         inplace = sh.local_rows(D)
         inplace.copy_(xl)
@@ -204,6 +289,21 @@ def test_layers_on_two_shards_match_the_whole_graph(dev, tmp_path):
     wb.backward(gl)
     assert torch.equal(torch.cat([p["bern"][0] for p in parts], 0), wb.detach().cpu()), "Bernoulli + in-norm on shards"
     assert_close(torch.cat([p["bern"][1] for p in parts], 0), xb.grad.cpu().numpy(), TOL, "Bernoulli + in-norm: d/dx")
+    Hh, Fh = 4, 16
+    g2 = torch.Generator().manual_seed(21)
+    el_h, er_h = torch.randn(n, Hh, generator=g2), torch.randn(n, Hh, generator=g2)
+    ft_h, gG = torch.randn(n, Hh, Fh, generator=g2), torch.randn(n, Hh, Fh, generator=g2)
+    for drop in (None, (0.5, 77, 3)):
+        el, er, ft = (t.to(dev).requires_grad_(True) for t in (el_h, er_h, ft_h))
+        wg = ops.gat_aggregate(g, el, er, ft, 0.2, stag_amd.EdgeNoise(g, Hh, _lib.NOISE_NORMAL, 1.0, 0.5, seed=6, offset=4),
+                               attn_drop=drop)
+        wg.backward(gG.to(dev))
+        for tag in ("halo", "allgather"):
+            key = f"gat_step_{tag}{'_drop' if drop else ''}"
+            assert torch.equal(torch.cat([p[key][0] for p in parts], 0), wg.detach().cpu()), f"{key}: bit-identical forward"
+            for j, (ref, nm) in enumerate(((ft.grad, "d ft"), (el.grad, "d el"), (er.grad, "d er")), 1):
+                sc_ = max(1.0, float(ref.abs().max()))
+                assert_close(torch.cat([p[key][j] for p in parts], 0) / sc_, (ref / sc_).cpu().numpy(), TOL, f"{key}: {nm}")
     sc = torch.arange(0, n, dtype=torch.float32, device=dev) * 0.01 + 0.5
     with torch.no_grad():
         ws = ops.aggregate(g, x.to(dev), stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, 1.0, 0.5, seed=4, offset=2), src_scale=sc)

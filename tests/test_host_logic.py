@@ -20,7 +20,7 @@ def test_abi_exports_every_declared_symbol():
     assert {"stag_agg_fwd", "stag_noise_materialize", "stag_gat_fwd", "stag_plan_fill"} <= names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/stag_hip.h but not exported"
-    assert lib.stag_abi_version() == 18
+    assert lib.stag_abi_version() == 19
     assert lib.stag_strerror(-22) == b"invalid argument"
 
 
@@ -30,7 +30,7 @@ def test_torch_library_front_end_loads_and_traces():
     from stag_amd import _torch_ext
     assert os.path.exists(os.path.join(ROOT, "stag_amd", "_stag_torch.so")), "build with make -C stag_amd/csrc"
     assert _torch_ext.loaded() and not _torch_ext.available()      # eager mode keeps ctypes (it is faster)
-    assert int(torch.ops.stag.abi_version()) == 18
+    assert int(torch.ops.stag.abi_version()) == 19
     ip = torch.zeros(6, dtype=torch.int32, device="meta")
     ix = torch.zeros(9, dtype=torch.int32, device="meta")
     x = torch.zeros(5, 12, device="meta")
