@@ -234,6 +234,22 @@ size_t stag_plan_xcd_ints(int32_t stride_heavy, int32_t stride_light);  /* STAG_
 int32_t stag_plan_xcd_fine(int32_t n_dst);
 int stag_plan_xcd(const stag_unit* units_host, int32_t n_units, int32_t n_heavy, int64_t n_edges, int32_t fine,
                   int32_t* xcd_host, int32_t* strides_out);
+/* (v19) The same order with the stripes given as a RANGE TABLE instead of equal eighths of the CSR: cuts[n_ranges + 1]
+ * ascending CSR positions, keys[n_ranges] in [0, 8 * fine) = stripe * fine + the stripe's fine range; a unit takes the key
+ * of the range its first edge lies in.  For a block-diagonal batch (`dgl.batch`, scripts/ppi_mle/run.py:12-14) the ranges
+ * are whole GRAPHS, bin-packed to the 8 stripes by edge count, a stripe's graphs packed into fine ranges that fit an
+ * XCD's 4 MB L2 at the launch's row width (stag_amd/graph.py: CsrView.xcd_ranges) — a graph never straddles two XCDs, and
+ * an XCD gathers from one L2-sized set of graphs at a time.  n_heavy = 0 puts every unit into the second (light) family of
+ * stripes: one pass over each fine range instead of a heavy pass and a light pass (the wide shapes, which have no slotted
+ * loop for heavy units).  Device form: cuts / keys are device arrays.  Results are bit-identical to every other order. */
+int stag_plan_xcd_ranges(const stag_unit* units_host, int32_t n_units, int32_t n_heavy, const int64_t* cuts_host,
+                         const int32_t* keys_host, int32_t n_ranges, int32_t fine, int32_t* xcd_host, int32_t* strides_out);
+int stag_plan_blocks_xcd_ranges(const stag_unit* units_host, int32_t n_units, const int64_t* cuts_host,
+                                const int32_t* keys_host, int32_t n_ranges, int32_t fine, int32_t max_edges, int32_t max_units,
+                                stag_unit* units_out_host, int32_t* block_ptr_host, int32_t* n_blocks_out);
+int stag_plan_xcd_device_count_ranges(const stag_unit* units, int32_t n_units, int32_t n_heavy, const int64_t* cuts,
+                                      const int32_t* keys, int32_t n_ranges, int32_t fine, int32_t* strides_out_host,
+                                      void* workspace, size_t workspace_bytes, void* stream);
 size_t stag_plan_xcd_device_workspace_bytes(int32_t n_units);
 int stag_plan_xcd_device_count(const stag_unit* units, int32_t n_units, int32_t n_heavy, int64_t n_edges, int32_t fine,
                                int32_t* strides_out_host, void* workspace, size_t workspace_bytes, void* stream);

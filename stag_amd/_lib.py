@@ -109,6 +109,10 @@ def bind(path):
     l.stag_concat_jobs.argtypes = [_vp, _vp, C.c_int32, C.c_int64, _vp]
     l.stag_stripe_locality.argtypes = [_vp, _vp, C.c_int32, C.c_int64, C.POINTER(C.c_int64), _vp, _vp]
     l.stag_plan_blocks_xcd.argtypes = [_vp, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, ip]
+    l.stag_plan_xcd_ranges.argtypes = [_vp, C.c_int32, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp]
+    l.stag_plan_blocks_xcd_ranges.argtypes = [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, ip]
+    l.stag_plan_xcd_device_count_ranges.argtypes = [_vp, C.c_int32, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp,
+                                                    C.c_size_t, _vp]
     l.stag_plan_xcd_ints.restype = C.c_size_t
     l.stag_plan_xcd_ints.argtypes = [C.c_int32, C.c_int32]
     l.stag_plan_xcd_fine.restype = C.c_int32

@@ -570,20 +570,40 @@ int32_t stag_plan_xcd_fine(int32_t n_dst) {
   return (int32_t)(m < 1 ? 1 : m > STAG_XCD_FINE_MAX ? STAG_XCD_FINE_MAX : m);
 }
 
-int stag_plan_xcd(const stag_unit* units_host, int32_t n_units, int32_t n_heavy, int64_t n_edges, int32_t fine,
+extern "C++" {
+namespace {
+// key of a unit in [0, 8 * fine): which XCD stripe, and which of the stripe's `fine` ranges, its rows belong to.
+//   by position: where its first edge lies in the CSR, in 8 * fine equal parts (contiguous destination-row ranges with the
+//                same number of edges each);
+//   by range table: cuts[R + 1] ascending CSR positions, keys[R] — the key of every unit whose first edge lies in
+//                [cuts[r], cuts[r + 1]) (a block-diagonal batch: whole graphs, bin-packed to the stripes).
+struct XcdKeyByPosition {
+  int64_t E; int S;
+  int operator()(int32_t start) const {
+    const int64_t k = (int64_t)start * S / E;
+    return (int)(k < 0 ? 0 : k >= S ? S - 1 : k);
+  }
+};
+struct XcdKeyByRange {
+  const int64_t* cuts; const int32_t* keys; int32_t R;
+  int operator()(int32_t start) const {
+    int32_t lo = 0, hi = R;                       // last r with cuts[r] <= start (r = 0 below the table)
+    while (hi - lo > 1) {
+      const int32_t mid = lo + (hi - lo) / 2;
+      if (cuts[mid] <= (int64_t)start) lo = mid; else hi = mid;
+    }
+    return keys[lo];
+  }
+};
+
+template <class KeyFn>
+int plan_xcd_impl(const stag_unit* units_host, int32_t n_units, int32_t n_heavy, int32_t fine, const KeyFn& keyfn,
                   int32_t* xcd_host, int32_t* strides_out) {
-  if (n_units < 0 || n_heavy < 0 || n_heavy > n_units || n_edges < 0 || !strides_out || (n_units > 0 && !units_host) ||
-      fine < 1 || fine > STAG_XCD_FINE_MAX) return STAG_EINVAL;
-  // stripe of a unit: where its first edge lies in the CSR, in eighths — contiguous destination-row ranges with an
-  // eighth of the edges each — and inside the eighth in `fine` finer ranges, which the XCD walks one after the other
-  // (the rows one of them gathers should fit its L2).  A stable partition of the heavy prefix and of the rest by
-  // fine stripe: inside one the plan's order (segments, then longest first) stands.
-  const int64_t E = n_edges > 0 ? n_edges : 1;
+  // A stable partition of the heavy prefix and of the rest by key: inside one key the plan's order (segments, then
+  // longest first) stands; the `fine` ranges of one XCD stripe lie one after the other and the XCD walks them in turn
+  // (the rows one of them gathers should fit its L2).
   const int S = STAG_XCD_STRIPES * fine;
-  auto key = [&](int32_t i) {
-    const int64_t k = (int64_t)units_host[i].start * S / E;
-    return (int)(i >= n_heavy ? S : 0) + (int)(k < 0 ? 0 : k >= S ? S - 1 : k);
-  };
+  auto key = [&](int32_t i) { return (int)(i >= n_heavy ? S : 0) + keyfn(units_host[i].start); };
   std::vector<int32_t> count((size_t)2 * S, 0);
   for (int32_t i = 0; i < n_units; ++i) count[key(i)] += 1;
   int32_t per[2 * STAG_XCD_STRIPES] = {0};           // units per XCD stripe: heavy [0, 8), the others [8, 16)
@@ -604,12 +624,36 @@ int stag_plan_xcd(const stag_unit* units_host, int32_t n_units, int32_t n_heavy,
   const int64_t n_rec = (int64_t)STAG_XCD_STRIPES * ((int64_t)sh + sl);
   for (int64_t i = 0; i < n_rec; ++i) rec[i] = stag_unit{-1, 0, 0, -1};
   std::vector<int64_t> cursor((size_t)2 * S);
-  for (int x = 0; x < 2 * STAG_XCD_STRIPES; ++x) {   // fine stripes of one XCD stripe lie one after the other
+  for (int x = 0; x < 2 * STAG_XCD_STRIPES; ++x) {   // fine ranges of one XCD stripe lie one after the other
     int64_t at = x < STAG_XCD_STRIPES ? (int64_t)x * sh : (int64_t)STAG_XCD_STRIPES * sh + (int64_t)(x - STAG_XCD_STRIPES) * sl;
     for (int f = 0; f < fine; ++f) { cursor[(size_t)x * fine + f] = at; at += count[(size_t)x * fine + f]; }
   }
   for (int32_t i = 0; i < n_units; ++i) rec[cursor[key(i)]++] = units_host[i];
   return STAG_OK;
+}
+
+bool xcd_ranges_ok(const int64_t* cuts, const int32_t* keys, int32_t R, int32_t fine) {
+  if (R < 1 || !cuts || !keys) return false;
+  for (int32_t r = 0; r < R; ++r)
+    if (cuts[r + 1] < cuts[r] || keys[r] < 0 || keys[r] >= STAG_XCD_STRIPES * fine) return false;
+  return true;
+}
+}  // namespace
+}  // extern "C++"
+
+int stag_plan_xcd(const stag_unit* units_host, int32_t n_units, int32_t n_heavy, int64_t n_edges, int32_t fine,
+                  int32_t* xcd_host, int32_t* strides_out) {
+  if (n_units < 0 || n_heavy < 0 || n_heavy > n_units || n_edges < 0 || !strides_out || (n_units > 0 && !units_host) ||
+      fine < 1 || fine > STAG_XCD_FINE_MAX) return STAG_EINVAL;
+  return plan_xcd_impl(units_host, n_units, n_heavy, fine, XcdKeyByPosition{n_edges > 0 ? n_edges : 1, STAG_XCD_STRIPES * fine},
+                       xcd_host, strides_out);
+}
+
+int stag_plan_xcd_ranges(const stag_unit* units_host, int32_t n_units, int32_t n_heavy, const int64_t* cuts_host,
+                         const int32_t* keys_host, int32_t n_ranges, int32_t fine, int32_t* xcd_host, int32_t* strides_out) {
+  if (n_units < 0 || n_heavy < 0 || n_heavy > n_units || !strides_out || (n_units > 0 && !units_host) || fine < 1 ||
+      fine > STAG_XCD_FINE_MAX || !xcd_ranges_ok(cuts_host, keys_host, n_ranges, fine)) return STAG_EINVAL;
+  return plan_xcd_impl(units_host, n_units, n_heavy, fine, XcdKeyByRange{cuts_host, keys_host, n_ranges}, xcd_host, strides_out);
 }
 
 int stag_plan_blocks(const stag_unit* units_host, int32_t n_units, int32_t max_edges, int32_t max_units,
@@ -636,21 +680,18 @@ int stag_plan_blocks(const stag_unit* units_host, int32_t n_units, int32_t max_e
   return STAG_OK;
 }
 
-int stag_plan_blocks_xcd(const stag_unit* units_host, int32_t n_units, int64_t n_edges, int32_t fine, int32_t max_edges,
+extern "C++" {
+namespace {
+template <class KeyFn>
+int plan_blocks_xcd_impl(const stag_unit* units_host, int32_t n_units, int32_t fine, const KeyFn& keyfn, int32_t max_edges,
                          int32_t max_units, stag_unit* units_out_host, int32_t* block_ptr_host, int32_t* n_blocks_out) {
-  if (n_units < 0 || n_edges < 0 || fine < 1 || fine > STAG_XCD_FINE_MAX || max_edges <= 0 || max_units <= 0 ||
-      !n_blocks_out || (n_units > 0 && !units_host) || ((units_out_host == nullptr) != (block_ptr_host == nullptr)))
-    return STAG_EINVAL;
-  // units by fine stripe (stable: the plan's order inside one), batched greedily inside each fine stripe, then the
-  // batches of the 8 XCD stripes dealt out in turn: batch b belongs to stripe b mod 8, a stripe that has run out of
-  // batches gets empty ones
-  const int64_t E = n_edges > 0 ? n_edges : 1;
+  // units by key (stable: the plan's order inside one), batched greedily inside each fine range, then the batches of the
+  // 8 XCD stripes dealt out in turn: batch b belongs to stripe b mod 8, a stripe that has run out of batches gets empty ones
   const int S = STAG_XCD_STRIPES * fine;
   std::vector<int32_t> key((size_t)n_units), start((size_t)S + 1, 0), order((size_t)n_units);
   for (int32_t i = 0; i < n_units; ++i) {
     if (units_host[i].len < 0) return STAG_EINVAL;
-    const int64_t k = (int64_t)units_host[i].start * S / E;
-    key[i] = (int32_t)(k < 0 ? 0 : k >= S ? S - 1 : k);
+    key[i] = (int32_t)keyfn(units_host[i].start);
     start[(size_t)key[i] + 1] += 1;
   }
   for (int k = 0; k < S; ++k) start[(size_t)k + 1] += start[k];
@@ -688,6 +729,27 @@ int stag_plan_blocks_xcd(const stag_unit* units_host, int32_t n_units, int64_t n
       block_ptr_host[j * STAG_XCD_STRIPES + x + 1] = at;
     }
   return STAG_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int stag_plan_blocks_xcd(const stag_unit* units_host, int32_t n_units, int64_t n_edges, int32_t fine, int32_t max_edges,
+                         int32_t max_units, stag_unit* units_out_host, int32_t* block_ptr_host, int32_t* n_blocks_out) {
+  if (n_units < 0 || n_edges < 0 || fine < 1 || fine > STAG_XCD_FINE_MAX || max_edges <= 0 || max_units <= 0 ||
+      !n_blocks_out || (n_units > 0 && !units_host) || ((units_out_host == nullptr) != (block_ptr_host == nullptr)))
+    return STAG_EINVAL;
+  return plan_blocks_xcd_impl(units_host, n_units, fine, XcdKeyByPosition{n_edges > 0 ? n_edges : 1, STAG_XCD_STRIPES * fine},
+                              max_edges, max_units, units_out_host, block_ptr_host, n_blocks_out);
+}
+
+int stag_plan_blocks_xcd_ranges(const stag_unit* units_host, int32_t n_units, const int64_t* cuts_host,
+                                const int32_t* keys_host, int32_t n_ranges, int32_t fine, int32_t max_edges, int32_t max_units,
+                                stag_unit* units_out_host, int32_t* block_ptr_host, int32_t* n_blocks_out) {
+  if (n_units < 0 || fine < 1 || fine > STAG_XCD_FINE_MAX || max_edges <= 0 || max_units <= 0 || !n_blocks_out ||
+      (n_units > 0 && !units_host) || ((units_out_host == nullptr) != (block_ptr_host == nullptr)) ||
+      !xcd_ranges_ok(cuts_host, keys_host, n_ranges, fine)) return STAG_EINVAL;
+  return plan_blocks_xcd_impl(units_host, n_units, fine, XcdKeyByRange{cuts_host, keys_host, n_ranges}, max_edges, max_units,
+                              units_out_host, block_ptr_host, n_blocks_out);
 }
 
 size_t stag_plan_workspace_bytes(int32_t n_seg, int32_t D, int32_t in_norm) {

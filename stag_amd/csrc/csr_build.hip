@@ -230,6 +230,23 @@ __global__ void xcd_keys_kernel(const stag_unit* units, int32_t n_units, int32_t
   idx[i] = i;
 }
 
+// the same with a range table (stag_plan_xcd_device_count_ranges): key of the range the unit's first edge lies in
+__global__ void xcd_keys_ranges_kernel(const stag_unit* units, int32_t n_units, int32_t n_heavy, const int64_t* cuts,
+                                       const int32_t* rkeys, int32_t R, int32_t S, uint32_t* keys, int32_t* idx) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_units) return;
+  const int64_t start = units[i].start;
+  int32_t lo = 0, hi = R;
+  while (hi - lo > 1) {
+    const int32_t mid = lo + (hi - lo) / 2;
+    if (cuts[mid] <= start) lo = mid; else hi = mid;
+  }
+  int k = rkeys[lo];
+  k = k < 0 ? 0 : k >= S ? S - 1 : k;
+  keys[i] = (uint32_t)((i >= n_heavy ? S : 0) + k);
+  idx[i] = i;
+}
+
 // starts[k] = first sorted position with key >= k, k in [0, 2 S]
 __global__ void xcd_starts_kernel(const uint32_t* keys_s, int32_t n_units, int32_t S, int32_t* starts) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -297,9 +314,10 @@ extern "C" size_t stag_plan_xcd_device_workspace_bytes(int32_t n_units) {
   return align_up((size_t)n_units * 4) * 4 + kXcdStartsBytes + align_up(sort_tmp);
 }
 
-extern "C" int stag_plan_xcd_device_count(const stag_unit* units, int32_t n_units, int32_t n_heavy, int64_t n_edges,
-                                          int32_t fine, int32_t* strides_out_host, void* workspace,
-                                          size_t workspace_bytes, void* stream) {
+static int xcd_device_count_impl(const stag_unit* units, int32_t n_units, int32_t n_heavy, int64_t n_edges,
+                                 const int64_t* cuts, const int32_t* rkeys, int32_t n_ranges,
+                                 int32_t fine, int32_t* strides_out_host, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
   if (n_units < 0 || n_heavy < 0 || n_heavy > n_units || n_edges < 0 || !strides_out_host || fine < 1 ||
       fine > STAG_XCD_FINE_MAX || (n_units > 0 && !units) || ((uintptr_t)units & 15)) return STAG_EINVAL;
   if (!workspace || workspace_bytes < stag_plan_xcd_device_workspace_bytes(n_units)) return STAG_ENOMEM;
@@ -311,8 +329,11 @@ extern "C" int stag_plan_xcd_device_count(const stag_unit* units, int32_t n_unit
   unsigned bits = 1;
   while ((1u << bits) < (unsigned)(2 * S)) ++bits;
   const dim3 grid((unsigned)((n_units + 255) / 256)), block(256);
-  hipLaunchKernelGGL(xcd_keys_kernel, grid, block, 0, s, units, n_units, n_heavy, n_edges > 0 ? n_edges : (int64_t)1, S,
-                     x.keys, x.idx);
+  if (cuts)
+    hipLaunchKernelGGL(xcd_keys_ranges_kernel, grid, block, 0, s, units, n_units, n_heavy, cuts, rkeys, n_ranges, S, x.keys, x.idx);
+  else
+    hipLaunchKernelGGL(xcd_keys_kernel, grid, block, 0, s, units, n_units, n_heavy, n_edges > 0 ? n_edges : (int64_t)1, S,
+                       x.keys, x.idx);
   size_t tmp_bytes = x.tmp_bytes;
   if (rocprim::radix_sort_pairs(x.tmp, tmp_bytes, x.keys, x.keys_s, x.idx, x.idx_s, (size_t)n_units, 0u, bits, s) != hipSuccess)
     return STAG_EIO;
@@ -325,6 +346,22 @@ extern "C" int stag_plan_xcd_device_count(const stag_unit* units, int32_t n_unit
     strides_out_host[1] = std::max(strides_out_host[1], h[S + (k + 1) * fine] - h[S + k * fine]);
   }
   return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
+}
+
+extern "C" int stag_plan_xcd_device_count(const stag_unit* units, int32_t n_units, int32_t n_heavy, int64_t n_edges,
+                                          int32_t fine, int32_t* strides_out_host, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  return xcd_device_count_impl(units, n_units, n_heavy, n_edges, nullptr, nullptr, 0, fine, strides_out_host, workspace,
+                               workspace_bytes, stream);
+}
+
+extern "C" int stag_plan_xcd_device_count_ranges(const stag_unit* units, int32_t n_units, int32_t n_heavy,
+                                                 const int64_t* cuts, const int32_t* keys, int32_t n_ranges, int32_t fine,
+                                                 int32_t* strides_out_host, void* workspace, size_t workspace_bytes,
+                                                 void* stream) {
+  if (n_ranges < 1 || !cuts || !keys) return STAG_EINVAL;
+  return xcd_device_count_impl(units, n_units, n_heavy, 0, cuts, keys, n_ranges, fine, strides_out_host, workspace,
+                               workspace_bytes, stream);
 }
 
 extern "C" int stag_plan_xcd_device_fill(const stag_unit* units, int32_t n_units, const int32_t* strides, int32_t fine,

@@ -418,12 +418,14 @@ class Graph:
     def _array_ptrs(self):
         """Device addresses of (src, dst, csr: indptr, indices, eid, csr_t: indptr, indices, eid, nidx) — what batch()
         lays end to end; kept, so that a batch of thousands of graphs does not make thousands of calls to ask for them."""
-        p = self.__dict__.get("_ptrs")
-        if p is None:
-            a, b = self.csr, self.csr_t
-            p = self._ptrs = np.array([t.data_ptr() for t in (self._src, self._dst, a.indptr, a.indices, a.eid, b.indptr,
-                                                              b.indices, b.eid, b.nidx)], np.int64)
-        return p
+        a, b = self.csr, self.csr_t
+        got = self.__dict__.get("_ptrs")
+        # (kept WITH the views they were read from: a view that has been rebuilt or replaced is noticed, and a view that is
+        # still referenced here cannot have been freed — its arrays are write-once)
+        if got is None or got[0] is not a or got[1] is not b:
+            got = self._ptrs = (a, b, np.array([t.data_ptr() for t in (self._src, self._dst, a.indptr, a.indices, a.eid,
+                                                                       b.indptr, b.indices, b.eid, b.nidx)], np.int64))
+        return got[2]
 
     # ---- structure --------------------------------------------------------------
     @property
@@ -618,8 +620,27 @@ def add_reverse_edges(g, copy_ndata=True, copy_edata=False):
 # same combination again within a few epochs, and a validation set batched once per epoch always does.  A hit costs the
 # frames' concatenation only and inherits the cached union's plans (and, once it has been launched 16 times, its
 # XCD-aware order).  The parts are held weakly; 0 switches it off.
+# What is kept is a FRAME-LESS structure object: the graph handed to the caller is a copy that shares it (hit or miss), so a
+# cached entry never holds a batch's feature tensors.  An entry goes when any of its parts dies (weakref callback), when
+# more than BATCH_CACHE_SIZE unions are kept, or when the kept structures exceed BATCH_CACHE_MB of device memory (estimated
+# from the union's size: COO, both CSR views, plans and unit orders).
 BATCH_CACHE_SIZE = int(os.environ.get("STAG_BATCH_CACHE", "128"))
-_batch_cache = collections.OrderedDict()
+BATCH_CACHE_MB = float(os.environ.get("STAG_BATCH_CACHE_MB", "1024"))
+_batch_cache = collections.OrderedDict()       # key -> (weak refs to the parts, structure, estimated bytes)
+
+
+def _structure_bytes(g):
+    """Device bytes a cached union may come to hold: src, dst, two views of (indptr, indices, eid) + nidx, and per view a
+    plan (a 16-byte record per row) with its XCD-aware copies for a few row widths."""
+    E, N = g.number_of_edges(), g.number_of_nodes()
+    return 4 * (9 * E + 2 * (N + 1)) + 2 * 16 * N * 4
+
+
+def _view_of(struct):
+    """The graph the caller gets: shares the kept structure (views, plans, degree vectors live on `struct`), owns its frames."""
+    out = struct._share_structure()
+    out.ndata, out.edata, out._origin = {}, {}, struct
+    return out
 
 
 def _batch_cached(graphs):
@@ -630,17 +651,18 @@ def _batch_cached(graphs):
     hit = _batch_cache.get(key)
     if hit is not None and all(r() is o for r, o in zip(hit[0], owners)):
         _batch_cache.move_to_end(key)
-        out = hit[1]._share_structure()
-        out.ndata, out.edata, out._origin = {}, {}, hit[1]
-        return out, key
+        return _view_of(hit[1]), key
     return None, key
 
 
-def _batch_remember(key, graphs, out):
+def _batch_remember(key, graphs, struct):
     if key is None:
         return
-    _batch_cache[key] = ([weakref.ref(g._cache_owner()) for g in graphs], out)
-    while len(_batch_cache) > BATCH_CACHE_SIZE:
+    drop = lambda _ref, key=key: _batch_cache.pop(key, None)       # a part died: its ids may be reused, the entry goes now
+    _batch_cache[key] = ([weakref.ref(g._cache_owner(), drop) for g in graphs], struct, _structure_bytes(struct))
+    cap = BATCH_CACHE_MB * 2 ** 20
+    while len(_batch_cache) > 1 and (len(_batch_cache) > BATCH_CACHE_SIZE
+                                     or sum(v[2] for v in _batch_cache.values()) > cap):
         _batch_cache.popitem(last=False)
 
 
@@ -650,9 +672,11 @@ def batch(graphs):
     cached, key = _batch_cached(graphs)
     if cached is not None:
         return _batch_frames(cached, graphs)
-    out = _batch_build(graphs)
-    _batch_remember(key, graphs, out)
-    return _batch_frames(out, graphs)
+    struct = _batch_build(graphs)
+    if key is None:
+        return _batch_frames(struct, graphs)
+    _batch_remember(key, graphs, struct)
+    return _batch_frames(_view_of(struct), graphs)
 
 
 def _batch_build(graphs):
@@ -664,6 +688,10 @@ def _batch_build(graphs):
     total = int(sum(sizes))
     node_off = np.concatenate([[0], np.cumsum(sizes[:-1])]).astype(np.int64) if graphs else np.zeros(0, np.int64)
     E = int(sum(n_edges))
+    if any(g.device != dev for g in graphs):
+        # (the one-launch path below hands raw device addresses of every part to a kernel: a part on the host or on
+        # another card would be a GPU memory fault there, not the clean error torch.cat used to raise)
+        raise ValueError(f"batch(): all graphs must live on one device; got {sorted({str(g.device) for g in graphs})}")
     if dev.type == "cuda" and 1 < len(graphs) <= BATCH_CONCAT_MAX_GRAPHS and E > 0:
         # the union's COO and both CSR views are the parts' arrays laid end to end (the parts keep their views: a data
         # loader hands the same graphs out again every epoch) — every piece of every array in one launch, no sort

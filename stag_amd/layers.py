@@ -88,9 +88,7 @@ class StagLayer(torch.nn.Module):
 
     def forward(self, graph, feat):
         graph = graph.local_var()
-        # on a node-range shard the KL term is this rank's SHARE (kl_divergence)
-        self._kl_share = ((graph.number_of_edges() / max(graph.n_edges_global, 1), 1.0 / graph.world)
-                          if getattr(graph, "is_shard", False) else None)
+        self._set_kl_share(graph)
         self.q_a.condition(graph, feat)
         dn = self._sample_dimension(feat)
         w = self.rsample_noise(graph, dn)
@@ -118,6 +116,12 @@ class StagLayer(torch.nn.Module):
         extra = getattr(self.base_layer, "extra_offsets_per_forward", None)
         return (1 if self.consumes_offset else 0) + (extra() if callable(extra) else 0)
 
+    def _set_kl_share(self, graph):
+        """On a node-range shard the KL term is this rank's SHARE (kl_divergence): (E_local / E_global, 1 / world);
+        None on a whole graph.  Set by every call that sees a graph, so the value never outlives it."""
+        self._kl_share = ((graph.number_of_edges() / max(graph.n_edges_global, 1), 1.0 / graph.world)
+                          if getattr(graph, "is_shard", False) else None)
+
     def forward_mc(self, graph, feat, n_samples, offset_stride=1):
         """n_samples forward passes on the SAME input from one pass over the gathered rows:
         [n_samples, N, out], sample s drawn at this call's offset + s * offset_stride (what the
@@ -126,6 +130,7 @@ class StagLayer(torch.nn.Module):
         if not getattr(self.base_layer, "supports_edge_noise_mc", False):
             return None
         graph = graph.local_var()
+        self._set_kl_share(graph)      # (every entry that conditions on a graph: a stale share would scale the KL term)
         self.q_a.condition(graph, feat)
         dist = self.q_a.base_distribution
         if not fusable(dist):

@@ -1421,8 +1421,12 @@ def gat_aggregate(graph, el, er, ft, neg_slope=0.2, weight=None, want_attn=False
         # with its derivatives and returns the finished parameter gradients (stag_gat_bwd_dp) — no [E, H] tensor.
         # Otherwise the H-wide weights are formed from the kernel's standard draw and the live parameters ([E, H]:
         # 37 MB at cfg5), enter as explicit weights, the edge pass returns dw[E, H] and autograd does the affine map.
+        # (the preconditions of stag_gat_bwd_dp mirrored here — channel shards' chunk_base, the plan's segment length
+        # inside gat_cooperative_shape — so that a shape it refuses takes the materialised route below instead of
+        # failing in the middle of a backward pass)
         if (_GAT_VI_FUSED and not noise.in_norm and noise.param_mode <= _lib.PARAM_PER_CHANNEL and ft.is_cuda
-                and gat_cooperative_shape(H, F, seg_len) and _GAT_BWD_FUSED and not want_attn):
+                and gat_cooperative_shape(H, F, seg_len) and _GAT_BWD_FUSED and not want_attn
+                and int(getattr(noise, "chunk_base", 0) or 0) == 0):
             live = tuple(torch.as_tensor(p, dtype=torch.float32, device=ft.device) for p in noise.grad_params)
         else:
             w, noise = noise.materialize(), None

@@ -248,9 +248,27 @@ def test_batch_structure_cache():
     assert stag_amd.batch([p.local_var() for p in parts]).csr is a.csr, "local_var() copies are the same graphs"
     others = [stag_amd.Graph(torch.from_numpy(rng.integers(0, 20, 50)), torch.from_numpy(rng.integers(0, 20, 50)), 20) for _ in range(3)]
     key_like = stag_amd.batch(others)
+    assert len(G._batch_cache) == 3
+    # what is kept is a frame-less structure: no entry holds a batch's feature tensors (a cached union used to
+    # BE the first caller's graph, frames and all)
+    assert all(not v[1].ndata and not v[1].edata for v in G._batch_cache.values())
+    assert a.ndata and a._cache_owner() is not a and a._cache_owner() is b._cache_owner()
     del others
     gc.collect()
-    assert len(G._batch_cache) == 3                  # (a dead entry goes when the cache fills up or its ids come back)
+    assert len(G._batch_cache) == 2, "an entry goes as soon as one of its parts dies (weakref callback)"
+    assert key_like.csr.n_edges == 150              # (the caller's graph is whole without the cache entry)
+    # ... and the kept structures are bounded in BYTES, not only in number
+    old_mb = G.BATCH_CACHE_MB
+    G.BATCH_CACHE_MB = 1.5 * G._structure_bytes(a) / 2 ** 20
+    try:
+        stag_amd.batch(parts[1:] + parts[:1])
+        assert len(G._batch_cache) == 1 and stag_amd.batch(parts[1:] + parts[:1]).csr is not a.csr
+    finally:
+        G.BATCH_CACHE_MB = old_mb
+    with pytest.raises(ValueError, match="one device"):
+        class _Elsewhere(stag_amd.Graph):
+            device = property(lambda self: torch.device("meta"))
+        stag_amd.batch([parts[0], _Elsewhere(parts[1]._src, parts[1]._dst, 20)])
     old = G.BATCH_CACHE_SIZE
     G.BATCH_CACHE_SIZE = 0
     try:
