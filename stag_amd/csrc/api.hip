@@ -851,7 +851,7 @@ static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x
     // are added in block order, which stays the plan's own
     if (plan->xcd_order && !(eg && eg->dp_part)) {
       const int64_t sh = plan->xcd_stride_heavy, sl = plan->xcd_stride_light;
-      if (!aligned16(plan->xcd_order) || sh < 0 || sl < 0 || sh > plan->n_heavy || sl > plan->n_units - plan->n_heavy ||
+      if (!aligned16(plan->xcd_order) || sh < 0 || sl < 0 || sh > plan->n_heavy || sl > plan->n_units ||     /* (sl may count heavy units: stag_plan_xcd_ranges with n_heavy = 0) */
           STAG_XCD_STRIPES * (sh + sl) < plan->n_units || STAG_XCD_STRIPES * (sh + sl) > 0x7FFFFFFFll) return STAG_EINVAL;
       a.xcd = plan->xcd_order;
       a.units = reinterpret_cast<const stag_unit*>(plan->xcd_order + STAG_XCD_HEADER);

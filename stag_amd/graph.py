@@ -41,7 +41,70 @@ XCD_MIN_LOCALITY = 0.25
 XCD_FINE = int(os.environ.get("STAG_XCD_FINE", "0"))   # finer row ranges inside an XCD's stripe; 0: CsrView.xcd_fine_for(width)
 XCD_RANGE_BYTES = 2_500_000
 XCD_AFTER_LAUNCHES = 16
+# block-diagonal batches: whole graphs per XCD (xcd_graph_ranges) | equal eighths of the CSR, which cut graphs (A/B)
+WHOLE_GRAPHS_PER_XCD = os.environ.get("STAG_XCD_GRAPHS", "1") != "0"
+MERGE_HEAVY_WIDE = os.environ.get("STAG_XCD_MERGE_HEAVY", "1") != "0"
+MERGE_HEAVY_ABOVE = int(os.environ.get("STAG_XCD_MERGE_ABOVE", "128"))     # floats per row
 PLAN_AFTER_LAUNCHES = 16     # launches a short-row view runs without a plan before one is built for it
+
+
+def xcd_graph_ranges(edge_cuts, rows, width, range_bytes=None, stripes=None, fine_max=None):
+    """The range table of stag_plan_xcd_ranges for a block-diagonal batch: whole GRAPHS per XCD.
+
+    edge_cuts [G + 1]: CSR position where every graph's rows begin (and the edge count at the end); rows [G]: its row
+    count; width: floats per gathered row.  -> (cuts int64 [R + 1], keys int32 [R], fine):
+      1. graphs go to the 8 stripes by edge count — longest-processing-time first (the lightest stripe takes the next
+         largest graph; 24 PPI graphs: the stripes differ by a few per cent, where 8 contiguous runs differ by 20-30) — or,
+         for hundreds of small graphs per stripe (a molecule batch), as 8 contiguous runs;
+      2. a stripe's graphs, in batch order, are packed into fine ranges of at most `range_bytes` of gathered rows — what an
+         XCD's 4 MB L2 holds beside the streams passing through it — which the XCD walks one after the other; a graph
+         larger than that is cut into ranges of its own by edge position;
+      3. more than STAG_XCD_FINE_MAX ranges in a stripe: the budget doubles until they fit.
+    A graph never straddles two XCDs, and no fine range mixes part of one graph with another."""
+    stripes = _lib.XCD_STRIPES if stripes is None else stripes
+    fine_max = _lib.XCD_FINE_MAX if fine_max is None else fine_max
+    rb = float(XCD_RANGE_BYTES if range_bytes is None else range_bytes)
+    edge_cuts = np.asarray(edge_cuts, np.int64)
+    rows = np.asarray(rows, np.int64)
+    G, E = len(rows), int(edge_cuts[-1])
+    e = np.diff(edge_cuts)
+    if G >= 64 * stripes:
+        stripe = np.minimum(stripes - 1, ((edge_cuts[:-1] + e // 2) * stripes) // max(E, 1)).astype(np.int64)
+    else:
+        stripe = np.zeros(G, np.int64)
+        load = np.zeros(stripes, np.int64)
+        for g in np.argsort(-e, kind="stable"):
+            k = int(np.argmin(load))
+            stripe[g] = k
+            load[k] += max(int(e[g]), 1)
+    row_bytes = 4 * min(max(int(width), 1), 256)          # (wider rows are tiled at 256 floats)
+    while True:
+        out, fine = [], 1
+        for k in range(stripes):
+            f, acc = 0, 0.0
+            for g in np.nonzero(stripe == k)[0]:
+                b = float(rows[g]) * row_bytes
+                if b > rb:
+                    if acc > 0:
+                        f, acc = f + 1, 0.0
+                    nsub = int(-(-b // rb))
+                    for j in range(nsub):
+                        out.append((int(edge_cuts[g] + e[g] * j // nsub), k, f))
+                        f += 1
+                else:
+                    if acc > 0 and acc + b > rb:
+                        f, acc = f + 1, 0.0
+                    out.append((int(edge_cuts[g]), k, f))
+                    acc += b
+            fine = max(fine, f + (1 if acc > 0 else 0))
+        if fine <= fine_max:
+            break
+        rb *= 2
+    out.sort(key=lambda t: t[0])         # (stable: graphs without edges keep their place)
+    cuts = np.array([t[0] for t in out] + [E], np.int64)
+    cuts[0] = 0
+    keys = np.array([t[1] * fine + t[2] for t in out], np.int32)
+    return cuts, keys, int(fine)
 
 
 class CsrView:
@@ -57,6 +120,9 @@ class CsrView:
         self._plans = {}
         self._degrees = None
         self._struct = None
+        self.xcd_graphs = self.xcd_merge = None     # per-view overrides of WHOLE_GRAPHS_PER_XCD / MERGE_HEAVY_WIDE (A/B tools)
+        self.part_sizes = None       # rows of every graph of a block-diagonal batch (tensor / array; Graph sets it): the
+        self._part_cuts = None       # XCD-aware order then keeps whole graphs per XCD (xcd_ranges)
 
     def struct(self):
         """The ctypes stag_csr (built once: the tensors it points into live as long as this view)."""
@@ -105,20 +171,53 @@ class CsrView:
         hipGraph is being captured and the arrays for this width do not exist yet (they are built on the host)."""
         if not plan.get("xcd_on"):
             return None
-        fine = self.xcd_fine_for(width, cap=None)
-        got = plan.setdefault("gat_orders", {}).get(fine)
+        ranges = self.xcd_ranges(width) if not (plan["units"].is_cuda and torch.cuda.is_current_stream_capturing()) else None
+        fine = self.xcd_fine_for(width, cap=None) if ranges is None else ranges[2]
+        okey = fine if ranges is None else ("graphs", min(int(width), 256))
+        got = plan.setdefault("gat_orders", {}).get(okey)
         if got is None:
             if plan["units"].is_cuda and torch.cuda.is_current_stream_capturing():
                 return None
             lib, nu, dev = _lib.lib(), plan["n_units"], plan["units"].device
             units_h = np.ascontiguousarray(plan["units"][:nu].cpu().numpy(), dtype=np.int32)
             nb = C.c_int32(0)
-            args = (units_h.ctypes.data, nu, self.n_edges, fine, _lib.BLOCK_EDGES, _lib.BLOCK_UNITS)
-            _lib.check(lib.stag_plan_blocks_xcd(*args, None, None, C.byref(nb)), "stag_plan_blocks_xcd")
+            if ranges is None:
+                fn_, args = lib.stag_plan_blocks_xcd, (units_h.ctypes.data, nu, self.n_edges, fine, _lib.BLOCK_EDGES, _lib.BLOCK_UNITS)
+            else:       # whole graphs per XCD (stag_plan_blocks_xcd_ranges)
+                cuts, keys = ranges[0], ranges[1]
+                fn_, args = lib.stag_plan_blocks_xcd_ranges, (units_h.ctypes.data, nu, cuts.ctypes.data, keys.ctypes.data,
+                                                              len(keys), fine, _lib.BLOCK_EDGES, _lib.BLOCK_UNITS)
+            _lib.check(fn_(*args, None, None, C.byref(nb)), "stag_plan_blocks_xcd")
             out = np.zeros((max(nu, 1), 4), np.int32)
             ptr = np.zeros(nb.value + 1, np.int32)
-            _lib.check(lib.stag_plan_blocks_xcd(*args, out.ctypes.data, ptr.ctypes.data, C.byref(nb)), "stag_plan_blocks_xcd")
-            got = plan["gat_orders"][fine] = (torch.from_numpy(out).to(dev), torch.from_numpy(ptr).to(dev), nb.value, fine)
+            _lib.check(fn_(*args, out.ctypes.data, ptr.ctypes.data, C.byref(nb)), "stag_plan_blocks_xcd")
+            # (the struct cache of ops._plan_struct is keyed by the last element: one value per order)
+            tag = fine if ranges is None else 1000 + min(int(width), 256)
+            got = plan["gat_orders"][okey] = (torch.from_numpy(out).to(dev), torch.from_numpy(ptr).to(dev), nb.value, tag)
+        return got
+
+    def xcd_ranges(self, width):
+        """(cuts, keys, fine, device cuts, device keys) of xcd_graph_ranges for launches that gather rows of `width`
+        floats, or None when this view is not a batch of several graphs (then the stripes are equal eighths of the CSR).
+        One read-back of G + 1 row pointers, kept; the table is kept per row-byte class."""
+        if self.part_sizes is None or not (WHOLE_GRAPHS_PER_XCD if self.xcd_graphs is None else self.xcd_graphs):
+            return None
+        if self._part_cuts is None:
+            sizes = (self.part_sizes.detach().cpu().numpy() if torch.is_tensor(self.part_sizes) else
+                     np.asarray(self.part_sizes)).astype(np.int64)
+            if len(sizes) < 2 or int(sizes.sum()) != self.n_dst or self.n_edges == 0:
+                self.part_sizes = None
+                return None
+            node_off = np.concatenate([[0], np.cumsum(sizes)])
+            at = torch.from_numpy(node_off).to(self.indptr.device)
+            self._part_cuts = (sizes, self.indptr[at].cpu().numpy().astype(np.int64), {})
+        sizes, edge_cuts, tables = self._part_cuts
+        cls = min(max(int(width), 1), 256)
+        got = tables.get(cls)
+        if got is None:
+            cuts, keys, fine = xcd_graph_ranges(edge_cuts, sizes, cls)
+            dev = self.indptr.device
+            got = tables[cls] = (cuts, keys, fine, torch.from_numpy(cuts).to(dev), torch.from_numpy(keys).to(dev))
         return got
 
     def xcd_fine_for(self, width, cap=256):
@@ -131,43 +230,66 @@ class CsrView:
         nbytes = rows * 4 * (min(max(int(width), 1), cap) if cap else max(int(width), 1))   # (wider rows are tiled at 256)
         return int(min(_lib.XCD_FINE_MAX, max(1, -(-nbytes // XCD_RANGE_BYTES))))
 
-    def _build_xcd_order(self, plan, fine):
+    def _build_xcd_order(self, plan, fine, ranges=None, merge_heavy=False):
         """stag_plan.xcd_order for `plan` (stag_plan_xcd on host records, stag_plan_xcd_device_* on device records: the same
         ints): the units grouped by the eighth of the CSR their rows lie in — inside it by `fine` finer ranges — for
-        workgroup b to take stripe b mod 8."""
-        nu, nh = plan["n_units"], plan["n_heavy"]
+        workgroup b to take stripe b mod 8.  ranges (xcd_ranges): the stripes and fine ranges are whole graphs of a
+        block-diagonal batch instead (stag_plan_xcd_ranges); merge_heavy: no separate heavy stripes (the wide shapes have
+        no slotted loop for them) — an XCD then passes over each fine range once instead of twice."""
+        nu, nh = plan["n_units"], (0 if merge_heavy else plan["n_heavy"])
         lib, units, dev = _lib.lib(), plan["units"], plan["units"].device
         st = (C.c_int32 * 2)()
         if units.is_cuda:
             nbytes = lib.stag_plan_xcd_device_workspace_bytes(nu)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             with _lib.on_device(dev):
-                _lib.check(lib.stag_plan_xcd_device_count(_lib.ptr(units), nu, nh, self.n_edges, fine, st, _lib.ptr(ws), nbytes,
-                                                          _lib.stream_of(dev)), "stag_plan_xcd_device_count")
+                if ranges is None:
+                    _lib.check(lib.stag_plan_xcd_device_count(_lib.ptr(units), nu, nh, self.n_edges, fine, st, _lib.ptr(ws),
+                                                              nbytes, _lib.stream_of(dev)), "stag_plan_xcd_device_count")
+                else:
+                    _lib.check(lib.stag_plan_xcd_device_count_ranges(_lib.ptr(units), nu, nh, _lib.ptr(ranges[3]),
+                                                                     _lib.ptr(ranges[4]), len(ranges[1]), fine, st, _lib.ptr(ws),
+                                                                     nbytes, _lib.stream_of(dev)), "stag_plan_xcd_device_count_ranges")
                 order = torch.empty(lib.stag_plan_xcd_ints(st[0], st[1]), dtype=torch.int32, device=dev)
                 _lib.check(lib.stag_plan_xcd_device_fill(_lib.ptr(units), nu, st, fine, _lib.ptr(order), _lib.ptr(ws), nbytes,
                                                          _lib.stream_of(dev)), "stag_plan_xcd_device_fill")
         else:
             units_h = np.ascontiguousarray(units[:nu].numpy(), dtype=np.int32)
-            _lib.check(lib.stag_plan_xcd(units_h.ctypes.data, nu, nh, self.n_edges, fine, None, st), "stag_plan_xcd")
+            if ranges is None:
+                call = lambda out: lib.stag_plan_xcd(units_h.ctypes.data, nu, nh, self.n_edges, fine, out, st)
+            else:
+                call = lambda out: lib.stag_plan_xcd_ranges(units_h.ctypes.data, nu, nh, ranges[0].ctypes.data,
+                                                            ranges[1].ctypes.data, len(ranges[1]), fine, out, st)
+            _lib.check(call(None), "stag_plan_xcd")
             order_h = np.zeros(lib.stag_plan_xcd_ints(st[0], st[1]), np.int32)
-            _lib.check(lib.stag_plan_xcd(units_h.ctypes.data, nu, nh, self.n_edges, fine, order_h.ctypes.data, st),
-                       "stag_plan_xcd")
+            _lib.check(call(order_h.ctypes.data), "stag_plan_xcd")
             order = torch.from_numpy(order_h)
         return order, (int(st[0]), int(st[1]))
 
     def xcd_order(self, plan, width):
-        """(order, strides, fine) of `plan` for launches of this row width, or (None, (0, 0), 0): the plan has none (see
-        XCD_ORDER), or the one for this width is not built yet and a hipGraph is being captured (it reads counts back)."""
+        """(order, strides, tag) of `plan` for launches of this row width, or (None, (0, 0), 0): the plan has none (see
+        XCD_ORDER), or the one for this width is not built yet and a hipGraph is being captured (it reads counts back).
+        tag: one value per distinct order (ops._plan_struct keys its struct cache by it)."""
         if not plan.get("xcd_on"):
             return None, (0, 0), 0
-        fine = self.xcd_fine_for(width)
-        got = plan["xcd_orders"].get(fine)
+        capturing = plan["units"].is_cuda and torch.cuda.is_current_stream_capturing()
+        ranges = None if capturing and self._part_cuts is None else self.xcd_ranges(width)
+        if ranges is None:
+            fine, merge = self.xcd_fine_for(width), False
+            okey = tag = fine
+        else:
+            cls = min(max(int(width), 1), 256)
+            # one family of stripes where a row takes a whole wave (LPE 64: no slotted loop for heavy units, and the PPI
+            # batch at D = 256 without noise reads 71.6 against 74.5 us; at D = 128 the split order wins, 36.0 against 41.6)
+            fine = ranges[2]
+            merge = (MERGE_HEAVY_WIDE if self.xcd_merge is None else self.xcd_merge) and cls > MERGE_HEAVY_ABOVE
+            okey, tag = ("graphs", cls), 1000 + cls
+        got = plan["xcd_orders"].get(okey)
         if got is None:
-            if plan["units"].is_cuda and torch.cuda.is_current_stream_capturing():
+            if capturing:
                 return None, (0, 0), 0
-            got = plan["xcd_orders"][fine] = self._build_xcd_order(plan, fine)
-        return got[0], got[1], fine
+            got = plan["xcd_orders"][okey] = self._build_xcd_order(plan, fine, ranges, merge)
+        return got[0], got[1], tag
 
     def _add_xcd_order(self, plan):
         """Switch the XCD-aware order on for `plan`; plan["xcd"] / ["xcd_strides"] show the one for 128-wide rows."""
@@ -470,6 +592,8 @@ class Graph:
         if o._csr is None:
             indptr, indices, eid = build_csr(self._src, self._dst, self._n, self._n)
             o._csr = CsrView(self._n, self._n, indptr, indices, eid)
+        if o._csr.part_sizes is None and o._csr._part_cuts is None and self._batch_num_nodes is not None:
+            o._csr.part_sizes = self._batch_num_nodes
         return o._csr
 
     @property
@@ -488,6 +612,8 @@ class Graph:
             else:
                 nidx = pos_of_eid
             o._csr_t = CsrView(self._n, self._n, indptr, indices, eid, nidx)
+        if o._csr_t.part_sizes is None and o._csr_t._part_cuts is None and self._batch_num_nodes is not None:
+            o._csr_t.part_sizes = self._batch_num_nodes      # (block-diagonal: both orientations share the boundaries)
         return o._csr_t
 
     def to(self, device):
@@ -706,6 +832,8 @@ def _batch_build(graphs):
         jobs.run(dev)
         out = Graph(src, dst, total, batch_num_nodes=torch.tensor(sizes, dtype=torch.int64, device=dev), _trusted=True)
         out._csr, out._csr_t = views
+        for v in views:
+            v.part_sizes = np.asarray(sizes, np.int64)      # (known on the host: no read-back when the order is built)
         return out
     if dev.type == "cuda":      # on the device, output size given: no host pass over the edges, no read-back
         edge_off = torch.repeat_interleave(torch.from_numpy(node_off).to(dev), torch.tensor(n_edges, dtype=torch.int64, device=dev),

@@ -1700,11 +1700,16 @@ def test_gat_with_xcd_aware_batches_equals_plan_order(dev, oracle, monkeypatch, 
     from util import random_graph
     G = importlib.import_module("stag_amd.graph")
     s3, d3, sizes = synthetic.ppi_like(n_graphs=6, n_nodes=3000, n_edges=40000, seed=5)
+    # "batch_graphs": the union knows its graphs (batch_num_nodes): batches of whole graphs per stripe, bin-packed
+    # (stag_plan_blocks_xcd_ranges; the budget lowered so that these small graphs make several fine ranges)
+    monkeypatch.setattr(G, "XCD_RANGE_BYTES", 150_000)
     graphs = [("batch", lambda: stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), int(sizes.sum()), device=dev)),
+              ("batch_graphs", lambda: stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), int(sizes.sum()),
+                                                      batch_num_nodes=torch.from_numpy(sizes).to(dev), device=dev)),
               ("hubs", lambda: random_graph(1500, 12000, seed=3, hub=2500, device=dev)),
               ("tiny", lambda: random_graph(5, 12, seed=9, device=dev))]
     if H * F > 256:
-        graphs = graphs[:1]
+        graphs = graphs[:2]
     rng = np.random.default_rng(H * 100 + F)
     for name, mk in graphs:
         monkeypatch.setattr(G, "XCD_ORDER", "1")
@@ -1717,6 +1722,8 @@ def test_gat_with_xcd_aware_batches_equals_plan_order(dev, oracle, monkeypatch, 
         pb = gb.csr.plan(64, need=True)
         gb.csr_t.plan(64, need=True)
         assert pa["xcd_on"] and not pb.get("xcd_on")
+        if name == "batch_graphs":
+            assert ga.csr.gat_blocks(pa, H * F)[3] == 1000 + min(H * F, 256), "the range-table batches are the ones launched"
         n, E = ga.number_of_nodes(), ga.number_of_edges()
         t = lambda *shape: torch.tensor(rng.standard_normal(shape).astype(np.float32), device=dev)
         el0, er0, ft0, gout = t(n, H), t(n, H), t(n, H, F), t(n, H, F)

@@ -1029,8 +1029,14 @@ def test_xcd_aware_unit_order_changes_no_bit(dev, oracle, D, monkeypatch):
     from stag_amd import ops, synthetic
     monkeypatch.setattr(importlib.import_module("stag_amd.graph"), "XCD_ORDER", "1")
     s3, d3, sizes = synthetic.ppi_like(n_graphs=6, n_nodes=3000, n_edges=40000, seed=5)
+    # "batch_graphs": the union KNOWS its graphs (batch_num_nodes): the stripes are whole graphs, bin-packed, and the wide
+    # shapes walk one family of stripes (stag_plan_xcd_ranges; the budget lowered so that these small graphs make several
+    # fine ranges and one of them is cut in two)
+    monkeypatch.setattr(importlib.import_module("stag_amd.graph"), "XCD_RANGE_BYTES", 40_000 * max(1, min(D, 256)) // 64)
     graphs = [("hubs", lambda: random_graph(2500, 30000, seed=3, hub=3000, device=dev)),
               ("batch", lambda: stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), int(sizes.sum()), device=dev)),
+              ("batch_graphs", lambda: stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), int(sizes.sum()),
+                                                      batch_num_nodes=torch.from_numpy(sizes).to(dev), device=dev)),
               ("tiny", lambda: random_graph(5, 12, seed=9, device=dev))]
     rng = np.random.default_rng(D)
     for name, mk in graphs:
@@ -1038,6 +1044,13 @@ def test_xcd_aware_unit_order_changes_no_bit(dev, oracle, D, monkeypatch):
         for view in (gb.csr, gb.csr_t):
             _without_xcd_order(view, 64)
         assert ga.csr.plan(64, need=True)["xcd_on"] and not gb.csr.plan(64)["xcd_on"]
+        if name == "batch_graphs":
+            order, strides, tag = ga.csr.xcd_order(ga.csr.plan(64), D)
+            assert tag == 1000 + min(D, 256) and (strides[0] == 0) == (D > 128)
+            # the device builder (stable radix sort of the range keys) and the host one: the same ints
+            gh = stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), int(sizes.sum()), batch_num_nodes=torch.from_numpy(sizes))
+            oh, sh_, _ = gh.csr.xcd_order(gh.csr.plan(64, need=True), D)
+            assert sh_ == strides and torch.equal(order.cpu(), oh), "device and host builders of the range-table order"
         og = oracle_graph(oracle, ga)
         n = ga.number_of_nodes()
         xh = rng.standard_normal((n, D)).astype(np.float32)

@@ -320,6 +320,93 @@ def test_xcd_block_plan_deals_batches_to_stripes(fine, monkeypatch):
     assert empty < 8 * 40, "only the tails of the shorter stripes are empty"
 
 
+@pytest.mark.parametrize("width,merge", [(256, True), (50, False), (128, False)])
+def test_xcd_order_keeps_whole_graphs_per_stripe(width, merge, monkeypatch):
+    """Block-diagonal batches (scripts/ppi_mle/run.py:12-14): the XCD-aware order's stripes are whole GRAPHS, bin-packed
+    by edge count (xcd_graph_ranges -> stag_plan_xcd_ranges): a graph never straddles two stripes, no fine range mixes
+    part of a graph with another graph, the stripes carry near-equal edge counts, the records are a permutation of the
+    plan's units in the plan's order inside every fine range — and for the wide shapes (no slotted loop for heavy units)
+    there is ONE family of stripes, so an XCD passes over each fine range once."""
+    import importlib
+    import stag_amd
+    from stag_amd import _lib, synthetic
+    G = importlib.import_module("stag_amd.graph")
+    monkeypatch.setattr(G, "XCD_ORDER", "1")
+    monkeypatch.setattr(G, "XCD_RANGE_BYTES", 400_000)          # (small graphs: a small budget)
+    s3, d3, sizes = synthetic.ppi_like(n_graphs=24, n_nodes=12000, n_edges=170000, seed=5)
+    n = int(sizes.sum())
+    g = stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), n, batch_num_nodes=torch.from_numpy(sizes))
+    view = g.csr
+    p = view.plan(64, need=True)
+    nu, nh = p["n_units"], p["n_heavy"]
+    units = p["units"].numpy()[:nu]
+    node_off = np.concatenate([[0], np.cumsum(sizes)])
+    indptr = view.indptr.numpy().astype(np.int64)
+    edge_cuts = indptr[node_off]
+    cuts, keys, fine = G.xcd_graph_ranges(edge_cuts, sizes, width)
+    assert cuts[0] == 0 and cuts[-1] == len(s3) and (np.diff(cuts) >= 0).all() and keys.min() >= 0 and keys.max() < 8 * fine
+    assert 1 <= fine <= _lib.XCD_FINE_MAX
+    # graph of a CSR position, stripe of a graph
+    graph_of = lambda pos: np.clip(np.searchsorted(edge_cuts, pos, side="right") - 1, 0, len(sizes) - 1)
+    key_of = lambda pos: keys[np.clip(np.searchsorted(cuts, pos, side="right") - 1, 0, len(keys) - 1)]
+    mids = (edge_cuts[:-1] + edge_cuts[1:]) // 2
+    stripe_of_graph = key_of(mids) // fine
+    for gi in range(len(sizes)):                 # every edge position of a graph has the graph's stripe
+        pos = np.arange(edge_cuts[gi], edge_cuts[gi + 1], max(1, (edge_cuts[gi + 1] - edge_cuts[gi]) // 50))
+        assert (key_of(pos) // fine == stripe_of_graph[gi]).all(), "a graph never straddles two stripes"
+    load = np.bincount(stripe_of_graph, weights=np.diff(edge_cuts), minlength=8)
+    assert load.max() <= 1.12 * load.mean(), f"stripes by edge count: {load}"
+    # no fine range mixes a PART of a graph with another graph
+    for k in np.unique(keys):
+        gs = np.unique(graph_of(cuts[:-1][keys == k]))
+        if len(gs) > 1:
+            for gi in gs:
+                assert (keys[(cuts[:-1] >= edge_cuts[gi]) & (cuts[:-1] < max(edge_cuts[gi + 1], edge_cuts[gi] + 1))] == k).all()
+    # the library's order from that table
+    order, (sh, sl), tag = view.xcd_order(p, width)
+    assert tag == 1000 + min(width, 256) and view.xcd_ranges(width)[2] == fine
+    o = order.numpy()
+    rec = o[_lib.XCD_HEADER:].reshape(-1, 4)
+    if merge:
+        assert sh == 0 and list(o[:8]) == [0] * 8, "one family of stripes for the wide shapes"
+    else:
+        assert sh > 0 and o[:8].sum() == nh
+    assert o[:16].sum() == nu and o[16] == sh and o[17] == sl and o[18] == fine
+    real = rec[rec[:, 0] >= 0]
+    assert sorted(map(tuple, real)) == sorted(map(tuple, units))
+    heavy_idx = {tuple(u): i for i, u in enumerate(units)}
+    for fam, (base, stride) in enumerate(((0, sh), (8 * sh, sl))):
+        for k in range(8):
+            blk = rec[base + k * stride: base + (k + 1) * stride]
+            blk = blk[blk[:, 0] >= 0]
+            if len(blk) == 0:
+                continue
+            assert (key_of(blk[:, 1].astype(np.int64)) // fine == k)[blk[:, 2] > 0].all(), "units lie in their graph's stripe"
+            kk = key_of(blk[:, 1].astype(np.int64))
+            assert (np.diff(kk) >= 0).all(), "fine ranges one after the other"
+            for f in np.unique(kk):                     # the plan's order inside a fine range
+                idx = [heavy_idx[tuple(u)] for u in blk[kk == f]]
+                assert idx == sorted(idx)
+                if not merge:
+                    assert all((i < nh) == (fam == 0) for i in idx)
+    # the cooperative GAT kernels' batches from the same table
+    U, bp, nb, gtag = view.gat_blocks(p, width)
+    U, bp = U.numpy()[:nu], bp.numpy()
+    assert gtag == tag and nb % 8 == 0 and bp[-1] == nu and sorted(map(tuple, U)) == sorted(map(tuple, units))
+    for b in range(nb):
+        blk = U[bp[b]:bp[b + 1]]
+        blk = blk[blk[:, 2] > 0]
+        if len(blk):
+            kk = key_of(blk[:, 1].astype(np.int64))
+            assert (kk == kk[0]).all() and kk[0] // fine == b % 8
+    # hundreds of small graphs per stripe (a molecule batch): contiguous runs, a few fine ranges
+    s4, d4, sz4 = synthetic.molecules_like(1200)
+    g4 = stag_amd.Graph(torch.from_numpy(s4), torch.from_numpy(d4), int(sz4.sum()), batch_num_nodes=torch.from_numpy(sz4))
+    off4 = g4.csr.indptr.numpy().astype(np.int64)[np.concatenate([[0], np.cumsum(sz4)])]
+    c4, k4, f4 = G.xcd_graph_ranges(off4, sz4, 128, range_bytes=200_000)
+    assert f4 <= _lib.XCD_FINE_MAX and (np.diff(k4 // f4) >= 0).all() and len(np.unique(k4 // f4)) == 8
+
+
 @pytest.mark.parametrize("seg_len", [64, 16, 300])
 def test_block_plan_batches_units(seg_len):
     """stag_plan_blocks: consecutive units of the plan in batches of at most STAG_BLOCK_EDGES edges and

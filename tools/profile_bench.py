@@ -22,8 +22,32 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = None      # --lib: a build variant (tools/_bin/libstag_<name>.so) instead of stag_amd/libstag_hip.so
-SQ = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU",
-      "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"]
+# Two SQ passes, each with its OWN cycle counter: a ratio is formed from counters of one pass only (round 3 divided
+# counters of one replay by the cycles of another, at another clock: "VALU busy" 1.049 — VERDICT r03)
+SQ_A = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"]
+SQ_B = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"]
+
+
+def derived(a, b):
+    """Ratios from the two SQ passes (a: SQ_A's per-dispatch averages, b: SQ_B's), each normalised by the cycles counted
+    in ITS pass.  GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_ACTIVE_INST_VALU counts quad-cycles (x4 = SIMD cycles
+    issuing VALU; 1024 SIMDs).  A busy fraction cannot exceed 1: a raw value above it (counter granularity, the replay's
+    clock) is reported as 1.0 with `valu_saturated`."""
+    out = {}
+    if b.get("GRBM_GUI_ACTIVE"):
+        cyc = b["GRBM_GUI_ACTIVE"] / 8.0
+        raw = b["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc)
+        out.update({"valu_busy_frac": min(raw, 1.0), "valu_busy_frac_raw": raw, "valu_saturated": raw >= 0.995,
+                    "cycles_per_valu_inst": b["SQ_ACTIVE_INST_VALU"] * 4.0 / max(b["SQ_INSTS_VALU"], 1.0),
+                    "xcd_cycles_valu_pass": cyc})
+    if a.get("GRBM_GUI_ACTIVE"):
+        cyc = a["GRBM_GUI_ACTIVE"] / 8.0
+        out.update({"avg_waves_per_simd": a["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * cyc),
+                    "wait_frac_of_wave_life": a["SQ_WAIT_ANY"] / max(a["SQ_WAVE_CYCLES"], 1.0),
+                    "xcd_cycles_wave_pass": cyc})
+    if a.get("SQ_WAVES") and b.get("SQ_INSTS_VALU"):
+        out["valu_insts_per_wave"] = b["SQ_INSTS_VALU"] / max(a["SQ_WAVES"], 1.0)    # (both are counts: no clock in it)
+    return out
 
 
 def run_prof(tag, prof_args, bench_args, scratch):
@@ -71,6 +95,7 @@ def main():
     ap.add_argument("--feat", type=int, default=128)
     ap.add_argument("--graph", default="arxiv")
     ap.add_argument("--seg-len", type=int, default=64)
+    ap.add_argument("--workload", default="agg", choices=["agg", "gat"])
     ap.add_argument("--tag", default="n1", help="file-name tag: bench_<tag>.json, bench_<tag>_kernel_stats.csv, ...")
     ap.add_argument("--lib", default=None, help="profile a build variant: path of its libstag_*.so")
     ap.add_argument("--summarize-only", action="store_true",
@@ -86,8 +111,8 @@ def main():
     dst = os.path.join(ROOT, "gpurun_out", "profiles", args.round)
     os.makedirs(dst, exist_ok=True)
     common = ["--noise", args.noise, "--feat", str(args.feat), "--graph", args.graph,
-              "--seg-len", str(args.seg_len), "--no-cpu-baseline", "--no-variants"]   # one workload per profile
-    kernel_sub = "agg_kernel"
+              "--seg-len", str(args.seg_len), "--workload", args.workload, "--no-cpu-baseline", "--no-variants"]   # one workload per profile
+    kernel_sub = "gat_fwd" if args.workload == "gat" else "agg_kernel"
 
     out, line = run_prof("stats", ["--kernel-trace", "--stats"], ["--steps", "200", "--warmup", "20", *common], scratch)
     stats = find(out, "kernel_stats.csv")
@@ -103,14 +128,15 @@ def main():
 
     summary = {}
     short = ["--steps", "20", "--warmup", "5", "--settle-ms", "0", *common]     # counters do not need warm clocks
-    for tag, ctrs in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_sq", SQ)):
+    for tag, ctrs in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_sq_a", SQ_A), ("pmc_sq_b", SQ_B)):
         out, _ = run_prof(tag, ["--pmc", *ctrs], short, scratch)
         name, nd, avg = counters(out, kernel_sub)
         summary[tag] = {"kernel": name, "dispatches": nd, "counters_avg_per_dispatch": avg}
     fetch_kb = summary["pmc_fetch"]["counters_avg_per_dispatch"]["FETCH_SIZE"]
     write_kb = summary["pmc_write"]["counters_avg_per_dispatch"]["WRITE_SIZE"]
     summary["traffic"] = {
-        "workload": f"{args.graph}/{args.noise}/D{args.feat}/seg{args.seg_len}",
+        "workload": (f"{args.graph}/{args.noise}/D{args.feat}/seg{args.seg_len}" if args.workload == "agg" else
+                     f"{args.graph}/gat8x32/{args.noise}/seg{args.seg_len}"),
         "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
         "correction": "gfx950: FETCH_SIZE counts 128-B fabric read requests at 64 B => x2 for 16-B-per-lane "
                       "loads (MI355X_MICROARCH.md HBM); WRITE_SIZE exact for 16-B-per-lane stores",
@@ -118,20 +144,11 @@ def main():
         "note": "counters sit on the fabric side of L2 and include Infinity-Cache hits: x (86.7 MB) stays "
                 "resident in the 256 MB Infinity Cache (an nt gather, which bypasses it, is 36 % slower), so "
                 "this is L2-miss traffic, an upper bound on HBM bytes"}
-    sq = summary["pmc_sq"]["counters_avg_per_dispatch"]
-    if agg and sq.get("SQ_BUSY_CYCLES"):
+    d = derived(summary["pmc_sq_a"]["counters_avg_per_dispatch"], summary["pmc_sq_b"]["counters_avg_per_dispatch"])
+    if agg and d:
         dur_us = float(agg[0]["AverageNs"]) / 1e3
-        xcd_cycles = sq["GRBM_GUI_ACTIVE"] / 8.0          # the counter is summed over the 8 XCDs
-        summary["derived"] = {
-            "kernel_avg_us_from_stats_pass": dur_us,
-            "clock_ghz_est": xcd_cycles / (dur_us * 1e3),
-            # SQ_ACTIVE_INST_VALU counts quad-cycles: x4 = SIMD cycles spent issuing VALU; 1024 SIMDs
-            "valu_busy_frac": sq["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * xcd_cycles),
-            "valu_insts_per_wave": sq["SQ_INSTS_VALU"] / max(sq["SQ_WAVES"], 1.0),
-            "cycles_per_valu_inst": sq["SQ_ACTIVE_INST_VALU"] * 4.0 / max(sq["SQ_INSTS_VALU"], 1.0),
-            "avg_waves_per_simd": sq["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * xcd_cycles),
-            "wait_frac_of_wave_life": sq["SQ_WAIT_ANY"] / max(sq["SQ_WAVE_CYCLES"], 1.0),
-        }
+        d["kernel_avg_us_from_stats_pass"] = dur_us
+        summary["derived"] = d
     with open(os.path.join(dst, f"bench_{args.tag}_pmc_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
         f.write("\n")

@@ -21,8 +21,34 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SQ = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU",
-      "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"]
+# Two SQ passes, each with its OWN cycle counter: a ratio is formed from counters of one pass only (round 3 divided
+# counters of one replay by the cycles of another, at another clock: "VALU busy" 1.049 — VERDICT r03)
+SQ_A = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"]
+SQ_B = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"]
+
+
+def derived(a, b):
+    """Ratios from the two SQ passes (a: SQ_A's per-dispatch averages, b: SQ_B's), each normalised by the cycles counted
+    in ITS pass.  GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_ACTIVE_INST_VALU counts quad-cycles (x4 = SIMD cycles
+    issuing VALU; 1024 SIMDs).  A busy fraction cannot exceed 1: a raw value above it (counter granularity, the replay's
+    clock) is reported as 1.0 with `valu_saturated`."""
+    out = {}
+    if b.get("GRBM_GUI_ACTIVE"):
+        cyc = b["GRBM_GUI_ACTIVE"] / 8.0
+        raw = b["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc)
+        out.update({"valu_busy_frac": min(raw, 1.0), "valu_busy_frac_raw": raw, "valu_saturated": raw >= 0.995,
+                    "cycles_per_valu_inst": b["SQ_ACTIVE_INST_VALU"] * 4.0 / max(b["SQ_INSTS_VALU"], 1.0),
+                    "xcd_cycles_valu_pass": cyc})
+    if a.get("GRBM_GUI_ACTIVE"):
+        cyc = a["GRBM_GUI_ACTIVE"] / 8.0
+        out.update({"avg_waves_per_simd": a["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * cyc),
+                    "wait_frac_of_wave_life": a["SQ_WAIT_ANY"] / max(a["SQ_WAVE_CYCLES"], 1.0),
+                    "xcd_cycles_wave_pass": cyc})
+    if a.get("SQ_WAVES") and b.get("SQ_INSTS_VALU"):
+        out["valu_insts_per_wave"] = b["SQ_INSTS_VALU"] / max(a["SQ_WAVES"], 1.0)    # (both are counts: no clock in it)
+    return out
+
+
 KERNELS = re.compile(r"agg_kernel|gat_\w+_kernel|segment_reduce_kernel|agg_bwd_w_kernel|noise_materialize")
 
 
@@ -83,17 +109,18 @@ def main():
         print("kernel stats:", {k[:70]: v for k, v in avg_ns.items()}, flush=True)
         summary = {"config": cfg, "noise": args.noise, "script_lines": lines, "kernels": {}}
         passes = {}
-        for ptag, ctrs in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_sq", SQ)):
+        for ptag, ctrs in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_sq_a", SQ_A), ("pmc_sq_b", SQ_B)):
             out, _ = run_prof(ptag, ["--pmc", *ctrs], [*prog, "--steps", "10", "--warmup", "2", "--settle-ms", "0"], scratch)
             passes[ptag] = counters(out)
         for name in sorted(set().union(*[set(p) for p in passes.values()])):
             k = {"avg_us_stats_pass": avg_ns.get(name, (None, 0))[0] and avg_ns[name][0] / 1e3,
                  "calls_stats_pass": avg_ns.get(name, (None, 0))[1]}
-            c = {}
+            c, per_pass = {}, {}
             for ptag in passes:
                 if name in passes[ptag]:
                     k[f"dispatches_{ptag}"] = passes[ptag][name][0]
-                    c.update(passes[ptag][name][1])
+                    per_pass[ptag] = passes[ptag][name][1]
+                    c.update({(f"{cn}@{ptag}" if cn == "GRBM_GUI_ACTIVE" else cn): v for cn, v in passes[ptag][name][1].items()})
             k["counters_avg_per_dispatch"] = c
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 # gfx950: FETCH_SIZE tallies 128-B fabric read requests at 64 B => x2 (MI355X_MICROARCH.md, HBM);
@@ -101,14 +128,9 @@ def main():
                 k["traffic_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
                 if k["avg_us_stats_pass"]:
                     k["traffic_TBs"] = k["traffic_bytes_per_launch"] / (k["avg_us_stats_pass"] * 1e-6) / 1e12
-            if c.get("GRBM_GUI_ACTIVE") and k["avg_us_stats_pass"]:
-                xcd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0
-                k["derived"] = {
-                    "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * xcd_cycles),
-                    "valu_insts_per_wave": c["SQ_INSTS_VALU"] / max(c["SQ_WAVES"], 1.0),
-                    "avg_waves_per_simd": c["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * xcd_cycles),
-                    "wait_frac_of_wave_life": c["SQ_WAIT_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0),
-                }
+            d = derived(per_pass.get("pmc_sq_a", {}), per_pass.get("pmc_sq_b", {}))
+            if d:
+                k["derived"] = d
             summary["kernels"][name] = k
         with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as f:
             json.dump(summary, f, indent=1)
