@@ -44,6 +44,13 @@ XCD_AFTER_LAUNCHES = 16
 # block-diagonal batches: whole graphs per XCD (xcd_graph_ranges) | equal eighths of the CSR, which cut graphs (A/B)
 WHOLE_GRAPHS_PER_XCD = os.environ.get("STAG_XCD_GRAPHS", "1") != "0"
 MERGE_HEAVY_WIDE = os.environ.get("STAG_XCD_MERGE_HEAVY", "1") != "0"
+# Measured on the PPI batch (tools/xcd_graphs_probe.py, profiles/r04/xcd_graphs_*.txt; us, eighths | graphs | graphs merged):
+#   D = 128  no draw 35.2 | 36.2 | 42.0   Normal  62.3 |  64.0 |  74.0      (an eighth of the table fits an L2 either way)
+#   D = 256  no draw 77.6 | 74.6 | 71.8   Normal 121.7 | 122.7 | 126.1      (fabric traffic 402 -> 170 MB without a draw)
+#   GAT forward H*F = 256: 108.1 | 96.3,  4 x 256: 379 | 354
+# so whole graphs per XCD are for rows of more than GRAPHS_ABOVE floats (1 KB and up: a stripe's share of the table no longer
+# fits the 4 MB L2), and the one-family order for launches that do not draw (a drawing launch is the VALU's either way).
+GRAPHS_ABOVE = int(os.environ.get("STAG_XCD_GRAPHS_ABOVE", "128"))         # floats per row
 MERGE_HEAVY_ABOVE = int(os.environ.get("STAG_XCD_MERGE_ABOVE", "128"))     # floats per row
 PLAN_AFTER_LAUNCHES = 16     # launches a short-row view runs without a plan before one is built for it
 
@@ -202,6 +209,8 @@ class CsrView:
         One read-back of G + 1 row pointers, kept; the table is kept per row-byte class."""
         if self.part_sizes is None or not (WHOLE_GRAPHS_PER_XCD if self.xcd_graphs is None else self.xcd_graphs):
             return None
+        if min(max(int(width), 1), 256) <= GRAPHS_ABOVE and self.xcd_graphs is None:
+            return None
         if self._part_cuts is None:
             sizes = (self.part_sizes.detach().cpu().numpy() if torch.is_tensor(self.part_sizes) else
                      np.asarray(self.part_sizes)).astype(np.int64)
@@ -266,9 +275,10 @@ class CsrView:
             order = torch.from_numpy(order_h)
         return order, (int(st[0]), int(st[1]))
 
-    def xcd_order(self, plan, width):
+    def xcd_order(self, plan, width, drawn=False):
         """(order, strides, tag) of `plan` for launches of this row width, or (None, (0, 0), 0): the plan has none (see
         XCD_ORDER), or the one for this width is not built yet and a hipGraph is being captured (it reads counts back).
+        drawn: the launch draws noise (it then keeps the heavy units' own stripes: see GRAPHS_ABOVE).
         tag: one value per distinct order (ops._plan_struct keys its struct cache by it)."""
         if not plan.get("xcd_on"):
             return None, (0, 0), 0
@@ -282,8 +292,8 @@ class CsrView:
             # one family of stripes where a row takes a whole wave (LPE 64: no slotted loop for heavy units, and the PPI
             # batch at D = 256 without noise reads 71.6 against 74.5 us; at D = 128 the split order wins, 36.0 against 41.6)
             fine = ranges[2]
-            merge = (MERGE_HEAVY_WIDE if self.xcd_merge is None else self.xcd_merge) and cls > MERGE_HEAVY_ABOVE
-            okey, tag = ("graphs", cls), 1000 + cls
+            merge = ((MERGE_HEAVY_WIDE and not drawn) if self.xcd_merge is None else self.xcd_merge) and cls > MERGE_HEAVY_ABOVE
+            okey, tag = ("graphs", cls, merge), 1000 + cls + (512 if merge else 0)
         got = plan["xcd_orders"].get(okey)
         if got is None:
             if capturing:

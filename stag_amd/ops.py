@@ -72,7 +72,7 @@ def _spec_in_norm(spec):
     return bool(spec[0][3]) if isinstance(spec, tuple) else bool(spec.in_norm)
 
 
-def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None, width=None, gat_width=None):
+def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None, width=None, gat_width=None, drawn=False):
     """ctypes stag_plan for csrv (None when planning is off), plus the tensors it points into.
     plan_t: a sub-plan of csrv (CsrView.subplan) instead of its whole plan.  width: the row width of an aggregation
     launch — it may walk the plan's XCD-aware order (stag_plan.xcd_order).  gat_width: H * F of a cooperative GAT
@@ -90,7 +90,7 @@ def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None, width=None, gat
     if counters is None:
         counters = torch.zeros(max(plan_t["n_long"], 1) * tiles, dtype=torch.int32, device=dev)
         plan_t["counters"][key] = counters
-    order, strides, fine = csrv.xcd_order(plan_t, width) if width and plan_t.get("xcd_on") else (None, (0, 0), 0)
+    order, strides, fine = csrv.xcd_order(plan_t, width, drawn) if width and plan_t.get("xcd_on") else (None, (0, 0), 0)
     units, block_ptr, n_blocks = plan_t["units"], plan_t["block_ptr"], plan_t["n_blocks"]
     if gat_width and plan_t.get("xcd_on"):
         blocks = csrv.gat_blocks(plan_t, gat_width)
@@ -113,7 +113,7 @@ def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None, width=None, gat
 _NONE_ARGS = ([_lib.NOISE_NONE, 0, 0, 0, 0, 0, 0, 0], [0, 0, 0], [0.0, 0.0], None, None, None)
 
 
-def _plan_args(csrv, plan_t, tiles, dev, width=None):
+def _plan_args(csrv, plan_t, tiles, dev, width=None, drawn=False):
     """(units, long_rows, long_seg_ptr, block_ptr, xcd, counters, plan_ints) of torch.ops.stag.*"""
     if plan_t is None:
         return (None, None, None, None, None, None, [0, 0, 0, 0, 0, 0, 0, 0])
@@ -122,7 +122,7 @@ def _plan_args(csrv, plan_t, tiles, dev, width=None):
     if counters is None:
         counters = torch.zeros(max(plan_t["n_long"], 1) * tiles, dtype=torch.int32, device=dev)
         plan_t["counters"][key] = counters
-    order, strides, _ = csrv.xcd_order(plan_t, width) if width and plan_t.get("xcd_on") else (None, (0, 0), 0)
+    order, strides, _ = csrv.xcd_order(plan_t, width, drawn) if width and plan_t.get("xcd_on") else (None, (0, 0), 0)
     ints = [plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"], plan_t["n_heavy"], plan_t["n_blocks"],
             *strides]
     return (plan_t["units"], plan_t["long_rows"], plan_t["long_seg_ptr"], plan_t["block_ptr"], order, counters, ints)
@@ -133,7 +133,8 @@ def _agg_fwd_torch(csrv, x, noise_args, reduce, src_scale, dst_scale, seg_len, w
     dev = _lib.require_device(x, csrv.indptr, src_scale, dst_scale)
     D = x.numel() if broadcast_x else x.shape[1]
     plan_t = csrv.plan(seg_len)
-    out, ns = torch.ops.stag.agg_fwd(*csrv.torch_args(), *_plan_args(csrv, plan_t, (D + 255) // 256, dev, width=D), x,
+    out, ns = torch.ops.stag.agg_fwd(*csrv.torch_args(), *_plan_args(csrv, plan_t, (D + 255) // 256, dev, width=D,
+                                                                     drawn=noise_args[0][0] >= _lib.NOISE_NORMAL), x,
                                      broadcast_x, *noise_args, reduce, src_scale, dst_scale, want_norm_scale)
     return out, (ns if want_norm_scale else None)
 
@@ -156,7 +157,8 @@ def _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len, want_norm_
         plan_t = csrv.plan(seg_len)
     nbytes = (_lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], D, int(spec.in_norm))
               if plan_t is not None else 0)
-    plan_c, _keep = _plan_struct(csrv, seg_len, (D + 255) // 256, nbytes, dev, plan_t, width=D)
+    plan_c, _keep = _plan_struct(csrv, seg_len, (D + 255) // 256, nbytes, dev, plan_t, width=D,
+                                 drawn=spec.kind >= _lib.NOISE_NORMAL)
     # (spec is the ctypes form from here on)
     cs = csrv.struct()
     with _lib.on_device(dev):
@@ -185,7 +187,8 @@ def _agg_bwd_raw(csrv_t, g, D, spec, g_scale, row_scale, seg_len, want_dp):
     if isinstance(spec, tuple):
         dev = _lib.require_device(g, csrv_t.indptr, g_scale, row_scale)
         plan_t = csrv_t.plan(seg_len)
-        dx, t0, t1 = torch.ops.stag.agg_bwd(*csrv_t.torch_args(), *_plan_args(csrv_t, plan_t, (D + 255) // 256, dev, width=D),
+        dx, t0, t1 = torch.ops.stag.agg_bwd(*csrv_t.torch_args(), *_plan_args(csrv_t, plan_t, (D + 255) // 256, dev, width=D,
+                                                                               drawn=spec[0][0] >= _lib.NOISE_NORMAL),
                                             g, *spec, g_scale, row_scale, want_dp)
         return dx, (t0 if want_dp else None), (t1 if want_dp else None)
     dev = _lib.require_device(g, csrv_t.indptr, g_scale, row_scale)
@@ -195,7 +198,8 @@ def _agg_bwd_raw(csrv_t, g, D, spec, g_scale, row_scale, seg_len, want_dp):
     plan_t = csrv_t.plan(seg_len)
     nbytes = (_lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], (3 if want_dp else 1) * D, 0)
               if plan_t is not None else 0)
-    plan_c, _keep = _plan_struct(csrv_t, seg_len, (D + 255) // 256, nbytes, dev, plan_t=plan_t, width=D)
+    plan_c, _keep = _plan_struct(csrv_t, seg_len, (D + 255) // 256, nbytes, dev, plan_t=plan_t, width=D,
+                                 drawn=spec.kind >= _lib.NOISE_NORMAL)
     cs = csrv_t.struct()
     with _lib.on_device(dev):
         rc = _lib.lib().stag_agg_bwd(

@@ -1045,10 +1045,13 @@ def test_xcd_aware_unit_order_changes_no_bit(dev, oracle, D, monkeypatch):
             _without_xcd_order(view, 64)
         assert ga.csr.plan(64, need=True)["xcd_on"] and not gb.csr.plan(64)["xcd_on"]
         if name == "batch_graphs":
+            for view in (ga.csr, ga.csr_t):
+                view.xcd_graphs = True          # (by default only for rows of 1 KB and up: here at every width)
             order, strides, tag = ga.csr.xcd_order(ga.csr.plan(64), D)
-            assert tag == 1000 + min(D, 256) and (strides[0] == 0) == (D > 128)
+            assert tag == 1000 + min(D, 256) + (512 if D > 128 else 0) and (strides[0] == 0) == (D > 128)
             # the device builder (stable radix sort of the range keys) and the host one: the same ints
             gh = stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), int(sizes.sum()), batch_num_nodes=torch.from_numpy(sizes))
+            gh.csr.xcd_graphs = True
             oh, sh_, _ = gh.csr.xcd_order(gh.csr.plan(64, need=True), D)
             assert sh_ == strides and torch.equal(order.cpu(), oh), "device and host builders of the range-table order"
         og = oracle_graph(oracle, ga)

@@ -337,6 +337,9 @@ def test_xcd_order_keeps_whole_graphs_per_stripe(width, merge, monkeypatch):
     n = int(sizes.sum())
     g = stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), n, batch_num_nodes=torch.from_numpy(sizes))
     view = g.csr
+    assert view.xcd_ranges(128) is None and view.xcd_ranges(256) is not None, "by default: rows of 1 KB and up (GRAPHS_ABOVE)"
+    view.xcd_graphs = True                     # every width, to test the builders
+    view._part_cuts = None
     p = view.plan(64, need=True)
     nu, nh = p["n_units"], p["n_heavy"]
     units = p["units"].numpy()[:nu]
@@ -364,7 +367,10 @@ def test_xcd_order_keeps_whole_graphs_per_stripe(width, merge, monkeypatch):
                 assert (keys[(cuts[:-1] >= edge_cuts[gi]) & (cuts[:-1] < max(edge_cuts[gi + 1], edge_cuts[gi] + 1))] == k).all()
     # the library's order from that table
     order, (sh, sl), tag = view.xcd_order(p, width)
-    assert tag == 1000 + min(width, 256) and view.xcd_ranges(width)[2] == fine
+    assert tag == 1000 + min(width, 256) + (512 if merge else 0) and view.xcd_ranges(width)[2] == fine
+    if merge:       # a launch that draws keeps the heavy units' own stripes
+        o2, (sh2, _), tag2 = view.xcd_order(p, width, drawn=True)
+        assert tag2 == 1000 + min(width, 256) and sh2 > 0 and o2 is not order
     o = order.numpy()
     rec = o[_lib.XCD_HEADER:].reshape(-1, 4)
     if merge:
@@ -392,7 +398,7 @@ def test_xcd_order_keeps_whole_graphs_per_stripe(width, merge, monkeypatch):
     # the cooperative GAT kernels' batches from the same table
     U, bp, nb, gtag = view.gat_blocks(p, width)
     U, bp = U.numpy()[:nu], bp.numpy()
-    assert gtag == tag and nb % 8 == 0 and bp[-1] == nu and sorted(map(tuple, U)) == sorted(map(tuple, units))
+    assert gtag == 1000 + min(width, 256) and nb % 8 == 0 and bp[-1] == nu and sorted(map(tuple, U)) == sorted(map(tuple, units))
     for b in range(nb):
         blk = U[bp[b]:bp[b + 1]]
         blk = blk[blk[:, 2] > 0]
