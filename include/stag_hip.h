@@ -174,10 +174,11 @@ typedef struct stag_plan {
                                   of the table per XCD.  16-byte aligned; a header of STAG_XCD_HEADER ints (units per
                                   heavy stripe [0, 8), per other stripe [8, 16), the two strides, fine), then 8 heavy stripes
                                   of xcd_stride_heavy records and 8 stripes of xcd_stride_light records, each padded
-                                  with null records {-1, 0, 0, -1}.  Used by the plain aggregation launches (stag_agg_fwd
-                                  and stag_agg_bwd with one output and scalar / per-channel parameters; the Monte-Carlo,
-                                  derivative and per-edge-parameter forms keep `units`); every result is bit-identical
-                                  with and without it.                                                              */
+                                  with null records {-1, 0, 0, -1}.  Used by every aggregation launch that walks units
+                                  (stag_agg_fwd with any parameter mode, stag_agg_fwd_mc, stag_agg_bwd, stag_agg_bwd_edge;
+                                  v19: round 3 limited it to one output and scalar / per-channel parameters) except
+                                  stag_agg_bwd_dp, whose block partials are added in plan order; every result is
+                                  bit-identical with and without it.                                               */
   int32_t xcd_stride_heavy;    /* records per heavy stripe = units in the longest one; per other stripe (stag_plan_xcd) */
   int32_t xcd_stride_light;
 } stag_plan;

@@ -1177,9 +1177,14 @@ inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles
   constexpr int TPBH = STAG_BLOCK_THREADS / (LPE * HS);
   const bool slotted = !(HS == 1 || a.outx[0] || pedge == 3 || a.dp_part);
   if (!slotted) a.n_heavy = 0;
-  // the walk (XCD-aware order, row stripes without a plan) is the plain family's: one output, no per-edge parameters
+  // Two sets of instantiations.  The plain family (one output, scalar / per-channel parameters: the headline) keeps a
+  // kernel WITHOUT the walk for plan-order launches — as one kernel with a run-time walk its narrow shapes lost 2 us of 35
+  // (tools/ab_bench.py).  Every other family that walks units (Monte-Carlo samples, the derivative outputs, per-edge
+  // parameters and their gradients) exists ONLY with the walk (round 4): plan order is the one-stripe walk
+  // (smask 0: sh = the heavy prefix, sl = the rest), so the XCD-aware order and the row stripes of plan-less launches
+  // reach them without a second set of kernels.  (stag_agg_bwd_dp's kernel adds block partials in block order: plan order.)
   const bool plain = !a.outx[0] && !a.dp_part && pedge == 0;
-  if (a.xcd && !plain) { a.xcd = nullptr; a.units = a.units_plan; }
+  if (a.xcd && a.dp_part) { a.xcd = nullptr; a.units = a.units_plan; }
   a.n_heavy_blocks = (a.n_heavy + TPBH - 1) / TPBH;
   dim3 grid(a.n_heavy_blocks + (a.n_units - a.n_heavy + TPB - 1) / TPB, tiles);
   bool walk = false;
@@ -1192,36 +1197,43 @@ inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles
     w.lbase = STAG_XCD_STRIPES * w.sh;
     w.n_total = STAG_XCD_STRIPES * (w.sh + w.sl);
     grid.x = STAG_XCD_STRIPES * (w.jh_heavy + w.jh_light + (w.sl + TPB - 1) / TPB);
-  } else if (STAG_XCD_PLANLESS && plain && !a.units && a.n_units >= STAG_XCD_STRIPES * TPB && a.n_units < (1 << 30)) {
+  } else if (STAG_XCD_PLANLESS && !a.dp_part && !a.units && a.n_units >= STAG_XCD_STRIPES * TPB && a.n_units < (1 << 30)) {
     // a graph that runs without a plan (short rows only: a freshly batched minibatch of molecules) is striped by rows
     walk = true;
     w = AggArgs::Walk{STAG_XCD_STRIPES - 1, 3, 0, 0, 0, 0, 0, a.n_units};
     w.sl = ((a.n_units + STAG_XCD_STRIPES - 1) / STAG_XCD_STRIPES + TPB - 1) / TPB * TPB;
     grid.x = STAG_XCD_STRIPES * (w.sl / TPB);
+  } else if (!plain && !a.dp_part) {
+    // plan order (or row order without a plan) as the one-stripe walk
+    walk = true;
+    w = AggArgs::Walk{0, 0, 0, 0, a.n_heavy, a.n_heavy, a.n_units - a.n_heavy, a.n_units};
+    w.jh_heavy = slotted ? a.n_heavy_blocks : 0;
+    w.jh_light = slotted ? 0 : (w.sh + TPB - 1) / TPB;
+    grid.x = w.jh_heavy + w.jh_light + (w.sl + TPB - 1) / TPB;
   }
   if (grid.x == 0) return;
   const dim3 block(STAG_BLOCK_THREADS);
   if constexpr (KIND >= kNormal) {
     if (a.mc && a.outx[2]) {   // four Monte-Carlo samples per gathered row (validated on the host: !pedge)
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 4, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 4, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 4, true, false, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 4, true, false, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
       return;
     }
     if (a.mc && a.outx[0] && a.in_norm) {   // two, each with its own in-norm weight sums
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 2, true, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 2, true, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 2, true, true, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 2, true, true, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
       return;
     }
     if (a.mc && a.outx[0]) {   // two
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 2, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 2, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 2, true, false, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 2, true, false, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
       return;
     }
   }
   if constexpr (KIND == kNormal || KIND == kUniform) {
     if (a.outx[0]) {        // weight + both parameter derivatives in one pass (validated on the host: !pedge)
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 3>), grid, block, STAG_AGG_LDS_BYTES, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 3>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 3, false, false, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 3, false, false, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
       return;
     }
   }
@@ -1232,20 +1244,20 @@ inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles
       return;
     }
     if (pedge == 3) {       // [E, 1] parameters and their gradients (stag_agg_bwd_edge)
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 3>), grid, block, STAG_AGG_LDS_BYTES, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 3>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 3, 1, false, false, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 3, 1, false, false, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
       return;
     }
   }
   if constexpr (KIND >= kNormal) {
     if (pedge == 1) {       // [E, 1] parameters: one pair per edge
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 1>), grid, block, STAG_AGG_LDS_BYTES, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 1>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 1, 1, false, false, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 1, 1, false, false, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
       return;
     }
     if (pedge == 2) {       // [E, D] parameters: a row per edge
-      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 2>), grid, block, STAG_AGG_LDS_BYTES, s, a);
-      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 2>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 2, 1, false, false, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+      else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 2, 1, false, false, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
       return;
     }
   }

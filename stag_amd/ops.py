@@ -222,7 +222,7 @@ def _agg_bwd_edge_raw(csrv_t, g, x, D, spec, g_scale, row_scale, seg_len, want_d
     e1 = torch.empty_like(e0)
     plan_t = csrv_t.plan(seg_len)
     nbytes = _lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], D, 0) if plan_t is not None else 0
-    plan_c, _keep = _plan_struct(csrv_t, seg_len, 1, nbytes, dev, plan_t=plan_t)
+    plan_c, _keep = _plan_struct(csrv_t, seg_len, 1, nbytes, dev, plan_t=plan_t, width=D, drawn=True)
     cs = csrv_t.struct()
     with _lib.on_device(dev):
         rc = _lib.lib().stag_agg_bwd_edge(
@@ -373,9 +373,11 @@ def node_linear(x, w, bias=None, add=None):
         # gradient keeps its split-K form instead of a K = S*N single-tile-column reduction
         S, n = x.shape[0], x.shape[1]
         return _NodeLinear.apply(x.view(S * n, x.shape[2]), w, bias).view(S, n, w.shape[1])
-    if x.dim() != 2 or not x.is_contiguous():
+    if x.dim() != 2 or x.stride(1) != 1 or x.stride(0) < x.shape[1]:
         y = x @ w if bias is None else x @ w + bias
         return y if add is None else y + add
+    # (rows may be strided — the [:, :D] view of a padded aggregation result: the GEMMs take the leading dimension,
+    # the split-K weight gradient views the rows in groups, neither needs a packed copy)
     if add is not None and (add.shape != (x.shape[0], w.shape[1]) or add.dtype != x.dtype):
         return _NodeLinear.apply(x, w, bias) + add
     return _NodeLinear.apply(x, w, bias, add)
@@ -812,6 +814,38 @@ class _AggregateVI(torch.autograd.Function):
         return dx, dp0, dp1, None, None, None, None, None, None
 
 
+# ---- constant inputs of a width that is not a multiple of 4 (PPI's 50 input features: BASELINE configs[2], layer 1) ------
+# With D % 4 != 0 the kernels take their scalar row forms (4 bounds-checked stores per lane, more registers: 83 against 79
+# VGPRs at 16 lanes per row = 5 against 6 waves per SIMD).  A tensor that is a CONSTANT of the run — it carries no gradient
+# and the same object comes back unchanged, as dataset features do on every epoch — is zero-padded to the next multiple
+# of 4 ONCE (on its second sighting: a fresh tensor per step, e.g. a freshly batched minibatch's features, would pay the
+# copy the vector forms save — measured in round 1) and the launch runs at the padded width: the first D channels of the
+# result are the same bits (a Philox block covers 4 channels either way; the padded channels gather zeros), returned as a
+# view [:, :D] of the padded result, which the dense transform behind it reads through its row stride (node_linear).
+PAD_CONSTANT_INPUTS = True
+_const_pads = {}          # id(tensor) -> [weakref, _version, data_ptr, sightings, padded | None]
+
+
+def _padded_constant(x):
+    """The cached zero-padded copy [N, ceil4(D)] of a constant x [N, D], or None (first sighting, or it changed)."""
+    import weakref
+    key = id(x)
+    ent = _const_pads.get(key)
+    if ent is None or ent[0]() is not x or ent[1] != x._version or ent[2] != x.data_ptr():
+        if len(_const_pads) >= 64:
+            _const_pads.clear()
+        _const_pads[key] = [weakref.ref(x, lambda _r, key=key: _const_pads.pop(key, None)), x._version, x.data_ptr(), 1, None]
+        return None
+    ent[3] += 1
+    if ent[4] is None:
+        D = x.shape[1]
+        Dp = (D + 3) // 4 * 4
+        xp = torch.zeros((x.shape[0], Dp), dtype=torch.float32, device=x.device)
+        xp[:, :D].copy_(x)
+        ent[4] = xp
+    return ent[4]
+
+
 def aggregate_into(csrv, x, out, weight, reduce, src_scale, dst_scale, plan_t):
     """The rows of ONE sub-plan of csrv (CsrView.subplan) written into `out` [n_dst, D]; no autograd.
     How a node-range shard launches its local-source rows while the halo exchange is in flight and
@@ -873,13 +907,19 @@ def aggregate(graph, x, weight=None, reduce="sum", src_scale=None, dst_scale=Non
     if not (torch.is_grad_enabled() and (x.requires_grad or (w is not None and w.requires_grad))):
         # nothing to differentiate: straight to the library (no autograd node; host time of a call matters on
         # launch-bound graphs)
-        x = _f32c(x)
+        xin, x = x, _f32c(x)
         if noise is not None:
             spec = _noise_spec(noise)
         elif w is not None:
             spec = _explicit_spec(_f32c(w))
         else:
             spec = _none_spec()
+        if (PAD_CONSTANT_INPUTS and D % 4 and D > 4 and w is None and not _broadcast_x and x is xin and x.is_cuda
+                and not x.requires_grad and (noise is None or noise.param_mode == _lib.PARAM_SCALAR)):
+            xp = _padded_constant(x)
+            if xp is not None:
+                return _agg_raw(graph.csr, xp, xp.shape[1], spec, _REDUCE[reduce], _f32c(src_scale), _f32c(dst_scale),
+                                seg_len)[0][:, :D]
         return _agg_raw(graph.csr, x, D, spec, _REDUCE[reduce], _f32c(src_scale), _f32c(dst_scale), seg_len,
                         broadcast_x=_broadcast_x)[0]
     return _Aggregate.apply(x, w, graph, noise, _REDUCE[reduce], _f32c(src_scale),

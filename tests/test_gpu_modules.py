@@ -1776,3 +1776,56 @@ def test_gat_with_xcd_aware_batches_equals_plan_order(dev, oracle, monkeypatch, 
             for a, b, nm in zip(res[0][1:], res[1][1:], ("d loc", "d scale")):
                 sc = max(1.0, float(b.abs().max()))
                 assert_close(a / sc, (b / sc).cpu().numpy(), what=f"{name} vi H={H} F={F}: {nm}")
+
+
+@pytest.mark.gpu
+def test_constant_inputs_of_odd_width_are_padded_once(dev):
+    """PPI's 50 input features (BASELINE configs[2], layer 1): a tensor that carries no gradient and comes back unchanged
+    is zero-padded to 52 columns ONCE, on its second sighting, and the launch runs its vector forms at the padded width —
+    the result is a [:, :50] view of the padded output with the SAME bits as the unpadded launch (a Philox block covers 4
+    channels either way); a tensor that changed is padded again; the dense transform behind it reads the view through its
+    row stride (split-K weight gradient included)."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    from util import random_graph
+    g = random_graph(3000, 40000, seed=4, hub=900, device=dev)
+    n, D = g.number_of_nodes(), 50
+    x = torch.randn(n, D, device=dev)
+    mk = lambda: stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, 1.0, 0.5, seed=8, offset=2)
+    ops._const_pads.clear()
+    first = ops.aggregate(g, x, mk(), reduce="mean")
+    assert first.is_contiguous() and id(x) in ops._const_pads and ops._const_pads[id(x)][4] is None
+    second = ops.aggregate(g, x, mk(), reduce="mean")
+    third = ops.aggregate(g, x, mk(), reduce="mean")
+    assert second.stride() == (52, 1) and second.shape == (n, D) and ops._const_pads[id(x)][4].shape == (n, 52)
+    assert torch.equal(first, second) and torch.equal(first, third)
+    assert torch.equal(ops.aggregate(g, x, None), ops.aggregate(g, x.clone(), None))           # (no noise; a fresh tensor: unpadded)
+    x.mul_(2.0)                                                     # the constant changed: its padded copy must not be used
+    again = ops.aggregate(g, x, mk(), reduce="mean")
+    assert again.is_contiguous() and torch.equal(again, 2.0 * first)
+    assert torch.equal(ops.aggregate(g, x, mk(), reduce="mean"), again)
+    # per-channel parameters, an input that carries a gradient: the plain path
+    pc = stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, torch.full((D,), 1.0, device=dev), torch.full((D,), 0.5, device=dev), seed=8, offset=2)
+    for _ in range(3):
+        assert ops.aggregate(g, x, pc, reduce="mean").is_contiguous()
+    xg = x.clone().requires_grad_(True)
+    for _ in range(3):
+        assert ops.aggregate(g, xg, mk()).is_contiguous()
+    # the layer: GraphSAGE 50 -> 16 on a constant input, three steps; outputs and weight gradients do not depend on
+    # whether the padded form ran
+    torch.manual_seed(3)
+    layer = stag_amd.layers.StagLayer(stag_amd.zoo.GraphSAGE(D, 16, "mean"), q_a=torch.distributions.Normal(1.0, 0.5)).to(dev)
+    feat = torch.randn(n, D, device=dev)
+    outs, grads = [], []
+    for step in range(3):
+        stag_amd.manual_seed(5)
+        layer.zero_grad()
+        out = layer(g, feat)
+        out.square().sum().backward()
+        outs.append(out.detach().clone())
+        grads.append(layer.base_layer.fc_neigh.weight.grad.clone())
+    assert ops._const_pads[id(feat)][4] is not None, "the layer's constant input took the padded form from its second step"
+    for o, gr in zip(outs[1:], grads[1:]):
+        assert_close(o, outs[0].cpu().numpy(), what="SAGE on a padded constant input: output")
+        sc = max(1.0, float(grads[0].abs().max()))
+        assert_close(gr / sc, (grads[0] / sc).cpu().numpy(), what="SAGE on a padded constant input: d fc_neigh.weight")

@@ -1078,6 +1078,28 @@ def test_xcd_aware_unit_order_changes_no_bit(dev, oracle, D, monkeypatch):
                     ma = ops.aggregate_mc(ga, x, mk_noise(ga), 4, reduce=reduce)
                     mb = ops.aggregate_mc(gb, x, mk_noise(gb), 4, reduce=reduce)
                     assert torch.equal(ma, mb) and torch.equal(ma[0], ya), what + " mc"
+            if kind in ("normal", "uniform") and D <= 256:
+                # (round 4) the other kernel families walk the same order: per-edge [E, 1] and [E, D] parameters forward,
+                # the derivative outputs (stag_agg_bwd, three accumulator sets) and the [E, 1] parameter gradients
+                # (stag_agg_bwd_edge) on the transposed view
+                from stag_amd import _lib as L
+                E = ga.number_of_edges()
+                q0 = torch.tensor(rng.standard_normal((E, 1)).astype(np.float32) * 0.2 + 1.0, device=dev)
+                q1 = torch.tensor(rng.random((E, 1)).astype(np.float32) * 0.5 + (0.2 if kind == "normal" else 1.5), device=dev)
+                Q0, Q1 = q0.expand(E, D).contiguous() + 0.01, q1.expand(E, D).contiguous()
+                k_ = L.NOISE_NORMAL if kind == "normal" else L.NOISE_UNIFORM
+                for pa, pb, nm in ((q0, q1, "[E,1]"), (Q0, Q1, "[E,D]")):
+                    ya = ops.aggregate(ga, x, stag_amd.EdgeNoise(ga, D, k_, pa, pb, seed=11, offset=3))
+                    yb = ops.aggregate(gb, x, stag_amd.EdgeNoise(gb, D, k_, pa, pb, seed=11, offset=3))
+                    assert torch.equal(ya, yb), f"{name} {kind} D={D} per-edge parameters {nm}"
+                res = []
+                for g in (ga, gb):
+                    spec = ops._targs_or_c(ops._noise_spec(_noise(g, D, kind, p0, p1, seed=11, offset=3), in_norm=0))
+                    res.append(ops._agg_bwd_raw(g.csr_t, gout, D, spec, None, None, 64, True))
+                    se = ops._targs_or_c(ops._noise_spec(stag_amd.EdgeNoise(g, D, k_, q0, q1, seed=11, offset=3), in_norm=0))
+                    res[-1] = res[-1] + ops._agg_bwd_edge_raw(g.csr_t, gout, x, D, se, None, None, 64)
+                for a_, b_ in zip(*res):
+                    assert torch.equal(a_, b_), f"{name} {kind} D={D}: derivative outputs / [E,1] gradients under the walk"
             outs = []                     # backward: dx on the transposed plan, the noise regenerated
             for g in (ga, gb):
                 xr = x.clone().requires_grad_(True)
