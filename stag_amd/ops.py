@@ -237,6 +237,11 @@ def _agg_bwd_dp_raw(csrv_t, g, x, D, spec, g_scale, row_scale, seg_len, want_dx=
     """One stag_agg_bwd_dp launch on the source-major CSR: dx (if wanted) and the FINISHED gradients of scalar /
     per-channel parameters, dp0 [D], dp1 [D] (x = None: ones in its place)."""
     dev = _lib.require_device(g, x, csrv_t.indptr, g_scale, row_scale)
+    if isinstance(spec, tuple):     # the dispatcher op (csrc/torch_ext.cpp)
+        plan_t = csrv_t.plan(seg_len)
+        dx, dp0, dp1 = torch.ops.stag.agg_bwd_dp(*csrv_t.torch_args(), *_plan_args(csrv_t, plan_t, (D + 255) // 256, dev),
+                                                 g, x, *spec, g_scale, row_scale, bool(want_dx))
+        return (dx if want_dx else None), dp0, dp1
     dx = torch.empty((csrv_t.n_dst, D), dtype=torch.float32, device=dev) if want_dx else None
     dp0 = torch.empty(D, dtype=torch.float32, device=dev)
     dp1 = torch.empty(D, dtype=torch.float32, device=dev)
@@ -759,7 +764,7 @@ class _AggregateVI(torch.autograd.Function):
         dx = dp0 = dp1 = None
         per_edge = noise.param_mode >= _lib.PARAM_PER_EDGE1
         need_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-        if not per_edge and need_p and _AGG_BWD_DP_ONE_PASS and not isinstance(spec, tuple):
+        if not per_edge and need_p and _AGG_BWD_DP_ONE_PASS:
             # scalar / per-channel parameters: ONE transposed pass yields dx AND the finished gradients
             #   dp_i[k] = sum_e dw/dp_i[e,k] dv g'[v,k] s_u x[u,k]   (x[u] is the unit's own row there)
             dx, c0, c1 = _agg_bwd_dp_raw(graph.csr_t, g, x, D, spec, dvec, src_scale, ctx.seg_len,
@@ -993,6 +998,10 @@ def _agg_fwd_mc_raw(csrv, x, noise, n_samples, offset_stride, reduce, src_scale,
     """One stag_agg_fwd_mc call: [n_samples, n_dst, D]."""
     D = x.shape[1]
     dev = _lib.require_device(x, csrv.indptr, src_scale, dst_scale)
+    if _torch_ext.available():      # the dispatcher op (csrc/torch_ext.cpp): same library call, visible to a compiled graph
+        plan_t = csrv.plan(seg_len)
+        return torch.ops.stag.agg_fwd_mc(*csrv.torch_args(), *_plan_args(csrv, plan_t, (D + 255) // 256, dev, width=D, drawn=True),
+                                         x, *noise.torch_args(), int(n_samples), int(offset_stride), reduce, src_scale, dst_scale)
     out = torch.empty((n_samples, csrv.n_dst, D), dtype=torch.float32, device=dev)
     plan_t = csrv.plan(seg_len)
     nbytes = _lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], 4 * D, 0) if plan_t is not None else 0
@@ -1227,6 +1236,18 @@ class _GatAggregate(torch.autograd.Function):
         stats = (torch.empty((csrv.n_dst, 2 * H), dtype=torch.float32, device=dev)
                  if (want_attn or need_grad) else None)
         plan_t = csrv.plan(seg_len, need=True)       # the cooperative kernels want the plan's unit batches
+        if _torch_ext.available() and not want_attn and plan_t is not None:
+            # the dispatcher op (csrc/torch_ext.cpp: stag::gat_fwd): same library call, visible to a compiled graph
+            targs = noise.torch_args() if noise is not None else (_explicit_spec(w) if w is not None else _NONE_ARGS)
+            if attn_drop is not None and noise is None:
+                targs = (targs[0], [targs[1][0], targs[1][1], int(getattr(graph, "pos_base", 0))]) + tuple(targs[2:])
+            out, stats_t = torch.ops.stag.gat_fwd(*csrv.torch_args(), *_gat_plan_args(csrv, plan_t, dev, H * F), el, er, ft,
+                                                  float(neg_slope), *targs, nscale, *_gat_drop_args(attn_drop), bool(need_grad))
+            if need_grad:
+                ctx.graph, ctx.noise, ctx.neg_slope, ctx.seg_len = _owner(graph), noise, float(neg_slope), seg_len
+                ctx.attn_drop = attn_drop
+                ctx.save_for_backward(el, er, ft, w, stats_t, out, nscale)
+            return out
         nbytes = _lib.lib().stag_gat_workspace_bytes(plan_t["n_seg"], H, F) if plan_t is not None else 0
         plan_c, _keep = _plan_struct(csrv, seg_len, 1, nbytes, dev, plan_t=plan_t, gat_width=H * F)
         cs = csrv.struct()
@@ -1281,8 +1302,9 @@ class _GatAggregate(torch.autograd.Function):
                     torch.zeros_like(er) if ctx.needs_input_grad[1] else None,
                     torch.zeros_like(ft) if ctx.needs_input_grad[2] else None,
                     torch.zeros_like(w) if want_dw else None, None, None, None, None, None, None, zp(0), zp(1))
+        spec_tensors = ((noise.p0, noise.p1, noise.epoch) if noise is not None else (w, None, None))
         fused = _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, ctx.neg_slope, spec, nscale,
-                               want_dw, ctx.seg_len, dev, ctx.attn_drop, want_dp=want_dp)
+                               want_dw, ctx.seg_len, dev, ctx.attn_drop, want_dp=want_dp, spec_tensors=spec_tensors)
         if fused is not None:
             d_el, d_er, d_ft, dw = fused[:4]
             dps = [None, None]
@@ -1328,8 +1350,45 @@ class _GatAggregate(torch.autograd.Function):
         return d_el, d_er, d_ft, dw, None, None, None, None, None, None, None, None
 
 
+def _gat_plan_args(csrv, plan_t, dev, gat_width, transposed=False):
+    """The plan arguments of torch.ops.stag.gat_fwd / gat_bwd: (units, long_rows, long_seg_ptr, block_ptr, xcd, counters,
+    plan_ints), the unit batches the XCD-aware ones when the plan has them (transposed: the second plan of gat_bwd has no
+    xcd slot)."""
+    key = (1, _lib.stream_of(dev))
+    counters = plan_t["counters"].get(key)
+    if counters is None:
+        counters = torch.zeros(max(plan_t["n_long"], 1), dtype=torch.int32, device=dev)
+        plan_t["counters"][key] = counters
+    units, block_ptr, n_blocks, n_heavy = plan_t["units"], plan_t["block_ptr"], plan_t["n_blocks"], plan_t["n_heavy"]
+    if plan_t.get("xcd_on"):
+        blocks = csrv.gat_blocks(plan_t, gat_width)
+        if blocks is not None:
+            units, block_ptr, n_blocks, n_heavy = blocks[0], blocks[1], blocks[2], 0
+    ints = [plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"], n_heavy, n_blocks, 0, 0]
+    if transposed:
+        return (units, plan_t["long_rows"], plan_t["long_seg_ptr"], block_ptr, counters, ints)
+    return (units, plan_t["long_rows"], plan_t["long_seg_ptr"], block_ptr, None, counters, ints)
+
+
+def _gat_drop_args(attn_drop):
+    """(drop_floats, drop_u64, drop_epoch) of torch.ops.stag.gat_*: what _gat_drop_struct puts into a stag_gat_drop."""
+    if attn_drop is None:
+        return [], [], None
+    s64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v
+    seed, off = int(attn_drop[1]) & ((1 << 64) - 1), int(attn_drop[2]) & ((1 << 64) - 1)
+    return [1.0 - float(attn_drop[0])], [s64(seed), s64(off)], (attn_drop[3] if len(attn_drop) > 3 else None)
+
+
+def _ctypes_to_targs(s, tensors):
+    """A ctypes stag_noise_spec back as the argument tuple of torch.ops.stag.* (tensors: (p0, p1, epoch) it points into)."""
+    s64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v
+    p0, p1, epoch = tensors
+    return ([s.kind, s.param_mode, s.relu, s.in_norm, s.deriv, s.group, s.chunk_base, s.p1_log],
+            [s64(s.seed), s64(s.offset), s.pos_base], [s.p0_scalar, s.p1_scalar], p0, p1, epoch)
+
+
 def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec, nscale, want_dw, seg_len, dev,
-                   attn_drop=None, want_dp=False):
+                   attn_drop=None, want_dp=False, spec_tensors=(None, None, None)):
     """stag_gat_bwd: the whole backward on the workgroup-cooperative kernels (one gather of the [H*F] rows; the
     two-gather form stag_gat_bwd_two_pass stays for A/B); None when the shape or the plans are outside what it
     covers (the caller then composes the older kernels)."""
@@ -1340,6 +1399,22 @@ def _gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, neg_slope, spec,
             and (one or (lph & (lph - 1)) == 0)):      # the two-pass form wants F / 4 a power of two
         return None
     plan_f, plan_b = csrv.plan(seg_len, need=True), csrt.plan(seg_len, need=True)
+    if _torch_ext.available() and not want_dp and (_GAT_BWD_ONE_GATHER or attn_drop is not None):
+        # the dispatcher op (csrc/torch_ext.cpp: stag::gat_bwd): same library call, visible to a compiled graph
+        if isinstance(spec, tuple):
+            targs = spec
+        else:       # (this function is handed the ctypes form: back to the argument tuple, the tensors from the caller's)
+            targs = _ctypes_to_targs(spec, spec_tensors)
+        try:
+            d_el, d_er, d_ft, dw = torch.ops.stag.gat_bwd(
+                *csrv.torch_args(), *_gat_plan_args(csrv, plan_f, dev, H * F),
+                csrt.indptr, csrt.indices, csrt.eid, csrt.nidx, *_gat_plan_args(csrt, plan_b, dev, H * F, transposed=True),
+                el, er, ft, stats, G, out, float(neg_slope), *targs, nscale, *_gat_drop_args(attn_drop), bool(want_dw))
+        except RuntimeError as exc:
+            if "rc=-38" in str(exc):        # STAG_ENOSYS: a shape / plan outside the cooperative kernels
+                return None
+            raise
+        return d_el, d_er, d_ft, (dw if want_dw else None)
     nbytes = _lib.lib().stag_gat_bwd_workspace_bytes(plan_f["n_seg"], plan_b["n_seg"], H, F)
     pf, _k1 = _plan_struct(csrv, seg_len, 1, nbytes, dev, plan_t=plan_f, gat_width=H * F)
     pb, _k2 = _plan_struct(csrt, seg_len, 1, 0, dev, plan_t=plan_b, gat_width=H * F)

@@ -1814,7 +1814,7 @@ def test_constant_inputs_of_odd_width_are_padded_once(dev):
     # the layer: GraphSAGE 50 -> 16 on a constant input, three steps; outputs and weight gradients do not depend on
     # whether the padded form ran
     torch.manual_seed(3)
-    layer = stag_amd.layers.StagLayer(stag_amd.zoo.GraphSAGE(D, 16, "mean"), q_a=torch.distributions.Normal(1.0, 0.5)).to(dev)
+    layer = stag_amd.layers.StagLayer(stag_amd.zoo.GraphSAGE(D, 16, aggregator_type="mean"), q_a=torch.distributions.Normal(1.0, 0.5)).to(dev)
     feat = torch.randn(n, D, device=dev)
     outs, grads = [], []
     for step in range(3):

@@ -88,6 +88,96 @@ def test_torch_ops_equal_ctypes_binding(dev, monkeypatch):
             assert torch.equal(a_, b_), kind
 
 
+def test_torch_ops_of_round_4_equal_ctypes_binding(dev, monkeypatch):
+    """stag::agg_fwd_mc, stag::agg_bwd_dp, stag::gat_fwd, stag::gat_bwd (csrc/torch_ext.cpp, round 4) against the ctypes
+    binding of the same library calls: bit-identical outputs and gradients — Monte-Carlo batches (2, 3 and 4 samples, with
+    and without in-norm), `vi=True` parameter gradients finished in the dx pass, the GAT layer step with noise, with explicit
+    weights (dw), with in-norm and with attention dropout inside the kernels."""
+    import stag_amd
+    from stag_amd import _lib, _torch_ext, ops
+    g = random_graph(500, 6000, seed=6, hub=1100, device=dev)
+    E, D, H, F = g.number_of_edges(), 40, 4, 8
+    n = g.number_of_nodes()
+    x, gout = torch.randn(n, D, device=dev), torch.randn(n, D, device=dev)
+    loc = torch.rand(D, device=dev) + 0.5
+    el0, er0, ft0, G0 = torch.randn(n, H, device=dev), torch.randn(n, H, device=dev), torch.randn(n, H, F, device=dev), torch.randn(n, H, F, device=dev)
+    wE = torch.rand(E, H, device=dev) + 0.5
+
+    def run(kind):
+        if kind.startswith("mc"):
+            S = int(kind[2])
+            nz = stag_amd.EdgeNoise(g, D, _lib.NOISE_BERNOULLI if "norm" in kind else _lib.NOISE_NORMAL,
+                                    0.7 if "norm" in kind else 1.0, None if "norm" in kind else 0.4, seed=9, offset=2,
+                                    in_norm="norm" in kind)
+            with torch.no_grad():
+                return [ops.aggregate_mc(g, x, nz, S, offset_stride=3, reduce="mean")]
+        if kind == "vi_dp":
+            xg = x.clone().requires_grad_(True)
+            a = loc.clone().requires_grad_(True); b = (loc * 0.3).requires_grad_(True)
+            out = ops.aggregate(g, xg, stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, a, b, relu=True, seed=4, offset=1,
+                                                          differentiable=True))
+            out.backward(gout)
+            return [out.detach(), xg.grad, a.grad, b.grad]
+        el, er, ft = (t.clone().requires_grad_(True) for t in (el0, er0, ft0))
+        extra, drop, weight = [], None, None
+        if kind == "gat_noise":
+            weight = stag_amd.EdgeNoise(g, H, _lib.NOISE_NORMAL, 1.0, 0.3, seed=3, offset=1)
+        elif kind == "gat_norm_drop":
+            weight = stag_amd.EdgeNoise(g, H, _lib.NOISE_BERNOULLI, 0.8, None, seed=3, offset=1, in_norm=True)
+            drop = (0.4, 11, 5)
+        elif kind == "gat_w":
+            weight = wE.clone().requires_grad_(True); extra = [weight]
+        out = ops.gat_aggregate(g, el, er, ft, 0.2, weight, attn_drop=drop)
+        out.backward(G0)
+        return [out.detach(), el.grad, er.grad, ft.grad] + [t.grad for t in extra]
+
+    for kind in ("mc2", "mc3", "mc4", "mc2norm", "vi_dp", "gat_none", "gat_noise", "gat_norm_drop", "gat_w"):
+        monkeypatch.setenv("STAG_TORCH_OPS", "1")
+        assert _torch_ext.available()
+        via_ops = run(kind)
+        monkeypatch.delenv("STAG_TORCH_OPS")
+        assert not _torch_ext.available()
+        via_ctypes = run(kind)
+        assert len(via_ops) == len(via_ctypes)
+        for a_, b_ in zip(via_ops, via_ctypes):
+            assert torch.equal(a_, b_), kind
+
+
+def test_dispatcher_ops_compile_with_fullgraph(dev):
+    """The ops are ordinary custom ops to a compiled graph: `torch.compile(fullgraph=True)` of a function that calls
+    torch.ops.stag.gat_fwd / agg_fwd between torch ops traces through their Meta kernels without a graph break and
+    returns what eager returns.  (What is compiled is the op level.  A whole StagLayer step is not offered under
+    torch.compile: every call takes a fresh Philox offset from host state, which a traced graph would freeze — the
+    supported whole-step form is hipGraph capture with the device epoch)"""
+    import stag_amd
+    from stag_amd import _lib, _torch_ext, ops
+    assert _torch_ext.loaded()
+    g = random_graph(300, 4000, seed=8, hub=700, device=dev)
+    n, H, F, D = g.number_of_nodes(), 4, 8, 32
+    csrv = g.csr
+    plan = csrv.plan(64, need=True)
+    el, er, ft = torch.randn(n, H, device=dev), torch.randn(n, H, device=dev), torch.randn(n, H, F, device=dev)
+    x = torch.randn(n, D, device=dev)
+    gat_plan = ops._gat_plan_args(csrv, plan, dev, H * F)
+    agg_plan = ops._plan_args(csrv, plan, 1, dev, width=D)
+    nz_h = stag_amd.EdgeNoise(g, H, _lib.NOISE_NORMAL, 1.0, 0.3, seed=3, offset=1).torch_args()
+    nz_d = stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, 1.0, 0.3, seed=3, offset=2).torch_args()
+
+    def f(el, er, ft, x):
+        out, stats = torch.ops.stag.gat_fwd(*csrv.torch_args(), *gat_plan, el * 2.0, er, ft, 0.2, *nz_h, None, [], [], None, True)
+        agg, _ = torch.ops.stag.agg_fwd(*csrv.torch_args(), *agg_plan, x + 1.0, False, *nz_d, 0, None, None, False)
+        return out, torch.relu(out).sum(-1) + stats[:, :H], agg * 0.5
+
+    want = f(el, er, ft, x)
+    got = torch.compile(f, fullgraph=True, backend="aot_eager")(el, er, ft, x)
+    for a_, b_ in zip(got, want):
+        assert torch.equal(a_, b_)
+    with torch.no_grad():       # ... and the op is the library call the Python layer makes
+        ref = ops.gat_aggregate(g, el * 2.0, er, ft, 0.2, stag_amd.EdgeNoise(g, H, _lib.NOISE_NORMAL, 1.0, 0.3, seed=3, offset=1))
+        ref2 = ops.aggregate(g, x + 1.0, stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, 1.0, 0.3, seed=3, offset=2))
+    assert torch.equal(got[0], ref) and torch.equal(got[2], ref2 * 0.5)
+
+
 def test_philox_words_bit_exact(dev, oracle):
     from stag_amd import ops
     for seed, offset, pos0 in [(0, 0, 0), (0x5747A6, 3, 12345), (2**63 + 5, 2**40 + 9, 2**33 + 17)]:

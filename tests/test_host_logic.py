@@ -40,6 +40,18 @@ def test_torch_library_front_end_loads_and_traces():
     assert out.shape == (5, 12) and ns.shape == (5, 12) and out.device.type == "meta"
     dx, t0, t1 = torch.ops.stag.agg_bwd(ip, ix, None, None, 5, *plan, x, *noise, None, None, True)
     assert dx.shape == t0.shape == t1.shape == (5, 12)
+    # (round 4) the rest of the hot surface: Monte-Carlo batches, one-pass parameter gradients, GAT forward and backward
+    mc = torch.ops.stag.agg_fwd_mc(ip, ix, None, None, 5, *plan, x, *noise, 3, 1, 0, None, None)
+    assert mc.shape == (3, 5, 12) and mc.device.type == "meta"
+    dx, dp0, dp1 = torch.ops.stag.agg_bwd_dp(ip, ix, None, None, 5, *plan, x, x, *noise, None, None, True)
+    assert dx.shape == (5, 12) and dp0.shape == dp1.shape == (12,)
+    el, ft = torch.zeros(5, 2, device="meta"), torch.zeros(5, 2, 4, device="meta")
+    out, stats = torch.ops.stag.gat_fwd(ip, ix, None, None, 5, *plan, el, el, ft, 0.2, *noise, None, [0.6], [1, 2], None, True)
+    assert out.shape == (5, 2, 4) and stats.shape == (5, 4)
+    plan_t = plan[:4] + plan[5:]
+    d_el, d_er, d_ft, dw = torch.ops.stag.gat_bwd(ip, ix, None, None, 5, *plan, ip, ix, None, None, *plan_t, el, el, ft, stats,
+                                                  ft, ft, 0.2, *noise, None, [], [], None, True)
+    assert d_el.shape == d_er.shape == (5, 2) and d_ft.shape == (5, 2, 4) and dw.shape == (9, 2)
     # a CPU tensor is refused by the Python layer before the dispatcher would fail to find a CPU kernel
     import stag_amd
     from stag_amd._lib import StagHipError

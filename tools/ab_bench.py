@@ -40,23 +40,30 @@ def run(argv):
     ap.add_argument("--seg-len", type=int, default=64)
     ap.add_argument("--mc", type=int, default=0, help="time ops.aggregate_mc with this many Monte-Carlo samples per call")
     ap.add_argument("--per-edge", action="store_true", help="Normal noise with [E, 1] parameters (an AmortizedDistribution's heads)")
+    ap.add_argument("--graph", default="arxiv", choices=["arxiv", "ppi"],
+                    help="ppi: the 24-graph PPI-sized batch (BASELINE configs[2]) with the XCD-aware order on, mean reducer")
     args = ap.parse_args(argv)
     import stag_amd
     from stag_amd import _lib, ops, synthetic
     import bench
     dev = torch.device("cuda:0")
-    src, dst = synthetic.arxiv_like(seed=1)
-    n = synthetic.ARXIV_NODES
-    g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
+    red = "sum"
+    if args.graph == "ppi":
+        import importlib
+        importlib.import_module("stag_amd.graph").XCD_ORDER = "1"
+        src, dst, sizes = synthetic.ppi_like()
+        n, red = int(sizes.sum()), "mean"
+        g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, batch_num_nodes=torch.from_numpy(sizes).to(dev), device=dev)
+    else:
+        src, dst = synthetic.arxiv_like(seed=1)
+        n = synthetic.ARXIV_NODES
+        g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
     x = torch.randn(n, args.feat, device=dev)
     libs = sorted(glob.glob(os.path.join(BIN, "libstag_*.so")))
     base = _lib.lib()
     handles = {"current": base}
     for path in libs:
-        l = C.CDLL(path)
-        for fn in ("stag_agg_fwd", "stag_agg_fwd_mc", "stag_plan_workspace_bytes"):
-            getattr(l, fn).argtypes = getattr(base, fn).argtypes
-            getattr(l, fn).restype = getattr(base, fn).restype
+        l = _lib.bind(path)          # every prototype declared (and the ABI version checked)
         handles[os.path.basename(path)[len("libstag_"):-3]] = l
     times = {k: [] for k in handles}
     ref = None
@@ -68,7 +75,7 @@ def run(argv):
     elif args.mc:
         one = lambda i: ops.aggregate_mc(g, x, bench.make_noise(stag_amd, g, args.feat, args.noise, i), args.mc, seg_len=args.seg_len)
     else:
-        one = lambda i: ops.aggregate(g, x, bench.make_noise(stag_amd, g, args.feat, args.noise, i), seg_len=args.seg_len)
+        one = lambda i: ops.aggregate(g, x, bench.make_noise(stag_amd, g, args.feat, args.noise, i), reduce=red, seg_len=args.seg_len)
     for r in range(args.rounds + 1):
         for name, l in handles.items():
             _lib._lib = l
