@@ -1022,10 +1022,19 @@ constexpr int mult_of() {
 #ifndef STAG_HMULT
 #define STAG_HMULT 1
 #endif
-template <int LPE>
+// At 16 lanes per row (D in 33..64) Normal and Uniform take no slots (round 4): the slotted loop costs them registers and
+// with them a wave per SIMD, and their launch is the draw's, not the hub rows' — tools/ab_bench.py, us, two slots | none:
+//   PPI batch (BASELINE configs[2], layer 1) D = 52 Normal 41.8 | 36.8, D = 64 43.1 | 38.5; no draw at D = 52 24.2 | 26.6;
+//   arxiv (a 13k-edge hub) D = 64 Normal 67.6 | 68.7, Uniform 69.1 | 69.1, D = 48 Normal 65.8 | 66.7 — and Bernoulli + in-norm
+//   68.6 | 87.2: its draw is cheap, its launch IS the hub row's, so Bernoulli (like no draw, explicit weights) keeps them.
+#ifndef STAG_HSLOTS_LPE16_RNG
+#define STAG_HSLOTS_LPE16_RNG 1
+#endif
+template <int KIND, int LPE>
 constexpr int heavy_slots_of() {
   return LPE <= 4 ? STAG_HSLOTS_LPE4 : LPE == 8 ? STAG_HSLOTS_LPE8
-         : LPE == 16 ? STAG_HSLOTS_LPE16 : LPE == 32 ? STAG_HSLOTS_LPE32 : 1;
+         : LPE == 16 ? ((KIND == kNormal || KIND == kUniform) ? STAG_HSLOTS_LPE16_RNG : STAG_HSLOTS_LPE16)
+         : LPE == 32 ? STAG_HSLOTS_LPE32 : 1;
 }
 
 // The kernel arguments a unit needs before its first gather, fetched TOGETHER at the top of the kernel: left to
@@ -1073,7 +1082,7 @@ template <int KIND, int LPE, bool VEC, int PEDGE, int NOUT = 1, bool MC = false,
 __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_kernel(const AggArgs a_in) {
   AggArgs a = a_in;
   hoist_args<KIND, LPE, WALK>(a);
-  constexpr int HS = (NOUT == 1 && PEDGE != 3) ? heavy_slots_of<LPE>() : 1;
+  constexpr int HS = (NOUT == 1 && PEDGE != 3) ? heavy_slots_of<KIND, LPE>() : 1;
   const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
   constexpr int TPB = STAG_BLOCK_THREADS / LPE, TPBH = STAG_BLOCK_THREADS / (LPE * HS);
   if constexpr (!WALK) {
@@ -1173,7 +1182,7 @@ template <int KIND, int LPE>
 inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles, hipStream_t s) {
   AggArgs a = a_in;
   constexpr int TPB = STAG_BLOCK_THREADS / LPE;
-  constexpr int HS = heavy_slots_of<LPE>();
+  constexpr int HS = heavy_slots_of<KIND, LPE>();
   constexpr int TPBH = STAG_BLOCK_THREADS / (LPE * HS);
   const bool slotted = !(HS == 1 || a.outx[0] || pedge == 3 || a.dp_part);
   if (!slotted) a.n_heavy = 0;

@@ -851,6 +851,38 @@ def _padded_constant(x):
     return ent[4]
 
 
+_row_pads = {}            # id(row) -> (weakref, _version, {Dp: padded row})
+
+
+def _padded_noise(noise, Dp):
+    """The descriptor for a launch at the padded width: scalar parameters as they are; per-channel rows [D] extended to
+    [Dp] with their last entry (the padded channels' draws are multiplied by zeros), kept per row tensor — the rows a
+    layer hands over come from noise._expanded's own cache, so this costs nothing from the second call on.  None when
+    the descriptor has per-edge parameters (the plain path then)."""
+    if noise is None or noise.param_mode == _lib.PARAM_SCALAR:
+        return noise
+    if noise.param_mode != _lib.PARAM_PER_CHANNEL:
+        return None
+    import copy
+    import weakref
+    out = copy.copy(noise)
+    out.dn = Dp
+    for name in ("p0", "p1"):
+        row = getattr(noise, name)
+        if row is None:
+            continue
+        ent = _row_pads.get(id(row))
+        if ent is None or ent[0]() is not row or ent[1] != row._version:
+            if len(_row_pads) > 256:
+                _row_pads.clear()
+            ent = _row_pads[id(row)] = (weakref.ref(row, lambda _r, k=id(row): _row_pads.pop(k, None)), row._version, {})
+        pad = ent[2].get(Dp)
+        if pad is None:
+            pad = ent[2][Dp] = torch.cat([row, row[-1:].expand(Dp - row.shape[0])]).contiguous()
+        setattr(out, name, pad)
+    return out
+
+
 def aggregate_into(csrv, x, out, weight, reduce, src_scale, dst_scale, plan_t):
     """The rows of ONE sub-plan of csrv (CsrView.subplan) written into `out` [n_dst, D]; no autograd.
     How a node-range shard launches its local-source rows while the halo exchange is in flight and
@@ -920,10 +952,12 @@ def aggregate(graph, x, weight=None, reduce="sum", src_scale=None, dst_scale=Non
         else:
             spec = _none_spec()
         if (PAD_CONSTANT_INPUTS and D % 4 and D > 4 and w is None and not _broadcast_x and x is xin and x.is_cuda
-                and not x.requires_grad and (noise is None or noise.param_mode == _lib.PARAM_SCALAR)):
+                and not x.requires_grad and (noise is None or noise.param_mode <= _lib.PARAM_PER_CHANNEL)):
             xp = _padded_constant(x)
-            if xp is not None:
-                return _agg_raw(graph.csr, xp, xp.shape[1], spec, _REDUCE[reduce], _f32c(src_scale), _f32c(dst_scale),
+            noise_p = _padded_noise(noise, (D + 3) // 4 * 4) if xp is not None else None
+            if xp is not None and (noise is None or noise_p is not None):
+                spec_p = _noise_spec(noise_p) if noise_p is not None else spec
+                return _agg_raw(graph.csr, xp, xp.shape[1], spec_p, _REDUCE[reduce], _f32c(src_scale), _f32c(dst_scale),
                                 seg_len)[0][:, :D]
         return _agg_raw(graph.csr, x, D, spec, _REDUCE[reduce], _f32c(src_scale), _f32c(dst_scale), seg_len,
                         broadcast_x=_broadcast_x)[0]

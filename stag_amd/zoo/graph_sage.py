@@ -78,10 +78,13 @@ class GraphSAGE(torch.nn.Module):
         return out
 
     def forward(self, graph, feat, edge_weight=None):
+        # (an inactive dropout is skipped, not called: the input then reaches the aggregation as the SAME tensor object,
+        # which is how a constant input of odd width is recognised and padded once — ops._padded_constant)
+        drop = self.feat_drop if (self.training and self.feat_drop.p > 0) else (lambda t: t)
         if isinstance(feat, tuple):
-            feat_src, feat_dst = self.feat_drop(feat[0]), self.feat_drop(feat[1])
+            feat_src, feat_dst = drop(feat[0]), drop(feat[1])
         else:
-            feat_src = feat_dst = self.feat_drop(feat)
+            feat_src = feat_dst = drop(feat)
         if edge_weight is not None:
             check_edge_weight(graph, edge_weight)
         h_self = feat_dst

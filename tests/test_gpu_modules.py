@@ -1804,10 +1804,17 @@ def test_constant_inputs_of_odd_width_are_padded_once(dev):
     again = ops.aggregate(g, x, mk(), reduce="mean")
     assert again.is_contiguous() and torch.equal(again, 2.0 * first)
     assert torch.equal(ops.aggregate(g, x, mk(), reduce="mean"), again)
-    # per-channel parameters, an input that carries a gradient: the plain path
-    pc = stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, torch.full((D,), 1.0, device=dev), torch.full((D,), 0.5, device=dev), seed=8, offset=2)
+    # per-channel parameters (what a layer hands over for a distribution whose parameters are module buffers): their rows
+    # are extended to the padded width, the same bits; per-edge parameters and an input that carries a gradient: the plain path
+    loc_r, sc_r = torch.rand(D, device=dev) + 0.5, torch.rand(D, device=dev) * 0.5 + 0.1
+    pc = lambda: stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, loc_r, sc_r, seed=8, offset=2)
+    plain = ops.aggregate(g, x.clone(), pc(), reduce="mean")
     for _ in range(3):
-        assert ops.aggregate(g, x, pc, reduce="mean").is_contiguous()
+        got = ops.aggregate(g, x, pc(), reduce="mean")
+        assert got.stride() == (52, 1) and torch.equal(got, plain)
+    pe = stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, torch.rand(g.number_of_edges(), 1, device=dev) + 0.5,
+                            torch.rand(g.number_of_edges(), 1, device=dev) * 0.5 + 0.1, seed=8, offset=2)
+    assert ops.aggregate(g, x, pe, reduce="mean").is_contiguous()
     xg = x.clone().requires_grad_(True)
     for _ in range(3):
         assert ops.aggregate(g, xg, mk()).is_contiguous()
