@@ -828,6 +828,8 @@ class _AggregateVI(torch.autograd.Function):
 # result are the same bits (a Philox block covers 4 channels either way; the padded channels gather zeros), returned as a
 # view [:, :D] of the padded result, which the dense transform behind it reads through its row stride (node_linear).
 PAD_CONSTANT_INPUTS = True
+PAD_MIN_WIDTH = 32        # narrower rows (molhiv's 9 atom features) are launch-bound: the slice of the padded result and the
+                          # second descriptor cost the host more than the vector forms save the kernel (D = 9: 13 -> 24 us)
 _const_pads = {}          # id(tensor) -> [weakref, _version, data_ptr, sightings, padded | None]
 
 
@@ -945,20 +947,20 @@ def aggregate(graph, x, weight=None, reduce="sum", src_scale=None, dst_scale=Non
         # nothing to differentiate: straight to the library (no autograd node; host time of a call matters on
         # launch-bound graphs)
         xin, x = x, _f32c(x)
+        if (PAD_CONSTANT_INPUTS and D % 4 and D >= PAD_MIN_WIDTH and w is None and not _broadcast_x and x is xin and x.is_cuda
+                and not x.requires_grad and (noise is None or noise.param_mode <= _lib.PARAM_PER_CHANNEL)):
+            xp = _padded_constant(x)
+            noise_p = _padded_noise(noise, (D + 3) // 4 * 4) if xp is not None else None
+            if xp is not None and (noise is None or noise_p is not None):
+                spec_p = _noise_spec(noise_p) if noise_p is not None else _none_spec()
+                return _agg_raw(graph.csr, xp, xp.shape[1], spec_p, _REDUCE[reduce], _f32c(src_scale), _f32c(dst_scale),
+                                seg_len)[0][:, :D]
         if noise is not None:
             spec = _noise_spec(noise)
         elif w is not None:
             spec = _explicit_spec(_f32c(w))
         else:
             spec = _none_spec()
-        if (PAD_CONSTANT_INPUTS and D % 4 and D > 4 and w is None and not _broadcast_x and x is xin and x.is_cuda
-                and not x.requires_grad and (noise is None or noise.param_mode <= _lib.PARAM_PER_CHANNEL)):
-            xp = _padded_constant(x)
-            noise_p = _padded_noise(noise, (D + 3) // 4 * 4) if xp is not None else None
-            if xp is not None and (noise is None or noise_p is not None):
-                spec_p = _noise_spec(noise_p) if noise_p is not None else spec
-                return _agg_raw(graph.csr, xp, xp.shape[1], spec_p, _REDUCE[reduce], _f32c(src_scale), _f32c(dst_scale),
-                                seg_len)[0][:, :D]
         return _agg_raw(graph.csr, x, D, spec, _REDUCE[reduce], _f32c(src_scale), _f32c(dst_scale), seg_len,
                         broadcast_x=_broadcast_x)[0]
     return _Aggregate.apply(x, w, graph, noise, _REDUCE[reduce], _f32c(src_scale),
