@@ -290,6 +290,7 @@ class NativeComm:
         with torch.cuda.device(self.device):
             _lib.check(lib.stag_comm_init(box[0], self.rank, self.world, C.byref(self._handle)), "stag_comm_init")
         self._side = torch.cuda.Stream(device=self.device)
+        self._marshalled = {}
 
     def close(self):
         if self._handle:
@@ -322,11 +323,19 @@ class NativeComm:
         cur = torch.cuda.current_stream(self.device)
         self._side.wait_stream(cur)                       # the send rows are produced on the current stream
         n = len(sends)
-        sr = (C.c_int64 * self.world)(*[int(r) for r in in_rows])
-        rr = (C.c_int64 * self.world)(*[int(r) for r in out_rows])
-        sp = (C.c_void_p * n)(*[t.data_ptr() if t.numel() else None for t in sends])
-        rp = (C.c_void_p * n)(*[t.data_ptr() if t.numel() else None for t in recvs])
-        wd = (C.c_int32 * n)(*[int(w) for w in widths])
+        # the marshalled arguments of a step that repeats (persistent buffers, the shard's fixed row counts) are built
+        # once: five ctypes arrays per step were host time on a step whose local kernel is ~13 us at 8 ranks
+        key = (tuple(t.data_ptr() if t.numel() else 0 for t in sends), tuple(t.data_ptr() if t.numel() else 0 for t in recvs),
+               tuple(int(w) for w in widths), tuple(in_rows), tuple(out_rows))
+        args = self._marshalled.get(key)
+        if args is None:
+            if len(self._marshalled) > 64:
+                self._marshalled.clear()
+            args = self._marshalled[key] = (
+                (C.c_void_p * n)(*[p or None for p in key[0]]), (C.c_void_p * n)(*[p or None for p in key[1]]),
+                (C.c_int32 * n)(*key[2]), (C.c_int64 * self.world)(*[int(r) for r in in_rows]),
+                (C.c_int64 * self.world)(*[int(r) for r in out_rows]))
+        sp, rp, wd, sr, rr = args
         with torch.cuda.stream(self._side):
             rc = _lib.lib().stag_halo_exchange_multi(self._handle, n, sp, rp, wd, sr, rr, self._side.cuda_stream)
         _lib.check(rc, "stag_halo_exchange_multi")
