@@ -316,6 +316,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # STAG_BENCH_FORCE_DIST=1 (tests): the N > 1 code path — process group, partition, exchange, every extra of the line — with
+    # ONE rank: on a one-GPU box it is the only way to run that path over RCCL itself ("nccl"), which refuses two ranks on a card
+    multi = world > 1 or os.environ.get("STAG_BENCH_FORCE_DIST") == "1"
     rehearse = args.rehearse
     if os.environ.get("STAG_BENCH_FAIL_RANK") == str(rank) and world > 1:      # test hook: how the launcher reports a dead rank
         raise SystemExit(f"bench.py: rank {rank} asked to fail (STAG_BENCH_FAIL_RANK)")
@@ -330,8 +333,15 @@ def main():
         dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     backend = None
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:        # (the forced one-rank form, started without a launcher)
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", str(world))
         # RCCL ("nccl") always in a real run; STAG_BENCH_BACKEND=gloo only rehearses the N>1 code
         # path with several ranks sharing one card (RCCL refuses two ranks on one device)
         backend = "gloo" if rehearse else os.environ.get("STAG_BENCH_BACKEND", "nccl")
@@ -370,7 +380,7 @@ def main():
 
     def fence():
         sync()
-        if world > 1:
+        if multi:
             dist.barrier()
             sync()
 
@@ -408,7 +418,7 @@ def main():
     def make_step(workload, partition):
         """-> (step(i), description, parts).  All inputs end up resident in HBM here.  parts: for the node
         partition, the exchange alone and the kernels alone (timed separately for the `exchange` object)."""
-        if world == 1:
+        if not multi:
             graph = whole_graph()
             if workload == "gat":
                 el, er, ft = (t.to(dev) for t in gat_inputs())
@@ -511,7 +521,7 @@ def main():
         wall = t1 - t0
         dev_ms = ev0.elapsed_time(ev1) / steps if not rehearse else wall / steps * 1e3
         ranks_ms = None
-        if world > 1:
+        if multi:
             if per_rank:
                 own = torch.tensor([dev_ms], dtype=torch.float64, device=dev)
                 allr = [torch.zeros_like(own) for _ in range(world)]
@@ -535,7 +545,7 @@ def main():
                 sync()
                 done += 50
                 more = torch.tensor([1.0 if time.perf_counter() < t_end else 0.0], device=dev)
-                if world > 1:
+                if multi:
                     dist.all_reduce(more, op=dist.ReduceOp.MIN)   # ranks must agree: the step is a collective
                 if float(more) == 0.0:
                     return done
@@ -646,10 +656,10 @@ def main():
     partition = args.partition
     workload = args.workload
     step, parallelism, parts = make_step(workload, partition)
-    if world > 1 and args.native_comm and not rehearse and parts is not None:
+    if multi and args.native_comm and not rehearse and parts is not None:
         use_native(parts["shard"], True)
     cold = None
-    if world == 1 and not rehearse and not args.no_variants:
+    if not multi and not rehearse and not args.no_variants:
         # the same K steps BEFORE the settle phase: what a short run reads while the card is still raising its
         # clocks — reported beside the headline number, never as it
         cw, cd = timed(step, args.steps, args.warmup)
@@ -657,7 +667,7 @@ def main():
                 "warmup": args.warmup, "note": "timed before the settle phase (clocks still rising); the headline "
                                                "loop below runs after it"}
     settle_steps = settle(step)
-    if world > 1:
+    if multi:
         wall, dev_ms, dev_ms_ranks = timed(step, args.steps, args.warmup, per_rank=True)
     else:
         (wall, dev_ms), dev_ms_ranks = timed(step, args.steps, args.warmup), None
@@ -742,7 +752,7 @@ def main():
                                                    stripe_locality=g4.csr.stripe_locality())
         return out
 
-    variants = variant_loops() if (world == 1 and not rehearse and not args.no_variants) else None
+    variants = variant_loops() if (not multi and not rehearse and not args.no_variants) else None
 
     # ---------------------------------------------------------------------------- the line, as far as the headline
     line = None
@@ -750,7 +760,7 @@ def main():
         ms_per_step = wall / args.steps * 1e3
         b_alg = b_alg_of(workload, n, E, D)
         achieved = b_alg / (dev_ms * 1e-3) / 1e9
-        traffic, traffic_source = committed_profile(args, world)
+        traffic, traffic_source = committed_profile(args, 2 if multi else 1)
         row_bytes = 4 * (H * F if workload == "gat" else D)
         b_gather = b_alg - 4 * n * (row_bytes // 4) + E * row_bytes   # SURVEY §8d B_gather: every edge pulls its row
         n_blocks = E * (((H if workload == "gat" else D) + 3) // 4)
@@ -773,7 +783,7 @@ def main():
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl, "parallelism": parallelism, "partition": "none" if world == 1 else partition,
+            "config": {"workload": wl, "parallelism": parallelism, "partition": "none" if not multi else partition,
                        "seg_len": args.seg_len},
             # N > 1: whole-job algorithmic bytes over the slowest rank's device time, against N x 8 TB/s
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
@@ -810,7 +820,7 @@ def main():
             line["cold"] = cold
         if variants is not None:
             line["variants"] = variants
-        if world > 1:
+        if multi:
             line["device_ms_per_step_per_rank"] = dev_ms_ranks
             line["comm"] = {"backend": dist.get_backend(),
                             "headline_transport": "stag_halo_exchange_multi (library-owned RCCL communicator)"
@@ -833,7 +843,7 @@ def main():
         if line is not None and val is not None:
             line[name] = val
 
-    if world > 1 and parts is not None:
+    if multi and parts is not None:
         dog = Watchdog(args.extras_timeout_s, rank, lambda: dict(line or {})) if not rehearse else None
         width = (H * F + H) if workload == "gat" else D
         extra("exchange", lambda: exchange_report(parts, width, 200))
@@ -907,10 +917,10 @@ def main():
             dog.cancel()
 
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and not rehearse and workload == "agg":
+        if not multi and not args.no_cpu_baseline and not rehearse and workload == "agg":
             line["cpu_baseline"] = cpu_baseline(src, dst, n, x_host.numpy(), args.noise, args.cpu_budget_s)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         try:
             dist.destroy_process_group()
         except Exception:        # noqa: BLE001 — the line is out

@@ -122,6 +122,29 @@ def test_gpus4_full_size_through_the_real_collective_is_bit_identical():
             f.write(json.dumps(line, indent=1) + "\n")
 
 
+@pytest.mark.gpu
+def test_the_multi_gpu_code_path_over_rccl_itself_with_one_rank():
+    """RCCL refuses two ranks on one card, so the rehearsals above run over gloo.  What they cannot show is whether the
+    N > 1 code path is well-formed ON THE nccl BACKEND — `init_process_group("nccl", device_id=...)`, barriers, all_reduce /
+    all_gather of the line's float64 and int64 records, the partition checks, the library's own communicator as the second
+    transport.  STAG_BENCH_FORCE_DIST=1 runs exactly that path with ONE rank over RCCL: every extra of the line must be
+    there without an `error`."""
+    r = _run(["--gpus", "1", "--steps", "5", "--warmup", "2"], env={"STAG_BENCH_FORCE_DIST": "1", "STAG_BENCH_BACKEND": "nccl"},
+             timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = _line(r)
+    assert line["n_gpus"] == 1 and line["comm"]["backend"] == "nccl" and line["comm"]["rccl_version"][0].isdigit()
+    assert "extras_timed_out_after_s" not in line
+    for key in ("exchange", "partition_check", "gat_partition", "alt_partition", "comm_variants"):
+        assert key in line and "error" not in line[key], (key, line.get(key))
+    assert line["partition_check"]["partition_bit_identical"] and line["partition_check"]["rows_compared"] == 169343
+    gp = line["gat_partition"]
+    assert "error" not in gp["partition_check"] and gp["partition_check"]["partition_bit_identical"] and "error" not in gp["exchange"]
+    cv = line["comm_variants"]
+    assert cv["torch_distributed"]["headline"] is True and cv["native_rccl_group"]["device_ms_per_step"] > 0
+    assert cv["native_rccl_group"]["partition_check"]["partition_bit_identical"] is True
+
+
 def _torchrun(args, env=None, timeout=600):
     """The driver's own launch line: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N"""
     import socket
