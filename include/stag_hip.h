@@ -215,6 +215,9 @@ int stag_plan_blocks(const stag_unit* units_host, int32_t n_units, int32_t max_e
  * plan.n_blocks (the other fields as they are): every output is the same — the forward bit for bit, the block partials
  * of stag_gat_bwd_dp added in the new batch order.  units_out_host == block_ptr_host == NULL: count only.
  * On the PPI-sized batch the forward takes 100 instead of 140 us (H*F = 256), 395 instead of 510 us (4 x 256).      */
+/* (v19) A plan handed to stag_gat_fwd with these batches should also carry a non-NULL xcd_order (any device pointer: the GAT
+ * kernels do not read it): it tells the forward that its rows come out of an XCD's L2, where two rows in flight per team
+ * beat one (PPI batch, 4 x 256: 357 -> 334 us); on rows from the Infinity Cache one is best (cfg5: 222 against 238 us).  */
 int stag_plan_blocks_xcd(const stag_unit* units_host, int32_t n_units, int64_t n_edges, int32_t fine, int32_t max_edges,
                          int32_t max_units, stag_unit* units_out_host, int32_t* block_ptr_host, int32_t* n_blocks_out);
 

@@ -384,6 +384,9 @@ static_assert(kBlkUnits <= 64 && kBlkThreads % 64 == 0 && kBlkThreads <= 1024, "
 #ifndef STAG_GAT_NR_FWD
 #define STAG_GAT_NR_FWD 1
 #endif
+#ifndef STAG_GAT_NR_FWD_LOCAL
+#define STAG_GAT_NR_FWD_LOCAL 2
+#endif
 // (the one-gather backward keeps its branchy NR = 4 loop: branch-free loads there change nothing — cfg5 training step
 //  632.5 against 632.1 us — and fewer rows per round cost it: NR = 2 640.5, NR = 1 658 us)
 
@@ -410,7 +413,12 @@ static_assert(kBlkUnits <= 64 && kBlkThreads % 64 == 0 && kBlkThreads <= 1024, "
 #ifndef STAG_GAT_LDS_MIN_BWD
 #define STAG_GAT_LDS_MIN_BWD 32000  // backward passes: 5
 #endif
-template <int LPE, int CPL>
+// NRF: rows in flight per team in the gather — STAG_GAT_NR_FWD (1) when the rows come out of the Infinity Cache (cfg5: a
+// 173 MB table, uniformly random sources), STAG_GAT_NR_FWD_LOCAL (2) when the batches are XCD-local (stag_plan_blocks_xcd*:
+// the caller says so by a non-NULL plan->xcd_order) and the rows come out of an XCD's L2, where the gather is bound by
+// latency, not by the fabric (round 4; tools/bench_configs.py --lib, us, 1 | 2 | 4 rows: PPI batch 4 x 256 356.6 | 334.2 |
+// 337.3; cfg5 221.8 | 238.0 | 252.0).
+template <int LPE, int CPL, int NRF = STAG_GAT_NR_FWD>
 __global__ __launch_bounds__(kBlkThreads) STAG_GAT_SGPR_ATTR void gat_fwd_block_kernel(const GatArgs a) {
   extern __shared__ __align__(16) float lds[];
   const int H = a.H, F = a.F, HF = a.HF;
@@ -526,7 +534,7 @@ __global__ __launch_bounds__(kBlkThreads) STAG_GAT_SGPR_ATTR void gat_fwd_block_
 
   // ---- phase 2: a team per unit, weighted gather -------------------------------------------------------
   // lane c owns CPL chunks of 4 channels: [4 (c + LPE j), +4), j < CPL  (H*F <= 256: one; up to 1024: 2 or 4)
-  constexpr int TEAMS = kBlkThreads / LPE, NR = STAG_GAT_BRANCHFREE ? STAG_GAT_NR_FWD : (CPL >= 4 ? 2 : STAG_GAT_NR);
+  constexpr int TEAMS = kBlkThreads / LPE, NR = STAG_GAT_BRANCHFREE ? NRF : (CPL >= 4 ? 2 : STAG_GAT_NR);
   const int team = t / LPE, c = t % LPE;
   const int team_lane0 = (int)(t & 63) - c;
   int k0[CPL], hl[CPL];
@@ -1662,7 +1670,12 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
                      (size_t)(kBlkEdges + kBlkUnits + 4) * sizeof(int) + (size_t)kBlkUnits * sizeof(int4);
     if (lds_blk < STAG_GAT_LDS_MIN) lds_blk = STAG_GAT_LDS_MIN;
     const dim3 gb(plan->n_blocks);
-#define STAG_BLK_LAUNCH(L, Cc) hipLaunchKernelGGL((gat_fwd_block_kernel<L, Cc>), gb, dim3(kBlkThreads), lds_blk, s, a)
+    const bool local = plan->xcd_order != nullptr;      // the batches are XCD-local: the rows come out of an L2
+#define STAG_BLK_LAUNCH(L, Cc)                                                                                           \
+  do {                                                                                                                   \
+    if (local) hipLaunchKernelGGL((gat_fwd_block_kernel<L, Cc, STAG_GAT_NR_FWD_LOCAL>), gb, dim3(kBlkThreads), lds_blk, s, a); \
+    else       hipLaunchKernelGGL((gat_fwd_block_kernel<L, Cc>), gb, dim3(kBlkThreads), lds_blk, s, a);                 \
+  } while (0)
     if (cpl == 4) STAG_BLK_LAUNCH(64, 4);
     else if (cpl == 2) STAG_BLK_LAUNCH(64, 2);
     else switch (lpe) {

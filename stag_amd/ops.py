@@ -96,6 +96,7 @@ def _plan_struct(csrv, seg_len, tiles, nbytes, dev, plan_t=None, width=None, gat
         blocks = csrv.gat_blocks(plan_t, gat_width)
         if blocks is not None:
             units, block_ptr, n_blocks, fine = blocks[0], blocks[1], blocks[2], -blocks[3]
+            order = units       # (non-NULL xcd_order: "these batches are XCD-local" — the GAT forward keeps two rows in flight)
     # the struct is kept per (tiles, stream, order): only the workspace changes from call to call (host time of a
     # call matters on launch-bound graphs).  Safe to reuse: the library reads it during the call only.
     plan_c = plan_t.setdefault("_structs", {}).get(key + (fine,))
@@ -1396,14 +1397,16 @@ def _gat_plan_args(csrv, plan_t, dev, gat_width, transposed=False):
         counters = torch.zeros(max(plan_t["n_long"], 1), dtype=torch.int32, device=dev)
         plan_t["counters"][key] = counters
     units, block_ptr, n_blocks, n_heavy = plan_t["units"], plan_t["block_ptr"], plan_t["n_blocks"], plan_t["n_heavy"]
+    local = None
     if plan_t.get("xcd_on"):
         blocks = csrv.gat_blocks(plan_t, gat_width)
         if blocks is not None:
             units, block_ptr, n_blocks, n_heavy = blocks[0], blocks[1], blocks[2], 0
+            local = units       # (non-NULL xcd slot: "these batches are XCD-local", as in _plan_struct)
     ints = [plan_t["seg_len"], plan_t["n_units"], plan_t["n_long"], plan_t["n_seg"], n_heavy, n_blocks, 0, 0]
     if transposed:
         return (units, plan_t["long_rows"], plan_t["long_seg_ptr"], block_ptr, counters, ints)
-    return (units, plan_t["long_rows"], plan_t["long_seg_ptr"], block_ptr, None, counters, ints)
+    return (units, plan_t["long_rows"], plan_t["long_seg_ptr"], block_ptr, local, counters, ints)
 
 
 def _gat_drop_args(attn_drop):

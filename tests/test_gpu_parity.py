@@ -1234,6 +1234,58 @@ def test_fuzz_device_planner_equals_host_planner(dev, monkeypatch):
             assert (dplan["xcd"] is None and hplan["xcd"] is None) or torch.equal(dplan["xcd"].cpu(), hplan["xcd"].cpu()), what
 
 
+def test_fuzz_range_table_orders_host_equals_device(dev, monkeypatch):
+    """Seeded sweep of the range-table XCD orders (stag_plan_xcd_ranges on host records, stag_plan_xcd_device_count_ranges +
+    _fill on device records): random block-diagonal batches — 2 ... 40 graphs of 1 ... 900 nodes, some without edges, some
+    with a hub, batches smaller than 8 graphs — x row widths x L2 budgets x heavy-merged or not: the same ints from both
+    builders, every unit exactly once, and the aggregation over the order bit-identical to plan order."""
+    import importlib
+    import stag_amd
+    from stag_amd import ops
+    G = importlib.import_module("stag_amd.graph")
+    monkeypatch.setattr(G, "XCD_ORDER", "1")
+    rng = np.random.default_rng(20261104)
+    for it in range(12 * FUZZ_SCALE):
+        ng = int(rng.choice([2, 3, 7, 8, 9, 24, 40]))
+        sizes = rng.integers(1, 900, ng)
+        srcs, dsts, off = [], [], 0
+        for k, n_k in enumerate(sizes):
+            e_k = 0 if rng.random() < 0.15 else int(rng.integers(1, 12 * n_k + 2))
+            s_ = rng.integers(0, n_k, e_k)
+            d_ = rng.integers(0, n_k, e_k)
+            if e_k and rng.random() < 0.3:
+                d_[: e_k // 2] = int(rng.integers(0, n_k))          # a hub: segments of a long row inside one graph
+            srcs.append(s_ + off); dsts.append(d_ + off); off += int(n_k)
+        src, dst = np.concatenate(srcs), np.concatenate(dsts)
+        if len(src) == 0:
+            continue
+        monkeypatch.setattr(G, "XCD_RANGE_BYTES", int(rng.choice([20_000, 200_000, 2_500_000])))
+        width = int(rng.choice([24, 64, 128, 200, 256, 300]))
+        bn = torch.from_numpy(sizes.astype(np.int64))
+        gd = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), off, batch_num_nodes=bn.to(dev), device=dev)
+        gh = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), off, batch_num_nodes=bn)
+        what = f"range-table fuzz {it}: {ng} graphs, N={off}, E={len(src)}, width {width}"
+        for name in ("csr", "csr_t"):
+            vd, vh = getattr(gd, name), getattr(gh, name)
+            vd.xcd_graphs = vh.xcd_graphs = True
+            pd, ph = vd.plan(64, need=True), vh.plan(64, need=True)
+            for drawn in (False, True):
+                od, sd, td = vd.xcd_order(pd, width, drawn)
+                oh, sh_, th = vh.xcd_order(ph, width, drawn)
+                assert sd == sh_ and td == th and torch.equal(od.cpu(), oh), (what, name, drawn)
+                rec = oh.numpy()[32:].reshape(-1, 4)
+                real = rec[rec[:, 0] >= 0]
+                units = ph["units"].numpy()[:ph["n_units"]]
+                assert len(real) == len(units) and sorted(map(tuple, real)) == sorted(map(tuple, units)), (what, name)
+        x = torch.randn(off, width, device=dev)
+        gp = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), off, device=dev)
+        for view in (gp.csr, gp.csr_t):
+            _without_xcd_order(view, 64)
+        for noise in (None, _noise(gd, width, "normal", 1.0, 0.5, seed=5, offset=it)):
+            nz_p = None if noise is None else _noise(gp, width, "normal", 1.0, 0.5, seed=5, offset=it)
+            assert torch.equal(ops.aggregate(gd, x, noise, reduce="mean"), ops.aggregate(gp, x, nz_p, reduce="mean")), what
+
+
 def test_fuzz_backward_passes_against_oracle(dev, oracle):
     """Seeded sweep over graphs x widths x plans x kinds for the three backward entry points on the source-major
     CSR: stag_agg_bwd (dx + derivative aggregates), stag_agg_bwd_dp (dx + finished scalar / per-channel gradients),
