@@ -741,17 +741,7 @@ __device__ __forceinline__ void agg_unit(const AggArgs& a, const int unit, const
 #ifndef STAG_BLK_DP
 #define STAG_BLK_DP 1
 #endif
-  // The walk instantiation of the no-draw kernel — what an XCD-aware order or a plan-less row-striped launch runs, i.e. a
-  // graph whose rows come out of an XCD's L2 — keeps FOUR rows in flight per team (round 4) where a row takes 32 lanes or
-  // more: the L2-resident gather is bound by latency, not by the fabric.  tools/ab_bench.py, us, 2 | 4 | 6 | 8 rows: PPI
-  // batch D = 256 71.8 | 66.4 | 68.6 | 73.8, D = 128 35.6 | 35.0 | 37.4 | 41.8; narrower rows already fetch several blocks
-  // together (mult_of) and lose (D = 52 24.2 | 24.4, D = 16 15.8 | 30.6); on the arxiv graph (rows from the Infinity
-  // Cache: plan order, the other instantiation) 4 rows change nothing (95.3 | 95.6).
-#ifndef STAG_BLK_MEM_WALK
-#define STAG_BLK_MEM_WALK 4
-#endif
-  constexpr int BLK = PEDGE == 3 ? STAG_BLK_EG : PEDGE == 4 ? STAG_BLK_DP : (KIND >= kNormal) ? STAG_BLK_RNG
-                      : (NULLS && KIND == kNone && PEDGE == 0 && NOUT == 1 && LPE >= 32) ? STAG_BLK_MEM_WALK : STAG_BLK_MEM;
+  constexpr int BLK = PEDGE == 3 ? STAG_BLK_EG : PEDGE == 4 ? STAG_BLK_DP : (KIND >= kNormal) ? STAG_BLK_RNG : STAG_BLK_MEM;
   constexpr int NB = BLK * MULT;
 
   const uint32_t chunk = blockIdx.y * LPE + c;
@@ -1144,7 +1134,19 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
     }
     const int unit = unit0 + threadIdx.x / LPE;
     if (unit >= end) return;
-    agg_unit<KIND, LPE, VEC, PEDGE, 1, NOUT == 1 ? mult_of<KIND, LPE>() : 1, NOUT, MC, WN, true>(a, unit, c, 0);
+    // The walk instantiation of the no-draw kernel — what an XCD-aware order or a plan-less row-striped launch runs, i.e. a
+    // graph whose rows come out of an XCD's L2 — fetches TWO blocks (four rows) at a time where a row takes 32 lanes or
+    // more (round 4): the L2-resident gather is bound by latency, not by the fabric.  Two blocks of two edges, not one
+    // block of four: a block's sum is formed from zero and folded into the unit's sum, so the order of additions — and
+    // with it every bit of the result — is that of every other launch (one block of four was 2 us faster at D = 256 and
+    // is not the same sum).  tools/ab_bench.py, us, 1 | 2 blocks: PPI batch D = 256 71.8 | 68.0, D = 128 36.1 | 35.1;
+    // narrower rows already fetch several blocks together (mult_of); on the arxiv graph (rows from the Infinity Cache:
+    // plan order, the other instantiation) more rows in flight change nothing (95.3 | 95.6).
+#ifndef STAG_MULT_WALK_WIDE
+#define STAG_MULT_WALK_WIDE 2
+#endif
+    constexpr int MULT_W = NOUT != 1 ? 1 : (KIND == kNone && PEDGE == 0 && LPE >= 32) ? STAG_MULT_WALK_WIDE : mult_of<KIND, LPE>();
+    agg_unit<KIND, LPE, VEC, PEDGE, 1, MULT_W, NOUT, MC, WN, true>(a, unit, c, 0);
   }
 }
 
