@@ -1135,8 +1135,8 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
     const int unit = unit0 + threadIdx.x / LPE;
     if (unit >= end) return;
     // The walk instantiation of the no-draw kernel — what an XCD-aware order or a plan-less row-striped launch runs, i.e. a
-    // graph whose rows come out of an XCD's L2 — fetches TWO blocks (four rows) at a time where a row takes 32 lanes or
-    // more (round 4): the L2-resident gather is bound by latency, not by the fabric.  Two blocks of two edges, not one
+    // graph whose rows come out of an XCD's L2 — fetches TWO blocks (four rows) at a time where a row takes a whole wave
+    // (round 4): the L2-resident gather is bound by latency, not by the fabric.  Two blocks of two edges, not one
     // block of four: a block's sum is formed from zero and folded into the unit's sum, so the order of additions — and
     // with it every bit of the result — is that of every other launch (one block of four was 2 us faster at D = 256 and
     // is not the same sum).  tools/ab_bench.py, us, 1 | 2 blocks: PPI batch D = 256 71.8 | 68.0, D = 128 36.1 | 35.1;
@@ -1145,7 +1145,9 @@ __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_k
 #ifndef STAG_MULT_WALK_WIDE
 #define STAG_MULT_WALK_WIDE 2
 #endif
-    constexpr int MULT_W = NOUT != 1 ? 1 : (KIND == kNone && PEDGE == 0 && LPE >= 32) ? STAG_MULT_WALK_WIDE : mult_of<KIND, LPE>();
+    // (LPE 64 only: at 32 lanes per row the PPI batch gains 1 us of 36 and the molecule batch — rows of 2-4 edges, for
+    // which the second block is empty — loses 0.7 us of 22.4)
+    constexpr int MULT_W = NOUT != 1 ? 1 : (KIND == kNone && PEDGE == 0 && LPE >= 64) ? STAG_MULT_WALK_WIDE : mult_of<KIND, LPE>();
     agg_unit<KIND, LPE, VEC, PEDGE, 1, MULT_W, NOUT, MC, WN, true>(a, unit, c, 0);
   }
 }
