@@ -83,6 +83,62 @@ def test_cfg3_ppi_sage_mean_aggregation(dev, oracle, ppi, D):
     assert_close(ops.aggregate(g, xd, b, reduce="mean"), refb, what=f"cfg3 Bernoulli + in-norm D={D}")
 
 
+@pytest.mark.parametrize("D", [256, 128])
+def test_cfg3_whole_graphs_per_xcd_at_full_size(dev, oracle, D, monkeypatch):
+    """BASELINE configs[2] at full size with the XCD-aware order built from the range table (whole graphs per XCD, the one
+    family of stripes for the launch that does not draw, two blocks of rows in flight at D = 256): bit-identical to the
+    plan-order launch — no draw, Normal, Bernoulli + in-norm; forward, and the dx pass on the transposed view — and the
+    forward against the oracle; every unit of the plan appears exactly once in the order and no graph straddles two stripes."""
+    import importlib
+    import stag_amd
+    from stag_amd import _lib, ops, synthetic
+    G = importlib.import_module("stag_amd.graph")
+    src, dst, sizes = synthetic.ppi_like()
+    n = int(sizes.sum())
+    mk = lambda: stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n,
+                                batch_num_nodes=torch.from_numpy(sizes).to(dev), device=dev)
+    monkeypatch.setattr(G, "XCD_ORDER", "1")
+    ga = mk()
+    for view in (ga.csr, ga.csr_t):
+        view.xcd_graphs = True                      # (D = 128 too: by default only rows of 1 KB and up)
+        view.plan(64, need=True)
+    monkeypatch.setattr(G, "XCD_ORDER", "0")
+    gb = mk()
+    assert ga.csr.plan(64)["xcd_on"] and not gb.csr.plan(64, need=True).get("xcd_on")
+    order, (sh, sl), tag = ga.csr.xcd_order(ga.csr.plan(64), D)
+    assert tag == 1000 + D + (512 if D > 128 else 0) and (sh == 0) == (D > 128)
+    rec = order.cpu().numpy()[_lib.XCD_HEADER:].reshape(-1, 4)
+    plan = ga.csr.plan(64)
+    units = plan["units"].cpu().numpy()[:plan["n_units"]]
+    real = rec[rec[:, 0] >= 0]
+    assert len(real) == len(units) and sorted(map(tuple, real)) == sorted(map(tuple, units))
+    cuts, keys, fine = ga.csr.xcd_ranges(D)[:3]
+    edge_cuts = ga.csr.indptr.cpu().numpy().astype(np.int64)[np.concatenate([[0], np.cumsum(sizes)])]
+    stripe_of = lambda pos: keys[np.clip(np.searchsorted(cuts, pos, side="right") - 1, 0, len(keys) - 1)] // fine
+    for gi in range(len(sizes)):
+        pos = np.arange(edge_cuts[gi], edge_cuts[gi + 1], 97)
+        assert len(set(stripe_of(pos).tolist())) == 1, "a graph never straddles two XCD stripes"
+    x = torch.randn(n, D, generator=torch.Generator().manual_seed(D))
+    xd, gout = x.to(dev), torch.randn(n, D, device=dev)
+    og = oracle_graph(oracle, ga)
+    cases = (("none", lambda g: None, oracle.make_spec("none")),
+             ("normal", lambda g: _normal(g, D, 31, 2), oracle.make_spec("normal", 1.0, 0.5, seed=31, offset=2, Dn=D, n_edges=len(src))),
+             ("bernoulli+norm", lambda g: stag_amd.EdgeNoise(g, D, _lib.NOISE_BERNOULLI, 0.7, None, seed=5, offset=1, in_norm=True),
+              oracle.make_spec("bernoulli", 0.7, in_norm=True, seed=5, offset=1, Dn=D, n_edges=len(src))))
+    for name, noise, spec in cases:
+        outs = []
+        for g in (ga, gb):
+            xr = xd.clone().requires_grad_(True)
+            y = ops.aggregate(g, xr, noise(g), reduce="mean")
+            y.backward(gout)
+            outs.append((y.detach(), xr.grad))
+        assert torch.equal(outs[0][0], outs[1][0]), f"cfg3 D={D} {name}: whole graphs per XCD changed a bit of the forward"
+        assert torch.equal(outs[0][1], outs[1][1]), f"cfg3 D={D} {name}: ... of d/dx"
+        with hw_normals(oracle, dev):
+            ref = oracle.agg_fwd(og, x.numpy(), spec, reduce=oracle.REDUCE_MEAN)
+        assert_close(outs[0][0], ref, what=f"cfg3 D={D} {name}, whole graphs per XCD, vs oracle")
+
+
 def test_cfg3_sage_layer_stack_against_oracle_formula(dev, oracle, ppi):
     """StagLayer(GraphSAGE) 50 -> 256 -> 256 on the batch: every layer's output against
     fc_self(h) + fc_neigh(mean_in(w (.) h)) + bias computed from the oracle's aggregation in fp64

@@ -246,3 +246,58 @@ def test_cfg2_partitioned_backward_pieces_at_full_size(dev, arxiv, shards):
         assert torch.equal(dx, seq), f"rank {r}: own row first, then the peers in rank order, summed in the kernel's pairs"
         got.append(dx)
     assert_close(*_rel(torch.cat(got, 0), x.grad), what="cfg2 8 shards: d x through the partitioned backward's pieces")
+
+
+def test_cfg5_staged_gat_backward_equals_the_single_call_at_full_size(dev, arxiv, shards):
+    """stag_gat_bwd_stages (ABI v19) at BASELINE configs[4]'s size: on the whole graph the source pass cut into two random
+    complementary sub-plans (all 18k segments of the long rows riding in the first), and on shard 3 of 8 cut the way
+    `_ShardGat` cuts it (remote buffer rows first, then this rank's own) — row dots, two source passes, d er — write what
+    ONE stag_gat_bwd call writes, bit for bit; the first pass leaves its own rows complete (they are what the transposed
+    exchange would already be sending)."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    src, dst, n, g = arxiv
+    H, F = 8, 32
+    gen = torch.Generator().manual_seed(77)
+    mk = lambda graph: stag_amd.EdgeNoise(graph, H, _lib.NOISE_NORMAL, 1.0, 0.5, seed=0x5747A6, offset=11)
+    cases = [("whole graph", g, g.csr, g.csr_t, None)]
+    sh, gid = shards["halo"][3]
+    cases.append(("shard 3 of 8", sh, sh.csr, sh.csr_t, sh))
+    for name, graph, csrv, csrt, shard in cases:
+        n_dst, n_src = csrv.n_dst, csrt.n_dst
+        el = torch.randn(n_src, H, generator=gen).to(dev)
+        er = torch.randn(n_dst, H, generator=gen).to(dev)
+        ft = torch.randn(n_src, H, F, generator=gen).to(dev)
+        G = torch.randn(n_dst, H, F, generator=gen).to(dev)
+        noise = mk(graph)
+        if shard is not None:
+            noise.pos_base = shard.pos_base
+        spec = noise.spec()
+        drop = (0.6, 1234, 5)
+        dstruct = ops._gat_drop_struct(drop)
+        out = torch.empty(n_dst, H, F, device=dev)
+        stats = torch.empty(n_dst, 2 * H, device=dev)
+        ops._gat_fwd_into(csrv, csrv.plan(64, need=True), el, er, ft, H, F, 0.2, spec, None, dstruct, out, stats, dev)
+        d_el, d_er, d_ft, _ = ops._gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, 0.2, spec, None, False, 64, dev, drop)
+        if shard is None:
+            full_t = csrt.plan(64, need=True)
+            units_t = full_t["units"].cpu().numpy()[:full_t["n_units"]]
+            keep = (units_t[:, 3] < 0) & (np.random.default_rng(5).random(len(units_t)) < 0.5)
+            first, second = csrt.subplan(64, ~keep), csrt.subplan(64, keep)
+            rows_first = torch.from_numpy(units_t[~keep & (units_t[:, 3] < 0)][:, 0].astype(np.int64)).to(dev)
+        else:
+            first, second = shard.plan_split_t(64)
+            rows_first = torch.arange(shard.n_rows, shard.n_buf, device=dev)
+        assert first["n_units"] > 0 and second["n_units"] > 0
+        T_ft = torch.full((n_src + 3, H * F), float("nan"), device=dev)
+        T_el = torch.full((n_src + 3, H), float("nan"), device=dev)
+        e_r = torch.full((n_dst, H), float("nan"), device=dev)
+        st = ops._GatBwdStages(csrv, csrt, el, er, ft, stats, G, out, H, F, 0.2, spec, None, drop, 64, T_el, e_r, T_ft, dev)
+        st.rowdot()
+        st.source(first)
+        assert torch.equal(T_ft[rows_first], d_ft.reshape(n_src, -1)[rows_first]), f"{name}: the first pass's rows are complete"
+        assert torch.equal(T_el[rows_first], d_el[rows_first])
+        st.source(second)
+        st.der()
+        assert torch.equal(T_ft[:n_src], d_ft.reshape(n_src, -1)), f"{name}: d ft"
+        assert torch.equal(T_el[:n_src], d_el) and torch.equal(e_r, d_er), f"{name}: d el / d er"
