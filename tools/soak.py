@@ -55,6 +55,83 @@ def step(layer):
     return [y.detach(), x.grad] + [o.detach() for o in outs[1:]] + [p.grad for p in layer.parameters() if p.grad is not None]
 
 
+ap_only = os.environ.get("STAG_SOAK_ONLY", "")       # "r04": only the round-4 paths below
+
+# ---- round 4: the partitioned steps on a shard of one (the overlapped forward, the staged GAT backward with its
+#      fixed-order combine), and the whole-graphs-per-XCD orders on the PPI-sized batch (two blocks of rows in flight, the
+#      XCD-local GAT batches with two rows per round) -----------------------------------------------------------------------
+def r04_cases():
+    import importlib
+    from stag_amd import _lib, ops
+    from stag_amd.partition import GraphShard
+    G = importlib.import_module("stag_amd.graph")
+    sh = GraphShard(src, dst, n, 0, 1, device=dev)
+    H, F = 8, 32
+    el0, er0, ft0 = torch.randn(n, H, device=dev), torch.randn(n, H, device=dev), torch.randn(n, H, F, device=dev)
+    gG = torch.randn(n, H, F, device=dev)
+
+    def shard_gat():
+        el, er, ft = (t.clone().requires_grad_(True) for t in (el0, er0, ft0))
+        nz = stag_amd.EdgeNoise(sh, H, _lib.NOISE_NORMAL, 1.0, 0.5, seed=3, offset=4)
+        out = sh.gat_aggregate(el, er, ft, 0.2, nz, attn_drop=(0.6, 12, 5))
+        assert "ShardGat" in type(out.grad_fn).__name__
+        out.backward(gG)
+        return [out.detach(), ft.grad, el.grad, er.grad]
+
+    def shard_agg():
+        x = x0.clone().requires_grad_(True)
+        nz = stag_amd.EdgeNoise(sh, D, _lib.NOISE_BERNOULLI, 0.7, None, seed=3, offset=4, in_norm=True)
+        out = sh.aggregate(x, nz)
+        out.backward(gout[:, :D])
+        return [out.detach(), x.grad]
+
+    G.XCD_ORDER = "1"
+    s3, d3, z3 = synthetic.ppi_like()
+    n3 = int(z3.sum())
+    g3 = stag_amd.Graph(torch.from_numpy(s3), torch.from_numpy(d3), n3, batch_num_nodes=torch.from_numpy(z3).to(dev), device=dev)
+    x3 = torch.randn(n3, 256, device=dev)
+    g3o = torch.randn(n3, 256, device=dev)
+    e3, r3, f3 = torch.randn(n3, 4, device=dev), torch.randn(n3, 4, device=dev), torch.randn(n3, 4, 64, device=dev)
+    G3 = torch.randn(n3, 4, 64, device=dev)
+
+    def ppi_agg():
+        res = []
+        for nz in (None, stag_amd.EdgeNoise(g3, 256, _lib.NOISE_NORMAL, 1.0, 0.5, seed=3, offset=4)):
+            x = x3.clone().requires_grad_(True)
+            out = ops.aggregate(g3, x, nz, reduce="mean")
+            out.backward(g3o)
+            res += [out.detach(), x.grad]
+        return res
+
+    def ppi_gat():
+        el, er, ft = (t.clone().requires_grad_(True) for t in (e3, r3, f3))
+        out = ops.gat_aggregate(g3, el, er, ft, 0.2, stag_amd.EdgeNoise(g3, 4, _lib.NOISE_NORMAL, 1.0, 0.5, seed=3, offset=4))
+        out.backward(G3)
+        return [out.detach(), ft.grad, el.grad, er.grad]
+
+    return {"shard of one: GAT step (_ShardGat, stag_gat_bwd_stages, in-kernel dropout)": shard_gat,
+            "shard of one: Bernoulli + in-norm aggregation step (_ShardAggregate)": shard_agg,
+            "PPI batch D = 256, whole graphs per XCD: no draw and Normal, forward + dx": ppi_agg,
+            "PPI batch GAT 4 x 64 on XCD-local batches, forward + one-gather backward": ppi_gat}
+
+
+for name, fn in r04_cases().items():
+    first = [t.clone() for t in fn()]
+    bad, checked, t0 = 0, 0, time.perf_counter()
+    for i in range(1, args.steps):
+        res = fn()
+        if i % args.every == 0:
+            checked += 1
+            if not all(torch.equal(a, b) for a, b in zip(first, res)):
+                bad += 1
+    torch.cuda.synchronize()
+    print(f"{name}: {args.steps} steps in {time.perf_counter() - t0:.1f} s, {checked} compared, {bad} differing", flush=True)
+    if bad:
+        raise SystemExit(1)
+if ap_only == "r04":
+    print("soak ok (round-4 paths)")
+    raise SystemExit(0)
+
 for name, layer in layers.items():
     layer = layer.to(dev)
     first = [t.clone() for t in step(layer)]
