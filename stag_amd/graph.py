@@ -85,11 +85,17 @@ def xcd_graph_ranges(edge_cuts, rows, width, range_bytes=None, stripes=None, fin
             stripe[g] = k
             load[k] += max(int(e[g]), 1)
     row_bytes = 4 * min(max(int(width), 1), 256)          # (wider rows are tiled at 256 floats)
+    # (a budget below a sixteenth of the heaviest stripe cannot fit STAG_XCD_FINE_MAX ranges: start there instead of
+    # doubling up to it — a stripe of huge graphs under a tiny budget would otherwise be cut into millions of pieces first)
+    per_stripe = np.bincount(stripe, weights=rows.astype(np.float64) * row_bytes * (e > 0), minlength=stripes)
+    rb = max(rb, float(per_stripe.max()) / fine_max)
     while True:
         out, fine = [], 1
         for k in range(stripes):
             f, acc = 0, 0.0
             for g in np.nonzero(stripe == k)[0]:
+                if e[g] == 0:        # a graph without edges owns no CSR position (its rows' empty units ride with a neighbour)
+                    continue
                 b = float(rows[g]) * row_bytes
                 if b > rb:
                     if acc > 0:
@@ -107,7 +113,9 @@ def xcd_graph_ranges(edge_cuts, rows, width, range_bytes=None, stripes=None, fin
         if fine <= fine_max:
             break
         rb *= 2
-    out.sort(key=lambda t: t[0])         # (stable: graphs without edges keep their place)
+    out.sort(key=lambda t: t[0])         # (positions are distinct: every piece holds at least one edge ... except a large
+    if not out:                          #  graph cut into more pieces than it has edges: equal positions, any order)
+        out = [(0, 0, 0)]
     cuts = np.array([t[0] for t in out] + [E], np.int64)
     cuts[0] = 0
     keys = np.array([t[1] * fine + t[2] for t in out], np.int32)

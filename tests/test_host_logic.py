@@ -425,6 +425,32 @@ def test_xcd_order_keeps_whole_graphs_per_stripe(width, merge, monkeypatch):
     assert f4 <= _lib.XCD_FINE_MAX and (np.diff(k4 // f4) >= 0).all() and len(np.unique(k4 // f4)) == 8
 
 
+def test_fuzz_xcd_graph_ranges_invariants():
+    """Seeded sweep of graph.xcd_graph_ranges (the range table of stag_plan_xcd_ranges): 2 ... 4096 graphs of 0 ... 60,000 rows,
+    some without edges, widths 1 ... 1433, budgets from 1 KB up: at most STAG_XCD_FINE_MAX fine ranges per stripe, ascending cut
+    points from 0 to E, keys inside [0, 8 * fine), and every graph that has edges lies in ONE stripe at every one of its
+    positions (a graph without edges owns no position: round 4 found its range shadowing its neighbour's)."""
+    import importlib
+    from stag_amd import _lib
+    G = importlib.import_module("stag_amd.graph")
+    rng = np.random.default_rng(0)
+    for it in range(400):
+        ng = int(rng.choice([2, 3, 8, 9, 24, 100, 600, 4096]))
+        rows = rng.integers(0 if rng.random() < 0.3 else 1, int(rng.choice([3, 50, 4000, 60000])), ng)
+        e = (rows * rng.integers(0, 30, ng) * (rng.random(ng) > 0.2)).astype(np.int64)
+        cuts_e = np.concatenate([[0], np.cumsum(e)])
+        if cuts_e[-1] == 0:
+            continue
+        w = int(rng.choice([1, 9, 50, 128, 256, 1433]))
+        cuts, keys, fine = G.xcd_graph_ranges(cuts_e, rows, w, range_bytes=int(rng.choice([1000, 100_000, 2_500_000])))
+        assert 1 <= fine <= _lib.XCD_FINE_MAX and cuts[0] == 0 and cuts[-1] == cuts_e[-1] and (np.diff(cuts) >= 0).all()
+        assert keys.min() >= 0 and keys.max() < 8 * fine and len(keys) == len(cuts) - 1
+        for g in np.nonzero(e)[0]:
+            pos = np.unique(np.clip(np.linspace(cuts_e[g], cuts_e[g + 1] - 1, 7).astype(np.int64), cuts_e[g], cuts_e[g + 1] - 1))
+            k = keys[np.clip(np.searchsorted(cuts, pos, side="right") - 1, 0, len(keys) - 1)] // fine
+            assert len(set(k.tolist())) == 1, (it, int(g), k.tolist(), fine)
+
+
 @pytest.mark.parametrize("seg_len", [64, 16, 300])
 def test_block_plan_batches_units(seg_len):
     """stag_plan_blocks: consecutive units of the plan in batches of at most STAG_BLOCK_EDGES edges and
