@@ -356,3 +356,101 @@ def test_native_rccl_comm_single_rank(dev):
                 assert torch.equal(sh.aggregate(xs, mk(sh)), ops.aggregate(g, xs, mk(g)))
     finally:
         comm.close()
+
+
+def _fuzz_graphs():
+    """Small graphs that stress the partition's corners: ranks without rows, without edges, without remote sources,
+    without anything to send; a hub that makes one rank own a single row; duplicate edges; isolated nodes."""
+    rng = np.random.default_rng(20261105)
+    cases = []
+    for it in range(14):
+        n = int(rng.choice([2, 3, 5, 40, 400]))
+        e = int(rng.choice([1, 2, 7, 300, 3000]))
+        dst = rng.integers(0, n, e)
+        src = rng.integers(0, n, e)
+        kind = it % 5
+        if kind == 1:
+            dst[:] = 0                                   # every edge ends in row 0: the other rank owns rows without edges
+        elif kind == 2:
+            src = dst.copy()                             # self loops only: no rank needs a remote row
+        elif kind == 3 and n > 3:
+            dst = np.minimum(dst, n // 2 - 1) if n // 2 > 0 else dst      # the upper half of the nodes has no in-edge
+        elif kind == 4:
+            hub = int(rng.integers(0, n))
+            dst[: max(1, (3 * e) // 4)] = hub            # a hub: the cut gives one rank a single row
+        cases.append((src, dst, n))
+    return cases
+
+
+def _fuzz_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import stag_amd
+        from stag_amd import _lib
+        from stag_amd.partition import GraphShard
+        dev = torch.device("cuda:0")
+        res = []
+        for it, (src, dst, n) in enumerate(_fuzz_graphs()):
+            gen = torch.Generator().manual_seed(100 + it)
+            D, H, F = 24, 2, 8
+            x, gx = torch.randn(n, D, generator=gen), torch.randn(n, D, generator=gen)
+            el, er = torch.randn(n, H, generator=gen), torch.randn(n, H, generator=gen)
+            ft, gG = torch.randn(n, H, F, generator=gen), torch.randn(n, H, F, generator=gen)
+            out = {}
+            for exchange in ("halo", "allgather"):
+                sh = GraphShard(src, dst, n, rank, world, device=dev, exchange=exchange)
+                lo, hi = sh.row_lo, sh.row_hi
+                xl = x[lo:hi].to(dev).requires_grad_(True)
+                y = sh.aggregate(xl, stag_amd.EdgeNoise(sh, D, _lib.NOISE_NORMAL, 1.0, 0.5, seed=9, offset=it))
+                y.backward(gx[lo:hi].to(dev))
+                e_, r_, f_ = (t[lo:hi].to(dev).requires_grad_(True) for t in (el, er, ft))
+                z = sh.gat_aggregate(e_, r_, f_, 0.2, stag_amd.EdgeNoise(sh, H, _lib.NOISE_NORMAL, 1.0, 0.5, seed=9, offset=it),
+                                     attn_drop=(0.3, 5, it))
+                z.backward(gG[lo:hi].to(dev))
+                out[exchange] = [t.detach().cpu() for t in (y, xl.grad, z, f_.grad, e_.grad, r_.grad)]
+            res.append(out)
+        torch.save(res, os.path.join(tmp, f"fuzz{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fuzz_two_shards_on_degenerate_graphs(dev, tmp_path):
+    """Seeded sweep of the partitioned aggregation and GAT steps (both overlapped autograd Functions, both exchange layouts)
+    over two gloo ranks on graphs whose cut leaves a rank without rows, without edges, without remote sources or with
+    nothing to send: the forward equals the whole graph's bit for bit, the gradients at 1e-5."""
+    import torch.multiprocessing as mp
+    import stag_amd
+    from stag_amd import _lib, ops
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_fuzz_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(tmp_path / f"fuzz{r}.pt") for r in range(world)]
+    for it, (src, dst, n) in enumerate(_fuzz_graphs()):
+        gen = torch.Generator().manual_seed(100 + it)
+        D, H, F = 24, 2, 8
+        x, gx = torch.randn(n, D, generator=gen), torch.randn(n, D, generator=gen)
+        el, er = torch.randn(n, H, generator=gen), torch.randn(n, H, generator=gen)
+        ft, gG = torch.randn(n, H, F, generator=gen), torch.randn(n, H, F, generator=gen)
+        g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n, device=dev)
+        xw = x.to(dev).requires_grad_(True)
+        y = ops.aggregate(g, xw, stag_amd.EdgeNoise(g, D, _lib.NOISE_NORMAL, 1.0, 0.5, seed=9, offset=it))
+        y.backward(gx.to(dev))
+        e_, r_, f_ = (t.to(dev).requires_grad_(True) for t in (el, er, ft))
+        z = ops.gat_aggregate(g, e_, r_, f_, 0.2, stag_amd.EdgeNoise(g, H, _lib.NOISE_NORMAL, 1.0, 0.5, seed=9, offset=it),
+                              attn_drop=(0.3, 5, it))
+        z.backward(gG.to(dev))
+        want = [t.detach().cpu() for t in (y, xw.grad, z, f_.grad, e_.grad, r_.grad)]
+        for exchange in ("halo", "allgather"):
+            got = [torch.cat([p[it][exchange][k] for p in parts], 0) for k in range(6)]
+            what = f"partition fuzz {it} ({exchange}): n={n} E={len(src)}"
+            assert torch.equal(got[0], want[0]), what + ": aggregation forward"
+            assert torch.equal(got[2], want[2]), what + ": GAT forward"
+            for k, nm in ((1, "d x"), (3, "d ft"), (4, "d el"), (5, "d er")):
+                sc = max(1.0, float(want[k].abs().max()))
+                assert_close(got[k] / sc, (want[k] / sc).numpy(), TOL, what + ": " + nm)
