@@ -793,11 +793,13 @@ static int agg_common(const stag_csr* csr, const stag_plan* plan, const float* x
   if (rc) return rc;
   rc = check_spec(spec, csr->n_edges);
   if (rc) return rc;
-  // ldx == 0: one broadcast row; out may be NULL when only the in-norm factor (or the edge gradients) is wanted
-  if ((!out && !norm_scale_out && !eg) || D <= 0 || (ldx != 0 && ldx < D) || ldo < D) return STAG_EINVAL;
-  if (csr->n_edges > 0 && !x) return STAG_EINVAL;
+  if (D <= 0 || (ldx != 0 && ldx < D) || ldo < D) return STAG_EINVAL;
   if (reduce != STAG_REDUCE_SUM && reduce != STAG_REDUCE_MEAN) return STAG_EINVAL;
-  if (csr->n_dst == 0) return STAG_OK;
+  if (csr->n_dst == 0) return STAG_OK;        // no row, nothing to write (an output of no rows has no address: a shard
+                                              // whose cut left it without rows still makes the call)
+  // ldx == 0: one broadcast row; out may be NULL when only the in-norm factor (or the edge gradients) is wanted
+  if (!out && !norm_scale_out && !eg) return STAG_EINVAL;
+  if (csr->n_edges > 0 && !x) return STAG_EINVAL;
 
   AggArgs a{};
   a.indptr = csr->indptr; a.indices = csr->indices; a.eid = csr->eid; a.nidx = csr->nidx;

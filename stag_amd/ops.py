@@ -154,6 +154,8 @@ def _agg_raw(csrv, x, D, spec, reduce, src_scale, dst_scale, seg_len, want_norm_
         out = torch.empty((csrv.n_dst, D), dtype=torch.float32, device=dev)
     ns = ns_out if ns_out is not None else (
         torch.empty((csrv.n_dst, D), dtype=torch.float32, device=dev) if want_norm_scale else None)
+    if csrv.n_dst == 0:          # no row: nothing to launch (a node-range shard whose cut left it without rows)
+        return out, ns
     if plan_t is None:
         plan_t = csrv.plan(seg_len)
     nbytes = (_lib.lib().stag_plan_workspace_bytes(plan_t["n_seg"], D, int(spec.in_norm))

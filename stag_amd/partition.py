@@ -361,7 +361,11 @@ def _split_sorted(ids, bounds_t, world):
 
 
 class GraphShard:
-    """The rows of one rank, shaped like a stag_amd.Graph for the layers, ops.aggregate and EdgeNoise."""
+    """The rows of one rank, shaped like a stag_amd.Graph for the layers, ops.aggregate and EdgeNoise.
+
+    Every step is a collective — forward and, under autograd, backward (the transposed exchange): all ranks must run the
+    same steps, a rank whose loss does not reach its shard's outputs (e.g. a cut that left it without rows — more ranks
+    than rows with in-edges) included; give such a rank a zero-weight term over its outputs, or use fewer ranks."""
 
     is_block = False
     is_shard = True
@@ -916,6 +920,11 @@ class GraphShard:
             return _ShardGat.apply(el_local, er_local, ft_local, self, weight, float(neg_slope), seg_len, attn_drop,
                                    bool(overlap))
         ft_full, el_full = self.halo_gather_multi([ft_local, el_local])
+        if self.n_rows == 0:
+            # a cut that left this rank without rows: nothing to compute, but the exchange (and, under autograd, its
+            # transposed twin in the backward) is a collective every rank enters
+            empty = ft_full.new_zeros((0,) + tuple(ft_local.shape[1:])) + 0.0 * (ft_full.sum() + el_full.sum() + er_local.sum())
+            return (empty, el_full.new_zeros((0, el_local.shape[1]))) if want_attn else empty
         # attn_drop: the mask is keyed by GLOBAL forward position (pos_base), so shards draw the whole graph's mask
         return ops.gat_aggregate(self, el_full, er_local, ft_full, neg_slope, weight, want_attn=want_attn,
                                  seg_len=seg_len, _gathered=True, attn_drop=attn_drop)
