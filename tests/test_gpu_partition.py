@@ -418,14 +418,15 @@ def _fuzz_worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
-def test_fuzz_two_shards_on_degenerate_graphs(dev, tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_fuzz_two_shards_on_degenerate_graphs(dev, tmp_path, world):
     """Seeded sweep of the partitioned aggregation and GAT steps (both overlapped autograd Functions, both exchange layouts)
-    over two gloo ranks on graphs whose cut leaves a rank without rows, without edges, without remote sources or with
-    nothing to send: the forward equals the whole graph's bit for bit, the gradients at 1e-5."""
+    over two and three gloo ranks on graphs whose cut leaves a rank without rows, without edges, without remote sources or
+    with nothing to send: the forward equals the whole graph's bit for bit, the gradients at 1e-5.  (Round 4: a shard
+    without rows used to fail in stag_agg_fwd — an output of no rows has no address.)"""
     import torch.multiprocessing as mp
     import stag_amd
     from stag_amd import _lib, ops
-    world = 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
