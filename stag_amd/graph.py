@@ -186,7 +186,7 @@ class CsrView:
         hipGraph is being captured and the arrays for this width do not exist yet (they are built on the host)."""
         if not plan.get("xcd_on"):
             return None
-        ranges = self.xcd_ranges(width) if not (plan["units"].is_cuda and torch.cuda.is_current_stream_capturing()) else None
+        ranges = self.xcd_ranges(width, build=not (plan["units"].is_cuda and torch.cuda.is_current_stream_capturing()))
         fine = self.xcd_fine_for(width, cap=None) if ranges is None else ranges[2]
         okey = fine if ranges is None else ("graphs", min(int(width), 256))
         got = plan.setdefault("gat_orders", {}).get(okey)
@@ -211,7 +211,7 @@ class CsrView:
             got = plan["gat_orders"][okey] = (torch.from_numpy(out).to(dev), torch.from_numpy(ptr).to(dev), nb.value, tag)
         return got
 
-    def xcd_ranges(self, width):
+    def xcd_ranges(self, width, build=True):
         """(cuts, keys, fine, device cuts, device keys) of xcd_graph_ranges for launches that gather rows of `width`
         floats, or None when this view is not a batch of several graphs (then the stripes are equal eighths of the CSR).
         One read-back of G + 1 row pointers, kept; the table is kept per row-byte class."""
@@ -220,6 +220,8 @@ class CsrView:
         if min(max(int(width), 1), 256) <= GRAPHS_ABOVE and self.xcd_graphs is None:
             return None
         if self._part_cuts is None:
+            if not build:          # (a hipGraph is being captured: no read-back, no upload — what exists is used)
+                return None
             sizes = (self.part_sizes.detach().cpu().numpy() if torch.is_tensor(self.part_sizes) else
                      np.asarray(self.part_sizes)).astype(np.int64)
             if len(sizes) < 2 or int(sizes.sum()) != self.n_dst or self.n_edges == 0:
@@ -232,6 +234,8 @@ class CsrView:
         cls = min(max(int(width), 1), 256)
         got = tables.get(cls)
         if got is None:
+            if not build:
+                return None
             cuts, keys, fine = xcd_graph_ranges(edge_cuts, sizes, cls)
             dev = self.indptr.device
             got = tables[cls] = (cuts, keys, fine, torch.from_numpy(cuts).to(dev), torch.from_numpy(keys).to(dev))
@@ -291,7 +295,7 @@ class CsrView:
         if not plan.get("xcd_on"):
             return None, (0, 0), 0
         capturing = plan["units"].is_cuda and torch.cuda.is_current_stream_capturing()
-        ranges = None if capturing and self._part_cuts is None else self.xcd_ranges(width)
+        ranges = self.xcd_ranges(width, build=not capturing)
         if ranges is None:
             fine, merge = self.xcd_fine_for(width), False
             okey = tag = fine
