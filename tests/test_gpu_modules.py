@@ -1422,16 +1422,28 @@ def test_fuzz_amortized_head_kernels(dev):
         assert_close(pls.grad, plsd.grad.cpu().numpy(), what=what + " d prior log_scale")
 
 
+@pytest.mark.parametrize("front", ["ctypes", "dispatcher"])
 @pytest.mark.parametrize("n,E", [(5, 0), (1, 0), (3, 1)])
-def test_layers_on_edgeless_and_one_edge_graphs(dev, n, E):
+def test_layers_on_edgeless_and_one_edge_graphs(dev, n, E, front, monkeypatch):
     """Degenerate graphs through whole layers, forward and backward: no edges at all (per-edge arrays without an
     address; every gradient that flows through an edge is zero; the KL mean over zero edges is NaN as in the
     reference, stag/layers.py:136-139) and a single edge (an [E, 1] head of one element is still per edge)."""
     import stag_amd
+    from stag_amd import ops
     from stag_amd.distributions import AmortizedDistribution
     N = torch.distributions.Normal
+    if front == "dispatcher":       # (round 4) the same through torch.ops.stag.* — gat_fwd / gat_bwd / agg_fwd_mc / agg_bwd_dp too
+        monkeypatch.setenv("STAG_TORCH_OPS", "1")
     g = stag_amd.Graph(torch.zeros(E, dtype=torch.int64), torch.full((E,), min(1, n - 1), dtype=torch.int64), n, device=dev)
     x = torch.randn(n, 8, device=dev, requires_grad=True)
+    # a vi layer whose parameter gradients are finished in the dx pass, and a Monte-Carlo batch, on the same graphs
+    vi = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(8, 4, allow_zero_in_degree=True), q_a=N(1.0, 0.5), vi=True, relu=True).to(dev)
+    xv = torch.randn(n, 8, device=dev, requires_grad=True)
+    (vi(g, xv).sum() + vi.kl_divergence()).backward()
+    assert torch.isfinite(xv.grad).all() and all(torch.isfinite(p.grad).all() for p in vi.parameters() if p.grad is not None)
+    with torch.no_grad():
+        mc = ops.aggregate_mc(g, xv.detach(), stag_amd.EdgeNoise(g, 8, stag_amd._lib.NOISE_NORMAL, 1.0, 0.5, seed=1, offset=0), 3)
+    assert mc.shape == (3, n, 8) and torch.isfinite(mc).all() and (E > 0 or float(mc.abs().sum()) == 0.0)
     q = AmortizedDistribution(8, 1, init_like=N(1.0, 0.3)).to(dev)
     layer = stag_amd.layers.StagLayer(stag_amd.zoo.GCN(8, 4, allow_zero_in_degree=True), q_a=q, vi=True).to(dev)
     y = layer(g, x)
