@@ -24,8 +24,10 @@ exchange-free channel partition (`alt_partition`), per-rank device times, the ex
 kernels alone (`exchange`), the RCCL version, and the two transports of the exchange as timed
 variants (`comm_variants`: torch.distributed's all_to_all_single | the library's own grouped
 ncclSend/ncclRecv, `stag_halo_exchange_multi`).  Everything after the headline loop is best-effort:
-an exception becomes an `error` string in its object, and a watchdog prints the line as far as it
-got if an extra hangs.
+an exception becomes an `error` string in its object, a watchdog prints the line as far as it
+got if an extra hangs, and if a rank dies hard behind the headline loop (the launcher then tears the
+job down) rank 0's guardian process — forked before rank 0 touches the GPU — prints the last snapshot
+of the line with `extras_crashed`.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects: `roofline`
 (algorithmic bytes / device time of the op, measured with HIP events on the launch stream, against
@@ -283,8 +285,8 @@ class Watchdog:
     """Everything after the headline loop of an N > 1 run is best-effort.  If it has not finished after `seconds`
     (a collective that never completes), rank 0 prints the line as far as it got and every rank leaves."""
 
-    def __init__(self, seconds, rank, line_fn):
-        self.rank, self.line_fn, self.done = rank, line_fn, threading.Event()
+    def __init__(self, seconds, rank, line_fn, guardian=None):
+        self.rank, self.line_fn, self.done, self.guardian = rank, line_fn, threading.Event(), guardian
         self.t = threading.Thread(target=self._run, args=(seconds,), daemon=True)
         self.t.start()
 
@@ -295,6 +297,8 @@ class Watchdog:
             line = self.line_fn()
             line["extras_timed_out_after_s"] = seconds
             print(json.dumps(line), flush=True)
+            if self.guardian is not None:
+                self.guardian.done()
         sys.stderr.write(f"bench.py: rank {self.rank}: the extra loops did not finish in {seconds:.0f} s; "
                          f"the headline measurement stands, leaving.\n")
         sys.stderr.flush()
@@ -302,6 +306,59 @@ class Watchdog:
 
     def cancel(self):
         self.done.set()
+
+
+class Guardian:
+    """Rank 0 of an N > 1 run keeps a forked child — forked BEFORE this process touches the GPU; the child never
+    does — that holds the line as far as rank 0 got.  If rank 0 dies before it has printed the line itself (an
+    extra crashed a rank and the launcher tore the job down, a fault inside a collective), the child prints the
+    last snapshot with `extras_crashed`: the headline measurement of the first multi-GPU run is not lost with
+    the extras behind it.  Nothing is printed when rank 0 never got as far as the headline."""
+
+    def __init__(self):
+        import signal
+        r, w = os.pipe()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        pid = os.fork()
+        if pid == 0:                    # the child: pipe -> memory; os-level calls only
+            try:
+                os.close(w)
+                try:
+                    os.setsid()         # a launcher that signals rank 0's process group does not take the child along
+                except OSError:
+                    pass
+                for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+                    signal.signal(sig, signal.SIG_IGN)
+                data = b""
+                while True:
+                    chunk = os.read(r, 1 << 16)
+                    if not chunk:
+                        break
+                    data += chunk
+                msgs = [m for m in data.decode("utf-8", "replace").split("\n") if m]
+                if msgs and msgs[-1] != "DONE":
+                    snap = json.loads(msgs[-1])
+                    snap["extras_crashed"] = ("rank 0 ended before printing this line (an extra after the headline loop "
+                                              "failed hard on some rank); printed by its guardian process from the last "
+                                              "snapshot: everything present was complete when it was taken")
+                    os.write(1, (json.dumps(snap) + "\n").encode())
+            finally:
+                os._exit(0)
+        os.close(r)
+        self.w = w
+
+    def update(self, line):
+        if self.w is not None and line is not None:
+            os.write(self.w, (json.dumps(line) + "\n").encode())
+
+    def done(self):
+        if self.w is not None:
+            try:
+                os.write(self.w, b"DONE\n")
+                os.close(self.w)
+            finally:
+                self.w = None
 
 
 # ------------------------------------------------------------------------------------------------- main
@@ -322,6 +379,7 @@ def main():
     rehearse = args.rehearse
     if os.environ.get("STAG_BENCH_FAIL_RANK") == str(rank) and world > 1:      # test hook: how the launcher reports a dead rank
         raise SystemExit(f"bench.py: rank {rank} asked to fail (STAG_BENCH_FAIL_RANK)")
+    guardian = Guardian() if (world > 1 and rank == 0) else None      # forked before anything below initialises the GPU
     if not rehearse and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the stochastic-aggregation path has no CPU fallback "
                          "(--rehearse checks the multi-rank plumbing without one)")
@@ -842,9 +900,15 @@ def main():
             val = {"error": f"{type(exc).__name__}: {exc}", "where": traceback.format_exc().strip().splitlines()[-3:]}
         if line is not None and val is not None:
             line[name] = val
+        if guardian is not None:
+            guardian.update(line)
 
+    if guardian is not None:
+        guardian.update(line)            # the headline is safe from here on
     if multi and parts is not None:
-        dog = Watchdog(args.extras_timeout_s, rank, lambda: dict(line or {})) if not rehearse else None
+        if os.environ.get("STAG_BENCH_CRASH_IN_EXTRAS") == str(rank):      # test hook: a rank that dies hard behind the headline
+            os._exit(13)
+        dog = Watchdog(args.extras_timeout_s, rank, lambda: dict(line or {}), guardian) if not rehearse else None
         width = (H * F + H) if workload == "gat" else D
         extra("exchange", lambda: exchange_report(parts, width, 200))
         if not rehearse and not args.no_check:
@@ -920,6 +984,8 @@ def main():
         if not multi and not args.no_cpu_baseline and not rehearse and workload == "agg":
             line["cpu_baseline"] = cpu_baseline(src, dst, n, x_host.numpy(), args.noise, args.cpu_budget_s)
         print(json.dumps(line), flush=True)
+        if guardian is not None:
+            guardian.done()
     if multi:
         try:
             dist.destroy_process_group()

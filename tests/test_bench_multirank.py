@@ -76,6 +76,29 @@ def test_a_failing_rank_is_named_with_its_stderr():
     assert '"n_gpus"' not in r.stdout
 
 
+def test_a_rank_dying_behind_the_headline_does_not_lose_the_line():
+    """An extra that takes a rank down hard (os._exit in rank 1 after the headline loop): the launcher stops the job,
+    rank 0 dies in its collective — and its guardian process prints the line as far as it got, marked."""
+    r = _run(["--gpus", "2", "--rehearse", "--steps", "2", "--warmup", "1"], env={"STAG_BENCH_CRASH_IN_EXTRAS": "1"})
+    assert r.returncode != 0 and "rank 1 exited with code 13" in r.stderr
+    lines = [json.loads(t) for t in r.stdout.splitlines() if t.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and "ms_per_step" in lines[0]
+    # (rank 0 either died in the collective — the guardian's line — or saw its peer vanish as an exception inside the extra)
+    assert "extras_crashed" in lines[0] or "error" in lines[0]["exchange"]
+    # ... and a clean run prints exactly one line, without the mark
+    r = _run(["--gpus", "2", "--rehearse", "--steps", "2", "--warmup", "1"])
+    lines = [json.loads(t) for t in r.stdout.splitlines() if t.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1 and "extras_crashed" not in lines[0]
+
+
+def test_a_rank_dying_behind_the_headline_under_torchrun():
+    """The same under the driver's launcher: torchrun SIGTERMs rank 0 when rank 1 is gone; the guardian survives it."""
+    r = _torchrun(["--rehearse", "--steps", "2", "--warmup", "1"], env={"STAG_BENCH_CRASH_IN_EXTRAS": "1"})
+    lines = [json.loads(t) for t in r.stdout.splitlines() if t.startswith("{")]
+    assert r.returncode != 0 and len(lines) == 1 and lines[0]["n_gpus"] == 2
+    assert "extras_crashed" in lines[0] or "error" in lines[0]["exchange"]
+
+
 def test_world_size_mismatch_is_an_error():
     r = _run(["--gpus", "2", "--rehearse", "--steps", "1", "--warmup", "0"],
              env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
