@@ -512,8 +512,12 @@ struct AggTeam {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       if (p0 + j < pend) {
+#ifdef STAG_EXP_NO_ROWS   // experiment (tools/ab_bench.py): the launch without its row gathers — what the ids, the draw and the adds cost alone
+        for (int q = 0; q < 4; ++q) R.xv[j][q] = __int_as_float(0x3f800000 | ((I.u[j] + q) & 0xff));
+#else
         if (x_buf) bufrow4(rx, I.u[j], a.ldxb, koff, R.xv[j]);
         else loadrow4(row_at(a.x, I.u[j], a.ldxb, koff, (a.wide & 1) != 0), k0, a.D, VEC, R.xv[j]);
+#endif
         if (a.src_scale) R.xs[j] = a.src_scale[I.u[j]];
         if constexpr (KIND >= kNormal && P1) {
           R.P.q0[j] = a.p0[I.ee[j]];
