@@ -23,6 +23,11 @@ using namespace stag;
 
 namespace {
 
+#ifndef STAG_GAT_MERGE_NF
+#define STAG_GAT_MERGE_NF 4
+#endif
+constexpr int kGatMergeNF = STAG_GAT_MERGE_NF;   // segment states of a long row fetched per round trip by the row's merge
+
 struct GatArgs {
   const int32_t* indptr;
   const int32_t* indices;
@@ -666,15 +671,54 @@ __global__ __launch_bounds__(kBlkThreads) STAG_GAT_SGPR_ATTR void gat_fwd_block_
       if (!kin[cj]) continue;
       float M = -INFINITY, L = 0.f;
       float A[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int sg = s0; sg < s1; ++sg) M = fmaxf(M, a.ws[(int64_t)sg * a.ws_stride + HF + hl[cj]]);
-      for (int sg = s0; sg < s1; ++sg) {
-        const float* wr = a.ws + (int64_t)sg * a.ws_stride;
-        float tt[4];
-        load4(wr, k0[cj], HF, true, tt);
-        const float sc = __expf(wr[HF + hl[cj]] - M);
-        L += wr[HF + H + hl[cj]] * sc;
+      // The merge is a chain on the launch's critical path when the launch is small (a shard of an 8-way partition:
+      // the 13k-edge hub's 205 segment states, one L2 round trip each, were 97 of the shard's 145 us): the states are
+      // fetched kGatMergeNF (4) at a time — what fits the kernel's register budget: 8 at a time cost it two waves per SIMD — independent loads, clamped to the last segment instead of branching — and
+      // folded in segment order as before, so the row's bits do not change.
+      constexpr int NFM = CPL == 1 ? kGatMergeNF : 1;     // (wider rows, CPL chunks per lane: their register budget has no room, one state at a time as before)
+      // the row's maximum per head.  Where the team's lanes are exactly H heads x F/4 lanes (cfg5: 8 x 8 = 64), the F/4
+      // lanes of a head take every (F/4)-th segment each and exchange their maxima: 205 states in 4 round trips
+      // instead of 26 (a maximum does not care about the order)
+      const int lph = a.lphp;
+      if (CPL == 1 && lph >= 2 && lph * 4 == F && H * lph == LPE) {
+        const int g = c & (lph - 1);
+        for (int sg = s0 + g; sg < s1; sg += 2 * NFM * lph) {
+          float mm[2 * NFM];
 #pragma unroll
-        for (int x = 0; x < 4; ++x) A[x] = __builtin_fmaf(tt[x], sc, A[x]);
+          for (int i = 0; i < 2 * NFM; ++i)
+            mm[i] = a.ws[(int64_t)min(sg + i * lph, s1 - 1) * a.ws_stride + HF + hl[cj]];
+#pragma unroll
+          for (int i = 0; i < 2 * NFM; ++i) M = fmaxf(M, mm[i]);
+        }
+        for (int d = 1; d < lph; d <<= 1) M = fmaxf(M, __shfl_xor(M, d));
+      } else {
+        for (int sg = s0; sg < s1; sg += 2 * NFM) {
+          float mm[2 * NFM];
+#pragma unroll
+          for (int i = 0; i < 2 * NFM; ++i)
+            mm[i] = a.ws[(int64_t)min(sg + i, s1 - 1) * a.ws_stride + HF + hl[cj]];
+#pragma unroll
+          for (int i = 0; i < 2 * NFM; ++i) M = fmaxf(M, mm[i]);
+        }
+      }
+      for (int sg = s0; sg < s1; sg += NFM) {
+        float tt[NFM][4], ms[NFM], ls[NFM];
+#pragma unroll
+        for (int i = 0; i < NFM; ++i) {
+          const float* wr = a.ws + (int64_t)min(sg + i, s1 - 1) * a.ws_stride;
+          load4(wr, k0[cj], HF, true, tt[i]);
+          ms[i] = wr[HF + hl[cj]];
+          ls[i] = wr[HF + H + hl[cj]];
+        }
+#pragma unroll
+        for (int i = 0; i < NFM; ++i) {
+          if (sg + i < s1) {
+            const float sc = __expf(ms[i] - M);
+            L += ls[i] * sc;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) A[x] = __builtin_fmaf(tt[i][x], sc, A[x]);
+          }
+        }
       }
       const float inv = (L > 0.f) ? 1.0f / L : 0.f;
 #pragma unroll
