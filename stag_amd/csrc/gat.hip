@@ -392,6 +392,15 @@ static_assert(kBlkUnits <= 64 && kBlkThreads % 64 == 0 && kBlkThreads <= 1024, "
 #ifndef STAG_GAT_NR_FWD_LOCAL
 #define STAG_GAT_NR_FWD_LOCAL 2
 #endif
+// Round 4, re-measured on the kernel as it stands (three builds beside the shipped one in one call): on the one-GPU cfg5
+// launch the count no longer matters — 1: 221.0-221.7, 2: 219.8-221.3, 3: 219.7, 4: 220.3 us — and on a SHARD-sized launch
+// (an eighth of the graph: 900 batches, not fabric-bound: its time is the longest unit's chain of row round trips) it
+// decides: 52.1 | 42.1 | 38.8 | 37.9 us for 1 | 2 | 3 | 4.  Rows of one chunk per lane (H * F <= 256: every BASELINE
+// config) therefore keep 4 in flight; wider rows (2 or 4 chunks per lane: 4 rows would be 32-64 more registers) stay
+// as they were.
+#ifndef STAG_GAT_NR_FWD_NARROW
+#define STAG_GAT_NR_FWD_NARROW 4
+#endif
 // (the one-gather backward keeps its branchy NR = 4 loop: branch-free loads there change nothing — cfg5 training step
 //  632.5 against 632.1 us — and fewer rows per round cost it: NR = 2 640.5, NR = 1 658 us)
 
@@ -1715,21 +1724,25 @@ extern "C" int stag_gat_fwd(const stag_csr* csr, const stag_plan* plan, const fl
     if (lds_blk < STAG_GAT_LDS_MIN) lds_blk = STAG_GAT_LDS_MIN;
     const dim3 gb(plan->n_blocks);
     const bool local = plan->xcd_order != nullptr;      // the batches are XCD-local: the rows come out of an L2
-#define STAG_BLK_LAUNCH(L, Cc)                                                                                           \
+    // rows of at most 256 floats (one chunk per lane): STAG_GAT_NR_FWD_NARROW rows in flight, whatever the launch
+#define STAG_BLK_LAUNCH1(L) \
+  hipLaunchKernelGGL((gat_fwd_block_kernel<L, 1, STAG_GAT_NR_FWD_NARROW>), gb, dim3(kBlkThreads), lds_blk, s, a)
+#define STAG_BLK_LAUNCHW(Cc)                                                                                             \
   do {                                                                                                                   \
-    if (local) hipLaunchKernelGGL((gat_fwd_block_kernel<L, Cc, STAG_GAT_NR_FWD_LOCAL>), gb, dim3(kBlkThreads), lds_blk, s, a); \
-    else       hipLaunchKernelGGL((gat_fwd_block_kernel<L, Cc>), gb, dim3(kBlkThreads), lds_blk, s, a);                 \
+    if (local) hipLaunchKernelGGL((gat_fwd_block_kernel<64, Cc, STAG_GAT_NR_FWD_LOCAL>), gb, dim3(kBlkThreads), lds_blk, s, a); \
+    else       hipLaunchKernelGGL((gat_fwd_block_kernel<64, Cc>), gb, dim3(kBlkThreads), lds_blk, s, a);                 \
   } while (0)
-    if (cpl == 4) STAG_BLK_LAUNCH(64, 4);
-    else if (cpl == 2) STAG_BLK_LAUNCH(64, 2);
+    if (cpl == 4) STAG_BLK_LAUNCHW(4);
+    else if (cpl == 2) STAG_BLK_LAUNCHW(2);
     else switch (lpe) {
-      case 64: STAG_BLK_LAUNCH(64, 1); break;
-      case 32: STAG_BLK_LAUNCH(32, 1); break;
-      case 16: STAG_BLK_LAUNCH(16, 1); break;
-      case 8: STAG_BLK_LAUNCH(8, 1); break;
-      default: STAG_BLK_LAUNCH(4, 1); break;
+      case 64: STAG_BLK_LAUNCH1(64); break;
+      case 32: STAG_BLK_LAUNCH1(32); break;
+      case 16: STAG_BLK_LAUNCH1(16); break;
+      case 8: STAG_BLK_LAUNCH1(8); break;
+      default: STAG_BLK_LAUNCH1(4); break;
     }
-#undef STAG_BLK_LAUNCH
+#undef STAG_BLK_LAUNCH1
+#undef STAG_BLK_LAUNCHW
     return hipGetLastError() == hipSuccess ? STAG_OK : STAG_EIO;
   }
 #define STAG_GAT_LAUNCH(L)                                                                         \

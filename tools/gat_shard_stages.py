@@ -43,7 +43,13 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--ranks", default="all")
     ap.add_argument("--seg-len", type=int, default=64)
+    ap.add_argument("--lib", default=None, help="A/B: a build variant tools/_bin/libstag_<name>.so (tools/ab_bench.py build)")
+    ap.add_argument("--fwd-only", action="store_true", help="the forward launches only")
     args = ap.parse_args()
+    if args.lib:
+        lib = _lib.bind(os.path.join(ROOT, "tools", "_bin", f"libstag_{args.lib}.so"))
+        _lib._lib = lib
+        _lib.lib = lambda: lib
     dev = torch.device("cuda:0")
     src, dst = synthetic.arxiv_like(seed=1)
     n = synthetic.ARXIV_NODES
@@ -77,6 +83,9 @@ def main():
         f_loc = timeit(lambda: fwd(p_loc)) if p_loc["n_units"] else 0.0
         f_rem = timeit(lambda: fwd(p_rem)) if p_rem["n_units"] else 0.0
         fwd(whole)
+        if args.fwd_only:
+            print(f"{r:4d} {nr:6d} {sh.number_of_edges():7d} {nb - nr:7d} | fwd one {f_one:7.1f}  local {f_loc:6.1f} + remote {f_rem:6.1f}; batches {whole['n_blocks']}", flush=True)
+            continue
         b_one = timeit(lambda: ops._gat_bwd_fused(csrv, csrt, el, er, ft, stats, G, out, H, F, 0.2, spec, None, False, seg, dev, None))
         T_ft = torch.zeros((nb + ns, HF), device=dev)
         T_el = torch.zeros((nb + ns, H), device=dev)
@@ -101,6 +110,8 @@ def main():
               f"{t_cf:6.1f} + {t_ce:4.1f} | {100 * (f2 / f_one - 1):+5.1f} {100 * (b2 / b1 - 1):+5.1f}")
         del sh, csrv, csrt, st
     k = len(list(ranks))
+    if args.fwd_only:
+        return
     print(f"mean over {k} shards: forward {tot['f1'] / k:.1f} -> {tot['f2'] / k:.1f} us of kernels, backward {tot['b1'] / k:.1f} -> "
           f"{tot['b2'] / k:.1f} us; the collective of a step has the local launch (forward) and the own-rows source pass + d er "
           f"(backward) to hide behind")
