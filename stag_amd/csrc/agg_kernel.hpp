@@ -1034,11 +1034,24 @@ constexpr int mult_of() {
 #ifndef STAG_HSLOTS_LPE16_RNG
 #define STAG_HSLOTS_LPE16_RNG 1
 #endif
-template <int KIND, int LPE>
+// At 32 lanes per row (D in 65..128) a launch too small to be bound by the fabric is bound by its longest unit: a 64-edge
+// unit walked two edges per round trip is 32 trips = 30 us, whatever else the launch holds (a shard of an 8-way partition
+// of the arxiv graph: 146 k edges, 33 us).  Such launches (SMALL: a plan of at most STAG_SMALL_UNITS
+// units, plain family, plan order) give their heavy units two edge slots — tools/ab_bench-style A/B of four builds in one
+// process, us with | without the draw, one slot | two:  shard of 8: 34.3 | 33.1 -> 31.9 | 25.1; the hub's shard 52.6 | 51.2 ->
+// 42.9 | 36.3; shard of 4: 58.3 | 57.9 -> 47.9 | 42.8; shard of 2 (583 k edges): 54.5 | 60.5 -> 60.5 | 49.9; the whole graph
+// 103.6 | 95.0 -> 119.3 | 100.7 — so the big launches keep one.  Same bits (the slots fold their blocks in block order).
+#ifndef STAG_HSLOTS_LPE32_SMALL
+#define STAG_HSLOTS_LPE32_SMALL 2
+#endif
+#ifndef STAG_SMALL_UNITS
+#define STAG_SMALL_UNITS 49152
+#endif
+template <int KIND, int LPE, bool SMALL = false>
 constexpr int heavy_slots_of() {
   return LPE <= 4 ? STAG_HSLOTS_LPE4 : LPE == 8 ? STAG_HSLOTS_LPE8
          : LPE == 16 ? ((KIND == kNormal || KIND == kUniform) ? STAG_HSLOTS_LPE16_RNG : STAG_HSLOTS_LPE16)
-         : LPE == 32 ? STAG_HSLOTS_LPE32 : 1;
+         : LPE == 32 ? (SMALL ? STAG_HSLOTS_LPE32_SMALL : STAG_HSLOTS_LPE32) : 1;
 }
 
 // The kernel arguments a unit needs before its first gather, fetched TOGETHER at the top of the kernel: left to
@@ -1082,11 +1095,13 @@ __device__ __forceinline__ void hoist_args(AggArgs& l) {
 // (the plain family only: one output, scalar / per-channel parameters): the stripes of AggArgs::Walk — its own
 // instantiation, so that the plan-order kernels keep the code they were tuned with (as one kernel with a run-time
 // walk the narrow shapes lost 2 us of 35 with noise, tools/ab_bench.py).
-template <int KIND, int LPE, bool VEC, int PEDGE, int NOUT = 1, bool MC = false, bool WN = false, bool WALK = false>
+template <int KIND, int LPE, bool VEC, int PEDGE, int NOUT = 1, bool MC = false, bool WN = false, bool WALK = false,
+          bool SMALL = false>
 __global__ __launch_bounds__(STAG_BLOCK_THREADS, STAG_WAVES_PER_SIMD) void agg_kernel(const AggArgs a_in) {
   AggArgs a = a_in;
   hoist_args<KIND, LPE, WALK>(a);
-  constexpr int HS = (NOUT == 1 && PEDGE != 3) ? heavy_slots_of<KIND, LPE>() : 1;
+  static_assert(!SMALL || (LPE == 32 && !WALK && PEDGE == 0 && NOUT == 1), "SMALL: the plain plan-order launch at 32 lanes per row");
+  constexpr int HS = (NOUT == 1 && PEDGE != 3) ? heavy_slots_of<KIND, LPE, SMALL>() : 1;
   const int c = threadIdx.x % LPE;                // chunk lane inside the channel tile
   constexpr int TPB = STAG_BLOCK_THREADS / LPE, TPBH = STAG_BLOCK_THREADS / (LPE * HS);
   if constexpr (!WALK) {
@@ -1196,8 +1211,27 @@ hipError_t agg_launch(const AggArgs& a, bool vec, hipStream_t stream);
 #ifndef STAG_AGG_LDS_BYTES
 #define STAG_AGG_LDS_BYTES 0
 #endif
+// the SMALL instantiation of the plain plan-order launch at 32 lanes per row (heavy_slots_of)
+template <int KIND>
+inline void agg_launch_small(const AggArgs& a_in, bool vec, int tiles, hipStream_t s) {
+  AggArgs a = a_in;
+  constexpr int LPE = 32, TPB = STAG_BLOCK_THREADS / LPE, TPBH = STAG_BLOCK_THREADS / (LPE * heavy_slots_of<KIND, LPE, true>());
+  a.n_heavy_blocks = (a.n_heavy + TPBH - 1) / TPBH;
+  const dim3 grid(a.n_heavy_blocks + (a.n_units - a.n_heavy + TPB - 1) / TPB, tiles), block(STAG_BLOCK_THREADS);
+  if (grid.x == 0) return;
+  if (vec) hipLaunchKernelGGL((agg_kernel<KIND, LPE, true, 0, 1, false, false, false, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+  else     hipLaunchKernelGGL((agg_kernel<KIND, LPE, false, 0, 1, false, false, false, true>), grid, block, STAG_AGG_LDS_BYTES, s, a);
+}
+
 template <int KIND, int LPE>
 inline void agg_launch_shape(const AggArgs& a_in, bool vec, int pedge, int tiles, hipStream_t s) {
+  if constexpr (LPE == 32 && heavy_slots_of<KIND, 32, true>() != heavy_slots_of<KIND, 32, false>()) {
+    if (!a_in.outx[0] && !a_in.dp_part && pedge == 0 && !a_in.xcd && a_in.units && a_in.n_heavy > 0 &&
+        a_in.n_units <= STAG_SMALL_UNITS) {
+      agg_launch_small<KIND>(a_in, vec, tiles, s);
+      return;
+    }
+  }
   AggArgs a = a_in;
   constexpr int TPB = STAG_BLOCK_THREADS / LPE;
   constexpr int HS = heavy_slots_of<KIND, LPE>();

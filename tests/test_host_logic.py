@@ -787,9 +787,10 @@ def test_hot_kernel_register_budget():
     normal, none = usage("agg_normal"), usage("agg_none")
     for lpe in (32, 64):         # D = 128 (the headline) and D >= 256
         for walk in ("false", "true"):       # the plan-order kernel and its XCD-aware twin
-            v, occ = normal[f"void stag::agg_kernel<2, {lpe}, true, 0, 1, false, false, {walk}>(stag::AggArgs)"]
+            # (last argument: SMALL — the two-slot twin of the plan-order kernel for shard-sized launches is not budgeted)
+            v, occ = normal[f"void stag::agg_kernel<2, {lpe}, true, 0, 1, false, false, {walk}, false>(stag::AggArgs)"]
             assert occ >= 7 and v <= 72, f"Normal, LPE {lpe}, walk {walk}: {v} VGPRs, {occ} waves/SIMD"
-            v, occ = none[f"void stag::agg_kernel<0, {lpe}, true, 0, 1, false, false, {walk}>(stag::AggArgs)"]
+            v, occ = none[f"void stag::agg_kernel<0, {lpe}, true, 0, 1, false, false, {walk}, false>(stag::AggArgs)"]
             assert occ >= 7 and v <= 72, f"no noise, LPE {lpe}, walk {walk}: {v} VGPRs, {occ} waves/SIMD"
 
 
