@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--seg-len", type=int, default=64)
     ap.add_argument("--lib", default=None, help="A/B: a build variant tools/_bin/libstag_<name>.so (tools/ab_bench.py build)")
     ap.add_argument("--fwd-only", action="store_true", help="the forward launches only")
+    ap.add_argument("--heads", type=int, default=8)
+    ap.add_argument("--feat", type=int, default=32)
     args = ap.parse_args()
     if args.lib:
         lib = _lib.bind(os.path.join(ROOT, "tools", "_bin", f"libstag_{args.lib}.so"))
@@ -53,7 +55,7 @@ def main():
     dev = torch.device("cuda:0")
     src, dst = synthetic.arxiv_like(seed=1)
     n = synthetic.ARXIV_NODES
-    H, F, seg = 8, 32, args.seg_len
+    H, F, seg = args.heads, args.feat, args.seg_len
     HF = H * F
     ranks = range(args.world) if args.ranks == "all" else [int(r) for r in args.ranks.split(",")]
     gen = torch.Generator().manual_seed(3)
