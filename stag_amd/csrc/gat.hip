@@ -422,7 +422,10 @@ static_assert(kBlkUnits <= 64 && kBlkThreads % 64 == 0 && kBlkThreads <= 1024, "
 #define STAG_GAT_LDS_MIN 40000      // forward: 4 workgroups per CU
 #endif
 #ifndef STAG_GAT_LDS_MIN_ONE
-#define STAG_GAT_LDS_MIN_ONE 32000  // the one-gather backward
+// the one-gather backward: no cap beyond its registers' (80 VGPRs: 6 waves per SIMD).  Round 4, 32000 | 16000 B: the
+// one-GPU training step 621-628 | 618-624 us (no difference), the remote-rows source pass of a shard of eight 62.9 | 53.2 us
+// (85 k rows of 1.5 edges: latency x concurrency, not the fabric); 48000: 689 us and 74.9 us.
+#define STAG_GAT_LDS_MIN_ONE 16000
 #endif
 #ifndef STAG_GAT_LDS_MIN_BWD
 #define STAG_GAT_LDS_MIN_BWD 32000  // backward passes: 5
