@@ -683,10 +683,12 @@ __global__ __launch_bounds__(kBlkThreads) STAG_GAT_SGPR_ATTR void gat_fwd_block_
       if (!kin[cj]) continue;
       float M = -INFINITY, L = 0.f;
       float A[4] = {0.f, 0.f, 0.f, 0.f};
-      // The merge is a chain on the launch's critical path when the launch is small (a shard of an 8-way partition:
-      // the 13k-edge hub's 205 segment states, one L2 round trip each, were 97 of the shard's 145 us): the states are
-      // fetched kGatMergeNF (12) at a time — 121 VGPRs: under the 128 at which registers would cost a wave, because the kernel's LDS request already caps a SIMD at 4 waves (one-GPU cfg5, 4 | 8 | 12 at a time: 223.8 | 223.5 | 223.1 us; the hub's shard of eight 70.2 | 57.4 | 53.0) — independent loads, clamped to the last segment instead of branching — and
-      // folded in segment order as before, so the row's bits do not change.
+      // The merge is a chain on the launch's critical path when the launch is small (a shard of an 8-way partition: the
+      // 13k-edge hub's 205 segment states, one L2 round trip each, were 97 of the shard's 145 us).  The states are fetched
+      // kGatMergeNF (12) at a time — independent loads, clamped to the last segment instead of branching — and folded in
+      // segment order as before, so the row's bits do not change.  12 states are 121 VGPRs: free, because the kernel's LDS
+      // request (STAG_GAT_LDS_MIN) caps a SIMD at 4 waves, which registers allow up to 128 (one-GPU cfg5 with 4 | 8 | 12
+      // at a time: 223.8 | 223.5 | 223.1 us; the hub's shard of eight: 70.2 | 57.4 | 53.0 us).
       constexpr int NFM = CPL == 1 ? kGatMergeNF : 1;     // (wider rows, CPL chunks per lane: their register budget has no room, one state at a time as before)
       // the row's maximum per head.  Where the team's lanes are exactly H heads x F/4 lanes (cfg5: 8 x 8 = 64), the F/4
       // lanes of a head take every (F/4)-th segment each and exchange their maxima: 205 states in 4 round trips
