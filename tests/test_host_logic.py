@@ -792,6 +792,11 @@ def test_hot_kernel_register_budget():
             assert occ >= 7 and v <= 72, f"Normal, LPE {lpe}, walk {walk}: {v} VGPRs, {occ} waves/SIMD"
             v, occ = none[f"void stag::agg_kernel<0, {lpe}, true, 0, 1, false, false, {walk}, false>(stag::AggArgs)"]
             assert occ >= 7 and v <= 72, f"no noise, LPE {lpe}, walk {walk}: {v} VGPRs, {occ} waves/SIMD"
+    # the cooperative GAT forward asks for 40,000 B of LDS per workgroup = 4 waves per SIMD: its long-row merge may use
+    # registers up to the 128 that occupancy allows (12 segment states per round trip), not more
+    gat = usage("gat")
+    fwd = {k: v for k, v in gat.items() if "gat_fwd_block_kernel<" in k and ", 1, 4>" in k}
+    assert len(fwd) == 5 and all(v <= 128 and occ >= 4 for v, occ in fwd.values()), fwd
 
 
 def test_round2_host_helpers_on_cpu():
