@@ -1559,3 +1559,34 @@ def test_fuzz_monte_carlo_batches(dev, oracle):
                                  reduce=oracle.REDUCE_MEAN if reduce == "mean" else oracle.REDUCE_SUM, dst_scale=ds.cpu().numpy())
         tol = TOL if 0 < seg_len <= 64 else 2 * TOL
         assert_close(got[s], ref, tol=tol, what=what + f" sample {s} vs oracle")
+
+
+@pytest.mark.parametrize("kind", ["normal", "bernoulli", "none"])
+@pytest.mark.parametrize("D", [72, 128])
+def test_small_plan_twin_changes_no_bit(dev, kind, D):
+    """Plain plan-order launches at 32 lanes per row take a twin instantiation when the plan holds at most
+    STAG_SMALL_UNITS (49,152) units: heavy units on two edge slots (csrc/agg_kernel.hpp, heavy_slots_of).
+    The same rows inside a graph that is NOT small — the graph with 30,000 edge-less rows appended: every edge keeps its
+    CSR position, so its Philox counters — must come out bit for bit the same, hub rows (segments) and heavy rows included."""
+    import stag_amd
+    from stag_amd import _lib, ops
+    rng = np.random.default_rng(29)
+    n = 30000
+    deg = np.minimum(rng.zipf(1.7, n), 3000)          # many rows of 17..64 edges (heavy units), a few long ones (segments)
+    deg[:3] = (5000, 700, 65)
+    dst = np.repeat(np.arange(n), deg)
+    src = rng.integers(0, n, len(dst))
+    x = torch.randn(n + 30000, D, generator=torch.Generator().manual_seed(3)).to(dev)
+    outs = []
+    for extra in (0, 30000):
+        g = stag_amd.Graph(torch.from_numpy(src), torch.from_numpy(dst), n + extra, device=dev)
+        p = g.csr.plan(64)
+        assert (p["n_units"] <= 49152) == (extra == 0) and p["n_heavy"] > 0 and p["n_long"] >= 3
+        if kind == "none":
+            noise = None
+        else:
+            k, p0, p1 = {"normal": (_lib.NOISE_NORMAL, 1.0, 0.5), "bernoulli": (_lib.NOISE_BERNOULLI, 0.5, None)}[kind]
+            noise = stag_amd.EdgeNoise(g, D, k, p0, p1, seed=77, offset=5, in_norm=(kind == "bernoulli"))
+        outs.append(ops.aggregate(g, x[:n + extra], noise)[:n].clone())
+    assert torch.equal(outs[0], outs[1])
+    assert bool(torch.isfinite(outs[0]).all()) and float(outs[0].abs().max()) > 0
