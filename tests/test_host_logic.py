@@ -853,3 +853,13 @@ def test_sage_lstm_aggregator_composed():
     assert torch.allclose(out, ref, atol=1e-6)
     out.sum().backward()
     assert x.grad is not None and layer.lstm.weight_hh_l0.grad is not None
+
+
+def test_tools_and_entry_points_compile():
+    """Every script under tools/ (they run on the GPU box only) and the repo-root entry points at least parse."""
+    import ast
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "tools", "*.py"))) + [os.path.join(ROOT, f) for f in ("bench.py", "__graft_entry__.py")]
+    assert len(files) > 20
+    for f in files:
+        ast.parse(open(f).read(), filename=f)
