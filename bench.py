@@ -296,9 +296,10 @@ class Watchdog:
         if self.rank == 0:
             line = self.line_fn()
             line["extras_timed_out_after_s"] = seconds
-            print(json.dumps(line), flush=True)
             if self.guardian is not None:
-                self.guardian.done()
+                self.guardian.final(line)
+            else:
+                print(json.dumps(line), flush=True)
         sys.stderr.write(f"bench.py: rank {self.rank}: the extra loops did not finish in {seconds:.0f} s; "
                          f"the headline measurement stands, leaving.\n")
         sys.stderr.flush()
@@ -313,7 +314,8 @@ class Guardian:
     does — that holds the line as far as rank 0 got.  If rank 0 dies before it has printed the line itself (an
     extra crashed a rank and the launcher tore the job down, a fault inside a collective), the child prints the
     last snapshot with `extras_crashed`: the headline measurement of the first multi-GPU run is not lost with
-    the extras behind it.  Nothing is printed when rank 0 never got as far as the headline."""
+    the extras behind it.  Nothing is printed when rank 0 never got as far as the headline.  With a guardian, rank 0's own
+    finished line goes out through it as well (`final`): whatever kills rank 0, and whenever, stdout carries ONE line."""
 
     def __init__(self):
         import signal
@@ -337,28 +339,37 @@ class Guardian:
                         break
                     data += chunk
                 msgs = [m for m in data.decode("utf-8", "replace").split("\n") if m]
-                if msgs and msgs[-1] != "DONE":
+                if msgs and msgs[-1].startswith("FINAL "):         # rank 0 finished: its line, as it is
+                    os.write(1, (msgs[-1][6:] + "\n").encode())
+                elif msgs:
                     snap = json.loads(msgs[-1])
-                    snap["extras_crashed"] = ("rank 0 ended before printing this line (an extra after the headline loop "
+                    snap["extras_crashed"] = ("rank 0 ended before finishing this line (an extra after the headline loop "
                                               "failed hard on some rank); printed by its guardian process from the last "
                                               "snapshot: everything present was complete when it was taken")
                     os.write(1, (json.dumps(snap) + "\n").encode())
             finally:
                 os._exit(0)
         os.close(r)
-        self.w = w
+        self.w, self.pid = w, pid
 
     def update(self, line):
         if self.w is not None and line is not None:
             os.write(self.w, (json.dumps(line) + "\n").encode())
 
-    def done(self):
-        if self.w is not None:
-            try:
-                os.write(self.w, b"DONE\n")
-                os.close(self.w)
-            finally:
-                self.w = None
+    def final(self, line):
+        """The finished line goes out THROUGH the guardian (exactly one line whatever happens to this process between
+        here and its exit); returns when the guardian has written it."""
+        if self.w is None:
+            return
+        try:
+            os.write(self.w, ("FINAL " + json.dumps(line) + "\n").encode())
+            os.close(self.w)
+        finally:
+            self.w = None
+        try:
+            os.waitpid(self.pid, 0)
+        except OSError:
+            pass
 
 
 # ------------------------------------------------------------------------------------------------- main
@@ -985,9 +996,10 @@ def main():
     if rank == 0:
         if not multi and not args.no_cpu_baseline and not rehearse and workload == "agg":
             line["cpu_baseline"] = cpu_baseline(src, dst, n, x_host.numpy(), args.noise, args.cpu_budget_s)
-        print(json.dumps(line), flush=True)
         if guardian is not None:
-            guardian.done()
+            guardian.final(line)
+        else:
+            print(json.dumps(line), flush=True)
     if multi:
         try:
             dist.destroy_process_group()
