@@ -359,11 +359,13 @@ class Guardian:
     def final(self, line):
         """The finished line goes out THROUGH the guardian (exactly one line whatever happens to this process between
         here and its exit); returns when the guardian has written it."""
-        if self.w is None:
+        if self.w is None:                # (second call: the line is out already)
             return
         try:
             os.write(self.w, ("FINAL " + json.dumps(line) + "\n").encode())
             os.close(self.w)
+        except OSError:                   # the guardian is gone: print it ourselves
+            print(json.dumps(line), flush=True)
         finally:
             self.w = None
         try:
@@ -390,7 +392,12 @@ def main():
     rehearse = args.rehearse
     if os.environ.get("STAG_BENCH_FAIL_RANK") == str(rank) and world > 1:      # test hook: how the launcher reports a dead rank
         raise SystemExit(f"bench.py: rank {rank} asked to fail (STAG_BENCH_FAIL_RANK)")
-    guardian = Guardian() if (world > 1 and rank == 0) else None      # forked before anything below initialises the GPU
+    guardian = None
+    if world > 1 and rank == 0:           # forked before anything below initialises the GPU
+        try:
+            guardian = Guardian()
+        except OSError as exc:            # no fork: the line is printed the plain way
+            sys.stderr.write(f"bench.py: no guardian process ({exc}); continuing without one\n")
     if not rehearse and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the stochastic-aggregation path has no CPU fallback "
                          "(--rehearse checks the multi-rank plumbing without one)")
