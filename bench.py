@@ -354,7 +354,10 @@ class Guardian:
 
     def update(self, line):
         if self.w is not None and line is not None:
-            os.write(self.w, (json.dumps(line) + "\n").encode())
+            try:
+                os.write(self.w, (json.dumps(line) + "\n").encode())
+            except OSError:               # the guardian is gone: rank 0 carries on without it
+                pass
 
     def final(self, line):
         """The finished line goes out THROUGH the guardian (exactly one line whatever happens to this process between
