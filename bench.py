@@ -930,6 +930,7 @@ def main():
         guardian.update(line)            # the headline is safe from here on
     if multi and parts is not None:
         if os.environ.get("STAG_BENCH_CRASH_IN_EXTRAS") == str(rank):      # test hook: a rank that dies hard behind the headline
+            time.sleep(2.0)              # (somewhere inside the extras, not in the instant rank 0 is still forming its line)
             os._exit(13)
         dog = Watchdog(args.extras_timeout_s, rank, lambda: dict(line or {}), guardian) if not rehearse else None
         width = (H * F + H) if workload == "gat" else D
